@@ -1,0 +1,28 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.dirname(os.path.abspath(__file__))):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def refvec():
+    """Known answers held by the reference's own tests/examples (tests/golden/reference_vectors.json)."""
+    with open(os.path.join(ROOT, "tests", "golden", "reference_vectors.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def npvec():
+    """numpy/scipy full-precision vectors (tests/golden/make_golden.py)."""
+    return np.load(os.path.join(ROOT, "tests", "golden", "numpy_scipy_vectors.npz"))
