@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric: batched 1-D C2C FFT along the contiguous axis of an
+f64 array, GFFT-points/s (whole job) + achieved HBM GB/s vs the 8 TB/s roofline.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+Workload: N = 1 -> configs[1]: ndfft axis=1 on 4096x4096 Complex<f64>, device resident.
+          N > 1 -> configs[4]: 65536/8 = 8192 rows x 4096 per GPU (batch-sharded lanes, no data-path
+                   collective: lanes are independent, src/lib.rs:120-124), weak scaling.
+One "step" = one ndfft call over the whole resident array through the C ABI (ndfft_exec_device).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(n, rows, budget_s=12.0):
+    """The CPU oracle's restatement of ndfft_par (create_transform_par!, src/lib.rs:169-238, OpenMP
+    standing in for rayon) on the host cores; bounded sample of the same workload."""
+    import numpy as np
+    import synth
+    from oracle import oracle_ctypes as orc
+    x = synth.complex_array((rows, n))
+    y = np.zeros_like(x)
+    h = orc.FftHandler(n)
+    orc.ndfft_par(x, y, h, 1)                      # warm
+    t0 = time.perf_counter(); reps = 0
+    while True:
+        orc.ndfft_par(x, y, h, 1); reps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or reps >= 500:
+            break
+    pts = rows * n * reps
+    return {"value": round(pts / el / 1e9, 4), "unit": "GFFT-points/s", "cores": orc.num_threads(), "kind": "port",
+            "sample": f"{reps} x ndfft_par axis=1 on {rows}x{n} Complex<f64> (oracle/ndfft_oracle.c, OpenMP over lanes, "
+                      f"{el:.1f} s; CPU restatement of ndrustfft _par, not rustfft)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--rows", type=int, default=0, help="lanes per GPU (default: 4096 at 1 GPU, 8192 per GPU otherwise)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import synth
+    from ndrustfft_amd import FftHandler, _lib, ndfft
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    ngpu = max(world, 1)
+
+    n = args.n
+    rows = args.rows or (4096 if ngpu == 1 else 8192)
+    # device-resident shard: rank r holds global rows [r*rows, (r+1)*rows) of the (ngpu*rows) x n array
+    x = synth.complex_array((rows, n), offset=rank * rows * n)
+    xd = torch.from_numpy(x).to(dev)
+    yd = torch.empty_like(xd)
+    h = FftHandler(n)
+    lib = _lib.default()
+
+    def step():
+        ndfft(xd, yd, h, 1)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()                                   # torch's current stream == the stream exec_device launches on
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    path = lib.last_path()
+    if world > 1:
+        t = torch.tensor([el, dev_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el, dev_ms = float(t[0]), float(t[1])
+
+    # quick self-check of the timed output against the oracle on a few lanes (not timed)
+    if rank == 0:
+        from oracle import oracle_ctypes as orc
+        yo = np.zeros((4, n), np.complex128)
+        orc.ndfft(x[:4], yo, orc.FftHandler(n), 1)
+        err = np.abs(yd[:4].cpu().numpy() - yo).max() / np.abs(yo).max()
+        assert err < 1e-10, f"bench output differs from the oracle: {err}"
+
+    if rank == 0:
+        points = ngpu * rows * n * args.steps
+        bytes_per_launch = 2 * rows * n * 16           # 32 B/point = one read + one write of c64
+        kern_s = dev_ms / 1e3 / args.steps             # average launch duration on the launch stream (HIP events)
+        achieved = bytes_per_launch / kern_s / 1e9
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tj):
+            try:
+                traffic = json.load(open(tj)).get(f"{rows}x{n}")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "GFFT-points/s, batched 1-D C2C FFT f64 along the contiguous axis (+ achieved HBM GB/s vs roofline)",
+            "value": round(points / el / 1e9, 3), "unit": "GFFT-points/s",
+            "n_gpus": ngpu, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(el / args.steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"ndfft axis=1 on {ngpu * rows}x{n} Complex<f64> "
+                                   f"({'BASELINE configs[1]' if ngpu == 1 and rows == 4096 else 'BASELINE configs[4] shard shape: ' + str(rows) + ' rows per GPU'}), "
+                                   f"device-resident, splitmix64 U[-1,1) seed 20241008",
+                       "lanes_per_gpu": rows, "lane_len": n, "kernel_path": path,
+                       "sharding": "none" if ngpu == 1 else f"lanes split in {ngpu} contiguous blocks, one per GPU, no collective in the timed region"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "k_pow2<double,4096>", "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "avg_launch_us": round(kern_s * 1e6, 2)},
+        }
+        if not args.no_cpu_baseline and ngpu == 1:
+            out["cpu_baseline"] = cpu_baseline(n, min(rows, 4096))
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

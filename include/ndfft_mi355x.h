@@ -1,0 +1,142 @@
+/*
+ * ndfft_mi355x.h -- C ABI of the MI355X-native axis-transform engine (libndfft_mi355x.so).
+ *
+ * This is the drop-in boundary for ndrustfft's ONE hot path: "apply a 1-D transform
+ * (C2C / R2C / C2R / DCT-I..IV) to every lane of an n-d array along one axis".
+ * The reference has no FFI (it is a single Rust file, /root/reference/src/lib.rs); the boundary is
+ * placed at whole-call granularity: ONE call here replaces the whole body of one `nd*` /
+ * `nd*_par` call -- the lane iterator macros (src/lib.rs:100-167, 169-238), the handler's
+ * per-lane method (src/lib.rs:313-331, 497-523, 688-734) and the rustfft / realfft / rustdct
+ * kernels underneath (call sites src/lib.rs:317, 325, 502, 522, 697, 709, 721, 733).
+ *
+ * Plain pointers and sizes only; no C++/torch types.  Every function returns an ndfft_status and
+ * never unwinds; ndfft_last_error() gives the message (for NDFFT_ERR_SIZE_MISMATCH it is the
+ * reference's panic text, "Size mismatch in fft, got {} expected {}").
+ *
+ * The Rust-side binding a maintainer would add is shown in INTEGRATION.md (and rust/src/ffi.rs);
+ * a C++ mirror of the reference API lives in include/ndrustfft.hpp.
+ */
+#ifndef NDFFT_MI355X_H
+#define NDFFT_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NDFFT_ABI_VERSION 1
+
+typedef enum {
+    NDFFT_OK = 0,
+    NDFFT_ERR_INVALID_ARG = 1,    /* null pointer, bad enum, op does not belong to the plan's kind      */
+    NDFFT_ERR_SIZE_MISMATCH = 2,  /* lane length != handler n / n/2+1: lib.rs:340-347, 533-540, 743-750 */
+    NDFFT_ERR_SHAPE_MISMATCH = 3, /* a non-axis dimension differs between in and out (ndarray Zip panic, lib.rs:120-121) */
+    NDFFT_ERR_AXIS = 4,           /* axis >= ndim: the index panic at lib.rs:116                         */
+    NDFFT_ERR_UNSUPPORTED = 5,    /* lane too long for the single-pass LDS kernels       */
+    NDFFT_ERR_HIP = 6,            /* a HIP runtime call failed; message carries hipGetErrorString        */
+    NDFFT_ERR_NO_DEVICE = 7,      /* no gfx950 device visible -- there is NO CPU fallback                */
+    NDFFT_ERR_ALLOC = 8
+} ndfft_status;
+
+/* T: FftNum -- f32 and f64 only (lib.rs:111).  Complex<T> is {re, im} interleaved. */
+typedef enum { NDFFT_F32 = 0, NDFFT_F64 = 1 } ndfft_dtype;
+
+/* Which handler a plan stands for. */
+typedef enum {
+    NDFFT_KIND_C2C = 0, /* FftHandler<T>     lib.rs:269-348 */
+    NDFFT_KIND_R2C = 1, /* R2cFftHandler<T>  lib.rs:451-541 */
+    NDFFT_KIND_DCT = 2  /* DctHandler<T>     lib.rs:640-751 */
+} ndfft_kind;
+
+/* Which lane method to run; one per public nd* function (and its _par twin). */
+typedef enum {
+    NDFFT_OP_C2C_FWD = 0, /* ndfft / ndfft_par           -> FftHandler::fft_lane         lib.rs:313-318 */
+    NDFFT_OP_C2C_INV = 1, /* ndifft / ndifft_par         -> FftHandler::ifft_lane        lib.rs:321-331 */
+    NDFFT_OP_R2C = 2,     /* ndfft_r2c / ndfft_r2c_par   -> R2cFftHandler::fft_r2c_lane  lib.rs:497-503 */
+    NDFFT_OP_C2R = 3,     /* ndifft_r2c / ndifft_r2c_par -> R2cFftHandler::ifft_r2c_lane lib.rs:506-523 */
+    NDFFT_OP_DCT1 = 4,    /* nddct1 / nddct1_par         -> DctHandler::dct1_lane        lib.rs:688-698 */
+    NDFFT_OP_DCT2 = 5,    /* nddct2                      -> dct2_lane                    lib.rs:700-710 */
+    NDFFT_OP_DCT3 = 6,    /* nddct3                      -> dct3_lane                    lib.rs:712-722 */
+    NDFFT_OP_DCT4 = 7     /* nddct4                      -> dct4_lane                    lib.rs:724-734 */
+} ndfft_op;
+
+/*
+ * Normalization<T> (lib.rs:89-98).  None and Default are fused into the kernels at the point the
+ * reference applies them: C2C inverse = after, on the output lane (x 1/n); C2R = before, on the
+ * m-length complex lane (x 1/n, n = real length); DCT-I..IV = before, on the input lane (x 2).
+ * Forward C2C and R2C ignore it (lib.rs:313-318, 497-503).  NDFFT_NORM_SCALE applies the caller's
+ * scalar at that same point.  Normalization::Custom(fn) is a host function pointer and cannot
+ * cross to the GPU: the language shim applies it on the host and calls with NONE.
+ */
+typedef enum { NDFFT_NORM_NONE = 0, NDFFT_NORM_DEFAULT = 1, NDFFT_NORM_SCALE = 2 } ndfft_norm;
+
+typedef struct ndfft_plan ndfft_plan;
+
+/* ---- library / device ------------------------------------------------------------------- */
+int ndfft_abi_version(void);
+/* Message of the last failing call on THIS thread ("" if none). */
+const char *ndfft_last_error(void);
+/* Number of visible gfx950 devices (0 if none; never an error). */
+int ndfft_device_count(void);
+/* Select the device for this host thread (hipSetDevice). */
+int ndfft_set_device(int device);
+
+/* ---- plans: FftHandler::new / R2cFftHandler::new / DctHandler::new (lib.rs:294, 477, 665) --- */
+/* Infallible for any n in the reference; here it fails only on bad enums / no device / HIP errors.
+ * A plan is immutable after creation and may be used from many host threads at once (the
+ * reference shares &handler across rayon workers, lib.rs:192-194). */
+int ndfft_plan_create(int kind, int dtype, size_t n, ndfft_plan **out_plan);
+/* #[derive(Clone)] on the handlers is an Arc bump (lib.rs:269, 451, 640): retain/release. */
+int ndfft_plan_retain(ndfft_plan *plan);
+int ndfft_plan_destroy(ndfft_plan *plan); /* release; frees at refcount 0 */
+size_t ndfft_plan_n(const ndfft_plan *plan);
+int ndfft_plan_kind(const ndfft_plan *plan);
+int ndfft_plan_dtype(const ndfft_plan *plan);
+/* Length of the lane on each side for `op` under this plan (n, or n/2+1 on the complex side of R2C/C2R). */
+size_t ndfft_plan_lane_len_in(const ndfft_plan *plan, int op);
+size_t ndfft_plan_lane_len_out(const ndfft_plan *plan, int op);
+
+/* ---- execute: one nd* call ------------------------------------------------------------------
+ * in / out     : base pointers of the two array views (element [0,0,...,0])
+ * ndim         : D (same for both, as in the reference's signature lib.rs:105-110), 1..NDFFT_MAX_DIMS
+ * shape_*      : extents; must agree except along `axis`
+ * stride_*     : strides in ELEMENTS, signed (ndarray semantics; 0 = broadcast input is allowed)
+ * axis         : transform axis
+ * norm, scale  : see ndfft_norm; `scale` is read only for NDFFT_NORM_SCALE
+ *
+ * ndfft_exec        : host arrays.  Synchronous: `out` is fully written on return; nothing is
+ *                     retained.  Staging through HBM is internal.
+ * ndfft_exec_device : device-resident arrays (hipMalloc'd).  Asynchronous on `stream`
+ *                     (a hipStream_t, NULL = default stream).  This is what the roofline numbers
+ *                     are measured on and what multi-axis / multi-GPU callers chain.
+ * in and out must not overlap (Rust's &/&mut guarantee).
+ */
+#define NDFFT_MAX_DIMS 16
+
+int ndfft_exec(const ndfft_plan *plan, int op, const void *in, void *out, int ndim,
+               const int64_t *shape_in, const int64_t *stride_in,
+               const int64_t *shape_out, const int64_t *stride_out,
+               int axis, int norm, double scale);
+
+int ndfft_exec_device(const ndfft_plan *plan, int op, const void *d_in, void *d_out, int ndim,
+                      const int64_t *shape_in, const int64_t *stride_in,
+                      const int64_t *shape_out, const int64_t *stride_out,
+                      int axis, int norm, double scale, void *stream);
+
+/* Name of the kernel path the last successful exec on this thread dispatched to
+ * ("pow2_reg", "generic_row", "generic_col", "generic_strided", "transpose+row", ...). */
+const char *ndfft_last_path(void);
+
+/* ---- device memory helpers for shims that keep arrays resident between nd* calls ----------- */
+int ndfft_dev_alloc(void **d_ptr, size_t bytes);
+int ndfft_dev_free(void *d_ptr);
+int ndfft_dev_upload(void *d_dst, const void *h_src, size_t bytes);   /* synchronous */
+int ndfft_dev_download(void *h_dst, const void *d_src, size_t bytes); /* synchronous */
+int ndfft_dev_sync(void *stream);                                     /* hipStreamSynchronize */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NDFFT_MI355X_H */

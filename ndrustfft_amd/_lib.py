@@ -1,0 +1,90 @@
+"""ctypes binding of libndfft_mi355x.so (the C ABI of include/ndfft_mi355x.h).
+
+There is NO CPU fallback: if the in-tree HIP library is missing or no MI355X is visible the calls
+raise.  `Library(path)` exists so that tests can bind a differently built copy of the same sources;
+the package itself only ever loads the in-tree gfx950 build.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libndfft_mi355x.so")
+
+OK, ERR_INVALID_ARG, ERR_SIZE_MISMATCH, ERR_SHAPE_MISMATCH, ERR_AXIS, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE, ERR_ALLOC = range(9)
+F32, F64 = 0, 1
+KIND_C2C, KIND_R2C, KIND_DCT = 0, 1, 2
+OP_C2C_FWD, OP_C2C_INV, OP_R2C, OP_C2R, OP_DCT1, OP_DCT2, OP_DCT3, OP_DCT4 = range(8)
+NORM_NONE, NORM_DEFAULT, NORM_SCALE = 0, 1, 2
+
+# every symbol include/ndfft_mi355x.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "ndfft_abi_version", "ndfft_last_error", "ndfft_device_count", "ndfft_set_device",
+    "ndfft_plan_create", "ndfft_plan_retain", "ndfft_plan_destroy", "ndfft_plan_n", "ndfft_plan_kind",
+    "ndfft_plan_dtype", "ndfft_plan_lane_len_in", "ndfft_plan_lane_len_out",
+    "ndfft_exec", "ndfft_exec_device", "ndfft_last_path",
+    "ndfft_dev_alloc", "ndfft_dev_free", "ndfft_dev_upload", "ndfft_dev_download", "ndfft_dev_sync",
+]
+
+
+class NdfftError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(msg)
+        self.status = status
+
+
+class Panic(NdfftError):
+    """A condition on which the reference panics (size / axis / Zip mismatch); message text matches."""
+
+
+class Library:
+    def __init__(self, path=LIB_PATH):
+        if not os.path.exists(path):
+            raise ImportError(
+                f"{path} not found: build it with `make -C ndrustfft_amd/csrc` (or __graft_entry__.build()). "
+                "ndrustfft_amd has no CPU fallback.")
+        self.path = path
+        L = self.c = ctypes.CDLL(path)
+        vp, i32, sz, i64p, dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_double
+        L.ndfft_abi_version.restype = i32
+        L.ndfft_last_error.restype = ctypes.c_char_p
+        L.ndfft_last_path.restype = ctypes.c_char_p
+        L.ndfft_device_count.restype = i32
+        L.ndfft_set_device.argtypes = [i32]
+        L.ndfft_plan_create.argtypes = [i32, i32, sz, ctypes.POINTER(vp)]
+        L.ndfft_plan_retain.argtypes = [vp]
+        L.ndfft_plan_destroy.argtypes = [vp]
+        for f in (L.ndfft_plan_n,):
+            f.restype = sz; f.argtypes = [vp]
+        for f in (L.ndfft_plan_kind, L.ndfft_plan_dtype):
+            f.restype = i32; f.argtypes = [vp]
+        for f in (L.ndfft_plan_lane_len_in, L.ndfft_plan_lane_len_out):
+            f.restype = sz; f.argtypes = [vp, i32]
+        L.ndfft_exec.argtypes = [vp, i32, vp, vp, i32, i64p, i64p, i64p, i64p, i32, i32, dbl]
+        L.ndfft_exec_device.argtypes = [vp, i32, vp, vp, i32, i64p, i64p, i64p, i64p, i32, i32, dbl, vp]
+        L.ndfft_dev_alloc.argtypes = [ctypes.POINTER(vp), sz]
+        L.ndfft_dev_free.argtypes = [vp]
+        L.ndfft_dev_upload.argtypes = [vp, vp, sz]
+        L.ndfft_dev_download.argtypes = [vp, vp, sz]
+        L.ndfft_dev_sync.argtypes = [vp]
+
+    def check(self, status):
+        if status == OK:
+            return
+        msg = self.c.ndfft_last_error().decode() or f"ndfft status {status}"
+        if status in (ERR_SIZE_MISMATCH, ERR_SHAPE_MISMATCH, ERR_AXIS):
+            raise Panic(status, msg)
+        raise NdfftError(status, msg)
+
+    def last_path(self):
+        return self.c.ndfft_last_path().decode()
+
+
+_default = None
+
+
+def default():
+    """The in-tree gfx950 library; raises if it has not been built."""
+    global _default
+    if _default is None:
+        _default = Library()
+    return _default

@@ -1,0 +1,155 @@
+// engine.h -- internal declarations of libndfft_mi355x (gfx950 only; not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/ndfft_mi355x.h"
+
+namespace ndfft {
+
+// ------------------------------------------------------------------------------------------
+// complex helpers (Complex<T> = {re, im} interleaved = float2 / double2)
+// ------------------------------------------------------------------------------------------
+template <typename T> struct vec2;
+template <> struct vec2<float> { using type = float2; };
+template <> struct vec2<double> { using type = double2; };
+template <typename T> using cpx = typename vec2<T>::type;
+
+template <typename T> __host__ __device__ inline cpx<T> mk(T a, T b) { cpx<T> r; r.x = a; r.y = b; return r; }
+template <typename C> __host__ __device__ inline C cadd(C a, C b) { a.x += b.x; a.y += b.y; return a; }
+template <typename C> __host__ __device__ inline C csub(C a, C b) { a.x -= b.x; a.y -= b.y; return a; }
+template <typename C> __host__ __device__ inline C cmul(C a, C b) {
+    C r; r.x = a.x * b.x - a.y * b.y; r.y = a.x * b.y + a.y * b.x; return r;
+}
+template <typename C> __host__ __device__ inline C cconj(C a) { a.y = -a.y; return a; }
+// multiply by -i (forward quarter turn): (x, y) -> (y, -x)
+template <typename C> __host__ __device__ inline C cmul_mi(C a) { C r; r.x = a.y; r.y = -a.x; return r; }
+
+// ------------------------------------------------------------------------------------------
+// lane geometry: where lane `l`, element `j` of an n-d view lives (offsets in ELEMENTS)
+// ------------------------------------------------------------------------------------------
+constexpr int kMaxBatchDims = 4;
+struct LaneGeom {
+    int64_t axis_stride;             // between consecutive elements of one lane
+    int32_t nb;                      // batch dims in use (after merging), slowest first
+    int32_t pad_;
+    int64_t bshape[kMaxBatchDims];
+    int64_t bstride[kMaxBatchDims];
+};
+
+// internal op codes of the generic kernel = public ndfft_op, with parity variants resolved on host
+enum GenOp : int {
+    G_C2C_FWD = 0, G_C2C_INV,
+    G_R2C_EVEN, G_R2C_ODD, G_C2R_EVEN, G_C2R_ODD,
+    G_DCT1,               // n >= 2, F = n-1
+    G_DCT2_EVEN, G_DCT2_ODD, G_DCT3_EVEN, G_DCT3_ODD,
+    G_DCT4_EVEN, G_DCT4_ODD
+};
+
+constexpr int kMaxPasses = 16;
+constexpr int kMaxLpb = 64;
+
+enum IoMode : int { IO_ROW = 0, IO_COL = 1 };   // thread -> (lane, element) map for global IO
+
+template <typename T> struct GenArgs {
+    const void *in; void *out;
+    LaneGeom gin, gout;
+    int64_t nlanes;
+    int32_t op;              // GenOp
+    int32_t n;               // handler length (real length for R2C/C2R/DCT)
+    int32_t n_in, n_out;     // lane lengths in elements of the in / out element type
+    int32_t in_cplx, out_cplx;
+    int32_t F;               // complex FFT length
+    int32_t npass; int32_t radix[kMaxPasses];
+    int32_t lpb;             // lanes per block
+    int32_t pitch;           // LDS pitch per lane per buffer, in complex elements
+    int32_t load_mode, store_mode;
+    T scale;                 // normalisation scalar, applied where the reference applies it
+    const cpx<T> *tw;        // tw[k] = e^{-2 pi i k/F}
+    const cpx<T> *aux1, *aux2;
+    // Bluestein (when F has a prime factor the radix passes do not cover)
+    int32_t blue, M, npassM; int32_t radixM[kMaxPasses];
+    const cpx<T> *twM, *chirp, *bhat;
+};
+
+// ------------------------------------------------------------------------------------------
+// plan
+// ------------------------------------------------------------------------------------------
+struct HostTable { std::vector<long double> re, im; };   // built once in long double
+
+struct FftConfig {                 // one complex-FFT-of-length-F recipe + op tables
+    int F = 0;
+    std::vector<int> radix;
+    bool blue = false; int M = 0; std::vector<int> radixM;
+    HostTable tw, twM, chirp, bhat, aux1, aux2;
+    // tuned power-of-two path (register-resident Stockham), when eligible
+    bool pow2 = false;
+    HostTable twp;                 // per-pass transposed twiddles
+};
+
+struct DevConfig {                 // device copies (typed by dtype) of one FftConfig
+    void *tw = nullptr, *twM = nullptr, *chirp = nullptr, *bhat = nullptr, *aux1 = nullptr, *aux2 = nullptr, *twp = nullptr;
+};
+
+enum ConfigSlot { CFG_MAIN = 0, CFG_DCT1 = 1, CFG_DCT4 = 2, CFG_COUNT = 3 };
+
+struct DevTables { DevConfig cfg[CFG_COUNT]; };
+
+}  // namespace ndfft
+
+struct ndfft_plan {
+    int kind, dtype;
+    size_t n;
+    int refcount;
+    ndfft::FftConfig cfg[ndfft::CFG_COUNT];
+    bool has_cfg[ndfft::CFG_COUNT];
+    std::mutex mu;
+    std::map<int, ndfft::DevTables> dev;   // device id -> tables (lazily uploaded)
+};
+
+namespace ndfft {
+
+// error plumbing (thread-local message)
+int fail(int code, const std::string &msg);
+#define NDFFT_HIP(call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return ::ndfft::fail(NDFFT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+void set_last_path(const char *p);
+const char *last_path();
+const std::string &last_err();
+void clear_err();
+int get_dev_tables(const ndfft_plan *plan, const DevTables **out);
+
+// kernels_generic.hip
+template <typename T> int launch_generic(const GenArgs<T> &a, int threads, size_t lds_bytes, hipStream_t s);
+size_t generic_lds_bytes(int lpb, int pitch, size_t csize);
+
+// kernels_pow2.hip : register-resident Stockham for contiguous power-of-two C2C lanes
+struct Pow2Args {
+    const void *in; void *out;
+    int64_t nlanes;
+    int64_t pitch_in, pitch_out;   // elements between consecutive lanes
+    int32_t inverse;
+    double scale;
+    const void *twp;
+};
+bool pow2_supported(int dtype, int n);
+// layout of the per-pass transposed twiddle table for length n (host builder in plan.cpp)
+void pow2_build_twiddles(int dtype, int n, HostTable &out);
+int launch_pow2(int dtype, int n, const Pow2Args &a, hipStream_t s);
+
+// transpose.hip : batched LDS-padded 2-D transpose, elem size 4/8/16 bytes
+// out[b][c][r] = in[b][r][c];  in pitch = ld_in elements per row, out pitch = ld_out
+int launch_transpose(const void *in, void *out, int64_t batch, int64_t rows, int64_t cols, int64_t ld_in,
+                     int64_t ld_out, int64_t bstride_in, int64_t bstride_out, int elem_bytes, hipStream_t s);
+
+}  // namespace ndfft

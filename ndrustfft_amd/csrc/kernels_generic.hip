@@ -1,0 +1,336 @@
+// kernels_generic.hip -- the any-n, any-op lane kernel (gfx950).
+//
+// One workgroup owns `lpb` whole lanes in LDS and makes ONE pass over HBM:
+//   LOAD   global -> LDS, coalesced either along the lane (IO_ROW) or across adjacent lanes
+//          (IO_COL: the LDS-padded transpose that replaces the reference's per-lane
+//          x.to_vec() gather, src/lib.rs:133, 155);
+//   PRE    op-specific fold of the raw lane into the complex FFT input Z[0..F)
+//          (R2C packing, C2R/DCT-III Hermitian fold, Makhoul permutation, DCT-IV pre-twiddle,
+//          the "before" normalisations of C2R and DCT: src/lib.rs:511-521, 692-696);
+//   FFT    Stockham autosort radix passes ping-ponging two LDS buffers (Bluestein when F has a
+//          prime factor > 13), twiddles from a precomputed HBM table that stays in L1/L2;
+//   STORE  op-specific gather out of the FFT result (R2C split, DCT post-twiddles, the "after"
+//          normalisation of the C2C inverse, src/lib.rs:326-330), LDS -> global coalesced
+//          (replaces y.assign(&outvec), src/lib.rs:134).
+#include "butterflies.h"
+#include "engine.h"
+
+namespace ndfft {
+
+constexpr size_t kGenHeaderBytes = 2 * kMaxLpb * sizeof(int64_t) + 2 * kMaxPasses * sizeof(int32_t);   // 1152, 16-aligned
+
+template <typename T> struct GenCtx {
+    int64_t *off_in, *off_out;   // per-lane global offsets (elements)
+    int32_t *radix, *radixM;     // radix lists copied out of the kernarg segment
+    cpx<T> *buf[2];
+    int lanes;                   // lanes this block really owns (<= lpb)
+};
+
+// ---------------------------------------------------------------------------------------------
+// one Stockham pass over all lanes of the block
+// ---------------------------------------------------------------------------------------------
+template <typename T, int R>
+__device__ __forceinline__ void stockham_pass(const cpx<T> *__restrict__ src, cpx<T> *__restrict__ dst,
+                                              const cpx<T> *__restrict__ tw, int len, int Ns, int lanes,
+                                              int pitch) {
+    const int nb = len / R, total = lanes * nb, tws = len / (Ns * R);
+    for (int b = threadIdx.x; b < total; b += blockDim.x) {
+        const int l = b / nb, j = b - l * nb, k = j % Ns;
+        const cpx<T> *s = src + l * pitch;
+        cpx<T> *d = dst + l * pitch;
+        cpx<T> v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = s[j + r * nb];
+        if (Ns > 1) {
+            const int kt = k * tws;
+#pragma unroll
+            for (int r = 1; r < R; ++r) v[r] = cmul(v[r], tw[r * kt]);
+        }
+        Bfly<T, R>::run(v);
+        const int o = (j - k) * R + k;
+#pragma unroll
+        for (int q = 0; q < R; ++q) d[o + q * Ns] = v[q];
+    }
+}
+
+// runs the radix passes; returns the index of the buffer holding the result
+template <typename T>
+__device__ int run_passes(GenCtx<T> &c, int cur, int len, int npass, const int32_t *radix, const cpx<T> *tw,
+                          int pitch) {
+    int Ns = 1;
+    for (int p = 0; p < npass; ++p) {
+        const int R = radix[p];
+        __syncthreads();
+        const cpx<T> *s = c.buf[cur];
+        cpx<T> *d = c.buf[cur ^ 1];
+        switch (R) {
+            case 2: stockham_pass<T, 2>(s, d, tw, len, Ns, c.lanes, pitch); break;
+            case 3: stockham_pass<T, 3>(s, d, tw, len, Ns, c.lanes, pitch); break;
+            case 4: stockham_pass<T, 4>(s, d, tw, len, Ns, c.lanes, pitch); break;
+            case 5: stockham_pass<T, 5>(s, d, tw, len, Ns, c.lanes, pitch); break;
+            case 7: stockham_pass<T, 7>(s, d, tw, len, Ns, c.lanes, pitch); break;
+            case 8: stockham_pass<T, 8>(s, d, tw, len, Ns, c.lanes, pitch); break;
+            case 11: stockham_pass<T, 11>(s, d, tw, len, Ns, c.lanes, pitch); break;
+            default: stockham_pass<T, 13>(s, d, tw, len, Ns, c.lanes, pitch); break;
+        }
+        cur ^= 1;
+        Ns *= R;
+    }
+    __syncthreads();
+    return cur;
+}
+
+// ---------------------------------------------------------------------------------------------
+// PRE: Z[i] from the raw lane (raw real lanes are addressed as T*, raw complex as cpx<T>*)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ cpx<T> c2r_input(const GenArgs<T> &a, const cpx<T> *X, int k, int F_nyq) {
+    // lib.rs:511-521: scale first, then force DC (and even-n Nyquist) imaginary parts to zero
+    cpx<T> v = X[k];
+    v.x *= a.scale; v.y *= a.scale;
+    if (k == 0 || k == F_nyq) v.y = (T)0;
+    return v;
+}
+
+template <typename T>
+__device__ __forceinline__ cpx<T> herm_fold(cpx<T> a_, cpx<T> b_, cpx<T> w) {
+    // Zt = (a + b) + i * conj(w) * (a - b); returns conj(Zt) (inverse FFT via forward butterflies)
+    cpx<T> s = cadd(a_, b_), d = csub(a_, b_);
+    cpx<T> t = cmul(d, cconj(w));
+    return mk<T>(s.x - t.y, -(s.y + t.x));
+}
+
+template <typename T>
+__device__ __forceinline__ cpx<T> pre_elem(const GenArgs<T> &a, const void *raw_, int i) {
+    const T *xr = (const T *)raw_;
+    const cpx<T> *xc = (const cpx<T> *)raw_;
+    const int n = a.n, F = a.F;
+    switch (a.op) {
+        case G_C2R_EVEN: {
+            cpx<T> A = c2r_input(a, xc, i, F), B = cconj(c2r_input(a, xc, F - i, F));
+            return herm_fold<T>(A, B, a.aux1[i]);
+        }
+        case G_C2R_ODD: {
+            const int m = n / 2 + 1;
+            cpx<T> v = c2r_input(a, xc, i < m ? i : n - i, -1);
+            // full spectrum value is v (i<m) or conj(v); we store its conjugate
+            return i < m ? cconj(v) : v;
+        }
+        case G_DCT1: {   // even extension of length L = 2(n-1), packed two reals per complex
+            const int L = 2 * (n - 1), j0 = 2 * i, j1 = 2 * i + 1;
+            T e0 = xr[j0 < n ? j0 : L - j0], e1 = xr[j1 < n ? j1 : L - j1];
+            return mk<T>(e0 * a.scale, e1 * a.scale);
+        }
+        case G_DCT2_EVEN: {   // Makhoul: v[p] = x[2p] (p < n/2), v[p] = x[2(n-1-p)+1] otherwise
+            const int h = n / 2, p0 = 2 * i, p1 = 2 * i + 1;
+            T v0 = xr[p0 < h ? 2 * p0 : 2 * (n - 1 - p0) + 1], v1 = xr[p1 < h ? 2 * p1 : 2 * (n - 1 - p1) + 1];
+            return mk<T>(v0 * a.scale, v1 * a.scale);
+        }
+        case G_DCT2_ODD: {
+            const int h = (n + 1) / 2;
+            return mk<T>(xr[i < h ? 2 * i : 2 * (n - 1 - i) + 1] * a.scale, (T)0);
+        }
+        case G_DCT3_EVEN: {
+            // V[k] = 0.5 (x[k] - i x[n-k]) e^{+i pi k/(2n)}, k in [0,F], x[n] := 0 ; then Hermitian fold
+            const int k0 = i, k1 = F - i;
+            const T hs = (T)0.5 * a.scale;
+            cpx<T> v0 = cmul(mk<T>(xr[k0] * hs, k0 ? -xr[n - k0] * hs : (T)0), cconj(a.aux2[k0]));
+            cpx<T> v1 = cmul(mk<T>(xr[k1] * hs, -xr[n - k1] * hs), cconj(a.aux2[k1]));   // k1 >= 1 always
+            return herm_fold<T>(v0, cconj(v1), a.aux1[i]);
+        }
+        case G_DCT3_ODD: {
+            const T hs = (T)0.5 * a.scale;
+            cpx<T> v = cmul(mk<T>(xr[i] * hs, i ? -xr[n - i] * hs : (T)0), cconj(a.aux2[i]));
+            return cconj(v);
+        }
+        case G_DCT4_EVEN:
+            return cmul(mk<T>(xr[2 * i] * a.scale, xr[n - 1 - 2 * i] * a.scale), a.aux1[i]);
+        case G_DCT4_ODD: {
+            if (i >= n) return mk<T>((T)0, (T)0);
+            const T x = xr[i] * a.scale;
+            return mk<T>(x * a.aux1[i].x, x * a.aux1[i].y);
+        }
+        default: return mk<T>((T)0, (T)0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// POST: output element q from the FFT result `res` (length F)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ cpx<T> r2c_split(const cpx<T> *res, int k, int F, cpx<T> w) {
+    // X[k] = (Z[k] + conj Z[F-k])/2 + w (Z[k] - conj Z[F-k])/(2i)
+    cpx<T> A = res[k == F ? 0 : k], B = cconj(res[k == 0 ? 0 : F - k]);
+    cpx<T> e = mk<T>((A.x + B.x) * (T)0.5, (A.y + B.y) * (T)0.5);
+    cpx<T> o = mk<T>((A.y - B.y) * (T)0.5, -(A.x - B.x) * (T)0.5);
+    return cadd(e, cmul(o, w));
+}
+
+template <typename T> __device__ __forceinline__ T post_real(const GenArgs<T> &a, const cpx<T> *res, int q) {
+    const int n = a.n, F = a.F;
+    switch (a.op) {
+        case G_C2R_EVEN: { cpx<T> c = res[q >> 1]; return (q & 1) ? -c.y : c.x; }
+        case G_C2R_ODD: return res[q].x;
+        case G_DCT1: return (T)0.5 * r2c_split<T>(res, q, F, a.aux1[q]).x;
+        case G_DCT2_EVEN: {
+            const int k = q <= F ? q : n - q;
+            cpx<T> t = cmul(r2c_split<T>(res, k, F, a.aux1[k]), a.aux2[k]);
+            return q <= F ? t.x : -t.y;
+        }
+        case G_DCT2_ODD: { cpx<T> t = cmul(res[q], a.aux2[q]); return t.x; }
+        case G_DCT3_EVEN: {
+            const int p = (q & 1) ? n - 1 - (q >> 1) : (q >> 1);
+            cpx<T> c = res[p >> 1];
+            return (p & 1) ? -c.y : c.x;
+        }
+        case G_DCT3_ODD: { const int p = (q & 1) ? n - 1 - (q >> 1) : (q >> 1); return res[p].x; }
+        case G_DCT4_EVEN: {
+            const int k = (q & 1) ? (n - 1 - q) >> 1 : q >> 1;
+            cpx<T> u = cmul(res[k], a.aux2[k]);
+            return (q & 1) ? -u.y : u.x;
+        }
+        case G_DCT4_ODD: { cpx<T> u = cmul(res[q], a.aux2[q]); return u.x; }
+        default: return (T)0;
+    }
+}
+
+template <typename T> __device__ __forceinline__ cpx<T> post_cplx(const GenArgs<T> &a, const cpx<T> *res, int q) {
+    switch (a.op) {
+        case G_C2C_INV: { cpx<T> c = res[q]; return mk<T>(c.x * a.scale, -c.y * a.scale); }   // lib.rs:326-330
+        case G_R2C_EVEN: return r2c_split<T>(res, q, a.F, a.aux1[q]);
+        default: return res[q];   // G_C2C_FWD, G_R2C_ODD
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t lane_offset(const LaneGeom &g, int64_t lane) {
+    int64_t off = 0;
+    for (int d = g.nb - 1; d >= 0; --d) {
+        const int64_t e = g.bshape[d], i = lane % e;
+        lane /= e;
+        off += i * g.bstride[d];
+    }
+    return off;
+}
+
+template <typename T> __global__ __launch_bounds__(1024) void k_generic(const GenArgs<T> a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    GenCtx<T> c;
+    c.off_in = (int64_t *)smem;
+    c.off_out = c.off_in + kMaxLpb;
+    c.radix = (int32_t *)(c.off_out + kMaxLpb);
+    c.radixM = c.radix + kMaxPasses;
+    c.buf[0] = (cpx<T> *)(smem + kGenHeaderBytes);
+    c.buf[1] = c.buf[0] + (size_t)a.lpb * a.pitch;
+    const int64_t lane0 = (int64_t)blockIdx.x * a.lpb;
+    c.lanes = (int)min((int64_t)a.lpb, a.nlanes - lane0);
+    const int tid = threadIdx.x, nthr = blockDim.x, pitch = a.pitch;
+
+    if (tid < kMaxPasses) { c.radix[tid] = a.radix[tid]; c.radixM[tid] = a.radixM[tid]; }
+    if (tid < c.lanes) {
+        c.off_in[tid] = lane_offset(a.gin, lane0 + tid);
+        c.off_out[tid] = lane_offset(a.gout, lane0 + tid);
+    }
+    __syncthreads();
+
+    // ---- LOAD ------------------------------------------------------------------------------
+    // ops whose PRE is elementwise load straight into Z (buffer 0); the others stage the raw lane
+    // in buffer 1 and fold it into buffer 0.
+    const bool direct = a.op == G_C2C_FWD || a.op == G_C2C_INV || a.op == G_R2C_EVEN || a.op == G_R2C_ODD;
+    {
+        const int n_in = a.n_in, total = c.lanes * n_in;
+        const int64_t as = a.gin.axis_stride;
+        for (int idx = tid; idx < total; idx += nthr) {
+            int l, j;
+            if (a.load_mode == IO_ROW) { l = idx / n_in; j = idx - l * n_in; }
+            else { j = idx / c.lanes; l = idx - j * c.lanes; }
+            const int64_t g = c.off_in[l] + (int64_t)j * as;
+            if (a.in_cplx) {
+                cpx<T> v = ((const cpx<T> *)a.in)[g];
+                if (a.op == G_C2C_INV) v.y = -v.y;
+                c.buf[direct ? 0 : 1][l * pitch + j] = v;
+            } else {
+                const T v = ((const T *)a.in)[g];
+                if (a.op == G_R2C_ODD) c.buf[0][l * pitch + j] = mk<T>(v, (T)0);
+                else ((T *)c.buf[direct ? 0 : 1])[l * 2 * pitch + j] = v;   // R2C_EVEN packs pairs in place
+            }
+        }
+    }
+    // ---- PRE -------------------------------------------------------------------------------
+    if (!direct) {
+        __syncthreads();
+        const int F = a.F, total = c.lanes * F;
+        for (int idx = tid; idx < total; idx += nthr) {
+            const int l = idx / F, i = idx - l * F;
+            c.buf[0][l * pitch + i] = pre_elem<T>(a, (const void *)(c.buf[1] + l * pitch), i);
+        }
+    }
+    // ---- FFT -------------------------------------------------------------------------------
+    int cur = 0;
+    if (!a.blue) {
+        cur = run_passes<T>(c, 0, a.F, a.npass, c.radix, a.tw, pitch);
+    } else {
+        // Bluestein: X[k] = chirp[k] * IFFT_M( FFT_M(z * chirp, zero padded) * bhat )[k]
+        __syncthreads();
+        const int F = a.F, M = a.M, total = c.lanes * M;
+        for (int idx = tid; idx < total; idx += nthr) {
+            const int l = idx / M, i = idx - l * M;
+            cpx<T> *z = c.buf[0] + l * pitch;
+            z[i] = i < F ? cmul(z[i], a.chirp[i]) : mk<T>((T)0, (T)0);
+        }
+        cur = run_passes<T>(c, 0, M, a.npassM, c.radixM, a.twM, pitch);
+        for (int idx = tid; idx < total; idx += nthr) {
+            const int l = idx / M, i = idx - l * M;
+            cpx<T> *z = c.buf[cur] + l * pitch;
+            z[i] = cconj(cmul(z[i], a.bhat[i]));          // bhat carries 1/M
+        }
+        cur = run_passes<T>(c, cur, M, a.npassM, c.radixM, a.twM, pitch);
+        const int totF = c.lanes * F;
+        for (int idx = tid; idx < totF; idx += nthr) {
+            const int l = idx / F, i = idx - l * F;
+            cpx<T> *z = c.buf[cur] + l * pitch;
+            z[i] = cmul(cconj(z[i]), a.chirp[i]);
+        }
+        __syncthreads();
+    }
+    // ---- STORE (with POST gather) ----------------------------------------------------------
+    {
+        const int n_out = a.n_out, total = c.lanes * n_out;
+        const int64_t as = a.gout.axis_stride;
+        const cpx<T> *resb = c.buf[cur];
+        for (int idx = tid; idx < total; idx += nthr) {
+            int l, q;
+            if (a.store_mode == IO_ROW) { l = idx / n_out; q = idx - l * n_out; }
+            else { q = idx / c.lanes; l = idx - q * c.lanes; }
+            const int64_t g = c.off_out[l] + (int64_t)q * as;
+            const cpx<T> *res = resb + l * pitch;
+            if (a.out_cplx) ((cpx<T> *)a.out)[g] = post_cplx<T>(a, res, q);
+            else ((T *)a.out)[g] = post_real<T>(a, res, q);
+        }
+    }
+}
+
+size_t generic_lds_bytes(int lpb, int pitch, size_t csize) {
+    return kGenHeaderBytes + 2 * (size_t)lpb * (size_t)pitch * csize;
+}
+
+template <typename T> int launch_generic(const GenArgs<T> &a, int threads, size_t lds_bytes, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_generic<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int64_t nblk = (a.nlanes + a.lpb - 1) / a.lpb;
+    if (nblk <= 0) return NDFFT_OK;
+    if (nblk > 0x7fffffffLL) return fail(NDFFT_ERR_UNSUPPORTED, "too many lanes for one launch");
+    hipLaunchKernelGGL(k_generic<T>, dim3((unsigned)nblk), dim3(threads), lds_bytes, s, a);
+    NDFFT_HIP(hipGetLastError());
+    return NDFFT_OK;
+}
+
+template int launch_generic<float>(const GenArgs<float> &, int, size_t, hipStream_t);
+template int launch_generic<double>(const GenArgs<double> &, int, size_t, hipStream_t);
+
+}  // namespace ndfft

@@ -1,0 +1,286 @@
+// plan.hip -- ndfft_plan: factorisation, long-double twiddle tables, lazy per-device upload.
+// Stands for FftHandler::new / R2cFftHandler::new / DctHandler::new (src/lib.rs:294, 477, 665):
+// plans are built eagerly (DctHandler plans all four types, lib.rs:666-670) and are immutable
+// afterwards, so one plan can be shared by any number of host threads (lib.rs:192-194).
+#include <cmath>
+#include <cstring>
+
+#include "engine.h"
+
+namespace ndfft {
+
+static thread_local std::string g_err;
+static thread_local const char *g_path = "";
+
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+void set_last_path(const char *p) { g_path = p; }
+const char *last_path() { return g_path; }
+const std::string &last_err() { return g_err; }
+void clear_err() { g_err.clear(); }
+
+static const long double kPiL = 3.14159265358979323846264338327950288L;
+
+// e^{-2 pi i num/den}, argument reduced exactly in integers first
+static void unit(HostTable &t, unsigned long long num, unsigned long long den) {
+    num %= den;
+    long double ang = 2.0L * kPiL * (long double)num / (long double)den;
+    t.re.push_back(cosl(ang));
+    t.im.push_back(-sinl(ang));
+}
+
+static bool factorize(int F, std::vector<int> &radix) {
+    radix.clear();
+    int m = F;
+    while (m % 8 == 0) { radix.push_back(8); m /= 8; }
+    while (m % 4 == 0) { radix.push_back(4); m /= 4; }
+    while (m % 2 == 0) { radix.push_back(2); m /= 2; }
+    const int odd[] = {3, 5, 7, 11, 13};
+    for (int p : odd) while (m % p == 0) { radix.push_back(p); m /= p; }
+    return m == 1 && radix.size() <= (size_t)kMaxPasses;
+}
+
+// fills F, radix / Bluestein, tw (and twM, chirp, bhat)
+static void build_fft(FftConfig &c, int F) {
+    c.F = F;
+    if (F <= 1) return;
+    if (factorize(F, c.radix)) {
+        for (int k = 0; k < F; ++k) unit(c.tw, k, F);
+        return;
+    }
+    // Bluestein: chirp[j] = e^{-i pi j^2/F}; bhat = FFT_M(conj chirp wrapped)/M computed here in
+    // long double by a direct radix-2 recursion so the device table is correctly rounded.
+    c.blue = true;
+    c.radix.clear();
+    int M = 1;
+    while (M < 2 * F - 1) M <<= 1;
+    c.M = M;
+    factorize(M, c.radixM);
+    for (int k = 0; k < M; ++k) unit(c.twM, k, M);
+    for (int j = 0; j < F; ++j) unit(c.chirp, ((unsigned long long)j * j) % (2ull * F), 2ull * F);
+    std::vector<long double> br(M, 0.0L), bi(M, 0.0L);
+    for (int j = 0; j < F; ++j) {
+        br[j] = c.chirp.re[j]; bi[j] = -c.chirp.im[j];
+        if (j) { br[M - j] = br[j]; bi[M - j] = bi[j]; }
+    }
+    // iterative radix-2 DIT FFT in long double
+    for (int i = 1, j = 0; i < M; ++i) {
+        int bit = M >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { std::swap(br[i], br[j]); std::swap(bi[i], bi[j]); }
+    }
+    for (int len = 2; len <= M; len <<= 1) {
+        for (int i = 0; i < M; i += len)
+            for (int k = 0; k < len / 2; ++k) {
+                long double ang = -2.0L * kPiL * (long double)k / (long double)len;
+                long double wr = cosl(ang), wi = sinl(ang);
+                int a = i + k, b = i + k + len / 2;
+                long double tr = br[b] * wr - bi[b] * wi, ti = br[b] * wi + bi[b] * wr;
+                br[b] = br[a] - tr; bi[b] = bi[a] - ti; br[a] += tr; bi[a] += ti;
+            }
+    }
+    for (int k = 0; k < M; ++k) { c.bhat.re.push_back(br[k] / M); c.bhat.im.push_back(bi[k] / M); }
+}
+
+static void build_plan_tables(ndfft_plan *p) {
+    const int n = (int)p->n;
+    for (int i = 0; i < CFG_COUNT; ++i) p->has_cfg[i] = false;
+    if (n == 0) return;
+    FftConfig &m = p->cfg[CFG_MAIN];
+    if (p->kind == NDFFT_KIND_C2C) {
+        build_fft(m, n);
+        if (pow2_supported(p->dtype, n)) { m.pow2 = true; pow2_build_twiddles(p->dtype, n, m.twp); }
+        p->has_cfg[CFG_MAIN] = true;
+    } else if (p->kind == NDFFT_KIND_R2C) {
+        if (n % 2 == 0) {
+            build_fft(m, n / 2);
+            for (int k = 0; k <= n / 2; ++k) unit(m.aux1, k, n);          // W_n^k
+        } else {
+            build_fft(m, n);
+        }
+        p->has_cfg[CFG_MAIN] = true;
+    } else {
+        // DCT-II / DCT-III (Makhoul through a real FFT of length n)
+        if (n % 2 == 0) {
+            build_fft(m, n / 2);
+            for (int k = 0; k <= n / 2; ++k) unit(m.aux1, k, n);          // W_n^k
+        } else {
+            build_fft(m, n);
+        }
+        for (int k = 0; k < n; ++k) unit(m.aux2, k, 4ull * n);            // e^{-i pi k/(2n)}
+        p->has_cfg[CFG_MAIN] = true;
+        // DCT-I: real FFT of the even extension, length 2(n-1)
+        if (n >= 2) {
+            FftConfig &d1 = p->cfg[CFG_DCT1];
+            build_fft(d1, n - 1);
+            for (int k = 0; k <= n - 1; ++k) unit(d1.aux1, k, 2ull * (n - 1));
+            p->has_cfg[CFG_DCT1] = true;
+        }
+        // DCT-IV
+        FftConfig &d4 = p->cfg[CFG_DCT4];
+        if (n % 2 == 0) {
+            build_fft(d4, n / 2);
+            for (int j = 0; j < n / 2; ++j) unit(d4.aux1, 4ull * j + 1, 8ull * n);   // e^{-i pi (4j+1)/(4n)}
+            for (int k = 0; k < n / 2; ++k) unit(d4.aux2, k, 2ull * n);              // e^{-i pi k/n}
+        } else {
+            build_fft(d4, 2 * n);
+            for (int j = 0; j < n; ++j) unit(d4.aux1, j, 4ull * n);                  // e^{-i pi j/(2n)}
+            for (int k = 0; k < n; ++k) unit(d4.aux2, 2ull * k + 1, 8ull * n);       // e^{-i pi (2k+1)/(4n)}
+        }
+        p->has_cfg[CFG_DCT4] = true;
+    }
+}
+
+template <typename T> static int upload(const HostTable &t, void **dptr) {
+    *dptr = nullptr;
+    const size_t cnt = t.re.size();
+    if (!cnt) return NDFFT_OK;
+    std::vector<T> h(2 * cnt);
+    for (size_t i = 0; i < cnt; ++i) { h[2 * i] = (T)t.re[i]; h[2 * i + 1] = (T)t.im[i]; }
+    NDFFT_HIP(hipMalloc(dptr, h.size() * sizeof(T)));
+    NDFFT_HIP(hipMemcpy(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return NDFFT_OK;
+}
+
+static int upload_any(int dtype, const HostTable &t, void **dptr) {
+    return dtype == NDFFT_F32 ? upload<float>(t, dptr) : upload<double>(t, dptr);
+}
+
+// device tables of `plan` on the CURRENT device (uploaded on first use, then cached)
+int get_dev_tables(const ndfft_plan *cplan, const DevTables **out) {
+    ndfft_plan *plan = const_cast<ndfft_plan *>(cplan);
+    int dev = 0;
+    NDFFT_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> g(plan->mu);
+    auto it = plan->dev.find(dev);
+    if (it != plan->dev.end()) { *out = &it->second; return NDFFT_OK; }
+    DevTables t;
+    for (int i = 0; i < CFG_COUNT; ++i) {
+        if (!plan->has_cfg[i]) continue;
+        const FftConfig &c = plan->cfg[i];
+        DevConfig &d = t.cfg[i];
+        int rc;
+        if ((rc = upload_any(plan->dtype, c.tw, &d.tw))) return rc;
+        if ((rc = upload_any(plan->dtype, c.twM, &d.twM))) return rc;
+        if ((rc = upload_any(plan->dtype, c.chirp, &d.chirp))) return rc;
+        if ((rc = upload_any(plan->dtype, c.bhat, &d.bhat))) return rc;
+        if ((rc = upload_any(plan->dtype, c.aux1, &d.aux1))) return rc;
+        if ((rc = upload_any(plan->dtype, c.aux2, &d.aux2))) return rc;
+        if ((rc = upload_any(plan->dtype, c.twp, &d.twp))) return rc;
+    }
+    auto ins = plan->dev.emplace(dev, t);
+    *out = &ins.first->second;
+    return NDFFT_OK;
+}
+
+}  // namespace ndfft
+
+using namespace ndfft;
+
+extern "C" {
+
+int ndfft_abi_version(void) { return NDFFT_ABI_VERSION; }
+const char *ndfft_last_error(void) { return last_err().c_str(); }
+const char *ndfft_last_path(void) { return last_path(); }
+
+int ndfft_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int ndfft_set_device(int device) {
+    clear_err();
+    NDFFT_HIP(hipSetDevice(device));
+    return NDFFT_OK;
+}
+
+int ndfft_plan_create(int kind, int dtype, size_t n, ndfft_plan **out_plan) {
+    clear_err();
+    if (!out_plan) return fail(NDFFT_ERR_INVALID_ARG, "out_plan is null");
+    *out_plan = nullptr;
+    if (kind < NDFFT_KIND_C2C || kind > NDFFT_KIND_DCT) return fail(NDFFT_ERR_INVALID_ARG, "bad kind");
+    if (dtype != NDFFT_F32 && dtype != NDFFT_F64) return fail(NDFFT_ERR_INVALID_ARG, "bad dtype (T must be f32 or f64)");
+    if (n > (size_t)(1 << 26)) return fail(NDFFT_ERR_UNSUPPORTED, "n too large");
+    if (ndfft_device_count() <= 0)
+        return fail(NDFFT_ERR_NO_DEVICE, "no HIP device visible: libndfft_mi355x has no CPU fallback");
+    ndfft_plan *p = new (std::nothrow) ndfft_plan();
+    if (!p) return fail(NDFFT_ERR_ALLOC, "out of host memory");
+    p->kind = kind; p->dtype = dtype; p->n = n; p->refcount = 1;
+    build_plan_tables(p);
+    const DevTables *t;
+    int rc = get_dev_tables(p, &t);   // eager upload to the current device
+    if (rc) { delete p; return rc; }
+    *out_plan = p;
+    return NDFFT_OK;
+}
+
+int ndfft_plan_retain(ndfft_plan *plan) {
+    if (!plan) return fail(NDFFT_ERR_INVALID_ARG, "plan is null");
+    std::lock_guard<std::mutex> g(plan->mu);
+    ++plan->refcount;
+    return NDFFT_OK;
+}
+
+int ndfft_plan_destroy(ndfft_plan *plan) {
+    if (!plan) return NDFFT_OK;
+    {
+        std::lock_guard<std::mutex> g(plan->mu);
+        if (--plan->refcount > 0) return NDFFT_OK;
+    }
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (auto &kv : plan->dev) {
+        (void)hipSetDevice(kv.first);
+        for (int i = 0; i < CFG_COUNT; ++i) {
+            DevConfig &d = kv.second.cfg[i];
+            void *ptrs[] = {d.tw, d.twM, d.chirp, d.bhat, d.aux1, d.aux2, d.twp};
+            for (void *q : ptrs) if (q) (void)hipFree(q);
+        }
+    }
+    (void)hipSetDevice(cur);
+    delete plan;
+    return NDFFT_OK;
+}
+
+size_t ndfft_plan_n(const ndfft_plan *plan) { return plan ? plan->n : 0; }
+int ndfft_plan_kind(const ndfft_plan *plan) { return plan ? plan->kind : -1; }
+int ndfft_plan_dtype(const ndfft_plan *plan) { return plan ? plan->dtype : -1; }
+
+size_t ndfft_plan_lane_len_in(const ndfft_plan *plan, int op) {
+    if (!plan) return 0;
+    return op == NDFFT_OP_C2R ? plan->n / 2 + 1 : plan->n;
+}
+size_t ndfft_plan_lane_len_out(const ndfft_plan *plan, int op) {
+    if (!plan) return 0;
+    return op == NDFFT_OP_R2C ? plan->n / 2 + 1 : plan->n;
+}
+
+int ndfft_dev_alloc(void **d_ptr, size_t bytes) {
+    clear_err();
+    if (!d_ptr) return fail(NDFFT_ERR_INVALID_ARG, "d_ptr is null");
+    NDFFT_HIP(hipMalloc(d_ptr, bytes ? bytes : 1));
+    return NDFFT_OK;
+}
+int ndfft_dev_free(void *d_ptr) {
+    clear_err();
+    if (d_ptr) NDFFT_HIP(hipFree(d_ptr));
+    return NDFFT_OK;
+}
+int ndfft_dev_upload(void *d_dst, const void *h_src, size_t bytes) {
+    clear_err();
+    if (bytes) NDFFT_HIP(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+    return NDFFT_OK;
+}
+int ndfft_dev_download(void *h_dst, const void *d_src, size_t bytes) {
+    clear_err();
+    if (bytes) NDFFT_HIP(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return NDFFT_OK;
+}
+int ndfft_dev_sync(void *stream) {
+    clear_err();
+    NDFFT_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return NDFFT_OK;
+}
+
+}  // extern "C"

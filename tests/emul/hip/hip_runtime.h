@@ -1,0 +1,64 @@
+// TEST INFRASTRUCTURE ONLY -- a single-threaded, fiber-based emulation of the handful of HIP
+// constructs the kernels in ndrustfft_amd/csrc use, so that the UNMODIFIED .hip sources can be
+// compiled with g++ (include path trick: -I tests/emul shadows <hip/hip_runtime.h>) and their index
+// arithmetic debugged / sanitised on the CPU-only build container.  Every workgroup runs as
+// blockDim.x fibers on one OS thread; __syncthreads() yields to the next fiber.
+// Nothing in the product (ndrustfft_amd/, include/) ever includes or loads this: the emulated
+// library is built into tests/emul/_build and bound only by tests/test_emul_*.py.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+
+#define __host__
+#define __device__
+#define __global__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__
+#define __launch_bounds__(...)
+#define __restrict__ __restrict
+
+struct float2 { float x, y; };
+struct double2 { double x, y; };
+struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+struct emul_idx { unsigned x, y, z; };
+extern emul_idx threadIdx, blockIdx, blockDim, gridDim;
+using std::min; using std::max;
+
+typedef int hipError_t;
+typedef void *hipStream_t;
+enum { hipSuccess = 0 };
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
+
+inline const char *hipGetErrorString(hipError_t) { return "emulated"; }
+inline hipError_t hipGetLastError() { return 0; }
+inline hipError_t hipGetDevice(int *d) { *d = 0; return 0; }
+inline hipError_t hipSetDevice(int) { return 0; }
+inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return 0; }
+inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
+inline hipError_t hipFree(void *p) { free(p); return 0; }
+inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return 0; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return 0; }
+
+void __syncthreads();
+
+namespace emul {
+// runs fn(arg) as grid x block fibers, with lds_bytes of zero-initialised "LDS" per block
+void launch(void (*fn)(void *), void *arg, dim3 grid, dim3 block, size_t lds_bytes);
+template <typename... A> struct Pack;
+template <typename A0> struct Pack<A0> {
+    void (*k)(A0); typename std::remove_const<A0>::type a0;
+    static void tramp(void *p) { Pack *s = (Pack *)p; s->k(s->a0); }
+};
+}  // namespace emul
+
+template <typename A0, typename B0>
+inline void hipLaunchKernelGGL(void (*k)(A0), dim3 grid, dim3 block, size_t lds, hipStream_t, const B0 &a0) {
+    emul::Pack<A0> p{k, a0};
+    emul::launch(&emul::Pack<A0>::tramp, &p, grid, block, lds);
+}

@@ -1,0 +1,272 @@
+"""Parity cases shared by tests/test_gpu_parity.py (the real thing: gfx950 library on an MI355X,
+through the C ABI) and tests/test_emul_parity.py (the same sources compiled for the host through
+tests/emul, CPU container).  Every case compares against the CPU oracle on the same seeded inputs
+and/or the committed golden vectors.  Tolerances are BASELINE.json's: 1e-10 (f64), 1e-4 (f32)."""
+import numpy as np
+
+import synth
+from helpers import TOL, assert_close, cdt_of
+from ndrustfft_amd import _lib, api, handlers
+from ndrustfft_amd.handlers import Normalization
+from oracle import oracle_ctypes as orc
+
+ORC_NORM = {"None": orc.NORM_NONE, "Default": orc.NORM_DEFAULT}
+
+OPS = {
+    # name: (api fn, oracle fn, handler class name, in complex, out complex)
+    "ndfft": (api.ndfft, orc.ndfft, "FftHandler", True, True),
+    "ndifft": (api.ndifft, orc.ndifft, "FftHandler", True, True),
+    "ndfft_r2c": (api.ndfft_r2c, orc.ndfft_r2c, "R2cFftHandler", False, True),
+    "ndifft_r2c": (api.ndifft_r2c, orc.ndifft_r2c, "R2cFftHandler", True, False),
+    "nddct1": (api.nddct1, orc.nddct1, "DctHandler", False, False),
+    "nddct2": (api.nddct2, orc.nddct2, "DctHandler", False, False),
+    "nddct3": (api.nddct3, orc.nddct3, "DctHandler", False, False),
+    "nddct4": (api.nddct4, orc.nddct4, "DctHandler", False, False),
+}
+
+
+def handlers_for(name, n, rdt, L, norm="Default"):
+    cls = OPS[name][2]
+    h = getattr(handlers, cls)(n, rdt, _library=L)
+    o = getattr(orc, cls)(n, rdt)
+    if norm != "Default":
+        h = h.normalization(Normalization(norm)); o = o.normalization(ORC_NORM[norm])
+    return h, o
+
+
+def shapes_for(name, shape, axis):
+    """(input shape, output shape) for op `name` on an array of `shape` (lane length n on `axis`)."""
+    n = shape[axis]; m = n // 2 + 1
+    sin, sout = list(shape), list(shape)
+    if name == "ndfft_r2c":
+        sout[axis] = m
+    if name == "ndifft_r2c":
+        sin[axis] = m
+    return tuple(sin), tuple(sout)
+
+
+def make_input(name, shape, rdt, offset=0):
+    return synth.complex_array(shape, cdt_of(rdt), offset=offset) if OPS[name][3] else synth.real_array(shape, rdt, offset=offset)
+
+
+def run_case(L, name, shape, axis, rdt, norm="Default", layout="C", tol=None, offset=0):
+    """One nd* call on the library under test vs the oracle; returns the path the library took."""
+    n = shape[axis]
+    fn, ofn, _, in_c, out_c = OPS[name]
+    sin, sout = shapes_for(name, shape, axis)
+    x = make_input(name, sin, rdt, offset)
+    odt = cdt_of(rdt) if out_c else np.dtype(rdt)
+    if layout == "F":
+        x = np.asfortranarray(x)
+    y = np.zeros(sout, odt, order="F" if layout == "F" else "C")
+    yo = np.zeros(sout, odt)
+    h, o = handlers_for(name, n, rdt, L, norm)
+    fn(x, y, h, axis)
+    path = L.last_path()
+    ofn(np.ascontiguousarray(x), yo, o, axis)
+    assert_close(y, yo, axis, tol or TOL[np.dtype(rdt)], f"{name} shape={shape} axis={axis} {np.dtype(rdt)} norm={norm} path={path}")
+    return path
+
+
+# ---- reference's own unit tests restated against the library (src/lib.rs:903-1406) ------------
+def reference_unit_tests(L, refvec):
+    m = np.asarray(refvec["test_matrix"]["data"], np.float64)
+    v = m + 1j * m
+    sol = np.asarray(refvec["fft_axis1"]["re"]) + 1j * np.asarray(refvec["fft_axis1"]["im"])
+    for f, b in ((api.ndfft, api.ndifft), (api.ndfft_par, api.ndifft_par)):      # test_fft, test_fft_par
+        vhat = np.zeros((6, 6), np.complex128); v2 = np.zeros_like(v); h = handlers.FftHandler(6, _library=L)
+        f(v, vhat, h, 1); b(vhat, v2, h, 1)
+        assert np.abs(vhat - sol).max() < 1e-3 and np.abs(v2 - v).max() < 1e-3
+    vf = np.asfortranarray(v)                                                    # test_fft_f_layout
+    vhat = np.zeros((6, 6), np.complex128); h = handlers.FftHandler(6, _library=L)
+    api.ndfft(vf, vhat, h, 1); assert np.abs(vhat - sol).max() < 1e-3
+    v2 = np.zeros((6, 6), np.complex128, order="F"); api.ndifft(vhat, v2, h, 1)
+    assert np.abs(v2 - v).max() < 1e-3
+    solr = np.asarray(refvec["rfft_axis1"]["re"]) + 1j * np.asarray(refvec["rfft_axis1"]["im"])
+    for f, b in ((api.ndfft_r2c, api.ndifft_r2c), (api.ndfft_r2c_par, api.ndifft_r2c_par)):   # test_fft_r2c(_par)
+        vhat = np.zeros((6, 4), np.complex128); m2 = np.zeros_like(m); h = handlers.R2cFftHandler(6, _library=L)
+        f(m, vhat, h, 1); b(vhat, m2, h, 1)
+        assert np.abs(vhat - solr).max() < 1e-3 and np.abs(m2 - m).max() < 1e-3
+    d = refvec["c2r_first_last"]; h = handlers.R2cFftHandler(6, _library=L)      # test_ifft_c2r_first_last_element
+    for ki, ko in (("first_in", "first_out"), ("last_in", "last_out")):
+        a = np.asarray(d[ki], np.float64); vh = a[:, 0] + 1j * a[:, 1]; out = np.zeros(6)
+        api.ndifft_r2c(vh, out, h, 0)
+        assert np.abs(out - np.asarray(d[ko])).max() < 1e-3
+    v3 = np.asarray(refvec["r2c_odd_roundtrip"]["data"], np.float64)            # test_fft_r2c_odd(_par)
+    vh = np.zeros((3, 2), np.complex128); v4 = np.zeros_like(v3); h = handlers.R2cFftHandler(3, _library=L)
+    api.ndfft_r2c(v3, vh, h, 1); api.ndifft_r2c(vh, v4, h, 1)
+    assert np.abs(v4 - v3).max() < 1e-3
+    for k in (1, 2, 3, 4):                                                       # test_dct1..4(_par)
+        sol_k = np.asarray(refvec[f"dct{k}_axis1"]["data"])
+        for fn in (getattr(api, f"nddct{k}"), getattr(api, f"nddct{k}_par")):
+            out = np.zeros_like(m); fn(m, out, handlers.DctHandler(6, _library=L), 1)
+            assert np.abs(out - sol_k).max() < 1e-3, k
+
+
+def reference_examples(L, refvec):
+    d = refvec["example_fft2"]; m = np.asarray(d["data"], np.float64); v = m + 1j * m       # examples/fft2.rs
+    sol = np.asarray(d["re"]) + 1j * np.asarray(d["im"])
+    work = np.zeros_like(v); vhat = np.zeros_like(v)
+    h0, h1 = handlers.FftHandler(3, _library=L), handlers.FftHandler(3, _library=L)
+    api.ndfft(v, work, h1, 1); api.ndfft(work, vhat, h0, 0)
+    assert np.abs(vhat - sol).max() < d["abs_tol"]
+    w2 = np.zeros_like(v); v2 = np.zeros_like(v)
+    api.ndifft(vhat, w2, h0, 0); api.ndifft(w2, v2, h1, 1)
+    assert np.abs(v2 - v).max() < d["abs_tol"]
+    d = refvec["example_rfft2"]; vr = np.asarray(d["data"], np.float64)                      # examples/rfft2.rs
+    sol = np.asarray(d["re"]) + 1j * np.asarray(d["im"])
+    work = np.zeros((3, 2), np.complex128); vhat = np.zeros_like(work)
+    hr = handlers.R2cFftHandler(3, _library=L)
+    api.ndfft_r2c(vr, work, hr, 1); api.ndfft(work, vhat, h0, 0)
+    assert np.abs(vhat - sol).max() < d["abs_tol"]
+    w2 = np.zeros_like(work); vr2 = np.zeros_like(vr)
+    api.ndifft(vhat, w2, h0, 0); api.ndifft_r2c(w2, vr2, hr, 1)
+    assert np.abs(vr2 - vr).max() < d["abs_tol"]
+    d = refvec["example_fft_norm"]; x = np.asarray(d["data"], np.float64); v = x + 1j * x    # examples/fft_norm.rs
+
+    def my_norm(lane):
+        lane *= 2.0 / lane.size
+
+    for norm, key in ((Normalization.default(), "default_roundtrip"), (Normalization.none(), "none_roundtrip"),
+                      (Normalization.custom(my_norm), "custom_2_over_n_roundtrip")):
+        h = handlers.FftHandler(3, _library=L).normalization(norm)
+        vhat = np.zeros(3, np.complex128); v2 = np.zeros(3, np.complex128)
+        api.ndfft(v, vhat, h, 0); api.ndifft(vhat, v2, h, 0)
+        e = np.asarray(d[key]); assert np.abs(v2 - (e + 1j * e)).max() < 1e-12
+    d = refvec["readme_r2c_6x4"]                                                              # BASELINE configs[0]
+    data = np.arange(24, dtype=np.float64).reshape(6, 4); vhat = np.zeros((4, 4), np.complex128)
+    api.ndfft_r2c(data, vhat, handlers.R2cFftHandler(6, _library=L), 0)
+    assert np.abs(vhat - (np.asarray(d["re"]) + 1j * np.asarray(d["im"]))).max() < d["abs_tol"]
+
+
+# ---- committed numpy/scipy golden vectors -------------------------------------------------------
+def golden_vectors(L, npvec, dt, n):
+    rdt = np.float64 if dt == "f64" else np.float32; cdt = cdt_of(rdt); tol = TOL[np.dtype(rdt)]
+    key = f"{dt}_n{n}"; m = n // 2 + 1
+    xc, xr, xh = npvec[key + "_c_in"], npvec[key + "_r_in"], npvec[key + "_h_in"]
+    h = handlers.FftHandler(n, rdt, _library=L); y = np.zeros_like(xc)
+    api.ndfft(xc, y, h, 1); assert_close(y, npvec[key + "_fft"], 1, tol, f"fft n={n}")
+    api.ndifft(xc, y, h, 1); assert_close(y, npvec[key + "_ifft"], 1, tol, f"ifft n={n}")
+    hr = handlers.R2cFftHandler(n, rdt, _library=L); yr = np.zeros((2, m), cdt)
+    api.ndfft_r2c(xr, yr, hr, 1); assert_close(yr, npvec[key + "_r2c"], 1, tol, f"r2c n={n}")
+    xo = np.zeros((2, n), rdt)
+    api.ndifft_r2c(xh, xo, hr, 1); assert_close(xo, npvec[key + "_c2r"], 1, tol, f"c2r n={n}")
+    hd = handlers.DctHandler(n, rdt, _library=L)
+    for k in (1, 2, 3, 4):
+        if k == 1 and n < 2:
+            continue
+        getattr(api, f"nddct{k}")(xr, xo, hd, 1)
+        assert_close(xo, npvec[key + f"_dct{k}"], 1, tol, f"dct{k} n={n}")
+
+
+# ---- layouts: the three iterator strategies + views ndarray allows -------------------------------
+def layouts(L):
+    seen = set()
+    for name in OPS:
+        for rdt in (np.float64, np.float32):
+            seen.add(run_case(L, name, (5, 12), 1, rdt))                 # strategy (i)
+            seen.add(run_case(L, name, (12, 5), 0, rdt))                 # strategy (ii), 2-D
+            seen.add(run_case(L, name, (3, 10, 7), 1, rdt))              # strategy (ii), middle axis of 3-D
+            seen.add(run_case(L, name, (3, 4, 9), 2, rdt))               # strategy (i), 3-D (rows() flattens)
+            seen.add(run_case(L, name, (6, 9), 1, rdt, layout="F"))      # strategy (iii)
+            seen.add(run_case(L, name, (6, 9), 0, rdt, layout="F"))      # strategy (iii), contiguous lanes
+    assert {"generic_row", "generic_col"} <= seen, seen
+    # negative strides, stepped views, broadcast (stride 0) input, non-dense output view
+    x = synth.complex_array((4, 8, 6))
+    h = handlers.FftHandler(8, _library=L); o = orc.FftHandler(8)
+    xv = x[::-1, :, ::2]
+    y = np.zeros(xv.shape, np.complex128); yo = np.zeros_like(y)
+    api.ndfft(xv, y, h, 1); orc.ndfft(xv, yo, o, 1); assert_close(y, yo, 1, 1e-10, "negative/stepped view")
+    xb = np.broadcast_to(x[0:1], (3, 8, 6))
+    y = np.zeros((3, 8, 6), np.complex128); yo = np.zeros_like(y)
+    api.ndfft(xb, y, h, 1); orc.ndfft(xb, yo, o, 1); assert_close(y, yo, 1, 1e-10, "broadcast input")
+    big = np.full((4, 8, 12), 7.5 + 0j); bigo = big.copy()
+    api.ndfft(x, big[:, :, ::2], h, 1); orc.ndfft(x, bigo[:, :, ::2], o, 1)
+    assert_close(big, bigo, 1, 1e-10, "strided output view"); assert np.all(big[:, :, 1::2] == 7.5)
+    # 5-D with a permuted (non-mergeable) layout: exercises > 4 batch dims peeling
+    x5 = synth.real_array((2, 3, 2, 6, 2, 3)).transpose(2, 0, 4, 3, 1, 5)
+    y5 = np.zeros(x5.shape).transpose(1, 0, 2, 3, 5, 4).copy().transpose(1, 0, 2, 3, 5, 4)
+    y5o = np.zeros(x5.shape)
+    hd = handlers.DctHandler(6, _library=L); od = orc.DctHandler(6)
+    api.nddct2(x5, y5, hd, 3); orc.nddct2(x5, y5o, od, 3); assert_close(y5, y5o, 3, 1e-10, "6-D permuted")
+
+
+# ---- normalisation: None / Default / Custom at the reference's three application points --------
+def normalization_modes(L):
+    for name in OPS:
+        for norm in ("None", "Default"):
+            run_case(L, name, (4, 12), 1, np.float64, norm=norm)
+            run_case(L, name, (4, 9), 1, np.float32, norm=norm)
+
+    def triple(lane):
+        lane *= 3.0
+
+    n = 6
+    for name in OPS:
+        fn, ofn, cls, in_c, out_c = OPS[name]
+        sin, sout = shapes_for(name, (3, n), 1)
+        x = make_input(name, sin, np.float64)
+        y = np.zeros(sout, np.complex128 if out_c else np.float64); yo = np.zeros_like(y)
+        h = getattr(handlers, cls)(n, _library=L).normalization(Normalization.custom(triple))
+        o = getattr(orc, cls)(n).normalization(orc.NORM_CUSTOM, triple)
+        fn(x, y, h, 1); ofn(x, yo, o, 1)
+        assert_close(y, yo, 1, 1e-10, f"custom norm {name}")
+
+
+# ---- restated panics ---------------------------------------------------------------------------------
+def panics(L):
+    import pytest
+    x = np.zeros((3, 5), np.complex128); y = np.zeros((3, 5), np.complex128)
+    with pytest.raises(_lib.Panic, match="Size mismatch in fft, got 5 expected 6"):
+        api.ndfft(x, y, handlers.FftHandler(6, _library=L), 1)
+    with pytest.raises(_lib.Panic, match="Size mismatch in dct, got 5 expected 4"):
+        api.nddct1(np.zeros((3, 5)), np.zeros((3, 5)), handlers.DctHandler(4, _library=L), 1)
+    with pytest.raises(_lib.Panic) as e:
+        api.ndfft(x, y, handlers.FftHandler(5, _library=L), 2)
+    assert e.value.status == _lib.ERR_AXIS
+    with pytest.raises(_lib.Panic) as e:
+        api.ndfft(x, np.zeros((4, 5), np.complex128), handlers.FftHandler(5, _library=L), 1)
+    assert e.value.status == _lib.ERR_SHAPE_MISMATCH
+    with pytest.raises(_lib.Panic, match="Size mismatch in fft, got 6 expected 4"):
+        api.ndfft_r2c(np.zeros((2, 6)), np.zeros((2, 6), np.complex128), handlers.R2cFftHandler(6, _library=L), 1)
+    # no lanes -> nothing runs -> no panic even with the wrong handler length
+    api.ndfft(np.zeros((0, 5), np.complex128), np.zeros((0, 5), np.complex128), handlers.FftHandler(6, _library=L), 1)
+    with pytest.raises(TypeError):
+        api.ndfft(x, y, handlers.DctHandler(5, _library=L), 1)
+    with pytest.raises(TypeError):
+        api.ndfft(x.astype(np.complex64), y, handlers.FftHandler(5, _library=L), 1)
+
+
+# ---- sizes: every kernel family --------------------------------------------------------------------
+SIZE_SWEEP = [1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 13, 16, 17, 25, 27, 32, 49, 60, 64, 74, 96, 121, 128, 169, 210, 256, 264,
+              265, 343, 512, 513, 1000, 1024, 2048]
+
+
+def size_sweep(L, n, rdt=np.float64):
+    for name in OPS:
+        run_case(L, name, (3, n), 1, rdt, offset=n)
+
+
+def reference_bench_shapes(L, sizes_fft=(128, 264, 512, 1024), sizes_dct=(129, 265, 513, 1025)):
+    """benches/ndrustfft.rs:6-7: n x n f64, axis 0 (strategy ii), fill re = im = flat index."""
+    for n in sizes_fft:
+        x = synth.bench_fill_complex((n, n)); y = np.zeros_like(x); yo = np.zeros_like(x)
+        api.ndfft(x, y, handlers.FftHandler(n, _library=L), 0); orc.ndfft(x, yo, orc.FftHandler(n), 0)
+        assert_close(y, yo, 0, 1e-10, f"bench fft2d n={n}")
+        xr = np.arange(n * n, dtype=np.float64).reshape(n, n); m = n // 2 + 1
+        yr = np.zeros((m, n), np.complex128); yro = np.zeros_like(yr)
+        api.ndfft_r2c(xr, yr, handlers.R2cFftHandler(n, _library=L), 0); orc.ndfft_r2c(xr, yro, orc.R2cFftHandler(n), 0)
+        assert_close(yr, yro, 0, 1e-10, f"bench rfft2d n={n}")
+    for n in sizes_dct:
+        xr = np.arange(n * n, dtype=np.float64).reshape(n, n); y = np.zeros_like(xr); yo = np.zeros_like(xr)
+        api.nddct1(xr, y, handlers.DctHandler(n, _library=L), 0); orc.nddct1(xr, yo, orc.DctHandler(n), 0)
+        assert_close(y, yo, 0, 1e-10, f"bench dct2d n={n}")
+
+
+def handler_clone_shares_plan(L):
+    h = handlers.FftHandler(16, _library=L)
+    h2 = h.clone()
+    del h
+    x = synth.complex_array((2, 16)); y = np.zeros_like(x)
+    api.ndfft(x, y, h2, 1)
+    assert_close(y, np.fft.fft(x, axis=1), 1, 1e-10, "cloned handler")

@@ -1,0 +1,58 @@
+"""CPU checks of the drop-in boundary: the gfx950 library loads and exports exactly the symbols
+include/ndfft_mi355x.h declares; with no GPU it refuses to plan (no CPU fallback)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from ndrustfft_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "ndrustfft_amd", "csrc"), "-s", "-j4"])
+    return _lib.Library()
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "ndfft_mi355x.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ndfft_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(lib):
+    declared = _declared()
+    assert declared == sorted(_lib.SYMBOLS), "binding's symbol list drifted from the header"
+    for s in declared:
+        assert hasattr(lib.c, s), f"{s} declared in include/ndfft_mi355x.h but not exported"
+    assert lib.c.ndfft_abi_version() == 1
+
+
+def test_library_is_gfx950_code_object():
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "-S", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert ".hip_fatbin" in out
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"gfx942" not in blob and b"sm_" not in blob
+
+
+def test_no_cpu_fallback(lib):
+    if lib.c.ndfft_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    p = ctypes.c_void_p()
+    st = lib.c.ndfft_plan_create(_lib.KIND_C2C, _lib.F64, 16, ctypes.byref(p))
+    assert st == _lib.ERR_NO_DEVICE and not p.value
+    assert b"no CPU fallback" in lib.c.ndfft_last_error()
+
+
+def test_product_never_touches_oracle():
+    """The product package must not import, load or mention the oracle (or the test emulation)."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "ndrustfft_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in txt.lower() and "emul" not in txt.lower(), os.path.join(dirpath, f)

@@ -1,0 +1,143 @@
+"""THE parity tests: hand-written HIP on a real MI355X, called through the C ABI
+(include/ndfft_mi355x.h) via the thin ctypes host layer, compared with the CPU oracle on the same
+seeded inputs, with the committed golden vectors, and -- at BASELINE.json's full sizes -- through
+size-independent properties plus oracle checks on sampled lanes."""
+import numpy as np
+import pytest
+
+import parity_suite as ps
+import synth
+from helpers import GOLDEN_SIZES, TOL, assert_close, rel_global
+from ndrustfft_amd import _lib, api, handlers
+from oracle import oracle_ctypes as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    lib = _lib.default()                      # in-tree gfx950 build; raises if missing
+    assert lib.c.ndfft_device_count() >= 1, "no MI355X visible"
+    return lib
+
+
+def test_reference_unit_tests(L, refvec): ps.reference_unit_tests(L, refvec)
+def test_reference_examples(L, refvec): ps.reference_examples(L, refvec)
+def test_layouts(L): ps.layouts(L)
+def test_normalization(L): ps.normalization_modes(L)
+def test_panics(L): ps.panics(L)
+def test_clone(L): ps.handler_clone_shares_plan(L)
+def test_reference_bench_shapes(L): ps.reference_bench_shapes(L)
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+@pytest.mark.parametrize("n", GOLDEN_SIZES)
+def test_golden(L, npvec, dt, n): ps.golden_vectors(L, npvec, dt, n)
+
+
+@pytest.mark.parametrize("n", ps.SIZE_SWEEP)
+def test_sizes_f64(L, n): ps.size_sweep(L, n, np.float64)
+
+
+@pytest.mark.parametrize("n", ps.SIZE_SWEEP)
+def test_sizes_f32(L, n): ps.size_sweep(L, n, np.float32)
+
+
+@pytest.mark.parametrize("n", [64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384])
+@pytest.mark.parametrize("rdt", [np.float64, np.float32])
+def test_pow2_tuned(L, n, rdt):
+    for name in ("ndfft", "ndifft"):
+        for norm in ("Default", "None"):
+            assert ps.run_case(L, name, (37, n), 1, rdt, norm=norm, offset=n) == "pow2_reg"
+
+
+# ---- BASELINE.json configs at full size --------------------------------------------------------
+def _sample_lanes_vs_oracle(x, y, ofn, oh, axis, nsample, tol, what):
+    """oracle on a seeded sample of lanes (the full array would take the scalar oracle too long)"""
+    lanes_x = np.moveaxis(x, axis, -1).reshape(-1, x.shape[axis])
+    lanes_y = np.moveaxis(y, axis, -1).reshape(-1, y.shape[axis])
+    rng = np.random.default_rng(7)
+    idx = np.unique(np.concatenate([[0, lanes_x.shape[0] - 1], rng.integers(0, lanes_x.shape[0], nsample)]))
+    xs = np.ascontiguousarray(lanes_x[idx]); yo = np.zeros((len(idx), y.shape[axis]), y.dtype)
+    ofn(xs, yo, oh, 1)
+    assert_close(lanes_y[idx], yo, 1, tol, what)
+
+
+def test_cfg2_fft_4096x4096_f64(L):
+    """configs[1]: ndfft axis=1 on 4096x4096 Complex<f64>, both fills."""
+    n = 4096
+    h = handlers.FftHandler(n, _library=L); oh = orc.FftHandler(n)
+    for fill in ("splitmix", "bench"):
+        x = synth.complex_array((n, n)) if fill == "splitmix" else synth.bench_fill_complex((n, n))
+        y = np.zeros_like(x)
+        api.ndfft(x, y, h, 1)
+        assert L.last_path() == "pow2_reg"
+        _sample_lanes_vs_oracle(x, y, orc.ndfft, oh, 1, 48, 1e-10, f"cfg2 {fill}")
+        # Parseval on every lane: sum|X|^2 = n sum|x|^2
+        e_in = (np.abs(x) ** 2).sum(axis=1); e_out = (np.abs(y) ** 2).sum(axis=1)
+        assert np.abs(e_out / (n * e_in) - 1).max() < 1e-12
+        # round trip through ndifft (Default 1/n) returns the input
+        z = np.zeros_like(x); api.ndifft(y, z, h, 1)
+        assert rel_global(z, x) < 1e-13
+    # linearity: F(a x + b y) = a F(x) + b F(y) on a slab
+    a, b = 0.75 - 0.5j, -1.25 + 2j
+    x1 = synth.complex_array((256, n), offset=1); x2 = synth.complex_array((256, n), offset=99991)
+    y1, y2, y3 = np.zeros_like(x1), np.zeros_like(x1), np.zeros_like(x1)
+    api.ndfft(x1, y1, h, 1); api.ndfft(x2, y2, h, 1); api.ndfft(a * x1 + b * x2, y3, h, 1)
+    assert rel_global(y3, a * y1 + b * y2) < 1e-13
+
+
+def test_cfg3_r2c_then_c2c_8192_f32(L):
+    """configs[2]: ndfft_r2c axis=0 then ndfft axis=1 on 8192x8192 f32."""
+    n = 8192; m = n // 2 + 1
+    x = synth.real_array((n, n), np.float32)
+    work = np.zeros((m, n), np.complex64)
+    hr = handlers.R2cFftHandler(n, np.float32, _library=L); hc = handlers.FftHandler(n, np.float32, _library=L)
+    api.ndfft_r2c(x, work, hr, 0)
+    _sample_lanes_vs_oracle(x, work, orc.ndfft_r2c, orc.R2cFftHandler(n, np.float32), 0, 32, 1e-4, "cfg3A r2c axis0")
+    out = np.zeros_like(work)
+    api.ndfft(work, out, hc, 1)
+    _sample_lanes_vs_oracle(work, out, orc.ndfft, orc.FftHandler(n, np.float32), 1, 32, 1e-4, "cfg3B c2c axis1")
+    # round trip back to the real array
+    w2 = np.zeros_like(work); api.ndifft(out, w2, hc, 1)
+    x2 = np.zeros_like(x); api.ndifft_r2c(w2, x2, hr, 0)
+    assert rel_global(x2, x) < 1e-4
+
+
+def test_cfg4_dct2_256x256x512_f64(L):
+    """configs[3]: nddct2 axis=2 on 256x256x512 f64; DCT-III undoes DCT-II up to 2n."""
+    shape = (256, 256, 512); n = 512
+    x = synth.real_array(shape)
+    y = np.zeros_like(x); h = handlers.DctHandler(n, _library=L)
+    api.nddct2(x, y, h, 2)
+    _sample_lanes_vs_oracle(x, y, orc.nddct2, orc.DctHandler(n), 2, 64, 1e-10, "cfg4 dct2")
+    z = np.zeros_like(x); api.nddct3(y, z, h, 2)
+    assert rel_global(z / (2.0 * n), x) < 1e-12      # scipy: dct3(dct2(x)) = 2n x under the Default (x2) scaling
+
+
+def test_cfg5_shard_shape_8192x4096_f64(L):
+    """configs[4] per-GPU shard (65536/8 rows): same kernel, bigger batch."""
+    rows, n = 8192, 4096
+    x = synth.complex_array((rows, n)); y = np.zeros_like(x)
+    h = handlers.FftHandler(n, _library=L)
+    api.ndfft(x, y, h, 1)
+    _sample_lanes_vs_oracle(x, y, orc.ndfft, orc.FftHandler(n), 1, 32, 1e-10, "cfg5 shard")
+
+
+def test_device_resident_path_matches_host_path(L):
+    torch = pytest.importorskip("torch")
+    assert torch.cuda.is_available()
+    n = 1024
+    x = synth.complex_array((64, n)); y = np.zeros_like(x)
+    h = handlers.FftHandler(n, _library=L)
+    api.ndfft(x, y, h, 1)
+    xd = torch.from_numpy(x).cuda(); yd = torch.zeros_like(xd)
+    api.ndfft(xd, yd, h, 1)
+    torch.cuda.synchronize()
+    assert np.array_equal(yd.cpu().numpy(), y)
+    # non-contiguous device views: axis 0 of a transposed tensor
+    xt = xd.t()                      # shape (n, 64), strides (1, n)
+    yt = torch.zeros((n, 64), dtype=xd.dtype, device="cuda")
+    api.ndfft(xt, yt, h, 0)
+    torch.cuda.synchronize()
+    assert_close(yt.cpu().numpy(), y.T, 0, 1e-10, "transposed device view")
