@@ -1,0 +1,167 @@
+// pow2_kernel.h -- register-resident Stockham kernel template (see kernels_pow2.hip for the design notes).
+#pragma once
+#include "butterflies.h"
+#include "engine.h"
+#include <cmath>
+
+namespace ndfft {
+
+template <int... Rs> struct RadixList {
+    static constexpr int NP = sizeof...(Rs);
+    static constexpr int at(int i) { constexpr int r[NP] = {Rs...}; return r[i]; }
+    // Ns before pass i
+    static constexpr int ns(int i) { int s = 1; for (int p = 0; p < i; ++p) s *= at(p); return s; }
+    // offset (in complex elements) of pass i's twiddle block inside twp; pass 0 has none
+    static constexpr int twoff(int i) { int o = 0; for (int p = 1; p < i; ++p) o += (at(p) - 1) * ns(p); return o; }
+};
+
+__device__ __forceinline__ int phi(int p) { return p + (p >> 4); }
+
+// Streaming (touch-once) global accesses.  A lane is read once and written once per call, so the
+// output is stored non-temporally: it then neither evicts the still-to-be-read input from the
+// 256 MiB Infinity Cache nor the twiddle tables from L2 (measured on MI355X: a 2 x 256 MiB copy
+// with this access pattern runs 6.9 TB/s with nt stores vs 5.2 TB/s without, tools/membench.hip).
+template <typename T> struct vec_of;
+template <> struct vec_of<float> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct vec_of<double> { typedef double type __attribute__((ext_vector_type(2))); };
+template <typename T, bool NT> __device__ __forceinline__ cpx<T> gload(const cpx<T> *p) {
+    if constexpr (NT) {
+        typename vec_of<T>::type v = __builtin_nontemporal_load((const typename vec_of<T>::type *)p);
+        return mk<T>(v.x, v.y);
+    } else {
+        return *p;
+    }
+}
+template <typename T, bool NT> __device__ __forceinline__ void gstore(cpx<T> *p, cpx<T> v) {
+    if constexpr (NT) {
+        typename vec_of<T>::type w; w.x = v.x; w.y = v.y;
+        __builtin_nontemporal_store(w, (typename vec_of<T>::type *)p);
+    } else {
+        *p = v;
+    }
+}
+
+// FLAGS is for ablation builds in tools/kbench.hip only (product kernels use 0):
+//   1 = skip twiddle multiplies, 2 = skip the LDS exchange, 4 = skip butterflies
+// NT: bit 0 = non-temporal stores, bit 1 = non-temporal loads
+template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS = 0, int MINW = 1, int NT = 1> struct Pow2Kernel {
+    static constexpr int MIN_WAVES = MINW;
+    static constexpr int E = N / TPL;
+    static constexpr int THREADS = TPL * LPB;
+    static constexpr int LANE_LDS = N + (N >> 4) + 1;                      // padded elements per lane
+    static constexpr size_t LDS_BYTES = (size_t)LPB * LANE_LDS * (HALF ? sizeof(T) : 2 * sizeof(T));
+
+    template <int P>
+    static __device__ __forceinline__ void passes(cpx<T> (&v)[E], const cpx<T> *__restrict__ twp, char *lds, int t) {
+        constexpr int R = RL::at(P), Ns = RL::ns(P), NBF = E / R;
+        if constexpr (P > 0 && !(FLAGS & 1)) {
+            const cpx<T> *tw = twp + RL::twoff(P);
+#pragma unroll
+            for (int q = 0; q < NBF; ++q) {
+                const int k = (t + q * TPL) & (Ns - 1);
+#pragma unroll
+                for (int r = 1; r < R; ++r) v[q * R + r] = cmul(v[q * R + r], tw[(r - 1) * Ns + k]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NBF; ++q) if constexpr (!(FLAGS & 4)) Bfly<T, R>::run(&v[q * R]);
+        if constexpr (P + 1 < RL::NP) {
+            constexpr int R2 = RL::at(P + 1), NB2 = N / R2, NBF2 = E / R2;
+            if constexpr (FLAGS & 2) {
+            } else if constexpr (HALF) {
+                T *s = (T *)lds;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    __syncthreads();
+#pragma unroll
+                    for (int q = 0; q < NBF; ++q) {
+                        const int j = t + q * TPL, k = j & (Ns - 1), o = (j - k) * R + k;
+#pragma unroll
+                        for (int r = 0; r < R; ++r) s[phi(o + r * Ns)] = half ? v[q * R + r].y : v[q * R + r].x;
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int q = 0; q < NBF2; ++q) {
+                        const int j = t + q * TPL;
+#pragma unroll
+                        for (int r = 0; r < R2; ++r) {
+                            const T x = s[phi(j + r * NB2)];
+                            if (half) v[q * R2 + r].y = x; else v[q * R2 + r].x = x;
+                        }
+                    }
+                }
+            } else {
+                cpx<T> *s = (cpx<T> *)lds;
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < NBF; ++q) {
+                    const int j = t + q * TPL, k = j & (Ns - 1), o = (j - k) * R + k;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) s[phi(o + r * Ns)] = v[q * R + r];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < NBF2; ++q) {
+                    const int j = t + q * TPL;
+#pragma unroll
+                    for (int r = 0; r < R2; ++r) v[q * R2 + r] = s[phi(j + r * NB2)];
+                }
+            }
+            passes<P + 1>(v, twp, lds, t);
+        }
+    }
+
+    static __device__ __forceinline__ void run(const Pow2Args &a) {
+        extern __shared__ __attribute__((aligned(16))) char smem[];
+        const int t = threadIdx.x % TPL, ll = threadIdx.x / TPL;
+        const int64_t lane = (int64_t)blockIdx.x * LPB + ll;
+        const bool live = lane < a.nlanes;
+        const cpx<T> *in = (const cpx<T> *)a.in + (live ? lane : 0) * a.pitch_in;
+        cpx<T> *out = (cpx<T> *)a.out + (live ? lane : 0) * a.pitch_out;
+        char *lds = smem + (size_t)ll * LANE_LDS * (HALF ? sizeof(T) : 2 * sizeof(T));
+        cpx<T> v[E];
+        {
+            constexpr int R0 = RL::at(0), NB0 = N / R0, NBF0 = E / R0;
+#pragma unroll
+            for (int q = 0; q < NBF0; ++q)
+#pragma unroll
+                for (int r = 0; r < R0; ++r) v[q * R0 + r] = gload<T, (NT & 2) != 0>(in + t + q * TPL + r * NB0);
+        }
+        if (a.inverse) {
+#pragma unroll
+            for (int i = 0; i < E; ++i) v[i].y = -v[i].y;
+        }
+        passes<0>(v, (const cpx<T> *)a.twp, lds, t);
+        if (!live) return;
+        constexpr int RL_ = RL::at(RL::NP - 1), NBL = N / RL_, NBFL = E / RL_;
+        if (a.inverse) {
+            const T sc = (T)a.scale;
+#pragma unroll
+            for (int i = 0; i < E; ++i) { v[i].x *= sc; v[i].y *= -sc; }   // conj + norm_default (lib.rs:333-338)
+        }
+#pragma unroll
+        for (int q = 0; q < NBFL; ++q)
+#pragma unroll
+            for (int r = 0; r < RL_; ++r) gstore<T, (NT & 1) != 0>(out + t + q * TPL + r * NBL, v[q * RL_ + r]);
+    }
+};
+
+template <typename K> __global__ __launch_bounds__(K::THREADS, K::MIN_WAVES) void k_pow2(const Pow2Args a) { K::run(a); }
+
+// host: per-pass transposed twiddles, tw_p[(r-1)*Ns + k] = e^{-2 pi i r k/(Ns R)}, long double
+template <typename RL> inline void build_tw(HostTable &out) {
+    const long double kPiL = 3.14159265358979323846264338327950288L;
+    for (int p = 1; p < RL::NP; ++p) {
+        const int R = RL::at(p), Ns = RL::ns(p);
+        // tw[(r-1)*Ns + k] = e^{-2 pi i r k/(Ns R)}
+        for (int r = 1; r < R; ++r)
+            for (int k = 0; k < Ns; ++k) {
+                const unsigned long long num = ((unsigned long long)r * k) % ((unsigned long long)Ns * R);
+                const long double ang = 2.0L * kPiL * (long double)num / (long double)((unsigned long long)Ns * R);
+                out.re.push_back(cosl(ang)); out.im.push_back(-sinl(ang));
+            }
+    }
+}
+
+
+}  // namespace ndfft
