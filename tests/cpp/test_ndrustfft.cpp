@@ -1,0 +1,186 @@
+// tests/cpp/test_ndrustfft.cpp -- the reference's unit tests (src/lib.rs:903-1406) and examples
+// (examples/fft2.rs, rfft2.rs, fft_norm.rs) re-stated against the C++ mirror include/ndrustfft.hpp,
+// i.e. through the C ABI onto the MI355X.  Same fixtures, same tolerances (1e-3 / 1e-4).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <string>
+
+#include "ndrustfft.hpp"
+#include "reference_vectors.h"
+
+using namespace ndrustfft;
+using C = Complex<double>;
+
+static int g_fail = 0;
+#define EXPECT(cond) do { if (!(cond)) { printf("    EXPECT failed: %s (%s:%d)\n", #cond, __FILE__, __LINE__); ++g_fail; } } while (0)
+
+static void approx_eq(const std::vector<double> &r, const std::vector<double> &e, double dif = 1e-3) {   // lib.rs:852-864
+    EXPECT(r.size() == e.size());
+    for (size_t i = 0; i < r.size() && i < e.size(); ++i)
+        if (std::fabs(r[i] - e[i]) > dif) { printf("    Large difference of values, got %g expected %g.\n", r[i], e[i]); ++g_fail; return; }
+}
+static void approx_eq_complex(const std::vector<C> &r, const std::vector<double> &ere, const std::vector<double> &eim, double dif = 1e-3) {
+    EXPECT(r.size() == ere.size());
+    for (size_t i = 0; i < r.size() && i < ere.size(); ++i)
+        if (std::fabs(r[i].real() - ere[i]) > dif || std::fabs(r[i].imag() - eim[i]) > dif) {
+            printf("    Large difference of values, got %g%+gi expected %g%+gi.\n", r[i].real(), r[i].imag(), ere[i], eim[i]); ++g_fail; return;
+        }
+}
+static std::vector<C> cplx_of(const std::vector<double> &m) { std::vector<C> v; for (double x : m) v.emplace_back(x, x); return v; }
+static std::vector<double> re_of(const std::vector<C> &v) { std::vector<double> r; for (auto &c : v) r.push_back(c.real()); return r; }
+static std::vector<double> im_of(const std::vector<C> &v) { std::vector<double> r; for (auto &c : v) r.push_back(c.imag()); return r; }
+
+static Array<double> test_matrix() { return Array<double>::from({6, 6}, refvec::test_matrix); }                    // lib.rs:880-889
+static Array<C> test_matrix_complex() { return Array<C>::from({6, 6}, cplx_of(refvec::test_matrix)); }             // lib.rs:891-893
+static Array<C> test_matrix_complex_f() { return Array<C>::from({6, 6}, cplx_of(refvec::test_matrix), true); }     // lib.rs:895-901
+
+template <bool PAR> static void test_fft() {                                                                       // lib.rs:903-994
+    auto v = test_matrix_complex(); auto v_copy = v;
+    auto vhat = Array<C>::zeros({6, 6});
+    FftHandler<double> handler(6);
+    if (PAR) { ndfft_par(v, vhat, handler, 1); ndifft_par(vhat, v, handler, 1); }
+    else { ndfft(v, vhat, handler, 1); ndifft(vhat, v, handler, 1); }
+    approx_eq_complex(vhat.to_logical(), refvec::fft_axis1_re, refvec::fft_axis1_im);
+    approx_eq_complex(v.to_logical(), re_of(v_copy.to_logical()), im_of(v_copy.to_logical()));
+}
+static void test_fft_f_layout() {                                                                                   // lib.rs:996-1040
+    auto v = test_matrix_complex_f(); auto v_copy = v;
+    auto vhat = Array<C>::zeros({6, 6});
+    FftHandler<double> handler(6);
+    ndfft(v, vhat, handler, 1); ndifft(vhat, v, handler, 1);
+    approx_eq_complex(vhat.to_logical(), refvec::fft_axis1_re, refvec::fft_axis1_im);
+    approx_eq_complex(v.to_logical(), re_of(v_copy.to_logical()), im_of(v_copy.to_logical()));
+}
+template <bool PAR> static void test_fft_r2c() {                                                                    // lib.rs:1042-1133
+    auto v = test_matrix(); auto v_copy = v;
+    auto vhat = Array<C>::zeros({6, 6 / 2 + 1});
+    R2cFftHandler<double> handler(6);
+    if (PAR) { ndfft_r2c_par(v, vhat, handler, 1); ndifft_r2c_par(vhat, v, handler, 1); }
+    else { ndfft_r2c(v, vhat, handler, 1); ndifft_r2c(vhat, v, handler, 1); }
+    approx_eq_complex(vhat.to_logical(), refvec::rfft_axis1_re, refvec::rfft_axis1_im);
+    approx_eq(v.to_logical(), v_copy.to_logical());
+}
+static void test_ifft_c2r_first_last_element() {                                                                    // lib.rs:1135-1167
+    const int n = 6;
+    auto v = Array<double>::zeros({n}); auto vhat = Array<C>::zeros({n / 2 + 1});
+    R2cFftHandler<double> rfft_handler(n);
+    vhat(0) = C(1., 100.);
+    ndifft_r2c(vhat, v, rfft_handler, 0);
+    approx_eq(v.to_logical(), refvec::c2r_first_out);
+    for (int i = 0; i < n / 2 + 1; ++i) vhat(i) = C(0., 0.);
+    vhat(3) = C(1., 100.);
+    ndifft_r2c(vhat, v, rfft_handler, 0);
+    approx_eq(v.to_logical(), refvec::c2r_last_out);
+}
+template <bool PAR> static void test_fft_r2c_odd() {                                                                // lib.rs:1169-1202
+    auto v = Array<double>::from({3, 3}, refvec::m3x3); auto v_copy = v;
+    auto vhat = Array<C>::zeros({3, 3 / 2 + 1});
+    R2cFftHandler<double> handler(3);
+    if (PAR) { ndfft_r2c_par(v, vhat, handler, 1); ndifft_r2c_par(vhat, v, handler, 1); }
+    else { ndfft_r2c(v, vhat, handler, 1); ndifft_r2c(vhat, v, handler, 1); }
+    approx_eq(v.to_logical(), v_copy.to_logical());
+}
+template <int K, bool PAR> static void test_dct() {                                                                 // lib.rs:1204-1406
+    auto v = test_matrix(); auto vhat = Array<double>::zeros({6, 6});
+    DctHandler<double> handler(6);
+    if (K == 1) { if (PAR) nddct1_par(v, vhat, handler, 1); else nddct1(v, vhat, handler, 1); }
+    if (K == 2) { if (PAR) nddct2_par(v, vhat, handler, 1); else nddct2(v, vhat, handler, 1); }
+    if (K == 3) { if (PAR) nddct3_par(v, vhat, handler, 1); else nddct3(v, vhat, handler, 1); }
+    if (K == 4) { if (PAR) nddct4_par(v, vhat, handler, 1); else nddct4(v, vhat, handler, 1); }
+    const std::vector<double> *sol[] = {&refvec::dct1_axis1, &refvec::dct2_axis1, &refvec::dct3_axis1, &refvec::dct4_axis1};
+    approx_eq(vhat.to_logical(), *sol[K - 1]);
+}
+
+static void example_fft2() {                                                                                        // examples/fft2.rs
+    auto v = Array<C>::from({3, 3}, cplx_of(refvec::m3x3));
+    auto vhat = Array<C>::zeros({3, 3});
+    FftHandler<double> handler_ax0(3), handler_ax1(3);
+    { auto work = Array<C>::zeros({3, 3}); ndfft(v, work, handler_ax1, 1); ndfft(work, vhat, handler_ax0, 0); }
+    approx_eq_complex(vhat.to_logical(), refvec::example_fft2_re, refvec::example_fft2_im, 1e-4);
+    auto v_new = Array<C>::zeros({3, 3});
+    { auto work = Array<C>::zeros({3, 3}); ndifft(vhat, work, handler_ax0, 0); ndifft(work, v_new, handler_ax1, 1); }
+    approx_eq_complex(v_new.to_logical(), refvec::m3x3, refvec::m3x3, 1e-4);
+}
+static void example_rfft2() {                                                                                       // examples/rfft2.rs
+    auto v = Array<double>::from({3, 3}, refvec::m3x3);
+    auto vhat = Array<C>::zeros({3, 2});
+    FftHandler<double> handler_ax0(3); R2cFftHandler<double> handler_ax1(3);
+    { auto work = Array<C>::zeros({3, 2}); ndfft_r2c(v, work, handler_ax1, 1); ndfft(work, vhat, handler_ax0, 0); }
+    approx_eq_complex(vhat.to_logical(), refvec::example_rfft2_re, refvec::example_rfft2_im, 1e-4);
+    auto v_new = Array<double>::zeros({3, 3});
+    { auto work = Array<C>::zeros({3, 2}); ndifft(vhat, work, handler_ax0, 0); ndifft_r2c(work, v_new, handler_ax1, 1); }
+    approx_eq(v_new.to_logical(), refvec::m3x3, 1e-4);
+}
+static void my_norm(C *data, std::size_t len) { const double n = 2. / (double)len; for (std::size_t i = 0; i < len; ++i) data[i] *= n; }
+static void example_fft_norm() {                                                                                    // examples/fft_norm.rs
+    auto v = Array<C>::from({3}, cplx_of({1., 2., 3.}));
+    auto vhat = Array<C>::zeros({3}); auto v2 = Array<C>::zeros({3});
+    auto handler = FftHandler<double>(3).normalization(Normalization<C>::dflt());
+    ndfft(v, vhat, handler, 0); ndifft(vhat, v2, handler, 0);
+    approx_eq_complex(v2.to_logical(), {1., 2., 3.}, {1., 2., 3.}, 1e-12);
+    handler = FftHandler<double>(3).normalization(Normalization<C>::none());
+    ndfft(v, vhat, handler, 0); ndifft(vhat, v2, handler, 0);
+    approx_eq_complex(v2.to_logical(), {3., 6., 9.}, {3., 6., 9.}, 1e-12);
+    handler = FftHandler<double>(3).normalization(Normalization<C>::custom(my_norm));
+    ndfft(v, vhat, handler, 0); ndifft(vhat, v2, handler, 0);
+    approx_eq_complex(v2.to_logical(), {2., 4., 6.}, {2., 4., 6.}, 1e-12);
+}
+static void readme_r2c_6x4() {                                                                                      // lib.rs:38-50 (BASELINE configs[0])
+    std::vector<double> d(24); for (int i = 0; i < 24; ++i) d[i] = i;
+    auto data = Array<double>::from({6, 4}, d); auto vhat = Array<C>::zeros({6 / 2 + 1, 4});
+    R2cFftHandler<double> handler(6);
+    ndfft_r2c(data, vhat, handler, 0);
+    approx_eq_complex(vhat.to_logical(), refvec::readme_r2c_6x4_re, refvec::readme_r2c_6x4_im, 1e-12);
+}
+static void panics() {                                                                                              // lib.rs:340-347, 116, 120-121
+    auto x = Array<C>::zeros({3, 5}); auto y = Array<C>::zeros({3, 5});
+    try { ndfft(x, y, FftHandler<double>(6), 1); EXPECT(!"no panic"); }
+    catch (const Panic &p) { EXPECT(std::string(p.what()) == "Size mismatch in fft, got 5 expected 6"); }
+    try { ndfft(x, y, FftHandler<double>(5), 2); EXPECT(!"no panic"); }
+    catch (const Panic &p) { EXPECT(p.status == NDFFT_ERR_AXIS); }
+    auto y4 = Array<C>::zeros({4, 5});
+    try { ndfft(x, y4, FftHandler<double>(5), 1); EXPECT(!"no panic"); }
+    catch (const Panic &p) { EXPECT(p.status == NDFFT_ERR_SHAPE_MISMATCH); }
+    auto xr = Array<double>::zeros({3, 5}); auto yr = Array<double>::zeros({3, 5});
+    try { nddct1(xr, yr, DctHandler<double>(4), 1); EXPECT(!"no panic"); }
+    catch (const Panic &p) { EXPECT(std::string(p.what()) == "Size mismatch in dct, got 5 expected 4"); }
+}
+static void f32_and_clone() {
+    std::vector<Complex<float>> in; for (int i = 0; i < 8; ++i) in.emplace_back((float)i, (float)-i);
+    auto x = Array<Complex<float>>::from({8}, in); auto y = Array<Complex<float>>::zeros({8}); auto z = Array<Complex<float>>::zeros({8});
+    FftHandler<float> h(8); FftHandler<float> h2 = h;   // Clone
+    ndfft(x, y, h, 0); ndifft(y, z, h2, 0);
+    auto zl = z.to_logical();
+    for (int i = 0; i < 8; ++i) EXPECT(std::abs(zl[i] - in[i]) < 1e-5f);
+    EXPECT(std::abs(y.to_logical()[0] - Complex<float>(28.f, -28.f)) < 1e-4f);
+}
+
+int main(int argc, char **argv) {
+    if (argc > 1 && !strcmp(argv[1], "--expect-no-device")) {
+        try { FftHandler<double> h(8); printf("unexpected: a plan was created\n"); return 1; }
+        catch (const Error &e) { printf("no device: %s\n", e.what()); return e.status == NDFFT_ERR_NO_DEVICE ? 0 : 1; }
+    }
+    struct T { const char *name; std::function<void()> fn; };
+    const T tests[] = {
+        {"test_fft", test_fft<false>}, {"test_fft_par", test_fft<true>}, {"test_fft_f_layout", test_fft_f_layout},
+        {"test_fft_r2c", test_fft_r2c<false>}, {"test_fft_r2c_par", test_fft_r2c<true>},
+        {"test_ifft_c2r_first_last_element", test_ifft_c2r_first_last_element},
+        {"test_fft_r2c_odd", test_fft_r2c_odd<false>}, {"test_fft_r2c_odd_par", test_fft_r2c_odd<true>},
+        {"test_dct1", test_dct<1, false>}, {"test_dct1_par", test_dct<1, true>}, {"test_dct2", test_dct<2, false>},
+        {"test_dct2_par", test_dct<2, true>}, {"test_dct3", test_dct<3, false>}, {"test_dct3_par", test_dct<3, true>},
+        {"test_dct4", test_dct<4, false>}, {"test_dct4_par", test_dct<4, true>},
+        {"example_fft2", example_fft2}, {"example_rfft2", example_rfft2}, {"example_fft_norm", example_fft_norm},
+        {"readme_r2c_6x4", readme_r2c_6x4}, {"panics", panics}, {"f32_and_clone", f32_and_clone},
+    };
+    int bad = 0;
+    for (const T &t : tests) {
+        const int before = g_fail;
+        try { t.fn(); } catch (const std::exception &e) { printf("    exception: %s\n", e.what()); ++g_fail; }
+        printf("test %s ... %s\n", t.name, g_fail == before ? "ok" : "FAILED");
+        bad += g_fail != before;
+    }
+    printf("test result: %s. %d passed; %d failed\n", bad ? "FAILED" : "ok", (int)(sizeof tests / sizeof tests[0]) - bad, bad);
+    return bad ? 1 : 0;
+}
