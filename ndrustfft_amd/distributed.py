@@ -1,0 +1,129 @@
+"""Batch-dimension sharding of one axis transform across the GPUs of a node.
+
+Every lane is transformed independently (the reference's own `_par` path relies on exactly that:
+Zip::par_for_each over lanes, src/lib.rs:190-194), so a single-axis nd* call shards with NO
+exchange step: split the lane index space into contiguous blocks along a non-transform dimension,
+one block per rank (one process per GPU), run the same kernels on each shard.
+
+RCCL (torch.distributed backend "nccl") is used only to move batch slices between a root and the
+ranks -- scatter before / gather after -- over xGMI; `scatter_lanes` / `gather_lanes` are plain
+point-to-point groups (one contiguous slice per peer link), never a ring.  Arrays that are born
+sharded (each rank produces / consumes its own block) need no communication at all: call the nd*
+function on the local shard.
+"""
+import numpy as np
+
+try:
+    import torch
+    import torch.distributed as dist
+except Exception:  # pragma: no cover
+    torch = None
+    dist = None
+
+
+def shard_dim(shape, axis):
+    """Dimension to split: the outermost non-transform dimension with extent > 1 (slices of a
+    C-layout array along it are contiguous byte ranges)."""
+    for d, e in enumerate(shape):
+        if d != axis and e > 1:
+            return d
+    raise ValueError("array has a single lane: nothing to shard")
+
+
+def shard_bounds(extent, world):
+    """Contiguous blocks [lo, hi) per rank; the first `extent % world` ranks get one extra row."""
+    base, rem = divmod(extent, world)
+    out, lo = [], 0
+    for r in range(world):
+        hi = lo + base + (1 if r < rem else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def local_shape(shape, axis, rank, world):
+    d = shard_dim(shape, axis)
+    lo, hi = shard_bounds(shape[d], world)[rank]
+    s = list(shape)
+    s[d] = hi - lo
+    return tuple(s), d, (lo, hi)
+
+
+def _slice(t, d, lo, hi):
+    idx = [slice(None)] * t.dim()
+    idx[d] = slice(lo, hi)
+    return t[tuple(idx)]
+
+
+def scatter_lanes(full, shape, dtype, axis, root=0, device=None, group=None):
+    """Root holds `full` (torch tensor of `shape`); every rank returns its contiguous shard.
+    Point-to-point: root posts one isend per peer, peers one irecv (7 concurrent xGMI links from
+    the root on an 8-GPU node)."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    lshape, d, _ = local_shape(shape, axis, rank, world)
+    bounds = shard_bounds(shape[d], world)
+    if rank == root:
+        ops, keep = [], []
+        mine = None
+        for r, (lo, hi) in enumerate(bounds):
+            piece = _slice(full, d, lo, hi).contiguous()
+            if r == root:
+                mine = piece.clone() if piece.data_ptr() == full.data_ptr() else piece
+            elif piece.numel():
+                keep.append(piece)
+                ops.append(dist.P2POp(dist.isend, piece, r, group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return mine
+    out = torch.empty(lshape, dtype=dtype, device=device)
+    if out.numel():
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, out, root, group)]):
+            w.wait()
+    return out
+
+
+def gather_lanes(local, full_shape, axis_out_shape_dim, root=0, out=None, group=None):
+    """Inverse of scatter_lanes for the OUTPUT array: `full_shape` is the output's global shape and
+    `axis_out_shape_dim` the dimension it was sharded along.  Root returns the assembled tensor."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    d = axis_out_shape_dim
+    bounds = shard_bounds(full_shape[d], world)
+    if rank == root:
+        if out is None:
+            out = torch.empty(full_shape, dtype=local.dtype, device=local.device)
+        ops, bufs = [], []
+        for r, (lo, hi) in enumerate(bounds):
+            if r == root:
+                _slice(out, d, lo, hi).copy_(local)
+                continue
+            s = list(full_shape); s[d] = hi - lo
+            buf = torch.empty(s, dtype=local.dtype, device=local.device)
+            if buf.numel():
+                bufs.append((buf, lo, hi))
+                ops.append(dist.P2POp(dist.irecv, buf, r, group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for buf, lo, hi in bufs:
+            _slice(out, d, lo, hi).copy_(buf)
+        return out
+    if local.numel():
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, local.contiguous(), root, group)]):
+            w.wait()
+    return None
+
+
+def transform_sharded(fn, full_in, in_shape, in_dtype, out_shape, out_dtype, handler, axis, root=0, device=None,
+                      group=None):
+    """root-scatter -> local nd* on every rank -> root-gather.  `fn` is one of the nd* functions
+    (or, in the CPU/gloo tests, a stand-in with the same signature).  Returns the full output on
+    root, None elsewhere.  NOTE: for a single transform the two transfers cost more than
+    the transform; the scalable use is arrays that stay sharded across many nd* calls."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    x = scatter_lanes(full_in if rank == root else None, in_shape, in_dtype, axis, root, device, group)
+    lshape_out, d, _ = local_shape(out_shape, axis, rank, world)
+    y = torch.zeros(lshape_out, dtype=out_dtype, device=device)
+    if x.numel() and y.numel():
+        fn(x, y, handler, axis)
+    return gather_lanes(y, tuple(out_shape), d, root, None, group)

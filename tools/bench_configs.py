@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Device-resident timing of every BASELINE.json config (and the reference bench shapes) with HIP
+events on the launch stream; prints one JSON line per workload with the roofline fraction.
+Not the driver contract (that is bench.py); this fills DESIGN.md's measurement table."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+
+import synth
+from ndrustfft_amd import (DctHandler, FftHandler, R2cFftHandler, _lib, nddct1, nddct2, nddct3, nddct4, ndfft, ndfft_r2c,
+                           ndifft, ndifft_r2c)
+
+PEAK = 8000.0
+
+
+def timeit(fn, steps, warmup=5):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / steps
+
+
+def run(name, fn, x, y, h, axis, points, steps):
+    t = timeit(lambda: fn(x, y, h, axis), steps)
+    nbytes = x.numel() * x.element_size() + y.numel() * y.element_size()
+    gbs = nbytes / t / 1e9
+    print(json.dumps({"workload": name, "us": round(t * 1e6, 2), "GFFT-points/s": round(points / t / 1e9, 2),
+                      "algorithmic_bytes": nbytes, "GB/s": round(gbs, 1), "frac_of_8TBs": round(gbs / PEAK, 4),
+                      "path": _lib.default().last_path()}), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=50); ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    want = lambda k: (not a.only) or a.only in k
+    if want("cfg2"):
+        x = torch.from_numpy(synth.complex_array((4096, 4096))).to(dev); y = torch.empty_like(x)
+        run("cfg2 ndfft axis=1 4096x4096 c128", ndfft, x, y, FftHandler(4096), 1, x.numel(), a.steps)
+        run("cfg2' ndifft axis=1 4096x4096 c128", ndifft, x, y, FftHandler(4096), 1, x.numel(), a.steps)
+    if want("cfg3"):
+        n = 8192; m = n // 2 + 1
+        x = torch.from_numpy(synth.real_array((n, n), np.float32)).to(dev)
+        w = torch.empty((m, n), dtype=torch.complex64, device=dev); o = torch.empty_like(w)
+        hr = R2cFftHandler(n, np.float32); hc = FftHandler(n, np.float32)
+        run("cfg3A ndfft_r2c axis=0 8192x8192 f32", ndfft_r2c, x, w, hr, 0, n * n, a.steps)
+        run("cfg3B ndfft axis=1 4097x8192 c64", ndfft, w, o, hc, 1, m * n, a.steps)
+        run("cfg3A' ndifft_r2c axis=0 -> 8192x8192 f32", ndifft_r2c, w, x, hr, 0, n * n, a.steps)
+        xr = torch.from_numpy(synth.real_array((n, n), np.float32)).to(dev); wr = torch.empty((n, m), dtype=torch.complex64, device=dev)
+        run("(rows) ndfft_r2c axis=1 8192x8192 f32", ndfft_r2c, xr, wr, hr, 1, n * n, a.steps)
+    if want("cfg4"):
+        x = torch.from_numpy(synth.real_array((256, 256, 512))).to(dev); y = torch.empty_like(x)
+        h = DctHandler(512)
+        for nm, fn in (("nddct2", nddct2), ("nddct3", nddct3), ("nddct1", nddct1), ("nddct4", nddct4)):
+            run(f"cfg4 {nm} axis=2 256x256x512 f64", fn, x, y, h, 2, x.numel(), a.steps)
+        h1 = DctHandler(256)
+        run("cfg4' nddct2 axis=1 256x256x512 f64", nddct2, x, y, h1, 1, x.numel(), a.steps)
+        run("cfg4'' nddct2 axis=0 256x256x512 f64", nddct2, x, y, h1, 0, x.numel(), a.steps)
+    if want("cfg5"):
+        x = torch.from_numpy(synth.complex_array((8192, 4096))).to(dev); y = torch.empty_like(x)
+        run("cfg5 shard ndfft axis=1 8192x4096 c128", ndfft, x, y, FftHandler(4096), 1, x.numel(), a.steps)
+    if want("refbench"):
+        for n in (128, 264, 512, 1024):
+            x = torch.from_numpy(synth.bench_fill_complex((n, n))).to(dev); y = torch.empty_like(x)
+            run(f"refbench fft2d n={n} axis=0 c128", ndfft, x, y, FftHandler(n), 0, n * n, a.steps)
+        for n in (129, 265, 513, 1025):
+            x = torch.from_numpy(np.arange(n * n, dtype=np.float64).reshape(n, n)).to(dev); y = torch.empty_like(x)
+            run(f"refbench dct2d n={n} axis=0 f64", nddct1, x, y, DctHandler(n), 0, n * n, a.steps)
+    if want("pow2sweep"):
+        for rdt, cdt in ((np.float64, np.complex128), (np.float32, np.complex64)):
+            for n in (64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384):
+                rows = (1 << 24) // n
+                x = torch.from_numpy(synth.complex_array((rows, n), cdt)).to(dev); y = torch.empty_like(x)
+                run(f"pow2 ndfft axis=1 {rows}x{n} {np.dtype(cdt).name}", ndfft, x, y, FftHandler(n, rdt), 1, x.numel(), a.steps)
+
+
+if __name__ == "__main__":
+    main()
