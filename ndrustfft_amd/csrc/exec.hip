@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <string>
 
 #include "engine.h"
 
@@ -154,11 +156,10 @@ static int dispatch_generic(const Problem &P, const void *d_in, void *d_out, con
     a.load_mode = (P.xs == 1 || P.xlen == 1 || !last_in1) ? IO_ROW : IO_COL;
     a.store_mode = (P.ys == 1 || P.ylen == 1 || !last_out1) ? IO_ROW : IO_COL;
 
-    // LDS pitch (complex elements): FFT length (or Bluestein M) and both raw lanes must fit
-    const int in_c = a.in_cplx ? a.n_in : (a.n_in + 1) / 2, out_c = a.out_cplx ? a.n_out : (a.n_out + 1) / 2;
-    int need = std::max(std::max(c.blue ? c.M : c.F, 1), std::max(in_c, out_c));
-    if (gop == G_R2C_ODD) need = std::max(need, a.n_in);
-    int pitch = need | 1;   // odd pitch: lanes land in different banks for the IO_COL transposes
+    // LDS pitch (complex elements): the padded FFT buffer (or Bluestein M) and the raw input lane must fit
+    const int in_c = a.in_cplx ? a.n_in : (a.n_in + 1) / 2;
+    const int len = std::max(c.blue ? c.M : c.F, 1);
+    const int pitch = std::max(generic_z_len(len), in_c) | 1;   // odd: lanes land in different banks for the IO_COL transposes
     const size_t csize = 2 * sizeof(T);
     const size_t lds_cap = 160 * 1024;
     if (generic_lds_bytes(1, pitch, csize) > lds_cap) {
@@ -181,12 +182,60 @@ static int dispatch_generic(const Problem &P, const void *d_in, void *d_out, con
     if ((int64_t)lpb > P.nlanes) lpb = (int)P.nlanes;
     // keep every CU busy: prefer >= 1024 blocks when lanes allow
     while (lpb > 1 && !col && (P.nlanes + lpb - 1) / lpb < 1024) lpb = (lpb + 1) / 2;
-    a.lpb = lpb; a.pitch = pitch;
+    int lpb_log = 0;
+    if (col) {   // the across-lanes thread map needs a power of two
+        while ((2 << lpb_log) <= lpb) ++lpb_log;
+        lpb = 1 << lpb_log;
+    }
+    a.lpb = lpb; a.pitch = pitch; a.lpb_log = lpb_log;
     const size_t lds = generic_lds_bytes(lpb, pitch, csize);
-    const int64_t work = (int64_t)lpb * std::max(c.blue ? c.M : c.F, std::max(a.n_in, a.n_out));
-    int threads = work >= 16384 ? 1024 : work >= 4096 ? 512 : work >= 1024 ? 256 : work >= 256 ? 128 : 64;
+    // power-of-two thread maps: threads per lane in the FFT phases (~ one radix-4 butterfly each) and in row IO
+    int fft_tpl = 1; while (fft_tpl < len / 4 && fft_tpl < 1024) fft_tpl <<= 1;
+    int threads = 64; while (threads < lpb * fft_tpl && threads < 1024) threads <<= 1;
+    if (col) while (threads < 4 * lpb && threads < 1024) threads <<= 1;
+    fft_tpl = std::min(fft_tpl, threads);
+    int io_tpl = 1; while (io_tpl < std::max(a.n_in, a.n_out) && io_tpl < threads) io_tpl <<= 1;
+    a.fft_tpl_log = 0; while ((1 << a.fft_tpl_log) < fft_tpl) ++a.fft_tpl_log;
+    a.io_tpl_log = 0; while ((1 << a.io_tpl_log) < io_tpl) ++a.io_tpl_log;
     set_last_path(col ? "generic_col" : (P.xs == 1 || P.xlen == 1) && (P.ys == 1 || P.ylen == 1) ? "generic_row" : "generic_strided");
     return launch_generic<T>(a, threads, lds, stream);
+}
+
+// per-(host thread, stream) scratch for the transpose route; grows, never shrinks
+struct Scratch { void *p = nullptr; size_t cap = 0; };
+static thread_local std::map<hipStream_t, Scratch> g_scratch[2];
+static int get_scratch(int which, hipStream_t s, size_t bytes, void **out) {
+    Scratch &sc = g_scratch[which][s];
+    if (bytes > sc.cap) {
+        if (sc.p) { NDFFT_HIP(hipStreamSynchronize(s)); NDFFT_HIP(hipFree(sc.p)); sc.p = nullptr; sc.cap = 0; }
+        NDFFT_HIP(hipMalloc(&sc.p, bytes));
+        sc.cap = bytes;
+    }
+    *out = sc.p;
+    return NDFFT_OK;
+}
+
+static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t stream);
+
+// Long lanes on a non-contiguous axis of a C-layout array, viewed as (outer, n, inner):
+// transpose -> row transform on contiguous lanes -> transpose back.
+static int dispatch_transposed(const Problem &P, const void *d_in, void *d_out, hipStream_t stream, int64_t outer,
+                               int64_t inner, size_t ein, size_t eout) {
+    const int64_t n_in = P.xlen, n_out = P.ylen;
+    void *s1, *s2;
+    int rc;
+    if ((rc = get_scratch(0, stream, (size_t)(outer * inner * n_in) * ein, &s1))) return rc;
+    if ((rc = get_scratch(1, stream, (size_t)(outer * inner * n_out) * eout, &s2))) return rc;
+    // in[o][j][i] -> s1[o][i][j]
+    if ((rc = launch_transpose(d_in, s1, outer, n_in, inner, inner, n_in, n_in * inner, inner * n_in, (int)ein, stream))) return rc;
+    Problem Q = P;
+    Q.xs = Q.ys = 1;
+    Q.b.clear();
+    Q.b.push_back({outer * inner, n_in, n_out});
+    if ((rc = dispatch(Q, s1, s2, stream))) return rc;
+    // s2[o][i][k] -> out[o][k][i]
+    if ((rc = launch_transpose(s2, d_out, outer, inner, n_out, n_out, inner, inner * n_out, n_out * inner, (int)eout, stream))) return rc;
+    return NDFFT_OK;
 }
 
 static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t stream) {
@@ -205,6 +254,31 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
         a.twp = dt->cfg[CFG_MAIN].twp;
         set_last_path("pow2_reg");
         return launch_pow2(plan->dtype, (int)plan->n, a, stream);
+    }
+    // strided axis of a C-layout array whose lanes are too long for a useful LDS tile of adjacent
+    // lanes (< 128 B contiguous per tile row): go through the batched transpose
+    if (P.xs != 1 && P.ys != 1 && P.xlen > 1 && !P.b.empty() && P.b.back().sin == 1 && P.b.back().sout == 1 && P.b.size() <= 2) {
+        const int64_t inner = P.b.back().shape;
+        const int64_t outer = P.b.size() == 2 ? P.b[0].shape : 1;
+        const size_t r = real_size(plan->dtype);
+        const size_t ein = op_in_cplx(P.op) ? 2 * r : r, eout = op_out_cplx(P.op) ? 2 * r : r;
+        const bool c_layout = P.xs == inner && P.ys == inner &&
+                              (P.b.size() == 1 || (P.b[0].sin == P.xlen * inner && P.b[0].sout == P.ylen * inner));
+        // LDS bytes one lane needs in the generic kernel (two padded complex buffers)
+        const int slot = P.op == NDFFT_OP_DCT1 && plan->n > 1 ? CFG_DCT1 : P.op == NDFFT_OP_DCT4 ? CFG_DCT4 : CFG_MAIN;
+        const FftConfig &c = plan->cfg[slot];
+        const size_t per_lane = 2 * (size_t)generic_z_len(std::max(c.blue ? c.M : c.F, 1)) * 2 * r;
+        const size_t fit = (160 * 1024 - 2048) / std::max<size_t>(per_lane, 1);
+        const size_t row_bytes = std::min<size_t>(fit, (size_t)inner) * std::min(ein, eout);
+        if (c_layout && row_bytes < 128 && inner >= 16) {
+            int rc2 = dispatch_transposed(P, d_in, d_out, stream, outer, inner, ein, eout);
+            if (!rc2) {
+                static thread_local std::string path;
+                path = std::string("transpose+") + last_path();
+                set_last_path(path.c_str());
+            }
+            return rc2;
+        }
     }
     return plan->dtype == NDFFT_F32 ? dispatch_generic<float>(P, d_in, d_out, *dt, stream)
                                     : dispatch_generic<double>(P, d_in, d_out, *dt, stream);

@@ -17,39 +17,57 @@
 
 namespace ndfft {
 
-constexpr size_t kGenHeaderBytes = 2 * kMaxLpb * sizeof(int64_t) + 2 * kMaxPasses * sizeof(int32_t);   // 1152, 16-aligned
+// LDS header: per-lane global offsets, radix lists and per-pass fast-division constants
+struct GenHeader {
+    int64_t off_in[kMaxLpb], off_out[kMaxLpb];
+    int32_t radix[kMaxPasses], radixM[kMaxPasses];
+};
+constexpr size_t kGenHeaderBytes = (sizeof(GenHeader) + 15) & ~size_t(15);
 
 template <typename T> struct GenCtx {
-    int64_t *off_in, *off_out;   // per-lane global offsets (elements)
-    int32_t *radix, *radixM;     // radix lists copied out of the kernarg segment
+    GenHeader *h;
     cpx<T> *buf[2];
     int lanes;                   // lanes this block really owns (<= lpb)
+    int fl, fj0, fstep, flstep;  // FFT-phase thread map: lane = fl (+= flstep), index = fj0 (+= fstep)
 };
+
+// Z buffers are padded by one element every 8 so that the stride-R writes of the first radix
+// passes (R = 4, 8: addresses 8j+q -> 9j+q) spread over all LDS banks for 8- and 16-byte elements
+__device__ __forceinline__ int zi(int p) { return p + (p >> 3); }
+
+// j mod d for j < 2^17, d < 2^15, with m = ceil(2^32 / d)
+__device__ __forceinline__ int fast_mod(int j, int d, uint32_t m) {
+    const uint32_t q = (uint32_t)(((uint64_t)(uint32_t)j * m) >> 32);
+    return j - (int)q * d;
+}
 
 // ---------------------------------------------------------------------------------------------
 // one Stockham pass over all lanes of the block
 // ---------------------------------------------------------------------------------------------
 template <typename T, int R>
-__device__ __forceinline__ void stockham_pass(const cpx<T> *__restrict__ src, cpx<T> *__restrict__ dst,
-                                              const cpx<T> *__restrict__ tw, int len, int Ns, int lanes,
-                                              int pitch) {
-    const int nb = len / R, total = lanes * nb, tws = len / (Ns * R);
-    for (int b = threadIdx.x; b < total; b += blockDim.x) {
-        const int l = b / nb, j = b - l * nb, k = j % Ns;
+__device__ __forceinline__ void stockham_pass(const GenCtx<T> &c, const cpx<T> *__restrict__ src, cpx<T> *__restrict__ dst,
+                                              const cpx<T> *__restrict__ tw, int len, int Ns, int pitch) {
+    const int nb = len / R, tws = len / (Ns * R);
+    const uint32_t magic = Ns > 1 ? (uint32_t)((0x100000000ull + (uint32_t)Ns - 1) / (uint32_t)Ns) : 0u;
+    for (int l = c.fl; l < c.lanes; l += c.flstep) {
         const cpx<T> *s = src + l * pitch;
         cpx<T> *d = dst + l * pitch;
-        cpx<T> v[R];
+        for (int j = c.fj0; j < nb; j += c.fstep) {
+            cpx<T> v[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) v[r] = s[j + r * nb];
-        if (Ns > 1) {
-            const int kt = k * tws;
+            for (int r = 0; r < R; ++r) v[r] = s[zi(j + r * nb)];
+            int k = 0;
+            if (Ns > 1) {
+                k = fast_mod(j, Ns, magic);
+                const int kt = k * tws;
 #pragma unroll
-            for (int r = 1; r < R; ++r) v[r] = cmul(v[r], tw[r * kt]);
+                for (int r = 1; r < R; ++r) v[r] = cmul(v[r], tw[r * kt]);
+            }
+            Bfly<T, R>::run(v);
+            const int o = (j - k) * R + k;
+#pragma unroll
+            for (int q = 0; q < R; ++q) d[zi(o + q * Ns)] = v[q];
         }
-        Bfly<T, R>::run(v);
-        const int o = (j - k) * R + k;
-#pragma unroll
-        for (int q = 0; q < R; ++q) d[o + q * Ns] = v[q];
     }
 }
 
@@ -64,14 +82,14 @@ __device__ int run_passes(GenCtx<T> &c, int cur, int len, int npass, const int32
         const cpx<T> *s = c.buf[cur];
         cpx<T> *d = c.buf[cur ^ 1];
         switch (R) {
-            case 2: stockham_pass<T, 2>(s, d, tw, len, Ns, c.lanes, pitch); break;
-            case 3: stockham_pass<T, 3>(s, d, tw, len, Ns, c.lanes, pitch); break;
-            case 4: stockham_pass<T, 4>(s, d, tw, len, Ns, c.lanes, pitch); break;
-            case 5: stockham_pass<T, 5>(s, d, tw, len, Ns, c.lanes, pitch); break;
-            case 7: stockham_pass<T, 7>(s, d, tw, len, Ns, c.lanes, pitch); break;
-            case 8: stockham_pass<T, 8>(s, d, tw, len, Ns, c.lanes, pitch); break;
-            case 11: stockham_pass<T, 11>(s, d, tw, len, Ns, c.lanes, pitch); break;
-            default: stockham_pass<T, 13>(s, d, tw, len, Ns, c.lanes, pitch); break;
+            case 2: stockham_pass<T, 2>(c, s, d, tw, len, Ns, pitch); break;
+            case 3: stockham_pass<T, 3>(c, s, d, tw, len, Ns, pitch); break;
+            case 4: stockham_pass<T, 4>(c, s, d, tw, len, Ns, pitch); break;
+            case 5: stockham_pass<T, 5>(c, s, d, tw, len, Ns, pitch); break;
+            case 7: stockham_pass<T, 7>(c, s, d, tw, len, Ns, pitch); break;
+            case 8: stockham_pass<T, 8>(c, s, d, tw, len, Ns, pitch); break;
+            case 11: stockham_pass<T, 11>(c, s, d, tw, len, Ns, pitch); break;
+            default: stockham_pass<T, 13>(c, s, d, tw, len, Ns, pitch); break;
         }
         cur ^= 1;
         Ns *= R;
@@ -81,7 +99,8 @@ __device__ int run_passes(GenCtx<T> &c, int cur, int len, int npass, const int32
 }
 
 // ---------------------------------------------------------------------------------------------
-// PRE: Z[i] from the raw lane (raw real lanes are addressed as T*, raw complex as cpx<T>*)
+// PRE: Z[i] from the raw lane (raw real lanes are addressed as T*, raw complex as cpx<T>*; raw
+// lanes are NOT padded)
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ cpx<T> c2r_input(const GenArgs<T> &a, const cpx<T> *X, int k, int F_nyq) {
@@ -100,12 +119,12 @@ __device__ __forceinline__ cpx<T> herm_fold(cpx<T> a_, cpx<T> b_, cpx<T> w) {
     return mk<T>(s.x - t.y, -(s.y + t.x));
 }
 
-template <typename T>
+template <typename T, int OP>
 __device__ __forceinline__ cpx<T> pre_elem(const GenArgs<T> &a, const void *raw_, int i) {
     const T *xr = (const T *)raw_;
     const cpx<T> *xc = (const cpx<T> *)raw_;
     const int n = a.n, F = a.F;
-    switch (a.op) {
+    switch (OP) {
         case G_C2R_EVEN: {
             cpx<T> A = c2r_input(a, xc, i, F), B = cconj(c2r_input(a, xc, F - i, F));
             return herm_fold<T>(A, B, a.aux1[i]);
@@ -155,50 +174,50 @@ __device__ __forceinline__ cpx<T> pre_elem(const GenArgs<T> &a, const void *raw_
 }
 
 // ---------------------------------------------------------------------------------------------
-// POST: output element q from the FFT result `res` (length F)
+// POST: output element q from the FFT result `res` (length F, padded by zi)
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ cpx<T> r2c_split(const cpx<T> *res, int k, int F, cpx<T> w) {
     // X[k] = (Z[k] + conj Z[F-k])/2 + w (Z[k] - conj Z[F-k])/(2i)
-    cpx<T> A = res[k == F ? 0 : k], B = cconj(res[k == 0 ? 0 : F - k]);
+    cpx<T> A = res[zi(k == F ? 0 : k)], B = cconj(res[zi(k == 0 ? 0 : F - k)]);
     cpx<T> e = mk<T>((A.x + B.x) * (T)0.5, (A.y + B.y) * (T)0.5);
     cpx<T> o = mk<T>((A.y - B.y) * (T)0.5, -(A.x - B.x) * (T)0.5);
     return cadd(e, cmul(o, w));
 }
 
-template <typename T> __device__ __forceinline__ T post_real(const GenArgs<T> &a, const cpx<T> *res, int q) {
+template <typename T, int OP> __device__ __forceinline__ T post_real(const GenArgs<T> &a, const cpx<T> *res, int q) {
     const int n = a.n, F = a.F;
-    switch (a.op) {
-        case G_C2R_EVEN: { cpx<T> c = res[q >> 1]; return (q & 1) ? -c.y : c.x; }
-        case G_C2R_ODD: return res[q].x;
+    switch (OP) {
+        case G_C2R_EVEN: { cpx<T> c = res[zi(q >> 1)]; return (q & 1) ? -c.y : c.x; }
+        case G_C2R_ODD: return res[zi(q)].x;
         case G_DCT1: return (T)0.5 * r2c_split<T>(res, q, F, a.aux1[q]).x;
         case G_DCT2_EVEN: {
             const int k = q <= F ? q : n - q;
             cpx<T> t = cmul(r2c_split<T>(res, k, F, a.aux1[k]), a.aux2[k]);
             return q <= F ? t.x : -t.y;
         }
-        case G_DCT2_ODD: { cpx<T> t = cmul(res[q], a.aux2[q]); return t.x; }
+        case G_DCT2_ODD: { cpx<T> t = cmul(res[zi(q)], a.aux2[q]); return t.x; }
         case G_DCT3_EVEN: {
             const int p = (q & 1) ? n - 1 - (q >> 1) : (q >> 1);
-            cpx<T> c = res[p >> 1];
+            cpx<T> c = res[zi(p >> 1)];
             return (p & 1) ? -c.y : c.x;
         }
-        case G_DCT3_ODD: { const int p = (q & 1) ? n - 1 - (q >> 1) : (q >> 1); return res[p].x; }
+        case G_DCT3_ODD: { const int p = (q & 1) ? n - 1 - (q >> 1) : (q >> 1); return res[zi(p)].x; }
         case G_DCT4_EVEN: {
             const int k = (q & 1) ? (n - 1 - q) >> 1 : q >> 1;
-            cpx<T> u = cmul(res[k], a.aux2[k]);
+            cpx<T> u = cmul(res[zi(k)], a.aux2[k]);
             return (q & 1) ? -u.y : u.x;
         }
-        case G_DCT4_ODD: { cpx<T> u = cmul(res[q], a.aux2[q]); return u.x; }
+        case G_DCT4_ODD: { cpx<T> u = cmul(res[zi(q)], a.aux2[q]); return u.x; }
         default: return (T)0;
     }
 }
 
-template <typename T> __device__ __forceinline__ cpx<T> post_cplx(const GenArgs<T> &a, const cpx<T> *res, int q) {
-    switch (a.op) {
-        case G_C2C_INV: { cpx<T> c = res[q]; return mk<T>(c.x * a.scale, -c.y * a.scale); }   // lib.rs:326-330
+template <typename T, int OP> __device__ __forceinline__ cpx<T> post_cplx(const GenArgs<T> &a, const cpx<T> *res, int q) {
+    switch (OP) {
+        case G_C2C_INV: { cpx<T> c = res[zi(q)]; return mk<T>(c.x * a.scale, -c.y * a.scale); }   // lib.rs:326-330
         case G_R2C_EVEN: return r2c_split<T>(res, q, a.F, a.aux1[q]);
-        default: return res[q];   // G_C2C_FWD, G_R2C_ODD
+        default: return res[zi(q)];   // G_C2C_FWD, G_R2C_ODD
     }
 }
 
@@ -215,99 +234,102 @@ __device__ __forceinline__ int64_t lane_offset(const LaneGeom &g, int64_t lane) 
     return off;
 }
 
-template <typename T> __global__ __launch_bounds__(1024) void k_generic(const GenArgs<T> a) {
+template <typename T, int OP> __global__ __launch_bounds__(1024) void k_generic(const GenArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     GenCtx<T> c;
-    c.off_in = (int64_t *)smem;
-    c.off_out = c.off_in + kMaxLpb;
-    c.radix = (int32_t *)(c.off_out + kMaxLpb);
-    c.radixM = c.radix + kMaxPasses;
+    c.h = (GenHeader *)smem;
     c.buf[0] = (cpx<T> *)(smem + kGenHeaderBytes);
     c.buf[1] = c.buf[0] + (size_t)a.lpb * a.pitch;
     const int64_t lane0 = (int64_t)blockIdx.x * a.lpb;
     c.lanes = (int)min((int64_t)a.lpb, a.nlanes - lane0);
     const int tid = threadIdx.x, nthr = blockDim.x, pitch = a.pitch;
+    // division-free thread maps (all counts are powers of two chosen on the host)
+    c.fl = tid >> a.fft_tpl_log; c.fj0 = tid & ((1 << a.fft_tpl_log) - 1);
+    c.fstep = 1 << a.fft_tpl_log; c.flstep = nthr >> a.fft_tpl_log;
 
-    if (tid < kMaxPasses) { c.radix[tid] = a.radix[tid]; c.radixM[tid] = a.radixM[tid]; }
+    if (tid < kMaxPasses) { c.h->radix[tid] = a.radix[tid]; c.h->radixM[tid] = a.radixM[tid]; }
     if (tid < c.lanes) {
-        c.off_in[tid] = lane_offset(a.gin, lane0 + tid);
-        c.off_out[tid] = lane_offset(a.gout, lane0 + tid);
+        c.h->off_in[tid] = lane_offset(a.gin, lane0 + tid);
+        c.h->off_out[tid] = lane_offset(a.gout, lane0 + tid);
     }
     __syncthreads();
 
     // ---- LOAD ------------------------------------------------------------------------------
     // ops whose PRE is elementwise load straight into Z (buffer 0); the others stage the raw lane
     // in buffer 1 and fold it into buffer 0.
-    const bool direct = a.op == G_C2C_FWD || a.op == G_C2C_INV || a.op == G_R2C_EVEN || a.op == G_R2C_ODD;
+    constexpr bool direct = OP == G_C2C_FWD || OP == G_C2C_INV || OP == G_R2C_EVEN || OP == G_R2C_ODD;
+    constexpr bool in_cplx = OP == G_C2C_FWD || OP == G_C2C_INV || OP == G_C2R_EVEN || OP == G_C2R_ODD;
+    constexpr bool out_cplx = OP == G_C2C_FWD || OP == G_C2C_INV || OP == G_R2C_EVEN || OP == G_R2C_ODD;
     {
-        const int n_in = a.n_in, total = c.lanes * n_in;
+        int l0, lstep, j0, jstep;
+        if (a.load_mode == IO_ROW) { l0 = tid >> a.io_tpl_log; lstep = nthr >> a.io_tpl_log; j0 = tid & ((1 << a.io_tpl_log) - 1); jstep = 1 << a.io_tpl_log; }
+        else { l0 = tid & ((1 << a.lpb_log) - 1); lstep = 1 << a.lpb_log; j0 = tid >> a.lpb_log; jstep = nthr >> a.lpb_log; }
+        const int n_in = a.n_in;
         const int64_t as = a.gin.axis_stride;
-        for (int idx = tid; idx < total; idx += nthr) {
-            int l, j;
-            if (a.load_mode == IO_ROW) { l = idx / n_in; j = idx - l * n_in; }
-            else { j = idx / c.lanes; l = idx - j * c.lanes; }
-            const int64_t g = c.off_in[l] + (int64_t)j * as;
-            if (a.in_cplx) {
-                cpx<T> v = ((const cpx<T> *)a.in)[g];
-                if (a.op == G_C2C_INV) v.y = -v.y;
-                c.buf[direct ? 0 : 1][l * pitch + j] = v;
-            } else {
-                const T v = ((const T *)a.in)[g];
-                if (a.op == G_R2C_ODD) c.buf[0][l * pitch + j] = mk<T>(v, (T)0);
-                else ((T *)c.buf[direct ? 0 : 1])[l * 2 * pitch + j] = v;   // R2C_EVEN packs pairs in place
+        for (int l = l0; l < c.lanes; l += lstep) {
+            const int64_t base = c.h->off_in[l];
+            for (int j = j0; j < n_in; j += jstep) {
+                const int64_t g = base + (int64_t)j * as;
+                if (in_cplx) {
+                    cpx<T> v = ((const cpx<T> *)a.in)[g];
+                    if (OP == G_C2C_INV) v.y = -v.y;
+                    if (direct) c.buf[0][l * pitch + zi(j)] = v; else c.buf[1][l * pitch + j] = v;
+                } else {
+                    const T v = ((const T *)a.in)[g];
+                    if (OP == G_R2C_ODD) c.buf[0][l * pitch + zi(j)] = mk<T>(v, (T)0);
+                    else if (OP == G_R2C_EVEN) ((T *)c.buf[0])[(l * pitch + zi(j >> 1)) * 2 + (j & 1)] = v;   // packs pairs in place
+                    else ((T *)c.buf[1])[l * 2 * pitch + j] = v;
+                }
             }
         }
     }
     // ---- PRE -------------------------------------------------------------------------------
     if (!direct) {
         __syncthreads();
-        const int F = a.F, total = c.lanes * F;
-        for (int idx = tid; idx < total; idx += nthr) {
-            const int l = idx / F, i = idx - l * F;
-            c.buf[0][l * pitch + i] = pre_elem<T>(a, (const void *)(c.buf[1] + l * pitch), i);
-        }
+        const int F = a.F;
+        for (int l = c.fl; l < c.lanes; l += c.flstep)
+            for (int i = c.fj0; i < F; i += c.fstep)
+                c.buf[0][l * pitch + zi(i)] = pre_elem<T, OP>(a, (const void *)(c.buf[1] + l * pitch), i);
     }
     // ---- FFT -------------------------------------------------------------------------------
     int cur = 0;
     if (!a.blue) {
-        cur = run_passes<T>(c, 0, a.F, a.npass, c.radix, a.tw, pitch);
+        cur = run_passes<T>(c, 0, a.F, a.npass, c.h->radix, a.tw, pitch);
     } else {
         // Bluestein: X[k] = chirp[k] * IFFT_M( FFT_M(z * chirp, zero padded) * bhat )[k]
         __syncthreads();
-        const int F = a.F, M = a.M, total = c.lanes * M;
-        for (int idx = tid; idx < total; idx += nthr) {
-            const int l = idx / M, i = idx - l * M;
+        const int F = a.F, M = a.M;
+        for (int l = c.fl; l < c.lanes; l += c.flstep) {
             cpx<T> *z = c.buf[0] + l * pitch;
-            z[i] = i < F ? cmul(z[i], a.chirp[i]) : mk<T>((T)0, (T)0);
+            for (int i = c.fj0; i < M; i += c.fstep) z[zi(i)] = i < F ? cmul(z[zi(i)], a.chirp[i]) : mk<T>((T)0, (T)0);
         }
-        cur = run_passes<T>(c, 0, M, a.npassM, c.radixM, a.twM, pitch);
-        for (int idx = tid; idx < total; idx += nthr) {
-            const int l = idx / M, i = idx - l * M;
+        cur = run_passes<T>(c, 0, M, a.npassM, c.h->radixM, a.twM, pitch);
+        for (int l = c.fl; l < c.lanes; l += c.flstep) {
             cpx<T> *z = c.buf[cur] + l * pitch;
-            z[i] = cconj(cmul(z[i], a.bhat[i]));          // bhat carries 1/M
+            for (int i = c.fj0; i < M; i += c.fstep) z[zi(i)] = cconj(cmul(z[zi(i)], a.bhat[i]));   // bhat carries 1/M
         }
-        cur = run_passes<T>(c, cur, M, a.npassM, c.radixM, a.twM, pitch);
-        const int totF = c.lanes * F;
-        for (int idx = tid; idx < totF; idx += nthr) {
-            const int l = idx / F, i = idx - l * F;
+        cur = run_passes<T>(c, cur, M, a.npassM, c.h->radixM, a.twM, pitch);
+        for (int l = c.fl; l < c.lanes; l += c.flstep) {
             cpx<T> *z = c.buf[cur] + l * pitch;
-            z[i] = cmul(cconj(z[i]), a.chirp[i]);
+            for (int i = c.fj0; i < F; i += c.fstep) z[zi(i)] = cmul(cconj(z[zi(i)]), a.chirp[i]);
         }
         __syncthreads();
     }
     // ---- STORE (with POST gather) ----------------------------------------------------------
     {
-        const int n_out = a.n_out, total = c.lanes * n_out;
+        int l0, lstep, j0, jstep;
+        if (a.store_mode == IO_ROW) { l0 = tid >> a.io_tpl_log; lstep = nthr >> a.io_tpl_log; j0 = tid & ((1 << a.io_tpl_log) - 1); jstep = 1 << a.io_tpl_log; }
+        else { l0 = tid & ((1 << a.lpb_log) - 1); lstep = 1 << a.lpb_log; j0 = tid >> a.lpb_log; jstep = nthr >> a.lpb_log; }
+        const int n_out = a.n_out;
         const int64_t as = a.gout.axis_stride;
-        const cpx<T> *resb = c.buf[cur];
-        for (int idx = tid; idx < total; idx += nthr) {
-            int l, q;
-            if (a.store_mode == IO_ROW) { l = idx / n_out; q = idx - l * n_out; }
-            else { q = idx / c.lanes; l = idx - q * c.lanes; }
-            const int64_t g = c.off_out[l] + (int64_t)q * as;
-            const cpx<T> *res = resb + l * pitch;
-            if (a.out_cplx) ((cpx<T> *)a.out)[g] = post_cplx<T>(a, res, q);
-            else ((T *)a.out)[g] = post_real<T>(a, res, q);
+        for (int l = l0; l < c.lanes; l += lstep) {
+            const int64_t base = c.h->off_out[l];
+            const cpx<T> *res = c.buf[cur] + l * pitch;
+            for (int q = j0; q < n_out; q += jstep) {
+                const int64_t g = base + (int64_t)q * as;
+                if (out_cplx) ((cpx<T> *)a.out)[g] = post_cplx<T, OP>(a, res, q);
+                else ((T *)a.out)[g] = post_real<T, OP>(a, res, q);
+            }
         }
     }
 }
@@ -315,19 +337,32 @@ template <typename T> __global__ __launch_bounds__(1024) void k_generic(const Ge
 size_t generic_lds_bytes(int lpb, int pitch, size_t csize) {
     return kGenHeaderBytes + 2 * (size_t)lpb * (size_t)pitch * csize;
 }
+int generic_z_len(int len) { return len + (len >> 3) + 1; }
 
-template <typename T> int launch_generic(const GenArgs<T> &a, int threads, size_t lds_bytes, hipStream_t s) {
+template <typename T, int OP> static int launch_op(const GenArgs<T> &a, int threads, size_t lds_bytes, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_generic<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_generic<T, OP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const int64_t nblk = (a.nlanes + a.lpb - 1) / a.lpb;
     if (nblk <= 0) return NDFFT_OK;
     if (nblk > 0x7fffffffLL) return fail(NDFFT_ERR_UNSUPPORTED, "too many lanes for one launch");
-    hipLaunchKernelGGL(k_generic<T>, dim3((unsigned)nblk), dim3(threads), lds_bytes, s, a);
+    hipLaunchKernelGGL((k_generic<T, OP>), dim3((unsigned)nblk), dim3(threads), lds_bytes, s, a);
     NDFFT_HIP(hipGetLastError());
     return NDFFT_OK;
+}
+
+template <typename T> int launch_generic(const GenArgs<T> &a, int threads, size_t lds_bytes, hipStream_t s) {
+    switch (a.op) {
+#define NDFFT_OPCASE(OP) case OP: return launch_op<T, OP>(a, threads, lds_bytes, s);
+        NDFFT_OPCASE(G_C2C_FWD) NDFFT_OPCASE(G_C2C_INV) NDFFT_OPCASE(G_R2C_EVEN) NDFFT_OPCASE(G_R2C_ODD)
+        NDFFT_OPCASE(G_C2R_EVEN) NDFFT_OPCASE(G_C2R_ODD) NDFFT_OPCASE(G_DCT1) NDFFT_OPCASE(G_DCT2_EVEN)
+        NDFFT_OPCASE(G_DCT2_ODD) NDFFT_OPCASE(G_DCT3_EVEN) NDFFT_OPCASE(G_DCT3_ODD) NDFFT_OPCASE(G_DCT4_EVEN)
+        NDFFT_OPCASE(G_DCT4_ODD)
+#undef NDFFT_OPCASE
+        default: return fail(NDFFT_ERR_INVALID_ARG, "bad generic op");
+    }
 }
 
 template int launch_generic<float>(const GenArgs<float> &, int, size_t, hipStream_t);

@@ -1,0 +1,57 @@
+// transpose.hip -- batched, LDS-padded 2-D transpose (gfx950).
+// out[b][c][r] = in[b][r][c].  Used when the transform axis is not the contiguous one AND a tile
+// of adjacent lanes would not fit LDS (long lanes, e.g. BASELINE cfg3-A: 8192-long f32 lanes at
+// stride 8192): lanes are made contiguous by one coalesced transpose, transformed by the row
+// kernels, and transposed back -- replacing the reference's per-lane x.to_vec() / y.assign()
+// strided copies (src/lib.rs:133-134), which touch one cache line per element.
+#include "engine.h"
+
+namespace ndfft {
+
+template <typename E, int TILE>
+__global__ __launch_bounds__(256) void k_transpose(const E *__restrict__ in, E *__restrict__ out, int64_t rows, int64_t cols,
+                                                   int64_t ld_in, int64_t ld_out, int64_t bs_in, int64_t bs_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    E(*tile)[TILE + 1] = (E(*)[TILE + 1])smem;   // +1 element of padding: column reads hit distinct banks
+    const E *src = in + (int64_t)blockIdx.z * bs_in;
+    E *dst = out + (int64_t)blockIdx.z * bs_out;
+    const int64_t c0 = (int64_t)blockIdx.x * TILE, r0 = (int64_t)blockIdx.y * TILE;
+    const int tx = threadIdx.x % TILE, ty = threadIdx.x / TILE;
+    constexpr int RSTEP = 256 / TILE;
+#pragma unroll
+    for (int i = ty; i < TILE; i += RSTEP) {
+        const int64_t r = r0 + i, c = c0 + tx;
+        if (r < rows && c < cols) tile[i][tx] = src[r * ld_in + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = ty; i < TILE; i += RSTEP) {
+        const int64_t c = c0 + i, r = r0 + tx;
+        if (r < rows && c < cols) __builtin_nontemporal_store(tile[tx][i], &dst[c * ld_out + r]);
+    }
+}
+
+struct alignas(16) E16 { double a, b; };
+typedef double E16v __attribute__((ext_vector_type(2)));
+
+int launch_transpose(const void *in, void *out, int64_t batch, int64_t rows, int64_t cols, int64_t ld_in,
+                     int64_t ld_out, int64_t bstride_in, int64_t bstride_out, int elem_bytes, hipStream_t s) {
+    if (batch <= 0 || rows <= 0 || cols <= 0) return NDFFT_OK;
+    if (batch > 65535) return fail(NDFFT_ERR_UNSUPPORTED, "transpose: batch too large");
+    if (elem_bytes == 4) {
+        dim3 g((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64), (unsigned)batch);
+        hipLaunchKernelGGL((k_transpose<float, 64>), g, dim3(256), 64 * 65 * 4, s, (const float *)in, (float *)out, rows, cols, ld_in, ld_out, bstride_in, bstride_out);
+    } else if (elem_bytes == 8) {
+        dim3 g((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64), (unsigned)batch);
+        hipLaunchKernelGGL((k_transpose<double, 64>), g, dim3(256), 64 * 65 * 8, s, (const double *)in, (double *)out, rows, cols, ld_in, ld_out, bstride_in, bstride_out);
+    } else if (elem_bytes == 16) {
+        dim3 g((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32), (unsigned)batch);
+        hipLaunchKernelGGL((k_transpose<E16v, 32>), g, dim3(256), 32 * 33 * 16, s, (const E16v *)in, (E16v *)out, rows, cols, ld_in, ld_out, bstride_in, bstride_out);
+    } else {
+        return fail(NDFFT_ERR_INVALID_ARG, "transpose: element size");
+    }
+    NDFFT_HIP(hipGetLastError());
+    return NDFFT_OK;
+}
+
+}  // namespace ndfft

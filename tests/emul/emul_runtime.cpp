@@ -34,10 +34,10 @@ void __syncthreads() {
 void emul::launch(void (*fn)(void *), void *arg, dim3 grid, dim3 block, size_t lds_bytes) {
     if (lds_bytes > 160 * 1024) { fprintf(stderr, "emul: LDS request %zu > 160 KiB\n", lds_bytes); abort(); }
     g_fn = fn; g_arg = arg;
-    blockDim = {block.x, 1, 1}; gridDim = {grid.x, 1, 1};
+    blockDim = {block.x, 1, 1}; gridDim = {grid.x, grid.y, grid.z};
     const size_t kStack = 256 * 1024;
     if (g_f.size() < block.x) g_f.resize(block.x);
-    for (unsigned b = 0; b < grid.x; ++b) {
+    for (unsigned bz = 0; bz < grid.z; ++bz) for (unsigned by = 0; by < grid.y; ++by) for (unsigned b = 0; b < grid.x; ++b) {
         memset(ndfft::smem, 0xA5, sizeof ndfft::smem);   // poison: uninitialised LDS reads show up
         for (unsigned t = 0; t < block.x; ++t) {
             Fiber &f = g_f[t];
@@ -56,7 +56,7 @@ void emul::launch(void (*fn)(void *), void *arg, dim3 grid, dim3 block, size_t l
                 if (g_f[t].done) continue;
                 any = true;
                 g_cur = (int)t;
-                threadIdx = {t, 0, 0}; blockIdx = {b, 0, 0};
+                threadIdx = {t, 0, 0}; blockIdx = {b, by, bz};
                 swapcontext(&g_main, &g_f[t].ctx);
             }
         }

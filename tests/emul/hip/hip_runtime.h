@@ -48,17 +48,15 @@ inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { ret
 void __syncthreads();
 
 namespace emul {
-// runs fn(arg) as grid x block fibers, with lds_bytes of zero-initialised "LDS" per block
+// runs fn(arg) as grid x block fibers, with lds_bytes of "LDS" per block
 void launch(void (*fn)(void *), void *arg, dim3 grid, dim3 block, size_t lds_bytes);
-template <typename... A> struct Pack;
-template <typename A0> struct Pack<A0> {
-    void (*k)(A0); typename std::remove_const<A0>::type a0;
-    static void tramp(void *p) { Pack *s = (Pack *)p; s->k(s->a0); }
-};
 }  // namespace emul
 
-template <typename A0, typename B0>
-inline void hipLaunchKernelGGL(void (*k)(A0), dim3 grid, dim3 block, size_t lds, hipStream_t, const B0 &a0) {
-    emul::Pack<A0> p{k, a0};
-    emul::launch(&emul::Pack<A0>::tramp, &p, grid, block, lds);
+#include <tuple>
+#include <utility>
+template <typename... KA, typename... A>
+inline void hipLaunchKernelGGL(void (*k)(KA...), dim3 grid, dim3 block, size_t lds, hipStream_t, A... a) {
+    struct Pack { void (*k)(KA...); std::tuple<typename std::decay<KA>::type...> args; };
+    Pack p{k, std::tuple<typename std::decay<KA>::type...>(a...)};
+    emul::launch([](void *q) { Pack *s = (Pack *)q; std::apply(s->k, s->args); }, &p, grid, block, lds);
 }

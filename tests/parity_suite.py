@@ -263,6 +263,16 @@ def reference_bench_shapes(L, sizes_fft=(128, 264, 512, 1024), sizes_dct=(129, 2
         assert_close(y, yo, 0, 1e-10, f"bench dct2d n={n}")
 
 
+def long_strided_lanes(L):
+    """Strategy (ii) with lanes too long for an LDS tile of adjacent lanes: the transpose route."""
+    cases = (("ndfft", (4096, 24), 0, np.float64, "transpose+pow2_reg"), ("ndifft", (4096, 24), 0, np.float64, "transpose+pow2_reg"),
+             ("ndfft_r2c", (8192, 40), 0, np.float32, "transpose+generic_row"), ("ndifft_r2c", (8192, 20), 0, np.float32, "transpose+generic_row"),
+             ("nddct2", (3, 4096, 17), 1, np.float64, "transpose+generic_row"), ("ndfft", (3000, 33), 0, np.float64, "transpose+generic_row"),
+             ("nddct3", (2, 4000, 16), 1, np.float32, "transpose+generic_row"))
+    for name, shape, axis, rdt, want in cases:
+        assert run_case(L, name, shape, axis, rdt) == want, (name, shape)
+
+
 def handler_clone_shares_plan(L):
     h = handlers.FftHandler(16, _library=L)
     h2 = h.clone()
