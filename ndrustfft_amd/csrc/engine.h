@@ -89,7 +89,7 @@ struct FftConfig {                 // one complex-FFT-of-length-F recipe + op ta
     bool blue = false; int M = 0; std::vector<int> radixM;
     HostTable tw, twM, chirp, bhat, aux1, aux2;
     // tuned power-of-two path (register-resident Stockham), when eligible
-    bool pow2 = false;
+    bool pow2 = false;             // C2C slot: pow2_kernel.h ; real-op slots: pow2_real.h
     HostTable twp;                 // per-pass transposed twiddles
 };
 
@@ -148,6 +148,12 @@ bool pow2_supported(int dtype, int n);
 // layout of the per-pass transposed twiddle table for length n (host builder in plan.cpp)
 void pow2_build_twiddles(int dtype, int n, HostTable &out);
 int launch_pow2(int dtype, int n, const Pow2Args &a, hipStream_t s);
+
+// kernels_pow2_real.hip : register-resident real-op kernels (R2C/C2R/DCT) for power-of-two inner FFT length F
+template <typename T> struct RealArgs;
+bool pow2_real_supported(int F);
+void pow2_real_build_twiddles(int F, HostTable &out);
+template <typename T> int launch_pow2_real(int gen_op, const RealArgs<T> &a, hipStream_t s);
 
 // transpose.hip : batched LDS-padded 2-D transpose, elem size 4/8/16 bytes
 // out[b][c][r] = in[b][r][c];  in pitch = ld_in elements per row, out pitch = ld_out

@@ -10,6 +10,7 @@
 #include <string>
 
 #include "engine.h"
+#include "pow2_real.h"
 
 namespace ndfft {
 
@@ -254,6 +255,39 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
         a.twp = dt->cfg[CFG_MAIN].twp;
         set_last_path("pow2_reg");
         return launch_pow2(plan->dtype, (int)plan->n, a, stream);
+    }
+    // tuned path for the real-data transforms with a power-of-two inner FFT, contiguous lanes
+    if (plan->kind != NDFFT_KIND_C2C && P.xs == 1 && P.ys == 1 && P.b.size() <= 1) {
+        const int n = (int)plan->n;
+        int slot = CFG_MAIN, gop = -1;
+        switch (P.op) {
+            case NDFFT_OP_R2C: if (n % 2 == 0) gop = G_R2C_EVEN; break;
+            case NDFFT_OP_C2R: if (n % 2 == 0) gop = G_C2R_EVEN; break;
+            case NDFFT_OP_DCT1: if (n >= 2) { gop = G_DCT1; slot = CFG_DCT1; } break;
+            case NDFFT_OP_DCT2: if (n % 2 == 0) gop = G_DCT2_EVEN; break;
+            case NDFFT_OP_DCT3: if (n % 2 == 0) gop = G_DCT3_EVEN; break;
+            case NDFFT_OP_DCT4: if (n % 2 == 0) { gop = G_DCT4_EVEN; slot = CFG_DCT4; } break;
+            default: break;
+        }
+        if (gop >= 0 && plan->cfg[slot].pow2) {
+            const FftConfig &c = plan->cfg[slot];
+            const DevConfig &d = dt->cfg[slot];
+            set_last_path("pow2_real");
+            auto fill = [&](auto &a) {
+                a.in = d_in; a.out = d_out; a.nlanes = P.nlanes;
+                a.pitch_in = P.b.empty() ? P.xlen : P.b[0].sin;
+                a.pitch_out = P.b.empty() ? P.ylen : P.b[0].sout;
+                a.n = n; a.F = c.F; a.n_in = (int)P.xlen; a.n_out = (int)P.ylen;
+            };
+            if (plan->dtype == NDFFT_F32) {
+                RealArgs<float> a; fill(a); a.scale = (float)P.scale;
+                a.aux1 = (const float2 *)d.aux1; a.aux2 = (const float2 *)d.aux2; a.twp = (const float2 *)d.twp;
+                return launch_pow2_real<float>(gop, a, stream);
+            }
+            RealArgs<double> a; fill(a); a.scale = P.scale;
+            a.aux1 = (const double2 *)d.aux1; a.aux2 = (const double2 *)d.aux2; a.twp = (const double2 *)d.twp;
+            return launch_pow2_real<double>(gop, a, stream);
+        }
     }
     // strided axis of a C-layout array whose lanes are too long for a useful LDS tile of adjacent
     // lanes (< 128 B contiguous per tile row): go through the batched transpose

@@ -14,6 +14,7 @@
 //          (replaces y.assign(&outvec), src/lib.rs:134).
 #include "butterflies.h"
 #include "engine.h"
+#include "realops.h"
 
 namespace ndfft {
 
@@ -34,6 +35,7 @@ template <typename T> struct GenCtx {
 // Z buffers are padded by one element every 8 so that the stride-R writes of the first radix
 // passes (R = 4, 8: addresses 8j+q -> 9j+q) spread over all LDS banks for 8- and 16-byte elements
 __device__ __forceinline__ int zi(int p) { return p + (p >> 3); }
+struct ZiPad8 { static __device__ __forceinline__ int map(int p) { return p + (p >> 3); } };
 
 // j mod d for j < 2^17, d < 2^15, with m = ceil(2^32 / d)
 __device__ __forceinline__ int fast_mod(int j, int d, uint32_t m) {
@@ -96,129 +98,6 @@ __device__ int run_passes(GenCtx<T> &c, int cur, int len, int npass, const int32
     }
     __syncthreads();
     return cur;
-}
-
-// ---------------------------------------------------------------------------------------------
-// PRE: Z[i] from the raw lane (raw real lanes are addressed as T*, raw complex as cpx<T>*; raw
-// lanes are NOT padded)
-// ---------------------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ cpx<T> c2r_input(const GenArgs<T> &a, const cpx<T> *X, int k, int F_nyq) {
-    // lib.rs:511-521: scale first, then force DC (and even-n Nyquist) imaginary parts to zero
-    cpx<T> v = X[k];
-    v.x *= a.scale; v.y *= a.scale;
-    if (k == 0 || k == F_nyq) v.y = (T)0;
-    return v;
-}
-
-template <typename T>
-__device__ __forceinline__ cpx<T> herm_fold(cpx<T> a_, cpx<T> b_, cpx<T> w) {
-    // Zt = (a + b) + i * conj(w) * (a - b); returns conj(Zt) (inverse FFT via forward butterflies)
-    cpx<T> s = cadd(a_, b_), d = csub(a_, b_);
-    cpx<T> t = cmul(d, cconj(w));
-    return mk<T>(s.x - t.y, -(s.y + t.x));
-}
-
-template <typename T, int OP>
-__device__ __forceinline__ cpx<T> pre_elem(const GenArgs<T> &a, const void *raw_, int i) {
-    const T *xr = (const T *)raw_;
-    const cpx<T> *xc = (const cpx<T> *)raw_;
-    const int n = a.n, F = a.F;
-    switch (OP) {
-        case G_C2R_EVEN: {
-            cpx<T> A = c2r_input(a, xc, i, F), B = cconj(c2r_input(a, xc, F - i, F));
-            return herm_fold<T>(A, B, a.aux1[i]);
-        }
-        case G_C2R_ODD: {
-            const int m = n / 2 + 1;
-            cpx<T> v = c2r_input(a, xc, i < m ? i : n - i, -1);
-            // full spectrum value is v (i<m) or conj(v); we store its conjugate
-            return i < m ? cconj(v) : v;
-        }
-        case G_DCT1: {   // even extension of length L = 2(n-1), packed two reals per complex
-            const int L = 2 * (n - 1), j0 = 2 * i, j1 = 2 * i + 1;
-            T e0 = xr[j0 < n ? j0 : L - j0], e1 = xr[j1 < n ? j1 : L - j1];
-            return mk<T>(e0 * a.scale, e1 * a.scale);
-        }
-        case G_DCT2_EVEN: {   // Makhoul: v[p] = x[2p] (p < n/2), v[p] = x[2(n-1-p)+1] otherwise
-            const int h = n / 2, p0 = 2 * i, p1 = 2 * i + 1;
-            T v0 = xr[p0 < h ? 2 * p0 : 2 * (n - 1 - p0) + 1], v1 = xr[p1 < h ? 2 * p1 : 2 * (n - 1 - p1) + 1];
-            return mk<T>(v0 * a.scale, v1 * a.scale);
-        }
-        case G_DCT2_ODD: {
-            const int h = (n + 1) / 2;
-            return mk<T>(xr[i < h ? 2 * i : 2 * (n - 1 - i) + 1] * a.scale, (T)0);
-        }
-        case G_DCT3_EVEN: {
-            // V[k] = 0.5 (x[k] - i x[n-k]) e^{+i pi k/(2n)}, k in [0,F], x[n] := 0 ; then Hermitian fold
-            const int k0 = i, k1 = F - i;
-            const T hs = (T)0.5 * a.scale;
-            cpx<T> v0 = cmul(mk<T>(xr[k0] * hs, k0 ? -xr[n - k0] * hs : (T)0), cconj(a.aux2[k0]));
-            cpx<T> v1 = cmul(mk<T>(xr[k1] * hs, -xr[n - k1] * hs), cconj(a.aux2[k1]));   // k1 >= 1 always
-            return herm_fold<T>(v0, cconj(v1), a.aux1[i]);
-        }
-        case G_DCT3_ODD: {
-            const T hs = (T)0.5 * a.scale;
-            cpx<T> v = cmul(mk<T>(xr[i] * hs, i ? -xr[n - i] * hs : (T)0), cconj(a.aux2[i]));
-            return cconj(v);
-        }
-        case G_DCT4_EVEN:
-            return cmul(mk<T>(xr[2 * i] * a.scale, xr[n - 1 - 2 * i] * a.scale), a.aux1[i]);
-        case G_DCT4_ODD: {
-            if (i >= n) return mk<T>((T)0, (T)0);
-            const T x = xr[i] * a.scale;
-            return mk<T>(x * a.aux1[i].x, x * a.aux1[i].y);
-        }
-        default: return mk<T>((T)0, (T)0);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// POST: output element q from the FFT result `res` (length F, padded by zi)
-// ---------------------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ cpx<T> r2c_split(const cpx<T> *res, int k, int F, cpx<T> w) {
-    // X[k] = (Z[k] + conj Z[F-k])/2 + w (Z[k] - conj Z[F-k])/(2i)
-    cpx<T> A = res[zi(k == F ? 0 : k)], B = cconj(res[zi(k == 0 ? 0 : F - k)]);
-    cpx<T> e = mk<T>((A.x + B.x) * (T)0.5, (A.y + B.y) * (T)0.5);
-    cpx<T> o = mk<T>((A.y - B.y) * (T)0.5, -(A.x - B.x) * (T)0.5);
-    return cadd(e, cmul(o, w));
-}
-
-template <typename T, int OP> __device__ __forceinline__ T post_real(const GenArgs<T> &a, const cpx<T> *res, int q) {
-    const int n = a.n, F = a.F;
-    switch (OP) {
-        case G_C2R_EVEN: { cpx<T> c = res[zi(q >> 1)]; return (q & 1) ? -c.y : c.x; }
-        case G_C2R_ODD: return res[zi(q)].x;
-        case G_DCT1: return (T)0.5 * r2c_split<T>(res, q, F, a.aux1[q]).x;
-        case G_DCT2_EVEN: {
-            const int k = q <= F ? q : n - q;
-            cpx<T> t = cmul(r2c_split<T>(res, k, F, a.aux1[k]), a.aux2[k]);
-            return q <= F ? t.x : -t.y;
-        }
-        case G_DCT2_ODD: { cpx<T> t = cmul(res[zi(q)], a.aux2[q]); return t.x; }
-        case G_DCT3_EVEN: {
-            const int p = (q & 1) ? n - 1 - (q >> 1) : (q >> 1);
-            cpx<T> c = res[zi(p >> 1)];
-            return (p & 1) ? -c.y : c.x;
-        }
-        case G_DCT3_ODD: { const int p = (q & 1) ? n - 1 - (q >> 1) : (q >> 1); return res[zi(p)].x; }
-        case G_DCT4_EVEN: {
-            const int k = (q & 1) ? (n - 1 - q) >> 1 : q >> 1;
-            cpx<T> u = cmul(res[zi(k)], a.aux2[k]);
-            return (q & 1) ? -u.y : u.x;
-        }
-        case G_DCT4_ODD: { cpx<T> u = cmul(res[zi(q)], a.aux2[q]); return u.x; }
-        default: return (T)0;
-    }
-}
-
-template <typename T, int OP> __device__ __forceinline__ cpx<T> post_cplx(const GenArgs<T> &a, const cpx<T> *res, int q) {
-    switch (OP) {
-        case G_C2C_INV: { cpx<T> c = res[zi(q)]; return mk<T>(c.x * a.scale, -c.y * a.scale); }   // lib.rs:326-330
-        case G_R2C_EVEN: return r2c_split<T>(res, q, a.F, a.aux1[q]);
-        default: return res[zi(q)];   // G_C2C_FWD, G_R2C_ODD
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -289,7 +168,7 @@ template <typename T, int OP> __global__ __launch_bounds__(1024) void k_generic(
         const int F = a.F;
         for (int l = c.fl; l < c.lanes; l += c.flstep)
             for (int i = c.fj0; i < F; i += c.fstep)
-                c.buf[0][l * pitch + zi(i)] = pre_elem<T, OP>(a, (const void *)(c.buf[1] + l * pitch), i);
+                c.buf[0][l * pitch + zi(i)] = pre_elem<T, OP, ZiPad8>(a, (const void *)(c.buf[1] + l * pitch), i);
     }
     // ---- FFT -------------------------------------------------------------------------------
     int cur = 0;
@@ -327,8 +206,8 @@ template <typename T, int OP> __global__ __launch_bounds__(1024) void k_generic(
             const cpx<T> *res = c.buf[cur] + l * pitch;
             for (int q = j0; q < n_out; q += jstep) {
                 const int64_t g = base + (int64_t)q * as;
-                if (out_cplx) ((cpx<T> *)a.out)[g] = post_cplx<T, OP>(a, res, q);
-                else ((T *)a.out)[g] = post_real<T, OP>(a, res, q);
+                if (out_cplx) ((cpx<T> *)a.out)[g] = post_cplx<T, OP, ZiPad8>(a, res, q);
+                else ((T *)a.out)[g] = post_real<T, OP, ZiPad8>(a, res, q);
             }
         }
     }

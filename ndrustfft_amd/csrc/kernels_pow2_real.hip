@@ -1,0 +1,83 @@
+// kernels_pow2_real.hip -- instantiations + launcher of the register-resident real-op kernels
+// (see pow2_real.h).  F = inner complex FFT length.
+#include "pow2_real.h"
+
+namespace ndfft {
+
+// F, threads per lane (E = F/TPL = 8 complex per thread), radices
+#define NDFFT_REAL_CONFIGS(X) \
+    X(64, 8, 8, 8)            \
+    X(128, 16, 8, 4, 4)       \
+    X(256, 32, 8, 8, 4)       \
+    X(512, 64, 8, 8, 8)       \
+    X(1024, 128, 8, 8, 4, 4)  \
+    X(2048, 256, 8, 8, 8, 4)  \
+    X(4096, 512, 8, 8, 8, 8)  \
+    X(8192, 1024, 8, 8, 8, 4, 4)
+
+template <int F> struct RealCfg;
+#define NDFFT_DEF_RCFG(F_, TPL_, ...)               \
+    template <> struct RealCfg<F_> {                \
+        static constexpr int TPL = TPL_;            \
+        using RL = RadixList<__VA_ARGS__>;          \
+    };
+NDFFT_REAL_CONFIGS(NDFFT_DEF_RCFG)
+
+bool pow2_real_supported(int F) {
+    switch (F) {
+#define NDFFT_CASE(F_, TPL_, ...) case F_: return true;
+        NDFFT_REAL_CONFIGS(NDFFT_CASE)
+#undef NDFFT_CASE
+        default: return false;
+    }
+}
+
+void pow2_real_build_twiddles(int F, HostTable &out) {
+    switch (F) {
+#define NDFFT_CASE(F_, TPL_, ...) case F_: build_tw<RealCfg<F_>::RL>(out); break;
+        NDFFT_REAL_CONFIGS(NDFFT_CASE)
+#undef NDFFT_CASE
+        default: break;
+    }
+}
+
+template <typename T, int F, int OP> static int launch_real_one(const RealArgs<T> &a, hipStream_t s) {
+    constexpr int TPL = RealCfg<F>::TPL, LPB = TPL >= 256 ? 1 : 256 / TPL;
+    using K = RealPow2Kernel<T, F, TPL, LPB, typename RealCfg<F>::RL, OP>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_pow2_real<K, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int64_t nblk = (a.nlanes + LPB - 1) / LPB;
+    if (nblk <= 0) return NDFFT_OK;
+    if (nblk > 0x7fffffffLL) return fail(NDFFT_ERR_UNSUPPORTED, "too many lanes for one launch");
+    hipLaunchKernelGGL((k_pow2_real<K, T>), dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, a);
+    NDFFT_HIP(hipGetLastError());
+    return NDFFT_OK;
+}
+
+template <typename T, int F> static int launch_real_F(int op, const RealArgs<T> &a, hipStream_t s) {
+    switch (op) {
+        case G_R2C_EVEN: return launch_real_one<T, F, G_R2C_EVEN>(a, s);
+        case G_C2R_EVEN: return launch_real_one<T, F, G_C2R_EVEN>(a, s);
+        case G_DCT1: return launch_real_one<T, F, G_DCT1>(a, s);
+        case G_DCT2_EVEN: return launch_real_one<T, F, G_DCT2_EVEN>(a, s);
+        case G_DCT3_EVEN: return launch_real_one<T, F, G_DCT3_EVEN>(a, s);
+        case G_DCT4_EVEN: return launch_real_one<T, F, G_DCT4_EVEN>(a, s);
+        default: return fail(NDFFT_ERR_INVALID_ARG, "pow2 real kernel: bad op");
+    }
+}
+
+template <typename T> int launch_pow2_real(int op, const RealArgs<T> &a, hipStream_t s) {
+    switch (a.F) {
+#define NDFFT_CASE(F_, TPL_, ...) case F_: return launch_real_F<T, F_>(op, a, s);
+        NDFFT_REAL_CONFIGS(NDFFT_CASE)
+#undef NDFFT_CASE
+        default: return fail(NDFFT_ERR_UNSUPPORTED, "pow2 real kernel: unsupported F");
+    }
+}
+template int launch_pow2_real<float>(int, const RealArgs<float> &, hipStream_t);
+template int launch_pow2_real<double>(int, const RealArgs<double> &, hipStream_t);
+
+}  // namespace ndfft

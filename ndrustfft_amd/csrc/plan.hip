@@ -95,6 +95,7 @@ static void build_plan_tables(ndfft_plan *p) {
         if (n % 2 == 0) {
             build_fft(m, n / 2);
             for (int k = 0; k <= n / 2; ++k) unit(m.aux1, k, n);          // W_n^k
+            if (pow2_real_supported(n / 2)) { m.pow2 = true; pow2_real_build_twiddles(n / 2, m.twp); }
         } else {
             build_fft(m, n);
         }
@@ -104,6 +105,7 @@ static void build_plan_tables(ndfft_plan *p) {
         if (n % 2 == 0) {
             build_fft(m, n / 2);
             for (int k = 0; k <= n / 2; ++k) unit(m.aux1, k, n);          // W_n^k
+            if (pow2_real_supported(n / 2)) { m.pow2 = true; pow2_real_build_twiddles(n / 2, m.twp); }
         } else {
             build_fft(m, n);
         }
@@ -114,6 +116,7 @@ static void build_plan_tables(ndfft_plan *p) {
             FftConfig &d1 = p->cfg[CFG_DCT1];
             build_fft(d1, n - 1);
             for (int k = 0; k <= n - 1; ++k) unit(d1.aux1, k, 2ull * (n - 1));
+            if (pow2_real_supported(n - 1)) { d1.pow2 = true; pow2_real_build_twiddles(n - 1, d1.twp); }
             p->has_cfg[CFG_DCT1] = true;
         }
         // DCT-IV
@@ -122,6 +125,7 @@ static void build_plan_tables(ndfft_plan *p) {
             build_fft(d4, n / 2);
             for (int j = 0; j < n / 2; ++j) unit(d4.aux1, 4ull * j + 1, 8ull * n);   // e^{-i pi (4j+1)/(4n)}
             for (int k = 0; k < n / 2; ++k) unit(d4.aux2, k, 2ull * n);              // e^{-i pi k/n}
+            if (pow2_real_supported(n / 2)) { d4.pow2 = true; pow2_real_build_twiddles(n / 2, d4.twp); }
         } else {
             build_fft(d4, 2 * n);
             for (int j = 0; j < n; ++j) unit(d4.aux1, j, 4ull * n);                  // e^{-i pi j/(2n)}

@@ -266,11 +266,22 @@ def reference_bench_shapes(L, sizes_fft=(128, 264, 512, 1024), sizes_dct=(129, 2
 def long_strided_lanes(L):
     """Strategy (ii) with lanes too long for an LDS tile of adjacent lanes: the transpose route."""
     cases = (("ndfft", (4096, 24), 0, np.float64, "transpose+pow2_reg"), ("ndifft", (4096, 24), 0, np.float64, "transpose+pow2_reg"),
-             ("ndfft_r2c", (8192, 40), 0, np.float32, "transpose+generic_row"), ("ndifft_r2c", (8192, 20), 0, np.float32, "transpose+generic_row"),
-             ("nddct2", (3, 4096, 17), 1, np.float64, "transpose+generic_row"), ("ndfft", (3000, 33), 0, np.float64, "transpose+generic_row"),
+             ("ndfft_r2c", (8192, 40), 0, np.float32, "transpose+pow2_real"), ("ndifft_r2c", (8192, 20), 0, np.float32, "transpose+pow2_real"),
+             ("nddct2", (3, 4096, 17), 1, np.float64, "transpose+pow2_real"), ("ndfft", (3000, 33), 0, np.float64, "transpose+generic_row"),
              ("nddct3", (2, 4000, 16), 1, np.float32, "transpose+generic_row"))
     for name, shape, axis, rdt, want in cases:
         assert run_case(L, name, shape, axis, rdt) == want, (name, shape)
+
+
+def pow2_real_sizes(L, sizes=(64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384), dtypes=(np.float64, np.float32)):
+    """The register-resident real-op kernels: every op x every supported inner FFT length F = n/2
+    (DCT-I: n = F + 1), both norms."""
+    for F in sizes:
+        for rdt in dtypes:
+            for name in ("ndfft_r2c", "ndifft_r2c", "nddct2", "nddct3", "nddct4"):
+                for norm in ("Default", "None"):
+                    assert run_case(L, name, (5, 2 * F), 1, rdt, norm=norm, offset=F) == "pow2_real", (name, F)
+            assert run_case(L, "nddct1", (5, F + 1), 1, rdt, offset=F) == "pow2_real", ("nddct1", F)
 
 
 def handler_clone_shares_plan(L):

@@ -50,3 +50,8 @@ def test_pow2_tuned_sizes(L):
 
 def test_reference_bench_shapes_small(L):
     ps.reference_bench_shapes(L, sizes_fft=(128, 264), sizes_dct=(129, 265))
+
+
+def test_pow2_real_sizes(L):
+    ps.pow2_real_sizes(L, sizes=(64, 128, 256, 512, 1024, 4096), dtypes=(np.float64,))
+    ps.pow2_real_sizes(L, sizes=(64, 2048, 8192), dtypes=(np.float32,))
