@@ -273,7 +273,7 @@ def long_strided_lanes(L):
         assert run_case(L, name, shape, axis, rdt) == want, (name, shape)
 
 
-def pow2_real_sizes(L, sizes=(64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384), dtypes=(np.float64, np.float32)):
+def pow2_real_sizes(L, sizes=(64, 128, 256, 512, 1024, 2048, 4096, 8192), dtypes=(np.float64, np.float32)):
     """The register-resident real-op kernels: every op x every supported inner FFT length F = n/2
     (DCT-I: n = F + 1), both norms."""
     for F in sizes:
