@@ -1,0 +1,46 @@
+//! Raw bindings to `include/ndfft_mi355x.h` (ABI version 1).  One `ndfft_exec` call replaces the
+//! whole body of one `nd*` call of the reference (lane iterator + handler lane method + rustfft /
+//! realfft / rustdct kernel).
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_double, c_int, c_void};
+
+#[repr(C)]
+pub struct ndfft_plan {
+    _private: [u8; 0],
+}
+
+pub const NDFFT_OK: c_int = 0;
+pub const NDFFT_ERR_SIZE_MISMATCH: c_int = 2;
+pub const NDFFT_ERR_SHAPE_MISMATCH: c_int = 3;
+pub const NDFFT_ERR_AXIS: c_int = 4;
+
+pub const NDFFT_F32: c_int = 0;
+pub const NDFFT_F64: c_int = 1;
+
+pub const NDFFT_KIND_C2C: c_int = 0;
+pub const NDFFT_KIND_R2C: c_int = 1;
+pub const NDFFT_KIND_DCT: c_int = 2;
+
+pub const NDFFT_OP_C2C_FWD: c_int = 0;
+pub const NDFFT_OP_C2C_INV: c_int = 1;
+pub const NDFFT_OP_R2C: c_int = 2;
+pub const NDFFT_OP_C2R: c_int = 3;
+pub const NDFFT_OP_DCT1: c_int = 4;
+pub const NDFFT_OP_DCT2: c_int = 5;
+pub const NDFFT_OP_DCT3: c_int = 6;
+pub const NDFFT_OP_DCT4: c_int = 7;
+
+pub const NDFFT_NORM_NONE: c_int = 0;
+pub const NDFFT_NORM_DEFAULT: c_int = 1;
+
+extern "C" {
+    pub fn ndfft_last_error() -> *const c_char;
+    pub fn ndfft_plan_create(kind: c_int, dtype: c_int, n: usize, out_plan: *mut *mut ndfft_plan) -> c_int;
+    pub fn ndfft_plan_retain(plan: *mut ndfft_plan) -> c_int;
+    pub fn ndfft_plan_destroy(plan: *mut ndfft_plan) -> c_int;
+    pub fn ndfft_exec(
+        plan: *const ndfft_plan, op: c_int, input: *const c_void, output: *mut c_void, ndim: c_int,
+        shape_in: *const i64, stride_in: *const i64, shape_out: *const i64, stride_out: *const i64,
+        axis: c_int, norm: c_int, scale: c_double,
+    ) -> c_int;
+}

@@ -1,0 +1,192 @@
+//! ndrustfft on an AMD MI355X.
+//!
+//! Same public surface as ndrustfft 0.5.0 -- `ndfft`, `ndifft`, `ndfft_r2c`, `ndifft_r2c`,
+//! `nddct1..4`, their `_par` twins, `FftHandler`, `R2cFftHandler`, `DctHandler`, `Normalization`,
+//! and the re-exports `Complex`, `Zero` -- but every call is ONE FFI call into `libndfft_mi355x`,
+//! whose other side is hand-written HIP for gfx950.  Arrays may have any layout ndarray allows
+//! (strides are passed through, signed, in elements).
+//!
+//! Differences a caller can observe:
+//! * `T` is `f32` or `f64` (the reference's `FftNum` bound admits nothing else in practice).
+//! * `Normalization::Custom(f)` runs `f` on the host, on a lane-major copy, at the point the
+//!   reference applies it (after the inverse C2C transform; before the C2R and DCT transforms).
+//! * Errors of the device runtime panic with the HIP error string.
+pub use num_complex::Complex;
+pub use num_traits::Zero;
+
+use ndarray::{ArrayBase, Axis, Data, DataMut, Dimension};
+use std::ffi::CStr;
+use std::os::raw::{c_int, c_void};
+
+pub mod ffi;
+
+/// Element types the device engine computes in.
+pub trait GpuFloat: Copy + Zero + 'static {
+    const DTYPE: c_int;
+}
+impl GpuFloat for f32 {
+    const DTYPE: c_int = ffi::NDFFT_F32;
+}
+impl GpuFloat for f64 {
+    const DTYPE: c_int = ffi::NDFFT_F64;
+}
+
+/// How the inverse / real / cosine transforms are scaled.
+#[derive(Clone)]
+pub enum Normalization<T> {
+    /// Raw, unscaled transform.
+    None,
+    /// scipy-like: 1/n on the inverse FFTs, x2 on the DCTs.
+    Default,
+    /// A host function applied to every lane at the handler-specific point.
+    Custom(fn(&mut [T])),
+}
+
+struct Plan(*mut ffi::ndfft_plan);
+unsafe impl Send for Plan {}
+unsafe impl Sync for Plan {} // plans are immutable after creation (see ndfft_mi355x.h)
+impl Plan {
+    fn new(kind: c_int, dtype: c_int, n: usize) -> Self {
+        let mut p = std::ptr::null_mut();
+        check(unsafe { ffi::ndfft_plan_create(kind, dtype, n, &mut p) });
+        Plan(p)
+    }
+}
+impl Clone for Plan {
+    fn clone(&self) -> Self {
+        check(unsafe { ffi::ndfft_plan_retain(self.0) });
+        Plan(self.0)
+    }
+}
+impl Drop for Plan {
+    fn drop(&mut self) {
+        unsafe { ffi::ndfft_plan_destroy(self.0) };
+    }
+}
+
+fn check(status: c_int) {
+    if status != ffi::NDFFT_OK {
+        let msg = unsafe { CStr::from_ptr(ffi::ndfft_last_error()) }.to_string_lossy().into_owned();
+        // size / axis / shape mismatches carry the reference's own panic text
+        panic!("{}", msg);
+    }
+}
+
+macro_rules! handler {
+    ($(#[$m:meta])* $name:ident, $kind:expr, $norm_elem:ty) => {
+        $(#[$m])*
+        #[derive(Clone)]
+        pub struct $name<T> {
+            n: usize,
+            plan: Plan,
+            norm: Normalization<$norm_elem>,
+        }
+        impl<T: GpuFloat> $name<T> {
+            /// Plans the transform of length `n` on the current device.
+            #[must_use]
+            pub fn new(n: usize) -> Self {
+                Self { n, plan: Plan::new($kind, T::DTYPE, n), norm: Normalization::Default }
+            }
+            /// Builder: replaces the normalization.
+            #[must_use]
+            pub fn normalization(mut self, norm: Normalization<$norm_elem>) -> Self {
+                self.norm = norm;
+                self
+            }
+            /// Transform length.
+            pub fn len(&self) -> usize { self.n }
+        }
+    };
+}
+handler!(/// Complex-to-complex handler.
+    FftHandler, ffi::NDFFT_KIND_C2C, Complex<T>);
+handler!(/// Real-to-complex / complex-to-real handler (`n` reals <-> `n/2+1` complex).
+    R2cFftHandler, ffi::NDFFT_KIND_R2C, Complex<T>);
+handler!(/// DCT-I..IV handler.
+    DctHandler, ffi::NDFFT_KIND_DCT, T);
+
+fn strides_i64<S, D: Dimension>(a: &ArrayBase<S, D>) -> (Vec<i64>, Vec<i64>)
+where
+    S: ndarray::RawData,
+{
+    (a.shape().iter().map(|&s| s as i64).collect(), a.strides().iter().map(|&s| s as i64).collect())
+}
+
+/// Applies a Custom normalization lane by lane (host side).
+fn apply_custom<A: Clone, S: DataMut<Elem = A>, D: Dimension>(arr: &mut ArrayBase<S, D>, axis: usize, f: fn(&mut [A])) {
+    for mut lane in arr.lanes_mut(Axis(axis)) {
+        let mut tmp = lane.to_vec();
+        f(&mut tmp);
+        lane.assign(&ndarray::ArrayView1::from(&tmp));
+    }
+}
+
+#[derive(PartialEq)]
+enum NormPoint { Ignored, After, Before }
+
+macro_rules! transform {
+    ($(#[$m:meta])* $name:ident, $par:ident, $a:ty, $b:ty, $h:ident, $op:expr, $point:expr) => {
+        $(#[$m])*
+        pub fn $name<R, S, T, D>(input: &ArrayBase<R, D>, output: &mut ArrayBase<S, D>, handler: &$h<T>, axis: usize)
+        where
+            T: GpuFloat,
+            R: Data<Elem = $a>,
+            S: Data<Elem = $b> + DataMut,
+            D: Dimension,
+        {
+            let (shape_in, stride_in) = strides_i64(input);
+            let (shape_out, stride_out) = strides_i64(output);
+            let mut mode = match handler.norm { Normalization::None => ffi::NDFFT_NORM_NONE, _ => ffi::NDFFT_NORM_DEFAULT };
+            let custom = match &handler.norm { Normalization::Custom(f) if $point != NormPoint::Ignored => Some(*f), _ => None };
+            if let Normalization::Custom(_) = handler.norm { mode = ffi::NDFFT_NORM_NONE; }
+            // Before-points act on the input: run on an owned copy so `input` stays untouched.
+            let staged;
+            let (in_ptr, shape_in, stride_in) = if let (Some(f), true) = (custom, $point == NormPoint::Before) {
+                let mut c = input.to_owned();
+                #[allow(clippy::unnecessary_cast)]
+                apply_custom(&mut c, axis.min(c.ndim().saturating_sub(1)), unsafe { std::mem::transmute::<_, fn(&mut [$a])>(f) });
+                let (s, st) = strides_i64(&c);
+                staged = c;
+                (staged.as_ptr() as *const c_void, s, st)
+            } else {
+                (input.as_ptr() as *const c_void, shape_in, stride_in)
+            };
+            check(unsafe {
+                ffi::ndfft_exec(handler.plan.0, $op, in_ptr, output.as_mut_ptr() as *mut c_void, input.ndim() as c_int,
+                                shape_in.as_ptr(), stride_in.as_ptr(), shape_out.as_ptr(), stride_out.as_ptr(),
+                                axis as c_int, mode, 0.0)
+            });
+            if let (Some(f), true) = (custom, $point == NormPoint::After) {
+                apply_custom(output, axis, unsafe { std::mem::transmute::<_, fn(&mut [$b])>(f) });
+            }
+        }
+        /// Parallel twin: on the GPU every lane is already processed in parallel.
+        #[cfg(feature = "parallel")]
+        pub fn $par<R, S, T, D>(input: &ArrayBase<R, D>, output: &mut ArrayBase<S, D>, handler: &$h<T>, axis: usize)
+        where
+            T: GpuFloat,
+            R: Data<Elem = $a>,
+            S: Data<Elem = $b> + DataMut,
+            D: Dimension,
+        {
+            $name(input, output, handler, axis)
+        }
+    };
+}
+
+transform!(/// Complex-to-complex forward FFT along `axis`.
+    ndfft, ndfft_par, Complex<T>, Complex<T>, FftHandler, ffi::NDFFT_OP_C2C_FWD, NormPoint::Ignored);
+transform!(/// Complex-to-complex inverse FFT along `axis`.
+    ndifft, ndifft_par, Complex<T>, Complex<T>, FftHandler, ffi::NDFFT_OP_C2C_INV, NormPoint::After);
+transform!(/// Real-to-complex FFT along `axis`.
+    ndfft_r2c, ndfft_r2c_par, T, Complex<T>, R2cFftHandler, ffi::NDFFT_OP_R2C, NormPoint::Ignored);
+transform!(/// Complex-to-real inverse FFT along `axis`.
+    ndifft_r2c, ndifft_r2c_par, Complex<T>, T, R2cFftHandler, ffi::NDFFT_OP_C2R, NormPoint::Before);
+transform!(/// DCT-I along `axis`.
+    nddct1, nddct1_par, T, T, DctHandler, ffi::NDFFT_OP_DCT1, NormPoint::Before);
+transform!(/// DCT-II along `axis`.
+    nddct2, nddct2_par, T, T, DctHandler, ffi::NDFFT_OP_DCT2, NormPoint::Before);
+transform!(/// DCT-III along `axis`.
+    nddct3, nddct3_par, T, T, DctHandler, ffi::NDFFT_OP_DCT3, NormPoint::Before);
+transform!(/// DCT-IV along `axis`.
+    nddct4, nddct4_par, T, T, DctHandler, ffi::NDFFT_OP_DCT4, NormPoint::Before);

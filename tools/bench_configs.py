@@ -70,6 +70,16 @@ def main():
     if want("cfg5"):
         x = torch.from_numpy(synth.complex_array((8192, 4096))).to(dev); y = torch.empty_like(x)
         run("cfg5 shard ndfft axis=1 8192x4096 c128", ndfft, x, y, FftHandler(4096), 1, x.numel(), a.steps)
+    if want("hostpath"):
+        import time
+        x = synth.complex_array((4096, 4096)); y = np.zeros_like(x); h = FftHandler(4096)
+        ndfft(x, y, h, 1)
+        t0 = time.perf_counter(); reps = 3
+        for _ in range(reps):
+            ndfft(x, y, h, 1)
+        t = (time.perf_counter() - t0) / reps
+        print(json.dumps({"workload": "hostpath ndfft_exec (pageable host arrays, PCIe both ways) 4096x4096 c128", "us": round(t * 1e6, 1),
+                          "GFFT-points/s": round(x.size / t / 1e9, 3), "host_GB/s": round(2 * x.nbytes / t / 1e9, 2)}), flush=True)
     if want("refbench"):
         for n in (128, 264, 512, 1024):
             x = torch.from_numpy(synth.bench_fill_complex((n, n))).to(dev); y = torch.empty_like(x)
