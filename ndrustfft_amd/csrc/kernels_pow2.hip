@@ -25,7 +25,8 @@
 namespace ndfft {
 
 // N, threads-per-lane, radices.  E = N / TPL must be a multiple of every radix.
-#define NDFFT_POW2_CONFIGS(X) \
+// f64 (16-byte elements, one element per global access)
+#define NDFFT_POW2_CONFIGS_F64(X) \
     X(64, 8, 8, 8)            \
     X(128, 8, 16, 8)          \
     X(256, 16, 16, 16)        \
@@ -35,40 +36,52 @@ namespace ndfft {
     X(4096, 512, 8, 8, 8, 8)  \
     X(8192, 512, 16, 16, 8, 4) \
     X(16384, 1024, 16, 16, 16, 4)
+// f32 (8-byte elements): first and last radix <= E/2 so that two adjacent elements (16 B) move per
+// global access (VEC = 2)
+#define NDFFT_POW2_CONFIGS_F32(X) \
+    X(64, 4, 8, 8)            \
+    X(128, 8, 8, 2, 8)        \
+    X(256, 16, 8, 4, 8)       \
+    X(512, 32, 8, 8, 8)       \
+    X(1024, 64, 8, 16, 8)     \
+    X(2048, 128, 8, 4, 8, 8)  \
+    X(4096, 256, 8, 8, 8, 8)  \
+    X(8192, 512, 8, 16, 8, 8) \
+    X(16384, 1024, 8, 16, 16, 8)
 
 static constexpr int lpb_for(int tpl) { return tpl >= 256 ? 1 : 256 / tpl; }
 
-template <int N> struct Pow2Cfg;
-#define NDFFT_DEF_CFG(N_, TPL_, ...)                \
-    template <> struct Pow2Cfg<N_> {                \
-        static constexpr int TPL = TPL_;            \
-        using RL = RadixList<__VA_ARGS__>;          \
-    };
-NDFFT_POW2_CONFIGS(NDFFT_DEF_CFG)
+template <typename T, int N> struct Pow2Cfg;
+#define NDFFT_DEF_CFG64(N_, TPL_, ...) \
+    template <> struct Pow2Cfg<double, N_> { static constexpr int TPL = TPL_; using RL = RadixList<__VA_ARGS__>; };
+#define NDFFT_DEF_CFG32(N_, TPL_, ...) \
+    template <> struct Pow2Cfg<float, N_> { static constexpr int TPL = TPL_; using RL = RadixList<__VA_ARGS__>; };
+NDFFT_POW2_CONFIGS_F64(NDFFT_DEF_CFG64)
+NDFFT_POW2_CONFIGS_F32(NDFFT_DEF_CFG32)
 
 bool pow2_supported(int dtype, int n) {
     (void)dtype;
     switch (n) {
 #define NDFFT_CASE(N_, TPL_, ...) case N_: return true;
-        NDFFT_POW2_CONFIGS(NDFFT_CASE)
+        NDFFT_POW2_CONFIGS_F64(NDFFT_CASE)
 #undef NDFFT_CASE
         default: return false;
     }
 }
 
 void pow2_build_twiddles(int dtype, int n, HostTable &out) {
-    (void)dtype;
     switch (n) {
-#define NDFFT_CASE(N_, TPL_, ...) case N_: build_tw<Pow2Cfg<N_>::RL>(out); break;
-        NDFFT_POW2_CONFIGS(NDFFT_CASE)
+#define NDFFT_CASE(N_, TPL_, ...) \
+    case N_: if (dtype == NDFFT_F32) build_tw<Pow2Cfg<float, N_>::RL>(out); else build_tw<Pow2Cfg<double, N_>::RL>(out); break;
+        NDFFT_POW2_CONFIGS_F64(NDFFT_CASE)
 #undef NDFFT_CASE
         default: break;
     }
 }
 
-template <typename T, int N, int NT> static int launch_one(const Pow2Args &a, hipStream_t s) {
-    constexpr int TPL = Pow2Cfg<N>::TPL, LPB = lpb_for(TPL);
-    using K = Pow2Kernel<T, N, TPL, LPB, true, typename Pow2Cfg<N>::RL, 0, 1, NT>;
+template <typename T, int N, int NT, int VEC> static int launch_one(const Pow2Args &a, hipStream_t s) {
+    constexpr int TPL = Pow2Cfg<T, N>::TPL, LPB = lpb_for(TPL);
+    using K = Pow2Kernel<T, N, TPL, LPB, true, typename Pow2Cfg<T, N>::RL, 0, 1, NT, VEC>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)k_pow2<K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -90,12 +103,15 @@ template <typename T, int N, int NT> static int launch_one(const Pow2Args &a, hi
 int launch_pow2(int dtype, int n, const Pow2Args &a, hipStream_t s) {
     const size_t in_bytes = (size_t)a.nlanes * (size_t)n * (dtype == NDFFT_F32 ? 8 : 16);
     const bool big = in_bytes > ((size_t)256 << 20);
+    // 16-byte accesses for f32 need even pitches and 16-byte aligned bases
+    const bool vec_ok = a.pitch_in % 2 == 0 && a.pitch_out % 2 == 0 && ((uintptr_t)a.in % 16) == 0 && ((uintptr_t)a.out % 16) == 0;
     switch (n) {
-#define NDFFT_CASE(N_, TPL_, ...)                                                                        \
-    case N_:                                                                                             \
-        if (big) return dtype == NDFFT_F32 ? launch_one<float, N_, 3>(a, s) : launch_one<double, N_, 3>(a, s); \
-        return dtype == NDFFT_F32 ? launch_one<float, N_, 1>(a, s) : launch_one<double, N_, 1>(a, s);
-        NDFFT_POW2_CONFIGS(NDFFT_CASE)
+#define NDFFT_CASE(N_, TPL_, ...)                                                               \
+    case N_:                                                                                    \
+        if (dtype == NDFFT_F64) return big ? launch_one<double, N_, 3, 1>(a, s) : launch_one<double, N_, 1, 1>(a, s); \
+        if (vec_ok) return big ? launch_one<float, N_, 3, 2>(a, s) : launch_one<float, N_, 1, 2>(a, s);              \
+        return big ? launch_one<float, N_, 3, 1>(a, s) : launch_one<float, N_, 1, 1>(a, s);
+        NDFFT_POW2_CONFIGS_F64(NDFFT_CASE)
 #undef NDFFT_CASE
         default: return fail(NDFFT_ERR_UNSUPPORTED, "pow2 kernel: unsupported n");
     }

@@ -32,6 +32,15 @@ template <typename T, bool NT> __device__ __forceinline__ cpx<T> gload(const cpx
         return *p;
     }
 }
+typedef float vec4f __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ vec4f gload4(const float *p) {
+    if constexpr (NT) return __builtin_nontemporal_load((const vec4f *)p);
+    else return *(const vec4f *)p;
+}
+template <bool NT> __device__ __forceinline__ void gstore4(float *p, vec4f v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, (vec4f *)p);
+    else *(vec4f *)p = v;
+}
 template <typename T, bool NT> __device__ __forceinline__ void gstore(cpx<T> *p, cpx<T> v) {
     if constexpr (NT) {
         typename vec_of<T>::type w; w.x = v.x; w.y = v.y;
@@ -44,12 +53,21 @@ template <typename T, bool NT> __device__ __forceinline__ void gstore(cpx<T> *p,
 // FLAGS is for ablation builds in tools/kbench.hip only (product kernels use 0):
 //   1 = skip twiddle multiplies, 2 = skip the LDS exchange, 4 = skip butterflies
 // NT: bit 0 = non-temporal stores, bit 1 = non-temporal loads
-template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS = 0, int MINW = 1, int NT = 1> struct Pow2Kernel {
+// VEC = 2 (f32 only): global loads/stores move TWO adjacent complex elements (16 B) per lane; the
+//   first and last pass then own adjacent butterfly pairs j = 2t, 2t+1 instead of j = t, t+TPL.
+//   Needs E/R >= 2 in those passes, even lane pitches and 16-byte aligned bases (checked on the host).
+template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS = 0, int MINW = 1, int NT = 1, int VEC = 1> struct Pow2Kernel {
     static constexpr int MIN_WAVES = MINW;
     static constexpr int E = N / TPL;
     static constexpr int THREADS = TPL * LPB;
     static constexpr int LANE_LDS = N + (N >> 4) + 1;                      // padded elements per lane
     static constexpr size_t LDS_BYTES = (size_t)LPB * LANE_LDS * (HALF ? sizeof(T) : 2 * sizeof(T));
+
+    // butterfly index owned by thread t, slot q, in pass P
+    template <int P> static __device__ __forceinline__ int jof(int t, int q) {
+        if constexpr (VEC == 2 && (P == 0 || P == RL::NP - 1)) return 2 * t + (q & 1) + (q >> 1) * (2 * TPL);
+        else return t + q * TPL;
+    }
 
     template <int P>
     static __device__ __forceinline__ void passes(cpx<T> (&v)[E], const cpx<T> *__restrict__ twp, char *lds, int t) {
@@ -58,7 +76,7 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
             const cpx<T> *tw = twp + RL::twoff(P);
 #pragma unroll
             for (int q = 0; q < NBF; ++q) {
-                const int k = (t + q * TPL) & (Ns - 1);
+                const int k = jof<P>(t, q) & (Ns - 1);
 #pragma unroll
                 for (int r = 1; r < R; ++r) v[q * R + r] = cmul(v[q * R + r], tw[(r - 1) * Ns + k]);
             }
@@ -75,14 +93,14 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
                     __syncthreads();
 #pragma unroll
                     for (int q = 0; q < NBF; ++q) {
-                        const int j = t + q * TPL, k = j & (Ns - 1), o = (j - k) * R + k;
+                        const int j = jof<P>(t, q), k = j & (Ns - 1), o = (j - k) * R + k;
 #pragma unroll
                         for (int r = 0; r < R; ++r) s[phi(o + r * Ns)] = half ? v[q * R + r].y : v[q * R + r].x;
                     }
                     __syncthreads();
 #pragma unroll
                     for (int q = 0; q < NBF2; ++q) {
-                        const int j = t + q * TPL;
+                        const int j = jof<P + 1>(t, q);
 #pragma unroll
                         for (int r = 0; r < R2; ++r) {
                             const T x = s[phi(j + r * NB2)];
@@ -95,14 +113,14 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
                 __syncthreads();
 #pragma unroll
                 for (int q = 0; q < NBF; ++q) {
-                    const int j = t + q * TPL, k = j & (Ns - 1), o = (j - k) * R + k;
+                    const int j = jof<P>(t, q), k = j & (Ns - 1), o = (j - k) * R + k;
 #pragma unroll
                     for (int r = 0; r < R; ++r) s[phi(o + r * Ns)] = v[q * R + r];
                 }
                 __syncthreads();
 #pragma unroll
                 for (int q = 0; q < NBF2; ++q) {
-                    const int j = t + q * TPL;
+                    const int j = jof<P + 1>(t, q);
 #pragma unroll
                     for (int r = 0; r < R2; ++r) v[q * R2 + r] = s[phi(j + r * NB2)];
                 }
@@ -122,10 +140,21 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
         cpx<T> v[E];
         {
             constexpr int R0 = RL::at(0), NB0 = N / R0, NBF0 = E / R0;
+            if constexpr (VEC == 2) {
+                static_assert(NBF0 % 2 == 0, "VEC=2 needs an even number of butterflies per thread in pass 0");
 #pragma unroll
-            for (int q = 0; q < NBF0; ++q)
+                for (int q = 0; q < NBF0; q += 2)
 #pragma unroll
-                for (int r = 0; r < R0; ++r) v[q * R0 + r] = gload<T, (NT & 2) != 0>(in + t + q * TPL + r * NB0);
+                    for (int r = 0; r < R0; ++r) {
+                        const vec4f w = gload4<(NT & 2) != 0>((const float *)(in + jof<0>(t, q) + r * NB0));
+                        v[q * R0 + r] = mk<T>(w.x, w.y); v[(q + 1) * R0 + r] = mk<T>(w.z, w.w);
+                    }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NBF0; ++q)
+#pragma unroll
+                    for (int r = 0; r < R0; ++r) v[q * R0 + r] = gload<T, (NT & 2) != 0>(in + t + q * TPL + r * NB0);
+            }
         }
         if (a.inverse) {
 #pragma unroll
@@ -139,10 +168,21 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
 #pragma unroll
             for (int i = 0; i < E; ++i) { v[i].x *= sc; v[i].y *= -sc; }   // conj + norm_default (lib.rs:333-338)
         }
+        if constexpr (VEC == 2) {
+            static_assert(NBFL % 2 == 0, "VEC=2 needs an even number of butterflies per thread in the last pass");
 #pragma unroll
-        for (int q = 0; q < NBFL; ++q)
+            for (int q = 0; q < NBFL; q += 2)
 #pragma unroll
-            for (int r = 0; r < RL_; ++r) gstore<T, (NT & 1) != 0>(out + t + q * TPL + r * NBL, v[q * RL_ + r]);
+                for (int r = 0; r < RL_; ++r) {
+                    vec4f w; w.x = v[q * RL_ + r].x; w.y = v[q * RL_ + r].y; w.z = v[(q + 1) * RL_ + r].x; w.w = v[(q + 1) * RL_ + r].y;
+                    gstore4<(NT & 1) != 0>((float *)(out + jof<RL::NP - 1>(t, q) + r * NBL), w);
+                }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NBFL; ++q)
+#pragma unroll
+                for (int r = 0; r < RL_; ++r) gstore<T, (NT & 1) != 0>(out + t + q * TPL + r * NBL, v[q * RL_ + r]);
+        }
     }
 };
 
