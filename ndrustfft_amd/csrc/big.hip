@@ -1,0 +1,94 @@
+// big.hip -- pieces of the four-step path for lanes longer than one workgroup's LDS
+// (the reference accepts any n: FftHandler::new(n) is infallible, src/lib.rs:294).
+//   F = F1 * F2 :  X[k1 + F1 k2] = sum_{n2} W_F2^{n2 k2} ( W_F^{n2 k1} sum_{n1} x[n1 F2 + n2] W_F1^{n1 k1} )
+// = transpose, batched length-F1 row FFTs, twiddle, transpose, batched length-F2 row FFTs, transpose,
+// all on the existing row kernels (exec.hip: big_fft).  The real-data ops add an elementwise PRE and
+// POST over global memory that reuse realops.h.
+#include <algorithm>
+
+#include "pow2_real.h"
+
+namespace ndfft {
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_big_twiddle(cpx<T> *data, int64_t total, int F1, int F2, const cpx<T> *twlo,
+                                                     const cpx<T> *twhi, int logB, int conj, T scale) {
+    // data[lane][n2][k1] *= W_F^{n2 k1} * scale
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i % ((int64_t)F1 * F2);
+        const int64_t n2 = r / F1, k1 = r - n2 * F1, m = n2 * k1;
+        cpx<T> w = cmul(twhi[m >> logB], twlo[m & (((int64_t)1 << logB) - 1)]);
+        if (conj) w.y = -w.y;
+        cpx<T> v = cmul(data[i], w);
+        v.x *= scale; v.y *= scale;
+        data[i] = v;
+    }
+}
+
+template <typename T>
+int launch_big_twiddle(cpx<T> *data, int64_t lanes, int F1, int F2, const cpx<T> *twlo, const cpx<T> *twhi, int logB, int conj,
+                       T scale, hipStream_t s) {
+    const int64_t total = lanes * F1 * F2;
+    const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_big_twiddle<T>, dim3(grid), dim3(256), 0, s, data, total, F1, F2, twlo, twhi, logB, conj, scale);
+    NDFFT_HIP(hipGetLastError());
+    return NDFFT_OK;
+}
+template int launch_big_twiddle<float>(float2 *, int64_t, int, int, const float2 *, const float2 *, int, int, float, hipStream_t);
+template int launch_big_twiddle<double>(double2 *, int64_t, int, int, const double2 *, const double2 *, int, int, double, hipStream_t);
+
+template <typename T, int OP> __global__ __launch_bounds__(256) void k_big_pre(const RealArgs<T> a, cpx<T> *z) {
+    constexpr bool in_cplx = OP == G_C2R_EVEN || OP == G_C2R_ODD;
+    const int64_t total = a.nlanes * a.F;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t lane = i / a.F; const int k = (int)(i - lane * a.F);
+        const void *raw = in_cplx ? (const void *)((const cpx<T> *)a.in + lane * a.pitch_in) : (const void *)((const T *)a.in + lane * a.pitch_in);
+        cpx<T> v;
+        if constexpr (OP == G_R2C_EVEN) v = ((const cpx<T> *)raw)[k];
+        else if constexpr (OP == G_R2C_ODD) v = mk<T>(((const T *)raw)[k], (T)0);
+        else v = pre_elem<T, OP, ZiNone>(a, raw, k);
+        z[i] = v;
+    }
+}
+template <typename T, int OP> __global__ __launch_bounds__(256) void k_big_post(const RealArgs<T> a, const cpx<T> *z) {
+    constexpr bool out_cplx = OP == G_R2C_EVEN || OP == G_R2C_ODD;
+    const int64_t total = a.nlanes * a.n_out;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t lane = i / a.n_out; const int q = (int)(i - lane * a.n_out);
+        const cpx<T> *res = z + lane * a.F;
+        if constexpr (out_cplx) ((cpx<T> *)a.out)[lane * a.pitch_out + q] = post_cplx<T, OP, ZiNone>(a, res, q);
+        else ((T *)a.out)[lane * a.pitch_out + q] = post_real<T, OP, ZiNone>(a, res, q);
+    }
+}
+
+#define NDFFT_BIG_OPS(X) X(G_R2C_EVEN) X(G_R2C_ODD) X(G_C2R_EVEN) X(G_C2R_ODD) X(G_DCT1) X(G_DCT2_EVEN) X(G_DCT2_ODD) \
+    X(G_DCT3_EVEN) X(G_DCT3_ODD) X(G_DCT4_EVEN) X(G_DCT4_ODD)
+
+template <typename T> int launch_big_pre(int op, const RealArgs<T> &a, cpx<T> *z, hipStream_t s) {
+    const unsigned grid = (unsigned)std::min<int64_t>((a.nlanes * a.F + 255) / 256, 8192);
+    switch (op) {
+#define NDFFT_C(OP) case OP: hipLaunchKernelGGL((k_big_pre<T, OP>), dim3(grid), dim3(256), 0, s, a, z); break;
+        NDFFT_BIG_OPS(NDFFT_C)
+#undef NDFFT_C
+        default: return fail(NDFFT_ERR_INVALID_ARG, "big pre: bad op");
+    }
+    NDFFT_HIP(hipGetLastError());
+    return NDFFT_OK;
+}
+template <typename T> int launch_big_post(int op, const RealArgs<T> &a, const cpx<T> *z, hipStream_t s) {
+    const unsigned grid = (unsigned)std::min<int64_t>((a.nlanes * a.n_out + 255) / 256, 8192);
+    switch (op) {
+#define NDFFT_C(OP) case OP: hipLaunchKernelGGL((k_big_post<T, OP>), dim3(grid), dim3(256), 0, s, a, z); break;
+        NDFFT_BIG_OPS(NDFFT_C)
+#undef NDFFT_C
+        default: return fail(NDFFT_ERR_INVALID_ARG, "big post: bad op");
+    }
+    NDFFT_HIP(hipGetLastError());
+    return NDFFT_OK;
+}
+template int launch_big_pre<float>(int, const RealArgs<float> &, float2 *, hipStream_t);
+template int launch_big_pre<double>(int, const RealArgs<double> &, double2 *, hipStream_t);
+template int launch_big_post<float>(int, const RealArgs<float> &, const float2 *, hipStream_t);
+template int launch_big_post<double>(int, const RealArgs<double> &, const double2 *, hipStream_t);
+
+}  // namespace ndfft

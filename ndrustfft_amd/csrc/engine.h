@@ -81,7 +81,10 @@ template <typename T> struct GenArgs {
 // ------------------------------------------------------------------------------------------
 // plan
 // ------------------------------------------------------------------------------------------
-struct HostTable { std::vector<long double> re, im; };   // built once in long double
+struct HostTable { std::vector<long double> re, im; };
+}  // namespace ndfft
+struct ndfft_plan;
+namespace ndfft {   // built once in long double
 
 struct FftConfig {                 // one complex-FFT-of-length-F recipe + op tables
     int F = 0;
@@ -91,10 +94,16 @@ struct FftConfig {                 // one complex-FFT-of-length-F recipe + op ta
     // tuned power-of-two path (register-resident Stockham), when eligible
     bool pow2 = false;             // C2C slot: pow2_kernel.h ; real-op slots: pow2_real.h
     HostTable twp;                 // per-pass transposed twiddles
+    // long lanes (one lane does not fit LDS): four-step F = F1 * F2 on top of the row kernels
+    bool big = false; int F1 = 0, F2 = 0, logB = 0;
+    ndfft_plan *sub1 = nullptr, *sub2 = nullptr;   // C2C sub-plans of length F1 / F2 (owned)
+    HostTable twlo, twhi;          // W_F^m = twhi[m >> logB] * twlo[m & (2^logB - 1)]
+    bool unsupported = false;      // no single-kernel fit and no usable factorisation (large prime factor)
 };
 
 struct DevConfig {                 // device copies (typed by dtype) of one FftConfig
     void *tw = nullptr, *twM = nullptr, *chirp = nullptr, *bhat = nullptr, *aux1 = nullptr, *aux2 = nullptr, *twp = nullptr;
+    void *twlo = nullptr, *twhi = nullptr;
 };
 
 enum ConfigSlot { CFG_MAIN = 0, CFG_DCT1 = 1, CFG_DCT4 = 2, CFG_COUNT = 3 };
@@ -114,6 +123,7 @@ struct ndfft_plan {
 };
 
 namespace ndfft {
+template <typename T> struct RealArgs;
 
 // error plumbing (thread-local message)
 int fail(int code, const std::string &msg);
@@ -150,10 +160,19 @@ void pow2_build_twiddles(int dtype, int n, HostTable &out);
 int launch_pow2(int dtype, int n, const Pow2Args &a, hipStream_t s);
 
 // kernels_pow2_real.hip : register-resident real-op kernels (R2C/C2R/DCT) for power-of-two inner FFT length F
-template <typename T> struct RealArgs;
 bool pow2_real_supported(int F);
 void pow2_real_build_twiddles(int F, HostTable &out);
 template <typename T> int launch_pow2_real(int gen_op, const RealArgs<T> &a, hipStream_t s);
+
+// big.hip : four-step pieces for lanes that do not fit LDS
+template <typename T>
+int launch_big_twiddle(cpx<T> *data, int64_t lanes, int F1, int F2, const cpx<T> *twlo, const cpx<T> *twhi, int logB, int conj,
+                       T scale, hipStream_t s);
+template <typename T>
+int launch_big_pre(int gen_op, const RealArgs<T> &a, cpx<T> *z, hipStream_t s);    // raw lanes (a.in, a.pitch_in) -> z[lane][F]
+template <typename T>
+int launch_big_post(int gen_op, const RealArgs<T> &a, const cpx<T> *z, hipStream_t s);   // z[lane][F] -> a.out
+size_t generic_max_len(size_t csize);   // longest complex FFT the single-launch LDS kernel can hold
 
 // transpose.hip : batched LDS-padded 2-D transpose, elem size 4/8/16 bytes
 // out[b][c][r] = in[b][r][c];  in pitch = ld_in elements per row, out pitch = ld_out

@@ -204,7 +204,7 @@ static int dispatch_generic(const Problem &P, const void *d_in, void *d_out, con
 
 // per-(host thread, stream) scratch for the transpose route; grows, never shrinks
 struct Scratch { void *p = nullptr; size_t cap = 0; };
-static thread_local std::map<hipStream_t, Scratch> g_scratch[2];
+static thread_local std::map<hipStream_t, Scratch> g_scratch[5];
 static int get_scratch(int which, hipStream_t s, size_t bytes, void **out) {
     Scratch &sc = g_scratch[which][s];
     if (bytes > sc.cap) {
@@ -217,6 +217,88 @@ static int get_scratch(int which, hipStream_t s, size_t bytes, void **out) {
 }
 
 static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t stream);
+
+static int transpose_batched(const void *in, void *out, int64_t batch, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out,
+                             int64_t bs_in, int64_t bs_out, int esz, hipStream_t s) {
+    for (int64_t b0 = 0; b0 < batch; b0 += 32768) {   // grid.z limit
+        const int64_t nb = std::min<int64_t>(32768, batch - b0);
+        int rc = launch_transpose((const char *)in + b0 * bs_in * esz, (char *)out + b0 * bs_out * esz, nb, rows, cols, ld_in, ld_out,
+                                  bs_in, bs_out, esz, s);
+        if (rc) return rc;
+    }
+    return NDFFT_OK;
+}
+
+// Four-step complex FFT of length F = F1*F2 on L lanes (zin / zout: lane pitches in elements).
+// zin may equal zout.  Sub-FFTs run through dispatch() on the row kernels.
+template <typename T>
+static int big_fft(const FftConfig &c, const DevConfig &d, const cpx<T> *zin, int64_t pitch_in, cpx<T> *zout, int64_t pitch_out,
+                   int64_t L, bool inverse, T scale, hipStream_t stream) {
+    const int F1 = c.F1, F2 = c.F2;
+    const int64_t F = (int64_t)F1 * F2;
+    const int esz = (int)sizeof(cpx<T>);
+    void *s1, *s2;
+    int rc;
+    if ((rc = get_scratch(2, stream, (size_t)(L * F) * esz, &s1))) return rc;
+    if ((rc = get_scratch(3, stream, (size_t)(L * F) * esz, &s2))) return rc;
+    // x[n1][n2] -> s1[n2][n1]
+    if ((rc = transpose_batched(zin, s1, L, F1, F2, F2, F1, pitch_in, F, esz, stream))) return rc;
+    Problem Q;
+    Q.plan = c.sub1; Q.op = inverse ? NDFFT_OP_C2C_INV : NDFFT_OP_C2C_FWD;
+    Q.xlen = Q.ylen = F1; Q.xs = Q.ys = 1; Q.nlanes = L * F2; Q.scale = 1.0;
+    Q.b.push_back({L * F2, (int64_t)F1, (int64_t)F1});
+    if ((rc = dispatch(Q, s1, s2, stream))) return rc;
+    if ((rc = launch_big_twiddle<T>((cpx<T> *)s2, L, F1, F2, (const cpx<T> *)d.twlo, (const cpx<T> *)d.twhi, c.logB, inverse ? 1 : 0, scale, stream))) return rc;
+    // s2[n2][k1] -> s1[k1][n2]
+    if ((rc = transpose_batched(s2, s1, L, F2, F1, F1, F2, F, F, esz, stream))) return rc;
+    Q.plan = c.sub2; Q.xlen = Q.ylen = F2; Q.nlanes = L * F1;
+    Q.b.clear(); Q.b.push_back({L * F1, (int64_t)F2, (int64_t)F2});
+    if ((rc = dispatch(Q, s1, s2, stream))) return rc;
+    // s2[k1][k2] -> out[k2][k1]  (flat index k1 + F1 k2)
+    return transpose_batched(s2, zout, L, F1, F2, F2, F1, F, pitch_out, esz, stream);
+}
+
+static int gen_op_of(int op, int n, int *slot) {
+    *slot = CFG_MAIN;
+    switch (op) {
+        case NDFFT_OP_C2C_FWD: return G_C2C_FWD;
+        case NDFFT_OP_C2C_INV: return G_C2C_INV;
+        case NDFFT_OP_R2C: return n % 2 ? G_R2C_ODD : G_R2C_EVEN;
+        case NDFFT_OP_C2R: return n % 2 ? G_C2R_ODD : G_C2R_EVEN;
+        case NDFFT_OP_DCT1: if (n == 1) return G_DCT2_ODD; *slot = CFG_DCT1; return G_DCT1;
+        case NDFFT_OP_DCT2: return n % 2 ? G_DCT2_ODD : G_DCT2_EVEN;
+        case NDFFT_OP_DCT3: return n % 2 ? G_DCT3_ODD : G_DCT3_EVEN;
+        default: *slot = CFG_DCT4; return n % 2 ? G_DCT4_ODD : G_DCT4_EVEN;
+    }
+}
+
+// contiguous lanes whose inner FFT does not fit one workgroup's LDS
+template <typename T>
+static int dispatch_big(const Problem &P, const void *d_in, void *d_out, const DevTables &dt, hipStream_t stream) {
+    const ndfft_plan *plan = P.plan;
+    int slot;
+    const int gop = gen_op_of(P.op, (int)plan->n, &slot);
+    const FftConfig &c = plan->cfg[slot];
+    const DevConfig &d = dt.cfg[slot];
+    const int64_t pin = P.b.empty() ? P.xlen : P.b[0].sin, pout = P.b.empty() ? P.ylen : P.b[0].sout;
+    if (gop == G_C2C_FWD || gop == G_C2C_INV) {
+        int rc0 = big_fft<T>(c, d, (const cpx<T> *)d_in, pin, (cpx<T> *)d_out, pout, P.nlanes, gop == G_C2C_INV, (T)P.scale, stream);
+        set_last_path("four_step");
+        return rc0;
+    }
+    RealArgs<T> a;
+    a.in = d_in; a.out = d_out; a.nlanes = P.nlanes; a.pitch_in = pin; a.pitch_out = pout;
+    a.n = (int)plan->n; a.F = c.F; a.n_in = (int)P.xlen; a.n_out = (int)P.ylen; a.scale = (T)P.scale;
+    a.aux1 = (const cpx<T> *)d.aux1; a.aux2 = (const cpx<T> *)d.aux2; a.twp = nullptr;
+    void *z;
+    int rc;
+    if ((rc = get_scratch(4, stream, (size_t)(P.nlanes * c.F) * sizeof(cpx<T>), &z))) return rc;
+    if ((rc = launch_big_pre<T>(gop, a, (cpx<T> *)z, stream))) return rc;
+    if ((rc = big_fft<T>(c, d, (const cpx<T> *)z, c.F, (cpx<T> *)z, c.F, P.nlanes, false, (T)1, stream))) return rc;
+    rc = launch_big_post<T>(gop, a, (const cpx<T> *)z, stream);
+    set_last_path("four_step");
+    return rc;
+}
 
 // Long lanes on a non-contiguous axis of a C-layout array, viewed as (outer, n, inner):
 // transpose -> row transform on contiguous lanes -> transpose back.
@@ -289,6 +371,16 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
             return launch_pow2_real<double>(gop, a, stream);
         }
     }
+    {   // long lanes: four-step on the row kernels (contiguous lanes) -- strided ones reach here via the transpose route
+        int slot;
+        (void)gen_op_of(P.op, (int)plan->n, &slot);
+        const FftConfig &c = plan->cfg[slot];
+        if (c.unsupported)
+            return fail(NDFFT_ERR_UNSUPPORTED, "lane length has a prime factor too large for the single-launch Bluestein and no usable "
+                                               "four-step split (DESIGN.md section 9)");
+        if (c.big && P.xs == 1 && P.ys == 1 && P.b.size() <= 1)
+            return plan->dtype == NDFFT_F32 ? dispatch_big<float>(P, d_in, d_out, *dt, stream) : dispatch_big<double>(P, d_in, d_out, *dt, stream);
+    }
     // strided axis of a C-layout array whose lanes are too long for a useful LDS tile of adjacent
     // lanes (< 128 B contiguous per tile row): go through the batched transpose
     if (P.xs != 1 && P.ys != 1 && P.xlen > 1 && !P.b.empty() && P.b.back().sin == 1 && P.b.back().sout == 1 && P.b.size() <= 2) {
@@ -302,9 +394,9 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
         const int slot = P.op == NDFFT_OP_DCT1 && plan->n > 1 ? CFG_DCT1 : P.op == NDFFT_OP_DCT4 ? CFG_DCT4 : CFG_MAIN;
         const FftConfig &c = plan->cfg[slot];
         const size_t per_lane = 2 * (size_t)generic_z_len(std::max(c.blue ? c.M : c.F, 1)) * 2 * r;
-        const size_t fit = (160 * 1024 - 2048) / std::max<size_t>(per_lane, 1);
+        const size_t fit = c.big ? 0 : (160 * 1024 - 2048) / std::max<size_t>(per_lane, 1);
         const size_t row_bytes = std::min<size_t>(fit, (size_t)inner) * std::min(ein, eout);
-        if (c_layout && row_bytes < 128 && inner >= 16) {
+        if (c_layout && row_bytes < 128 && (inner >= 16 || c.big)) {
             int rc2 = dispatch_transposed(P, d_in, d_out, stream, outer, inner, ein, eout);
             if (!rc2) {
                 static thread_local std::string path;

@@ -217,6 +217,11 @@ size_t generic_lds_bytes(int lpb, int pitch, size_t csize) {
     return kGenHeaderBytes + 2 * (size_t)lpb * (size_t)pitch * csize;
 }
 int generic_z_len(int len) { return len + (len >> 3) + 1; }
+size_t generic_max_len(size_t csize) {
+    size_t len = 1;
+    while (generic_lds_bytes(1, generic_z_len((int)(len + 1)) | 1, csize) <= 160 * 1024) ++len;
+    return len;
+}
 
 template <typename T, int OP> static int launch_op(const GenArgs<T> &a, int threads, size_t lds_bytes, hipStream_t s) {
     static bool attr_set = false;

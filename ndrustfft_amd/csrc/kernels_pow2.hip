@@ -34,7 +34,7 @@ namespace ndfft {
     X(1024, 64, 16, 8, 8)     \
     X(2048, 128, 16, 16, 8)   \
     X(4096, 512, 8, 8, 8, 8)  \
-    X(8192, 512, 16, 16, 8, 4) \
+    X(8192, 512, 8, 8, 8, 16) \
     X(16384, 1024, 16, 16, 16, 4)
 // f32 (8-byte elements): first and last radix <= E/2 so that two adjacent elements (16 B) move per
 // global access (VEC = 2)

@@ -39,20 +39,51 @@ static bool factorize(int F, std::vector<int> &radix) {
     return m == 1 && radix.size() <= (size_t)kMaxPasses;
 }
 
-// fills F, radix / Bluestein, tw (and twM, chirp, bhat)
-static void build_fft(FftConfig &c, int F) {
+static ndfft_plan *make_plan(int kind, int dtype, size_t n);
+
+static int blue_len(int F) { int M = 1; while (M < 2 * F - 1) M <<= 1; return M; }
+
+// can ONE launch of the row kernels transform a lane of this length?
+static bool single_kernel_ok(int len, int dtype) {
+    const size_t maxlen = generic_max_len(dtype == NDFFT_F32 ? 8 : 16);
+    if (len <= 1 || pow2_supported(dtype, len)) return true;
+    std::vector<int> r;
+    if (factorize(len, r)) return (size_t)len <= maxlen;
+    return (size_t)blue_len(len) <= maxlen;
+}
+
+// fills F, radix / Bluestein, tw (and twM, chirp, bhat); or the four-step split for long lanes
+static void build_fft(FftConfig &c, int F, int dtype) {
     c.F = F;
     if (F <= 1) return;
-    if (factorize(F, c.radix)) {
+    const size_t maxlen = generic_max_len(dtype == NDFFT_F32 ? 8 : 16);
+    const bool smooth = factorize(F, c.radix);
+    if (smooth && (size_t)F <= maxlen) {
         for (int k = 0; k < F; ++k) unit(c.tw, k, F);
+        return;
+    }
+    if (smooth || (size_t)blue_len(F) > maxlen) {
+        // long lane: F = F1 * F2 with both halves inside one launch, as square as possible
+        c.radix.clear();
+        int best = 0;
+        for (int d = 2; (int64_t)d * d <= F; ++d)
+            if (F % d == 0 && single_kernel_ok(d, dtype) && single_kernel_ok(F / d, dtype)) best = d;
+        if (!best) { c.unsupported = true; return; }
+        c.big = true; c.F2 = best; c.F1 = F / best;           // F1 >= F2
+        c.sub1 = make_plan(NDFFT_KIND_C2C, dtype, (size_t)c.F1);
+        c.sub2 = make_plan(NDFFT_KIND_C2C, dtype, (size_t)c.F2);
+        int logF = 0; while ((1ll << logF) < F) ++logF;
+        c.logB = (logF + 1) / 2;
+        const int64_t B = 1ll << c.logB;
+        for (int64_t k = 0; k < B && k < F; ++k) unit(c.twlo, k, F);
+        for (int64_t k = 0; k * B < F; ++k) unit(c.twhi, k * B, F);
         return;
     }
     // Bluestein: chirp[j] = e^{-i pi j^2/F}; bhat = FFT_M(conj chirp wrapped)/M computed here in
     // long double by a direct radix-2 recursion so the device table is correctly rounded.
     c.blue = true;
     c.radix.clear();
-    int M = 1;
-    while (M < 2 * F - 1) M <<= 1;
+    const int M = blue_len(F);
     c.M = M;
     factorize(M, c.radixM);
     for (int k = 0; k < M; ++k) unit(c.twM, k, M);
@@ -88,33 +119,33 @@ static void build_plan_tables(ndfft_plan *p) {
     if (n == 0) return;
     FftConfig &m = p->cfg[CFG_MAIN];
     if (p->kind == NDFFT_KIND_C2C) {
-        build_fft(m, n);
+        build_fft(m, n, p->dtype);
         if (pow2_supported(p->dtype, n)) { m.pow2 = true; pow2_build_twiddles(p->dtype, n, m.twp); }
         p->has_cfg[CFG_MAIN] = true;
     } else if (p->kind == NDFFT_KIND_R2C) {
         if (n % 2 == 0) {
-            build_fft(m, n / 2);
+            build_fft(m, n / 2, p->dtype);
             for (int k = 0; k <= n / 2; ++k) unit(m.aux1, k, n);          // W_n^k
             if (pow2_real_supported(n / 2)) { m.pow2 = true; pow2_real_build_twiddles(n / 2, m.twp); }
         } else {
-            build_fft(m, n);
+            build_fft(m, n, p->dtype);
         }
         p->has_cfg[CFG_MAIN] = true;
     } else {
         // DCT-II / DCT-III (Makhoul through a real FFT of length n)
         if (n % 2 == 0) {
-            build_fft(m, n / 2);
+            build_fft(m, n / 2, p->dtype);
             for (int k = 0; k <= n / 2; ++k) unit(m.aux1, k, n);          // W_n^k
             if (pow2_real_supported(n / 2)) { m.pow2 = true; pow2_real_build_twiddles(n / 2, m.twp); }
         } else {
-            build_fft(m, n);
+            build_fft(m, n, p->dtype);
         }
         for (int k = 0; k < n; ++k) unit(m.aux2, k, 4ull * n);            // e^{-i pi k/(2n)}
         p->has_cfg[CFG_MAIN] = true;
         // DCT-I: real FFT of the even extension, length 2(n-1)
         if (n >= 2) {
             FftConfig &d1 = p->cfg[CFG_DCT1];
-            build_fft(d1, n - 1);
+            build_fft(d1, n - 1, p->dtype);
             for (int k = 0; k <= n - 1; ++k) unit(d1.aux1, k, 2ull * (n - 1));
             if (pow2_real_supported(n - 1)) { d1.pow2 = true; pow2_real_build_twiddles(n - 1, d1.twp); }
             p->has_cfg[CFG_DCT1] = true;
@@ -122,17 +153,24 @@ static void build_plan_tables(ndfft_plan *p) {
         // DCT-IV
         FftConfig &d4 = p->cfg[CFG_DCT4];
         if (n % 2 == 0) {
-            build_fft(d4, n / 2);
+            build_fft(d4, n / 2, p->dtype);
             for (int j = 0; j < n / 2; ++j) unit(d4.aux1, 4ull * j + 1, 8ull * n);   // e^{-i pi (4j+1)/(4n)}
             for (int k = 0; k < n / 2; ++k) unit(d4.aux2, k, 2ull * n);              // e^{-i pi k/n}
             if (pow2_real_supported(n / 2)) { d4.pow2 = true; pow2_real_build_twiddles(n / 2, d4.twp); }
         } else {
-            build_fft(d4, 2 * n);
+            build_fft(d4, 2 * n, p->dtype);
             for (int j = 0; j < n; ++j) unit(d4.aux1, j, 4ull * n);                  // e^{-i pi j/(2n)}
             for (int k = 0; k < n; ++k) unit(d4.aux2, 2ull * k + 1, 8ull * n);       // e^{-i pi (2k+1)/(4n)}
         }
         p->has_cfg[CFG_DCT4] = true;
     }
+}
+
+static ndfft_plan *make_plan(int kind, int dtype, size_t n) {
+    ndfft_plan *p = new ndfft_plan();
+    p->kind = kind; p->dtype = dtype; p->n = n; p->refcount = 1;
+    build_plan_tables(p);
+    return p;
 }
 
 template <typename T> static int upload(const HostTable &t, void **dptr) {
@@ -171,6 +209,8 @@ int get_dev_tables(const ndfft_plan *cplan, const DevTables **out) {
         if ((rc = upload_any(plan->dtype, c.aux1, &d.aux1))) return rc;
         if ((rc = upload_any(plan->dtype, c.aux2, &d.aux2))) return rc;
         if ((rc = upload_any(plan->dtype, c.twp, &d.twp))) return rc;
+        if ((rc = upload_any(plan->dtype, c.twlo, &d.twlo))) return rc;
+        if ((rc = upload_any(plan->dtype, c.twhi, &d.twhi))) return rc;
     }
     auto ins = plan->dev.emplace(dev, t);
     *out = &ins.first->second;
@@ -205,13 +245,10 @@ int ndfft_plan_create(int kind, int dtype, size_t n, ndfft_plan **out_plan) {
     *out_plan = nullptr;
     if (kind < NDFFT_KIND_C2C || kind > NDFFT_KIND_DCT) return fail(NDFFT_ERR_INVALID_ARG, "bad kind");
     if (dtype != NDFFT_F32 && dtype != NDFFT_F64) return fail(NDFFT_ERR_INVALID_ARG, "bad dtype (T must be f32 or f64)");
-    if (n > (size_t)(1 << 26)) return fail(NDFFT_ERR_UNSUPPORTED, "n too large");
+    if (n > (size_t)(1 << 24)) return fail(NDFFT_ERR_UNSUPPORTED, "n > 2^24 is not supported yet");
     if (ndfft_device_count() <= 0)
         return fail(NDFFT_ERR_NO_DEVICE, "no HIP device visible: libndfft_mi355x has no CPU fallback");
-    ndfft_plan *p = new (std::nothrow) ndfft_plan();
-    if (!p) return fail(NDFFT_ERR_ALLOC, "out of host memory");
-    p->kind = kind; p->dtype = dtype; p->n = n; p->refcount = 1;
-    build_plan_tables(p);
+    ndfft_plan *p = make_plan(kind, dtype, n);
     const DevTables *t;
     int rc = get_dev_tables(p, &t);   // eager upload to the current device
     if (rc) { delete p; return rc; }
@@ -238,11 +275,12 @@ int ndfft_plan_destroy(ndfft_plan *plan) {
         (void)hipSetDevice(kv.first);
         for (int i = 0; i < CFG_COUNT; ++i) {
             DevConfig &d = kv.second.cfg[i];
-            void *ptrs[] = {d.tw, d.twM, d.chirp, d.bhat, d.aux1, d.aux2, d.twp};
+            void *ptrs[] = {d.tw, d.twM, d.chirp, d.bhat, d.aux1, d.aux2, d.twp, d.twlo, d.twhi};
             for (void *q : ptrs) if (q) (void)hipFree(q);
         }
     }
     (void)hipSetDevice(cur);
+    for (int i = 0; i < CFG_COUNT; ++i) { ndfft_plan_destroy(plan->cfg[i].sub1); ndfft_plan_destroy(plan->cfg[i].sub2); }
     delete plan;
     return NDFFT_OK;
 }

@@ -284,6 +284,28 @@ def pow2_real_sizes(L, sizes=(64, 128, 256, 512, 1024, 2048, 4096, 8192), dtypes
             assert run_case(L, "nddct1", (5, F + 1), 1, rdt, offset=F) == "pow2_real", ("nddct1", F)
 
 
+def long_lanes_four_step(L, full=True):
+    """Lanes longer than one workgroup's LDS: four-step on the row kernels (any op, C2C inverse scaling,
+    non-power-of-two splits, strided axis through the transpose route); and the documented refusal."""
+    import pytest
+    cases = [("ndfft", (2, 32768), 1, np.float64, "four_step"), ("ndifft", (2, 32768), 1, np.float64, "four_step"),
+             ("ndfft", (3, 6000), 1, np.float64, "four_step"), ("ndfft_r2c", (2, 20000), 1, np.float64, "four_step"),
+             ("ndifft_r2c", (2, 20000), 1, np.float64, "four_step"), ("nddct2", (2, 12000), 1, np.float64, "four_step"),
+             ("nddct3", (2, 12000), 1, np.float64, "four_step"), ("nddct1", (2, 10001), 1, np.float64, "four_step"),
+             ("nddct4", (2, 12000), 1, np.float64, "four_step"), ("ndfft", (2, 65536), 1, np.float32, "four_step"),
+             ("ndfft", (20000, 3), 0, np.float64, "transpose+four_step"), ("ndfft_r2c", (2, 9999), 1, np.float64, "four_step"),
+             ("nddct2", (2, 9999), 1, np.float32, "four_step")]
+    if full:
+        cases += [("ndfft", (2, 1 << 20), 1, np.float64, "four_step"), ("ndifft", (1, 1 << 22), 1, np.float32, "four_step"),
+                  ("nddct2", (3, 1 << 18), 1, np.float64, "four_step"), ("ndfft_r2c", (2, 3 * (1 << 17)), 1, np.float32, "four_step")]
+    for name, shape, axis, rdt, want in cases:
+        assert run_case(L, name, shape, axis, rdt) == want, (name, shape)
+    # a lane length with a huge prime factor and no usable split is refused, never computed on a CPU
+    with pytest.raises(_lib.NdfftError) as e:
+        run_case(L, "ndfft", (2, 2 * 10007), 1, np.float64)
+    assert e.value.status == _lib.ERR_UNSUPPORTED
+
+
 def handler_clone_shares_plan(L):
     h = handlers.FftHandler(16, _library=L)
     h2 = h.clone()

@@ -80,6 +80,13 @@ def main():
         t = (time.perf_counter() - t0) / reps
         print(json.dumps({"workload": "hostpath ndfft_exec (pageable host arrays, PCIe both ways) 4096x4096 c128", "us": round(t * 1e6, 1),
                           "GFFT-points/s": round(x.size / t / 1e9, 3), "host_GB/s": round(2 * x.nbytes / t / 1e9, 2)}), flush=True)
+    if want("longlanes"):
+        for n, rows, cdt, rdt in ((1 << 16, 256, np.complex128, np.float64), (1 << 20, 16, np.complex128, np.float64), (6000, 2048, np.complex128, np.float64),
+                                  (1 << 20, 32, np.complex64, np.float32)):
+            x = torch.from_numpy(synth.complex_array((rows, n), cdt)).to(dev); y = torch.empty_like(x)
+            run(f"long ndfft axis=1 {rows}x{n} {np.dtype(cdt).name}", ndfft, x, y, FftHandler(n, rdt), 1, x.numel(), max(a.steps // 3, 3))
+        x = torch.from_numpy(synth.real_array((64, 1 << 18))).to(dev); y = torch.empty_like(x)
+        run("long nddct2 axis=1 64x262144 f64", nddct2, x, y, DctHandler(1 << 18), 1, x.numel(), max(a.steps // 3, 3))
     if want("refbench"):
         for n in (128, 264, 512, 1024):
             x = torch.from_numpy(synth.bench_fill_complex((n, n))).to(dev); y = torch.empty_like(x)

@@ -65,86 +65,102 @@ template <typename K, typename T, typename RL> static Variant fft_variant(const 
     return v;
 }
 
-int main(int argc, char **argv) {
-    const int n = 4096;
-    const int64_t lanes = argc > 1 ? atoll(argv[1]) : 4096;
-    const int rounds = argc > 2 ? atoi(argv[2]) : 15;
-    const size_t elems = (size_t)lanes * n;
-    double2 *din, *dout, *dref;
-    CK(hipMalloc(&din, elems * 16)); CK(hipMalloc(&dout, elems * 16)); CK(hipMalloc(&dref, elems * 16));
-    {
-        std::vector<double2> h(elems);
+template <typename T> struct Bench {
+    int n; int64_t lanes; int rounds;
+    cpx<T> *din, *dout, *dref;
+    std::vector<Variant> vs;
+    void init() {
+        const size_t elems = (size_t)lanes * n;
+        CK(hipMalloc(&din, elems * sizeof(cpx<T>))); CK(hipMalloc(&dout, elems * sizeof(cpx<T>))); CK(hipMalloc(&dref, elems * sizeof(cpx<T>)));
+        std::vector<cpx<T>> h(elems);
         unsigned long long s = 88172645463325252ull;
         for (size_t i = 0; i < elems; ++i) {
-            s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[i].x = (double)(s >> 11) * (1.0 / 9007199254740992.0) * 2 - 1;
-            s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[i].y = (double)(s >> 11) * (1.0 / 9007199254740992.0) * 2 - 1;
+            s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[i].x = (T)((double)(s >> 11) * (1.0 / 9007199254740992.0) * 2 - 1);
+            s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[i].y = (T)((double)(s >> 11) * (1.0 / 9007199254740992.0) * 2 - 1);
         }
-        CK(hipMemcpy(din, h.data(), elems * 16, hipMemcpyHostToDevice));
+        CK(hipMemcpy(din, h.data(), elems * sizeof(cpx<T>), hipMemcpyHostToDevice));
     }
-    using R16 = RadixList<16, 16, 16>;
-    using R8 = RadixList<8, 8, 8, 8>;
-    using R1684 = RadixList<16, 16, 4, 4>;
-    std::vector<Variant> vs;
-#define FV(name, TPL, HALF, RL, FLAGS, MINW, NT) vs.push_back(fft_variant<Pow2Kernel<double, 4096, TPL, 1, HALF, RL, FLAGS, MINW, NT>, double, RL>(name, din, dout, lanes, n));
-    FV("half_256x16_r16^3 nt0", 256, true, R16, 0, 1, 0)
-    FV("half_256x16_r16^3 nt1(st)", 256, true, R16, 0, 1, 1)
-    FV("half_256x16_r16^3 nt2(ld)", 256, true, R16, 0, 1, 2)
-    FV("half_256x16_r16^3 nt3", 256, true, R16, 0, 1, 3)
-    FV("full_256x16_r16^3 nt1", 256, false, R16, 0, 1, 1)
-    FV("half_512x8_r8^4 nt0", 512, true, R8, 0, 1, 0)
-    FV("half_512x8_r8^4 nt1", 512, true, R8, 0, 1, 1)
-    FV("half_512x8_r8^4 nt3", 512, true, R8, 0, 1, 3)
-    FV("full_512x8_r8^4 nt1", 512, false, R8, 0, 1, 1)
-    FV("ablate: no twiddles nt1", 256, true, R16, 1, 1, 1)
-    FV("ablate: no LDS exchange nt1", 256, true, R16, 2, 1, 1)
-    FV("ablate: load+store only nt1", 256, true, R16, 7, 1, 1)
-    FV("ablate: load+store only nt3", 256, true, R16, 7, 1, 3)
-    FV("ablate: 512x8 load+store only nt1", 512, true, R8, 7, 1, 1)
-    for (auto &v : vs) if (v.name.rfind("ablate", 0) == 0) v.check = false;
-    {   // copy ceilings, occupancy limited through dummy LDS like the FFT kernel (34.8 KiB -> 4 blocks/CU)
-        const double bytes = 2.0 * elems * 16;
-        for (size_t lds : {(size_t)0, (size_t)34880, (size_t)69700}) {
-            CK(hipFuncSetAttribute((const void *)k_copy_lane<256, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            char nm[64]; snprintf(nm, sizeof nm, "copy lane-pattern 256x16, lds=%zu", lds);
-            vs.push_back({nm, [=]() { hipLaunchKernelGGL((k_copy_lane<256, 16>), dim3((unsigned)lanes), dim3(256), lds, 0, din, dout); }, bytes, false});
-        }
-        vs.push_back({"copy stream grid=2048", [=]() { hipLaunchKernelGGL(k_copy_stream, dim3(2048), dim3(256), 0, 0, din, dout, elems); }, bytes, false});
-        vs.push_back({"copy stream grid=8192", [=]() { hipLaunchKernelGGL(k_copy_stream, dim3(8192), dim3(256), 0, 0, din, dout, elems); }, bytes, false});
-    }
-    // reference output from the product variant
-    vs[0].launch(); CK(hipDeviceSynchronize());
-    CK(hipMemcpy(dref, dout, elems * 16, hipMemcpyDeviceToDevice));
-    std::vector<double2> href(1 << 16), hgot(1 << 16);
-    CK(hipMemcpy(href.data(), dref, href.size() * 16, hipMemcpyDeviceToHost));
-
-    std::vector<std::vector<float>> t(vs.size());
-    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const int inner = 10;
-    for (int r = 0; r < rounds; ++r)
-        for (size_t i = 0; i < vs.size(); ++i) {
-            vs[i].launch();   // warm
-            CK(hipEventRecord(e0, 0));
-            for (int k = 0; k < inner; ++k) vs[i].launch();
-            CK(hipEventRecord(e1, 0));
-            CK(hipEventSynchronize(e1));
-            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            t[i].push_back(ms * 1000.f / inner);
-            if (r == 0 && vs[i].check) {
-                CK(hipMemcpy(hgot.data(), dout, hgot.size() * 16, hipMemcpyDeviceToHost));
-                double md = 0, mr = 0;
-                for (size_t k = 0; k < hgot.size(); ++k) {
-                    md = std::max(md, std::max(fabs(hgot[k].x - href[k].x), fabs(hgot[k].y - href[k].y)));
-                    mr = std::max(mr, std::max(fabs(href[k].x), fabs(href[k].y)));
+    template <typename K, typename RL> void add(const char *name) { vs.push_back(fft_variant<K, T, RL>(name, din, dout, lanes, n)); }
+    void run(double tol) {
+        const size_t elems = (size_t)lanes * n;
+        vs[0].launch(); CK(hipDeviceSynchronize());
+        CK(hipMemcpy(dref, dout, elems * sizeof(cpx<T>), hipMemcpyDeviceToDevice));
+        std::vector<cpx<T>> href(1 << 16), hgot(1 << 16);
+        CK(hipMemcpy(href.data(), dref, href.size() * sizeof(cpx<T>), hipMemcpyDeviceToHost));
+        std::vector<std::vector<float>> t(vs.size());
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        const int inner = 10;
+        for (int r = 0; r < rounds; ++r)
+            for (size_t i = 0; i < vs.size(); ++i) {
+                vs[i].launch();
+                CK(hipEventRecord(e0, 0));
+                for (int k = 0; k < inner; ++k) vs[i].launch();
+                CK(hipEventRecord(e1, 0));
+                CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                t[i].push_back(ms * 1000.f / inner);
+                if (r == 0 && vs[i].check) {
+                    CK(hipMemcpy(hgot.data(), dout, hgot.size() * sizeof(cpx<T>), hipMemcpyDeviceToHost));
+                    double md = 0, mr = 0;
+                    for (size_t k = 0; k < hgot.size(); ++k) {
+                        md = std::max(md, std::max(fabs((double)hgot[k].x - href[k].x), fabs((double)hgot[k].y - href[k].y)));
+                        mr = std::max(mr, std::max(fabs((double)href[k].x), fabs((double)href[k].y)));
+                    }
+                    if (md / mr > tol) printf("!! %s differs from variant 0: rel %.3e\n", vs[i].name.c_str(), md / mr);
                 }
-                if (md / mr > 1e-12) printf("!! %s differs from product output: rel %.3e\n", vs[i].name.c_str(), md / mr);
+                CK(hipGetLastError());
             }
-            CK(hipGetLastError());
+        printf("%-46s %10s %10s %10s %8s\n", "variant", "median_us", "min_us", "GB/s(med)", "frac8T");
+        for (size_t i = 0; i < vs.size(); ++i) {
+            std::sort(t[i].begin(), t[i].end());
+            const double med = t[i][t[i].size() / 2], mn = t[i][0];
+            printf("%-46s %10.2f %10.2f %10.1f %8.3f\n", vs[i].name.c_str(), med, mn, vs[i].bytes / med / 1e3, vs[i].bytes / med / 1e3 / 8000.0);
         }
-    printf("%-42s %10s %10s %10s %8s\n", "variant", "median_us", "min_us", "GB/s(med)", "frac8T");
-    for (size_t i = 0; i < vs.size(); ++i) {
-        std::sort(t[i].begin(), t[i].end());
-        const double med = t[i][t[i].size() / 2], mn = t[i][0];
-        printf("%-42s %10.2f %10.2f %10.1f %8.3f\n", vs[i].name.c_str(), med, mn, vs[i].bytes / med / 1e3, vs[i].bytes / med / 1e3 / 8000.0);
+    }
+};
+
+#define V(B, T, N, name, TPL, HALF, NT, VEC, ...) B.template add<Pow2Kernel<T, N, TPL, (TPL >= 256 ? 1 : 256 / TPL), HALF, RadixList<__VA_ARGS__>, 0, 1, NT, VEC>, RadixList<__VA_ARGS__>>(name)
+
+int main(int argc, char **argv) {
+    const std::string what = argc > 1 ? argv[1] : "f32_8192";
+    const int rounds = argc > 2 ? atoi(argv[2]) : 11;
+    if (what == "f32_8192") {
+        Bench<float> b{8192, 4096, rounds}; b.init();
+        V(b, float, 8192, "half 512x16 8.16.8.8 vec2 (product)", 512, true, 1, 2, 8, 16, 8, 8);
+        V(b, float, 8192, "full 512x16 8.16.8.8 vec2", 512, false, 1, 2, 8, 16, 8, 8);
+        V(b, float, 8192, "half 1024x8 4.8.8.8.4 vec2", 1024, true, 1, 2, 4, 8, 8, 8, 4);
+        V(b, float, 8192, "full 1024x8 4.8.8.8.4 vec2", 1024, false, 1, 2, 4, 8, 8, 8, 4);
+        V(b, float, 8192, "half 256x32 16.16.8.4 vec2", 256, true, 1, 2, 16, 16, 8, 4);
+        V(b, float, 8192, "full 256x32 16.16.8.4 vec2", 256, false, 1, 2, 16, 16, 8, 4);
+        V(b, float, 8192, "half 256x32 16.32?no 8.8.8.16 vec2", 256, true, 1, 2, 8, 8, 8, 16);
+        V(b, float, 8192, "half 512x16 16.16.8.4 vec1", 512, true, 1, 1, 16, 16, 8, 4);
+        V(b, float, 8192, "half 512x16 8.16.8.8 vec2 nt3", 512, true, 3, 2, 8, 16, 8, 8);
+        b.run(1e-5);
+    } else if (what == "f32_4096") {
+        Bench<float> b{4096, 8192, rounds}; b.init();
+        V(b, float, 4096, "half 256x16 8.8.8.8 vec2 (product)", 256, true, 1, 2, 8, 8, 8, 8);
+        V(b, float, 4096, "full 256x16 8.8.8.8 vec2", 256, false, 1, 2, 8, 8, 8, 8);
+        V(b, float, 4096, "half 512x8 4.8.8.4.4 vec2", 512, true, 1, 2, 4, 8, 8, 4, 4);
+        V(b, float, 4096, "full 512x8 4.8.8.4.4 vec2", 512, false, 1, 2, 4, 8, 8, 4, 4);
+        V(b, float, 4096, "full 128x32 16.16.16 vec2", 128, false, 1, 2, 16, 16, 16);
+        V(b, float, 4096, "half 128x32 16.16.16 vec2", 128, true, 1, 2, 16, 16, 16);
+        b.run(1e-5);
+    } else if (what == "f64_8192") {
+        Bench<double> b{8192, 2048, rounds}; b.init();
+        V(b, double, 8192, "half 512x16 16.16.8.4 (product)", 512, true, 1, 1, 16, 16, 8, 4);
+        V(b, double, 8192, "half 1024x8 8.8.8.8.2", 1024, true, 1, 1, 8, 8, 8, 8, 2);
+        V(b, double, 8192, "half 1024x8 8.8.8.4.4", 1024, true, 1, 1, 8, 8, 8, 4, 4);
+        V(b, double, 8192, "half 512x16 8.8.8.16", 512, true, 1, 1, 8, 8, 8, 16);
+        V(b, double, 8192, "half 512x16 16.8.8.8", 512, true, 1, 1, 16, 8, 8, 8);
+        V(b, double, 8192, "half 256x32 16.16.32?no 16.16.8.4", 256, true, 1, 1, 16, 16, 8, 4);
+        b.run(1e-12);
+    } else if (what == "f64_16384") {
+        Bench<double> b{16384, 1024, rounds}; b.init();
+        V(b, double, 16384, "half 1024x16 16.16.16.4 (product)", 1024, true, 1, 1, 16, 16, 16, 4);
+        V(b, double, 16384, "half 1024x16 8.8.16.16", 1024, true, 1, 1, 8, 8, 16, 16);
+        V(b, double, 16384, "half 512x32 16.16.16.4", 512, true, 1, 1, 16, 16, 16, 4);
+        V(b, double, 16384, "half 1024x16 8.8.8.8.4", 1024, true, 1, 1, 8, 8, 8, 8, 4);
+        b.run(1e-12);
     }
     return 0;
 }
