@@ -94,6 +94,7 @@ struct FftConfig {                 // one complex-FFT-of-length-F recipe + op ta
     // tuned power-of-two path (register-resident Stockham), when eligible
     bool pow2 = false;             // C2C slot: pow2_kernel.h ; real-op slots: pow2_real.h
     HostTable twp;                 // per-pass transposed twiddles
+    HostTable twp_col;             // C2C slot only: twiddles in the radix order of the column kernel (pow2_real.h)
     // long lanes (one lane does not fit LDS): four-step F = F1 * F2 on top of the row kernels
     bool big = false; int F1 = 0, F2 = 0, logB = 0;
     ndfft_plan *sub1 = nullptr, *sub2 = nullptr;   // C2C sub-plans of length F1 / F2 (owned)
@@ -103,7 +104,7 @@ struct FftConfig {                 // one complex-FFT-of-length-F recipe + op ta
 
 struct DevConfig {                 // device copies (typed by dtype) of one FftConfig
     void *tw = nullptr, *twM = nullptr, *chirp = nullptr, *bhat = nullptr, *aux1 = nullptr, *aux2 = nullptr, *twp = nullptr;
-    void *twlo = nullptr, *twhi = nullptr;
+    void *twlo = nullptr, *twhi = nullptr, *twp_col = nullptr;
 };
 
 enum ConfigSlot { CFG_MAIN = 0, CFG_DCT1 = 1, CFG_DCT4 = 2, CFG_COUNT = 3 };
@@ -162,7 +163,8 @@ int launch_pow2(int dtype, int n, const Pow2Args &a, hipStream_t s);
 // kernels_pow2_real.hip : register-resident real-op kernels (R2C/C2R/DCT) for power-of-two inner FFT length F
 bool pow2_real_supported(int F);
 void pow2_real_build_twiddles(int F, HostTable &out);
-template <typename T> int launch_pow2_real(int gen_op, const RealArgs<T> &a, hipStream_t s);
+template <typename T> int launch_pow2_real(int gen_op, const RealArgs<T> &a, bool col, hipStream_t s);
+template <typename T> int pow2_real_col_lanes(int F);   // adjacent lanes per column tile (0: none)
 
 // big.hip : four-step pieces for lanes that do not fit LDS
 template <typename T>

@@ -338,37 +338,48 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
         set_last_path("pow2_reg");
         return launch_pow2(plan->dtype, (int)plan->n, a, stream);
     }
-    // tuned path for the real-data transforms with a power-of-two inner FFT, contiguous lanes
-    if (plan->kind != NDFFT_KIND_C2C && P.xs == 1 && P.ys == 1 && P.b.size() <= 1) {
+    // tuned paths on the register-resident real-op engine (pow2_real.h), power-of-two inner FFT:
+    //   row: R2C / C2R / DCT on contiguous lanes;  col: the same ops AND C2C on a strided axis whose
+    //   adjacent lanes are contiguous (strategy ii), through an LDS tile of adjacent lanes
+    {
         const int n = (int)plan->n;
-        int slot = CFG_MAIN, gop = -1;
-        switch (P.op) {
-            case NDFFT_OP_R2C: if (n % 2 == 0) gop = G_R2C_EVEN; break;
-            case NDFFT_OP_C2R: if (n % 2 == 0) gop = G_C2R_EVEN; break;
-            case NDFFT_OP_DCT1: if (n >= 2) { gop = G_DCT1; slot = CFG_DCT1; } break;
-            case NDFFT_OP_DCT2: if (n % 2 == 0) gop = G_DCT2_EVEN; break;
-            case NDFFT_OP_DCT3: if (n % 2 == 0) gop = G_DCT3_EVEN; break;
-            case NDFFT_OP_DCT4: if (n % 2 == 0) { gop = G_DCT4_EVEN; slot = CFG_DCT4; } break;
-            default: break;
+        int slot;
+        const int gop = gen_op_of(P.op, n, &slot);
+        const FftConfig &c = plan->cfg[slot];
+        const DevConfig &d = dt->cfg[slot];
+        const bool is_c2c = plan->kind == NDFFT_KIND_C2C;
+        const bool odd_variant = gop == G_R2C_ODD || gop == G_C2R_ODD || gop == G_DCT2_ODD || gop == G_DCT3_ODD || gop == G_DCT4_ODD;
+        const bool have_tw = is_c2c ? !c.twp_col.re.empty() : c.pow2;
+        const bool row = !is_c2c && P.xs == 1 && P.ys == 1 && P.b.size() <= 1;
+        bool col = false;
+        if (!row && have_tw && !odd_variant && P.xlen > 1 && !P.b.empty() && P.b.size() <= 2 && P.b.back().sin == 1 &&
+            P.b.back().sout == 1 && P.b.back().shape >= 8) {
+            const int lanes = plan->dtype == NDFFT_F32 ? pow2_real_col_lanes<float>(c.F) : pow2_real_col_lanes<double>(c.F);
+            col = lanes > 0;
         }
-        if (gop >= 0 && plan->cfg[slot].pow2) {
-            const FftConfig &c = plan->cfg[slot];
-            const DevConfig &d = dt->cfg[slot];
-            set_last_path("pow2_real");
+        if (have_tw && !odd_variant && (row || col)) {
             auto fill = [&](auto &a) {
                 a.in = d_in; a.out = d_out; a.nlanes = P.nlanes;
                 a.pitch_in = P.b.empty() ? P.xlen : P.b[0].sin;
                 a.pitch_out = P.b.empty() ? P.ylen : P.b[0].sout;
                 a.n = n; a.F = c.F; a.n_in = (int)P.xlen; a.n_out = (int)P.ylen;
+                a.inner = col ? P.b.back().shape : 1;
+                a.outer_in = col && P.b.size() == 2 ? P.b[0].sin : 0;
+                a.outer_out = col && P.b.size() == 2 ? P.b[0].sout : 0;
+                a.elem_in = P.xs; a.elem_out = P.ys;
             };
+            int rc2;
             if (plan->dtype == NDFFT_F32) {
                 RealArgs<float> a; fill(a); a.scale = (float)P.scale;
-                a.aux1 = (const float2 *)d.aux1; a.aux2 = (const float2 *)d.aux2; a.twp = (const float2 *)d.twp;
-                return launch_pow2_real<float>(gop, a, stream);
+                a.aux1 = (const float2 *)d.aux1; a.aux2 = (const float2 *)d.aux2; a.twp = (const float2 *)(is_c2c ? d.twp_col : d.twp);
+                rc2 = launch_pow2_real<float>(gop, a, col, stream);
+            } else {
+                RealArgs<double> a; fill(a); a.scale = P.scale;
+                a.aux1 = (const double2 *)d.aux1; a.aux2 = (const double2 *)d.aux2; a.twp = (const double2 *)(is_c2c ? d.twp_col : d.twp);
+                rc2 = launch_pow2_real<double>(gop, a, col, stream);
             }
-            RealArgs<double> a; fill(a); a.scale = P.scale;
-            a.aux1 = (const double2 *)d.aux1; a.aux2 = (const double2 *)d.aux2; a.twp = (const double2 *)d.twp;
-            return launch_pow2_real<double>(gop, a, stream);
+            set_last_path(col ? "pow2_col" : "pow2_real");
+            return rc2;
         }
     }
     {   // long lanes: four-step on the row kernels (contiguous lanes) -- strided ones reach here via the transpose route

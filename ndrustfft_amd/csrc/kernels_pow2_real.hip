@@ -41,15 +41,13 @@ void pow2_real_build_twiddles(int F, HostTable &out) {
     }
 }
 
-template <typename T, int F, int OP> static int launch_real_one(const RealArgs<T> &a, hipStream_t s) {
-    constexpr int TPL = RealCfg<F>::TPL, LPB = TPL >= 256 ? 1 : 256 / TPL;
-    using K = RealPow2Kernel<T, F, TPL, LPB, typename RealCfg<F>::RL, OP>;
+template <typename K, typename T> static int launch_k(const RealArgs<T> &a, int lpb, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)k_pow2_real<K, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    const int64_t nblk = (a.nlanes + LPB - 1) / LPB;
+    const int64_t nblk = (a.nlanes + lpb - 1) / lpb;
     if (nblk <= 0) return NDFFT_OK;
     if (nblk > 0x7fffffffLL) return fail(NDFFT_ERR_UNSUPPORTED, "too many lanes for one launch");
     hipLaunchKernelGGL((k_pow2_real<K, T>), dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, a);
@@ -57,27 +55,67 @@ template <typename T, int F, int OP> static int launch_real_one(const RealArgs<T
     return NDFFT_OK;
 }
 
-template <typename T, int F> static int launch_real_F(int op, const RealArgs<T> &a, hipStream_t s) {
+// threads of a COL workgroup: aim at 32 adjacent lanes per tile row, at most 1024 threads
+static constexpr int col_threads(int tpl) { return tpl * 32 > 1024 ? 1024 : (tpl * 32 < 256 ? 256 : tpl * 32); }
+template <typename T, int F> struct ColGeom {
+    static constexpr int TPL = RealCfg<F>::TPL;
+    static constexpr int LPB = col_threads(TPL) / TPL;
+    static constexpr size_t LDS = (size_t)LPB * (((F + (F >> 4) + 2) | 1)) * 2 * sizeof(T);
+    static constexpr bool OK = LPB >= 8 && LDS <= 160 * 1024;
+};
+
+template <typename T, int F, int OP> static int launch_real_one(const RealArgs<T> &a, bool col, hipStream_t s) {
+    constexpr int TPL = RealCfg<F>::TPL;
+    if (!col) {
+        if constexpr (OP == G_C2C_FWD || OP == G_C2C_INV) return fail(NDFFT_ERR_INVALID_ARG, "row C2C goes through k_pow2");
+        else {
+            constexpr int LPB = TPL >= 256 ? 1 : 256 / TPL;
+            return launch_k<RealPow2Kernel<T, F, TPL, LPB, typename RealCfg<F>::RL, OP, false>, T>(a, LPB, s);
+        }
+    }
+    if constexpr (ColGeom<T, F>::OK) {
+        constexpr int LPB = ColGeom<T, F>::LPB;
+        return launch_k<RealPow2Kernel<T, F, TPL, LPB, typename RealCfg<F>::RL, OP, true>, T>(a, LPB, s);
+    } else {
+        return fail(NDFFT_ERR_UNSUPPORTED, "pow2 real kernel: no column tile for this F");
+    }
+}
+
+template <typename T, int F> static int launch_real_F(int op, const RealArgs<T> &a, bool col, hipStream_t s) {
     switch (op) {
-        case G_R2C_EVEN: return launch_real_one<T, F, G_R2C_EVEN>(a, s);
-        case G_C2R_EVEN: return launch_real_one<T, F, G_C2R_EVEN>(a, s);
-        case G_DCT1: return launch_real_one<T, F, G_DCT1>(a, s);
-        case G_DCT2_EVEN: return launch_real_one<T, F, G_DCT2_EVEN>(a, s);
-        case G_DCT3_EVEN: return launch_real_one<T, F, G_DCT3_EVEN>(a, s);
-        case G_DCT4_EVEN: return launch_real_one<T, F, G_DCT4_EVEN>(a, s);
+        case G_C2C_FWD: return launch_real_one<T, F, G_C2C_FWD>(a, col, s);
+        case G_C2C_INV: return launch_real_one<T, F, G_C2C_INV>(a, col, s);
+        case G_R2C_EVEN: return launch_real_one<T, F, G_R2C_EVEN>(a, col, s);
+        case G_C2R_EVEN: return launch_real_one<T, F, G_C2R_EVEN>(a, col, s);
+        case G_DCT1: return launch_real_one<T, F, G_DCT1>(a, col, s);
+        case G_DCT2_EVEN: return launch_real_one<T, F, G_DCT2_EVEN>(a, col, s);
+        case G_DCT3_EVEN: return launch_real_one<T, F, G_DCT3_EVEN>(a, col, s);
+        case G_DCT4_EVEN: return launch_real_one<T, F, G_DCT4_EVEN>(a, col, s);
         default: return fail(NDFFT_ERR_INVALID_ARG, "pow2 real kernel: bad op");
     }
 }
 
-template <typename T> int launch_pow2_real(int op, const RealArgs<T> &a, hipStream_t s) {
+// lanes per column tile for inner FFT length F (0 = no column kernel)
+template <typename T> int pow2_real_col_lanes(int F) {
+    switch (F) {
+#define NDFFT_CASE(F_, TPL_, ...) case F_: return ColGeom<T, F_>::OK ? ColGeom<T, F_>::LPB : 0;
+        NDFFT_REAL_CONFIGS(NDFFT_CASE)
+#undef NDFFT_CASE
+        default: return 0;
+    }
+}
+template int pow2_real_col_lanes<float>(int);
+template int pow2_real_col_lanes<double>(int);
+
+template <typename T> int launch_pow2_real(int op, const RealArgs<T> &a, bool col, hipStream_t s) {
     switch (a.F) {
-#define NDFFT_CASE(F_, TPL_, ...) case F_: return launch_real_F<T, F_>(op, a, s);
+#define NDFFT_CASE(F_, TPL_, ...) case F_: return launch_real_F<T, F_>(op, a, col, s);
         NDFFT_REAL_CONFIGS(NDFFT_CASE)
 #undef NDFFT_CASE
         default: return fail(NDFFT_ERR_UNSUPPORTED, "pow2 real kernel: unsupported F");
     }
 }
-template int launch_pow2_real<float>(int, const RealArgs<float> &, hipStream_t);
-template int launch_pow2_real<double>(int, const RealArgs<double> &, hipStream_t);
+template int launch_pow2_real<float>(int, const RealArgs<float> &, bool, hipStream_t);
+template int launch_pow2_real<double>(int, const RealArgs<double> &, bool, hipStream_t);
 
 }  // namespace ndfft

@@ -121,6 +121,7 @@ static void build_plan_tables(ndfft_plan *p) {
     if (p->kind == NDFFT_KIND_C2C) {
         build_fft(m, n, p->dtype);
         if (pow2_supported(p->dtype, n)) { m.pow2 = true; pow2_build_twiddles(p->dtype, n, m.twp); }
+        if (pow2_real_supported(n)) pow2_real_build_twiddles(n, m.twp_col);
         p->has_cfg[CFG_MAIN] = true;
     } else if (p->kind == NDFFT_KIND_R2C) {
         if (n % 2 == 0) {
@@ -211,6 +212,7 @@ int get_dev_tables(const ndfft_plan *cplan, const DevTables **out) {
         if ((rc = upload_any(plan->dtype, c.twp, &d.twp))) return rc;
         if ((rc = upload_any(plan->dtype, c.twlo, &d.twlo))) return rc;
         if ((rc = upload_any(plan->dtype, c.twhi, &d.twhi))) return rc;
+        if ((rc = upload_any(plan->dtype, c.twp_col, &d.twp_col))) return rc;
     }
     auto ins = plan->dev.emplace(dev, t);
     *out = &ins.first->second;
@@ -275,7 +277,7 @@ int ndfft_plan_destroy(ndfft_plan *plan) {
         (void)hipSetDevice(kv.first);
         for (int i = 0; i < CFG_COUNT; ++i) {
             DevConfig &d = kv.second.cfg[i];
-            void *ptrs[] = {d.tw, d.twM, d.chirp, d.bhat, d.aux1, d.aux2, d.twp, d.twlo, d.twhi};
+            void *ptrs[] = {d.tw, d.twM, d.chirp, d.bhat, d.aux1, d.aux2, d.twp, d.twlo, d.twhi, d.twp_col};
             for (void *q : ptrs) if (q) (void)hipFree(q);
         }
     }

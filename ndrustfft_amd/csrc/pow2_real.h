@@ -18,40 +18,66 @@ namespace ndfft {
 
 template <typename T> struct RealArgs {
     const void *in; void *out;
-    int64_t nlanes, pitch_in, pitch_out;   // pitches in elements of the in / out element type
+    int64_t nlanes, pitch_in, pitch_out;   // row layout: pitches in elements of the in / out element type
     int32_t n, F, n_in, n_out;
     T scale;
     const cpx<T> *aux1, *aux2, *twp;
+    // column layout (COL kernels): lane L = (o, i), o = L / inner, i = L % inner;
+    // element j of lane L lives at o*outer_* + i + j*elem_*   (adjacent lanes are adjacent in memory)
+    int64_t inner, outer_in, outer_out, elem_in, elem_out;
 };
 
 struct ZiNone { static __device__ __forceinline__ int map(int p) { return p; } };
 struct ZiPhi { static __device__ __forceinline__ int map(int p) { return p + (p >> 4); } };
 
-template <typename T, int F, int TPL, int LPB, typename RL, int OP> struct RealPow2Kernel {
+// OP: G_R2C_EVEN, G_C2R_EVEN, G_DCT1, G_DCT2_EVEN, G_DCT3_EVEN, G_DCT4_EVEN, and (COL kernels) G_C2C_FWD / G_C2C_INV.
+// COL = false: lanes contiguous in memory (strategy i).  COL = true: the transform axis is strided and
+// ADJACENT LANES are contiguous (strategy ii on a C-layout array): the workgroup stages an LDS tile of
+// LPB lanes x n elements with lanes fastest -- the fused, LDS-padded transpose that replaces the
+// reference's per-lane x.to_vec() / y.assign() (src/lib.rs:133-134) -- and stores the same way.
+template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = false> struct RealPow2Kernel {
     static constexpr int E = F / TPL;
     static constexpr int THREADS = TPL * LPB;
-    static constexpr int LANE_LDS = F + (F >> 4) + 2;   // complex elements: padded Z, or F+1 raw complex (C2R)
+    static constexpr int LANE_LDS = (F + (F >> 4) + 2) | 1;   // complex elements (odd: lanes spread over banks); holds padded Z or F+1 raw complex
     static constexpr size_t LDS_BYTES = (size_t)LPB * LANE_LDS * 2 * sizeof(T);
-    static constexpr bool IN_CPLX = OP == G_C2R_EVEN;
-    static constexpr bool OUT_CPLX = OP == G_R2C_EVEN;
+    static constexpr bool IN_CPLX = OP == G_C2R_EVEN || OP == G_C2C_FWD || OP == G_C2C_INV;
+    static constexpr bool OUT_CPLX = OP == G_R2C_EVEN || OP == G_C2C_FWD || OP == G_C2C_INV;
     using FFT = Pow2Kernel<T, F, TPL, LPB, false, RL, 0, 1, 0>;
 
     static __device__ __forceinline__ void run(const RealArgs<T> &a) {
         extern __shared__ __attribute__((aligned(16))) char smem[];
         const int t = threadIdx.x % TPL, ll = threadIdx.x / TPL;
-        const int64_t lane = (int64_t)blockIdx.x * LPB + ll;
+        const int64_t lane0 = (int64_t)blockIdx.x * LPB;
+        const int64_t lane = lane0 + ll;
         const bool live = lane < a.nlanes;
-        const int64_t lsafe = live ? lane : 0;
         char *lds = smem + (size_t)ll * LANE_LDS * 2 * sizeof(T);
-        // ---- stage the raw lane ----
-        if constexpr (IN_CPLX) {
-            const cpx<T> *in = (const cpx<T> *)a.in + lsafe * a.pitch_in;
-            cpx<T> *raw = (cpx<T> *)lds;
-            for (int j = t; j < a.n_in; j += TPL) raw[j] = in[j];
+        // ---- stage the raw lane(s) ----
+        if constexpr (COL) {
+            // thread -> (lane cl = tid % LPB fastest, element j = tid / LPB)
+            const int cl = threadIdx.x % LPB, j0 = threadIdx.x / LPB;
+            const int64_t L = lane0 + cl;
+            if (L < a.nlanes) {
+                const int64_t base = (L / a.inner) * a.outer_in + (L % a.inner);
+                char *dst = smem + (size_t)cl * LANE_LDS * 2 * sizeof(T);
+                if constexpr (IN_CPLX) {
+                    const cpx<T> *in = (const cpx<T> *)a.in + base;
+                    for (int j = j0; j < a.n_in; j += THREADS / LPB) ((cpx<T> *)dst)[j] = in[(int64_t)j * a.elem_in];
+                } else {
+                    const T *in = (const T *)a.in + base;
+                    for (int j = j0; j < a.n_in; j += THREADS / LPB) ((T *)dst)[j] = in[(int64_t)j * a.elem_in];
+                }
+            }
         } else {
-            const T *in = (const T *)a.in + lsafe * a.pitch_in;
-            T *raw = (T *)lds;
-            for (int j = t; j < a.n_in; j += TPL) raw[j] = in[j];
+            const int64_t lsafe = live ? lane : 0;
+            if constexpr (IN_CPLX) {
+                const cpx<T> *in = (const cpx<T> *)a.in + lsafe * a.pitch_in;
+                cpx<T> *raw = (cpx<T> *)lds;
+                for (int j = t; j < a.n_in; j += TPL) raw[j] = in[j];
+            } else {
+                const T *in = (const T *)a.in + lsafe * a.pitch_in;
+                T *raw = (T *)lds;
+                for (int j = t; j < a.n_in; j += TPL) raw[j] = in[j];
+            }
         }
         __syncthreads();
         // ---- PRE into the first pass's register pattern ----
@@ -63,7 +89,8 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP> struct RealP
 #pragma unroll
                 for (int r = 0; r < R0; ++r) {
                     const int i = t + q * TPL + r * NB0;
-                    if constexpr (OP == G_R2C_EVEN) v[q * R0 + r] = ((const cpx<T> *)lds)[i];   // z[i] = (x[2i], x[2i+1])
+                    if constexpr (OP == G_R2C_EVEN || OP == G_C2C_FWD) v[q * R0 + r] = ((const cpx<T> *)lds)[i];   // z[i] = (x[2i], x[2i+1])
+                    else if constexpr (OP == G_C2C_INV) v[q * R0 + r] = cconj(((const cpx<T> *)lds)[i]);
                     else v[q * R0 + r] = pre_elem<T, OP, ZiNone>(a, (const void *)lds, i);
                 }
         }
@@ -80,15 +107,30 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP> struct RealP
                 for (int r = 0; r < RL_; ++r) z[ZiPhi::map(t + q * TPL + r * NBL)] = v[q * RL_ + r];
         }
         __syncthreads();
-        if (!live) return;
         // ---- POST gather + store ----
-        const cpx<T> *res = (const cpx<T> *)lds;
-        if constexpr (OUT_CPLX) {
-            cpx<T> *out = (cpx<T> *)a.out + lane * a.pitch_out;
-            for (int q = t; q < a.n_out; q += TPL) gstore<T, true>(out + q, post_cplx<T, OP, ZiPhi>(a, res, q));
+        if constexpr (COL) {
+            const int cl = threadIdx.x % LPB, j0 = threadIdx.x / LPB;
+            const int64_t L = lane0 + cl;
+            if (L >= a.nlanes) return;
+            const int64_t base = (L / a.inner) * a.outer_out + (L % a.inner);
+            const cpx<T> *res = (const cpx<T> *)(smem + (size_t)cl * LANE_LDS * 2 * sizeof(T));
+            if constexpr (OUT_CPLX) {
+                cpx<T> *out = (cpx<T> *)a.out + base;
+                for (int q = j0; q < a.n_out; q += THREADS / LPB) gstore<T, true>(out + (int64_t)q * a.elem_out, post_cplx<T, OP, ZiPhi>(a, res, q));
+            } else {
+                T *out = (T *)a.out + base;
+                for (int q = j0; q < a.n_out; q += THREADS / LPB) __builtin_nontemporal_store(post_real<T, OP, ZiPhi>(a, res, q), out + (int64_t)q * a.elem_out);
+            }
         } else {
-            T *out = (T *)a.out + lane * a.pitch_out;
-            for (int q = t; q < a.n_out; q += TPL) __builtin_nontemporal_store(post_real<T, OP, ZiPhi>(a, res, q), out + q);
+            if (!live) return;
+            const cpx<T> *res = (const cpx<T> *)lds;
+            if constexpr (OUT_CPLX) {
+                cpx<T> *out = (cpx<T> *)a.out + lane * a.pitch_out;
+                for (int q = t; q < a.n_out; q += TPL) gstore<T, true>(out + q, post_cplx<T, OP, ZiPhi>(a, res, q));
+            } else {
+                T *out = (T *)a.out + lane * a.pitch_out;
+                for (int q = t; q < a.n_out; q += TPL) __builtin_nontemporal_store(post_real<T, OP, ZiPhi>(a, res, q), out + q);
+            }
         }
     }
 };

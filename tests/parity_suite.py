@@ -306,6 +306,17 @@ def long_lanes_four_step(L, full=True):
     assert e.value.status == _lib.ERR_UNSUPPORTED
 
 
+def pow2_col_sizes(L, sizes=(64, 128, 256, 512, 1024), dtypes=(np.float64, np.float32)):
+    """Strategy (ii) on the register engine: a strided axis whose adjacent lanes are contiguous, tile of
+    adjacent lanes staged through LDS.  Every op (incl. C2C), 2-D axis 0 and 3-D middle axis, ragged tiles."""
+    for F in sizes:
+        for rdt in dtypes:
+            for name in OPS:
+                n = F if name in ("ndfft", "ndifft") else (F + 1 if name == "nddct1" else 2 * F)
+                for shape, axis in (((n, 40), 0), ((3, n, 17), 1), ((n, 9), 0)):
+                    assert run_case(L, name, shape, axis, rdt, offset=F) == "pow2_col", (name, shape)
+
+
 def handler_clone_shares_plan(L):
     h = handlers.FftHandler(16, _library=L)
     h2 = h.clone()

@@ -56,3 +56,8 @@ def test_reference_bench_shapes_small(L):
 def test_pow2_real_sizes(L):
     ps.pow2_real_sizes(L, sizes=(64, 128, 256, 512, 1024, 4096), dtypes=(np.float64,))
     ps.pow2_real_sizes(L, sizes=(64, 2048, 8192), dtypes=(np.float32,))
+
+
+def test_pow2_col_sizes(L):
+    ps.pow2_col_sizes(L, sizes=(64, 256), dtypes=(np.float64,))
+    ps.pow2_col_sizes(L, sizes=(128, 1024), dtypes=(np.float32,))
