@@ -43,6 +43,32 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
     static constexpr bool IN_CPLX = OP == G_C2R_EVEN || OP == G_C2C_FWD || OP == G_C2C_INV;
     static constexpr bool OUT_CPLX = OP == G_R2C_EVEN || OP == G_C2C_FWD || OP == G_C2C_INV;
     using FFT = Pow2Kernel<T, F, TPL, LPB, false, RL, 0, 1, 0>;
+    // ops whose POST is the real-FFT split: outputs k and F-k share one pair of LDS reads and one twiddle
+    static constexpr bool PAIR = OP == G_R2C_EVEN || OP == G_DCT1 || OP == G_DCT2_EVEN;
+
+    // writes every output derived from the spectrum pair (k, F-k); `st(q, value)` stores output element q
+    template <typename Store> static __device__ __forceinline__ void post_pair(const RealArgs<T> &a, const cpx<T> *res, int k, Store st) {
+        cpx<T> xk, xf;
+        r2c_split_pair<T, ZiPhi>(res, k, F, a.aux1[k], xk, xf);
+        const int kf = F - k;
+        if constexpr (OP == G_R2C_EVEN) {
+            st(k, xk);
+            if (kf != k) st(kf, xf);
+        } else if constexpr (OP == G_DCT1) {
+            st(k, (T)0.5 * xk.x);
+            if (kf != k) st(kf, (T)0.5 * xf.x);
+        } else {   // G_DCT2_EVEN: y[k] = Re(X[k] c_k), y[n-k] = -Im(X[k] c_k)
+            const int n = 2 * F;
+            cpx<T> tk = cmul(xk, a.aux2[k]);
+            st(k, tk.x);
+            if (k > 0) st(n - k, -tk.y);
+            if (kf != k) {
+                cpx<T> tf = cmul(xf, a.aux2[kf]);
+                st(kf, tf.x);
+                if (kf < F) st(n - kf, -tf.y);
+            }
+        }
+    }
 
     static __device__ __forceinline__ void run(const RealArgs<T> &a) {
         extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -114,7 +140,15 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
             if (L >= a.nlanes) return;
             const int64_t base = (L / a.inner) * a.outer_out + (L % a.inner);
             const cpx<T> *res = (const cpx<T> *)(smem + (size_t)cl * LANE_LDS * 2 * sizeof(T));
-            if constexpr (OUT_CPLX) {
+            if constexpr (PAIR) {
+                if constexpr (OUT_CPLX) {
+                    cpx<T> *out = (cpx<T> *)a.out + base;
+                    for (int k = j0; k <= F / 2; k += THREADS / LPB) post_pair(a, res, k, [&](int q, cpx<T> v) { gstore<T, true>(out + (int64_t)q * a.elem_out, v); });
+                } else {
+                    T *out = (T *)a.out + base;
+                    for (int k = j0; k <= F / 2; k += THREADS / LPB) post_pair(a, res, k, [&](int q, T v) { __builtin_nontemporal_store(v, out + (int64_t)q * a.elem_out); });
+                }
+            } else if constexpr (OUT_CPLX) {
                 cpx<T> *out = (cpx<T> *)a.out + base;
                 for (int q = j0; q < a.n_out; q += THREADS / LPB) gstore<T, true>(out + (int64_t)q * a.elem_out, post_cplx<T, OP, ZiPhi>(a, res, q));
             } else {
@@ -124,7 +158,15 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
         } else {
             if (!live) return;
             const cpx<T> *res = (const cpx<T> *)lds;
-            if constexpr (OUT_CPLX) {
+            if constexpr (PAIR) {
+                if constexpr (OUT_CPLX) {
+                    cpx<T> *out = (cpx<T> *)a.out + lane * a.pitch_out;
+                    for (int k = t; k <= F / 2; k += TPL) post_pair(a, res, k, [&](int q, cpx<T> v) { gstore<T, true>(out + q, v); });
+                } else {
+                    T *out = (T *)a.out + lane * a.pitch_out;
+                    for (int k = t; k <= F / 2; k += TPL) post_pair(a, res, k, [&](int q, T v) { __builtin_nontemporal_store(v, out + q); });
+                }
+            } else if constexpr (OUT_CPLX) {
                 cpx<T> *out = (cpx<T> *)a.out + lane * a.pitch_out;
                 for (int q = t; q < a.n_out; q += TPL) gstore<T, true>(out + q, post_cplx<T, OP, ZiPhi>(a, res, q));
             } else {

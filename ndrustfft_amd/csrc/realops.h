@@ -96,6 +96,18 @@ __device__ __forceinline__ cpx<T> r2c_split(const cpx<T> *res, int k, int F, cpx
     return cadd(e, cmul(o, w));
 }
 
+// both halves of the real-FFT split from ONE pair of reads:  X[k] = E + T,  X[F-k] = conj(E - T),
+// E = (Z[k] + conj Z[F-k])/2,  T = W_{2F}^k (Z[k] - conj Z[F-k])/(2i)     (W^{F-k} = -conj W^k)
+template <typename T, typename ZI>
+__device__ __forceinline__ void r2c_split_pair(const cpx<T> *res, int k, int F, cpx<T> w, cpx<T> &xk, cpx<T> &xfk) {
+    cpx<T> A = res[ZI::map(k == F ? 0 : k)], B = cconj(res[ZI::map(k == 0 ? 0 : F - k)]);
+    cpx<T> e = mk<T>((A.x + B.x) * (T)0.5, (A.y + B.y) * (T)0.5);
+    cpx<T> o = mk<T>((A.y - B.y) * (T)0.5, -(A.x - B.x) * (T)0.5);
+    cpx<T> t = cmul(o, w);
+    xk = cadd(e, t);
+    xfk = cconj(csub(e, t));
+}
+
 template <typename T, int OP, typename ZI, typename Args> __device__ __forceinline__ T post_real(const Args &a, const cpx<T> *res, int q) {
     const int n = a.n, F = a.F;
     switch (OP) {

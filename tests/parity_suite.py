@@ -317,6 +317,29 @@ def pow2_col_sizes(L, sizes=(64, 128, 256, 512, 1024), dtypes=(np.float64, np.fl
                     assert run_case(L, name, shape, axis, rdt, offset=F) == "pow2_col", (name, shape)
 
 
+def shared_handler_across_threads(L, nthreads=8):
+    """The reference shares &handler across rayon workers (lib.rs:192-194): one plan, many host threads."""
+    import threading
+    h = handlers.FftHandler(256, _library=L); hd = handlers.DctHandler(100, _library=L)
+    errs = []
+
+    def work(i):
+        try:
+            for rep in range(4):
+                x = synth.complex_array((16, 256), offset=1000 * i + rep); y = np.zeros_like(x)
+                api.ndfft(x, y, h, 1)
+                assert_close(y, np.fft.fft(x, axis=1), 1, 1e-10, f"thread {i}")
+                xr = synth.real_array((7, 100), offset=77 * i + rep); yr = np.zeros_like(xr); yo = np.zeros_like(xr)
+                api.nddct2(xr, yr, hd, 1); orc.nddct2(xr, yo, orc.DctHandler(100), 1)
+                assert_close(yr, yo, 1, 1e-10, f"thread {i} dct")
+        except Exception as e:  # pragma: no cover
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errs, errs
+
+
 def handler_clone_shares_plan(L):
     h = handlers.FftHandler(16, _library=L)
     h2 = h.clone()
