@@ -229,6 +229,7 @@ static int transpose_batched(const void *in, void *out, int64_t batch, int64_t r
     return NDFFT_OK;
 }
 
+
 // Four-step complex FFT of length F = F1*F2 on L lanes (zin / zout: lane pitches in elements).
 // zin may equal zout.  Sub-FFTs run through dispatch() on the row kernels.
 template <typename T>
@@ -305,20 +306,21 @@ static int dispatch_big(const Problem &P, const void *d_in, void *d_out, const D
 static int dispatch_transposed(const Problem &P, const void *d_in, void *d_out, hipStream_t stream, int64_t outer,
                                int64_t inner, size_t ein, size_t eout) {
     const int64_t n_in = P.xlen, n_out = P.ylen;
+    // scratch lanes are pitched to a multiple of 16 bytes so both transposes can use 16-byte accesses
+    const int64_t p_in = (n_in + 3) & ~(int64_t)3, p_out = (n_out + 3) & ~(int64_t)3;
     void *s1, *s2;
     int rc;
-    if ((rc = get_scratch(0, stream, (size_t)(outer * inner * n_in) * ein, &s1))) return rc;
-    if ((rc = get_scratch(1, stream, (size_t)(outer * inner * n_out) * eout, &s2))) return rc;
+    if ((rc = get_scratch(0, stream, (size_t)(outer * inner * p_in) * ein, &s1))) return rc;
+    if ((rc = get_scratch(1, stream, (size_t)(outer * inner * p_out) * eout, &s2))) return rc;
     // in[o][j][i] -> s1[o][i][j]
-    if ((rc = launch_transpose(d_in, s1, outer, n_in, inner, inner, n_in, n_in * inner, inner * n_in, (int)ein, stream))) return rc;
+    if ((rc = transpose_batched(d_in, s1, outer, n_in, inner, inner, p_in, n_in * inner, inner * p_in, (int)ein, stream))) return rc;
     Problem Q = P;
     Q.xs = Q.ys = 1;
     Q.b.clear();
-    Q.b.push_back({outer * inner, n_in, n_out});
+    Q.b.push_back({outer * inner, p_in, p_out});
     if ((rc = dispatch(Q, s1, s2, stream))) return rc;
     // s2[o][i][k] -> out[o][k][i]
-    if ((rc = launch_transpose(s2, d_out, outer, inner, n_out, n_out, inner, inner * n_out, n_out * inner, (int)eout, stream))) return rc;
-    return NDFFT_OK;
+    return transpose_batched(s2, d_out, outer, inner, n_out, p_out, inner, inner * p_out, n_out * inner, (int)eout, stream);
 }
 
 static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t stream) {
@@ -367,6 +369,8 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
                 a.outer_in = col && P.b.size() == 2 ? P.b[0].sin : 0;
                 a.outer_out = col && P.b.size() == 2 ? P.b[0].sout : 0;
                 a.elem_in = P.xs; a.elem_out = P.ys;
+                const size_t es_in = (op_in_cplx(P.op) ? 2 : 1) * real_size(plan->dtype);
+                a.vec_in = !col && ((uintptr_t)d_in % 16 == 0) && ((size_t)a.pitch_in * es_in) % 16 == 0;
             };
             int rc2;
             if (plan->dtype == NDFFT_F32) {

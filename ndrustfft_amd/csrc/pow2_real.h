@@ -25,6 +25,7 @@ template <typename T> struct RealArgs {
     // column layout (COL kernels): lane L = (o, i), o = L / inner, i = L % inner;
     // element j of lane L lives at o*outer_* + i + j*elem_*   (adjacent lanes are adjacent in memory)
     int64_t inner, outer_in, outer_out, elem_in, elem_out;
+    int32_t vec_in;   // row layout: every lane base is 16-byte aligned -> stage with 16-byte loads
 };
 
 struct ZiNone { static __device__ __forceinline__ int map(int p) { return p; } };
@@ -38,7 +39,9 @@ struct ZiPhi { static __device__ __forceinline__ int map(int p) { return p + (p 
 template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = false> struct RealPow2Kernel {
     static constexpr int E = F / TPL;
     static constexpr int THREADS = TPL * LPB;
-    static constexpr int LANE_LDS = (F + (F >> 4) + 2) | 1;   // complex elements (odd: lanes spread over banks); holds padded Z or F+1 raw complex
+    // complex elements per lane: padded Z, or F+1 raw complex.  COL: odd, so adjacent lanes spread over the
+    // banks; row: even, so every lane base stays 16-byte aligned for the vector staging stores.
+    static constexpr int LANE_LDS = COL ? ((F + (F >> 4) + 2) | 1) : ((F + (F >> 4) + 3) & ~1);
     static constexpr size_t LDS_BYTES = (size_t)LPB * LANE_LDS * 2 * sizeof(T);
     static constexpr bool IN_CPLX = OP == G_C2R_EVEN || OP == G_C2C_FWD || OP == G_C2C_INV;
     static constexpr bool OUT_CPLX = OP == G_R2C_EVEN || OP == G_C2C_FWD || OP == G_C2C_INV;
@@ -98,11 +101,24 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
             if constexpr (IN_CPLX) {
                 const cpx<T> *in = (const cpx<T> *)a.in + lsafe * a.pitch_in;
                 cpx<T> *raw = (cpx<T> *)lds;
-                for (int j = t; j < a.n_in; j += TPL) raw[j] = in[j];
+                if (sizeof(T) == 4 && a.vec_in) {   // two c64 per 16-byte load
+                    const int nv = a.n_in >> 1;
+                    for (int j = t; j < nv; j += TPL) ((vec4f *)raw)[j] = ((const vec4f *)in)[j];
+                    for (int j = 2 * nv + t; j < a.n_in; j += TPL) raw[j] = in[j];
+                } else {
+                    for (int j = t; j < a.n_in; j += TPL) raw[j] = in[j];
+                }
             } else {
                 const T *in = (const T *)a.in + lsafe * a.pitch_in;
                 T *raw = (T *)lds;
-                for (int j = t; j < a.n_in; j += TPL) raw[j] = in[j];
+                if (a.vec_in) {                      // 2 doubles / 4 floats per 16-byte load
+                    constexpr int W = 16 / sizeof(T);
+                    const int nv = a.n_in / W;
+                    for (int j = t; j < nv; j += TPL) ((vec4f *)raw)[j] = ((const vec4f *)in)[j];
+                    for (int j = W * nv + t; j < a.n_in; j += TPL) raw[j] = in[j];
+                } else {
+                    for (int j = t; j < a.n_in; j += TPL) raw[j] = in[j];
+                }
             }
         }
         __syncthreads();
