@@ -8,6 +8,24 @@
 
 namespace ndfft {
 
+// Tile order: 8x8 groups of tiles, so that the ~1000 concurrently resident workgroups read AND write
+// 8-tile-wide (2 KiB) contiguous runs instead of 256-byte pieces scattered over the whole array.
+__device__ __forceinline__ bool tile_coords(int64_t tiles_x, int64_t tiles_y, int64_t &tx, int64_t &ty) {
+    if (tiles_x < 8 || tiles_y < 8) {   // small tile grids (many small batches): plain row-major order
+        tx = blockIdx.x % tiles_x; ty = blockIdx.x / tiles_x;
+        return ty < tiles_y;
+    }
+    const int64_t b = blockIdx.x, gpr = (tiles_x + 7) / 8;
+    const int64_t g = b >> 6, w = b & 63;
+    tx = (g % gpr) * 8 + (w & 7);
+    ty = (g / gpr) * 8 + (w >> 3);
+    return tx < tiles_x && ty < tiles_y;
+}
+static inline unsigned swizzled_blocks(int64_t tiles_x, int64_t tiles_y) {
+    if (tiles_x < 8 || tiles_y < 8) return (unsigned)(tiles_x * tiles_y);
+    return (unsigned)(((tiles_x + 7) / 8) * ((tiles_y + 7) / 8) * 64);
+}
+
 template <typename E, int TILE>
 __global__ __launch_bounds__(256) void k_transpose(const E *__restrict__ in, E *__restrict__ out, int64_t rows, int64_t cols,
                                                    int64_t ld_in, int64_t ld_out, int64_t bs_in, int64_t bs_out) {
@@ -15,7 +33,9 @@ __global__ __launch_bounds__(256) void k_transpose(const E *__restrict__ in, E *
     E(*tile)[TILE + 1] = (E(*)[TILE + 1])smem;   // +1 element of padding: column reads hit distinct banks
     const E *src = in + (int64_t)blockIdx.z * bs_in;
     E *dst = out + (int64_t)blockIdx.z * bs_out;
-    const int64_t c0 = (int64_t)blockIdx.x * TILE, r0 = (int64_t)blockIdx.y * TILE;
+    int64_t tcx, tcy;
+    if (!tile_coords((cols + TILE - 1) / TILE, (rows + TILE - 1) / TILE, tcx, tcy)) return;
+    const int64_t c0 = tcx * TILE, r0 = tcy * TILE;
     const int tx = threadIdx.x % TILE, ty = threadIdx.x / TILE;
     constexpr int RSTEP = 256 / TILE;
 #pragma unroll
@@ -42,7 +62,9 @@ __global__ __launch_bounds__(256) void k_transpose_vec(const E *__restrict__ in,
     E(*tile)[TILE + 1] = (E(*)[TILE + 1])smem;
     const E *src = in + (int64_t)blockIdx.z * bs_in;
     E *dst = out + (int64_t)blockIdx.z * bs_out;
-    const int64_t c0 = (int64_t)blockIdx.x * TILE, r0 = (int64_t)blockIdx.y * TILE;
+    int64_t tcx, tcy;
+    if (!tile_coords((cols + TILE - 1) / TILE, (rows + TILE - 1) / TILE, tcx, tcy)) return;
+    const int64_t c0 = tcx * TILE, r0 = tcy * TILE;
 #pragma unroll
     for (int idx = threadIdx.x; idx < TILE * VPR; idx += 256) {
         const int r = idx / VPR, cv = (idx % VPR) * V;
@@ -86,15 +108,15 @@ int launch_transpose(const void *in, void *out, int64_t batch, int64_t rows, int
     const bool vec = elem_bytes < 16 && ld_in % V == 0 && ld_out % V == 0 && bstride_in % V == 0 && bstride_out % V == 0 &&
                      (uintptr_t)in % 16 == 0 && (uintptr_t)out % 16 == 0;
     if (elem_bytes == 4) {
-        dim3 g((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64), (unsigned)batch);
+        dim3 g(swizzled_blocks((cols + 63) / 64, (rows + 63) / 64), 1, (unsigned)batch);
         if (vec) hipLaunchKernelGGL((k_transpose_vec<float, 4>), g, dim3(256), 64 * 65 * 4, s, (const float *)in, (float *)out, rows, cols, ld_in, ld_out, bstride_in, bstride_out);
         else hipLaunchKernelGGL((k_transpose<float, 64>), g, dim3(256), 64 * 65 * 4, s, (const float *)in, (float *)out, rows, cols, ld_in, ld_out, bstride_in, bstride_out);
     } else if (elem_bytes == 8) {
-        dim3 g((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64), (unsigned)batch);
+        dim3 g(swizzled_blocks((cols + 63) / 64, (rows + 63) / 64), 1, (unsigned)batch);
         if (vec) hipLaunchKernelGGL((k_transpose_vec<double, 2>), g, dim3(256), 64 * 65 * 8, s, (const double *)in, (double *)out, rows, cols, ld_in, ld_out, bstride_in, bstride_out);
         else hipLaunchKernelGGL((k_transpose<double, 64>), g, dim3(256), 64 * 65 * 8, s, (const double *)in, (double *)out, rows, cols, ld_in, ld_out, bstride_in, bstride_out);
     } else if (elem_bytes == 16) {
-        dim3 g((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32), (unsigned)batch);
+        dim3 g(swizzled_blocks((cols + 31) / 32, (rows + 31) / 32), 1, (unsigned)batch);
         hipLaunchKernelGGL((k_transpose<E16v, 32>), g, dim3(256), 32 * 33 * 16, s, (const E16v *)in, (E16v *)out, rows, cols, ld_in, ld_out, bstride_in, bstride_out);
     } else {
         return fail(NDFFT_ERR_INVALID_ARG, "transpose: element size");
