@@ -87,6 +87,17 @@ def main():
             run(f"long ndfft axis=1 {rows}x{n} {np.dtype(cdt).name}", ndfft, x, y, FftHandler(n, rdt), 1, x.numel(), max(a.steps // 3, 3))
         x = torch.from_numpy(synth.real_array((64, 1 << 18))).to(dev); y = torch.empty_like(x)
         run("long nddct2 axis=1 64x262144 f64", nddct2, x, y, DctHandler(1 << 18), 1, x.numel(), max(a.steps // 3, 3))
+    if want("generic"):
+        for n in (1000, 264, 1331, 1009, 3000, 96):
+            rows = (1 << 24) // n
+            x = torch.from_numpy(synth.complex_array((rows, n))).to(dev); y = torch.empty_like(x)
+            run(f"generic ndfft axis=1 {rows}x{n} c128", ndfft, x, y, FftHandler(n), 1, x.numel(), a.steps)
+        x = torch.from_numpy(synth.complex_array((1000, 16384))).to(dev); y = torch.empty_like(x)
+        run("generic ndfft axis=0 1000x16384 c128", ndfft, x, y, FftHandler(1000), 0, x.numel(), a.steps)
+        x = torch.from_numpy(synth.real_array((16384, 1000))).to(dev); y = torch.empty_like(x)
+        run("generic nddct2 axis=1 16384x1000 f64", nddct2, x, y, DctHandler(1000), 1, x.numel(), a.steps)
+        x = torch.from_numpy(synth.complex_array((16384, 1000), np.complex64)).to(dev); y = torch.empty_like(x)
+        run("generic ndfft axis=1 16384x1000 c64", ndfft, x, y, FftHandler(1000, np.float32), 1, x.numel(), a.steps)
     if want("refbench"):
         for n in (128, 264, 512, 1024):
             x = torch.from_numpy(synth.bench_fill_complex((n, n))).to(dev); y = torch.empty_like(x)
