@@ -25,6 +25,16 @@ NDFFT_ODDTAB_S(11, {0.0, 0.5406408174555975821076, 0.9096319953545183714117, 0.9
 NDFFT_ODDTAB(13, {1.0, 0.8854560256532098959004, 0.5680647467311558025118, 0.1205366802553230533491, -0.3546048870425356259696, -0.7485107481711010986346, -0.970941817426052027157, -0.970941817426052027157, -0.7485107481711010986346, -0.3546048870425356259696, 0.1205366802553230533491, 0.5680647467311558025118, 0.8854560256532098959004})
 NDFFT_ODDTAB_S(13, {0.0, 0.464723172043768545656, 0.8229838658936563945796, 0.9927088740980539928008, 0.9350162426854148234398, 0.6631226582407952023768, 0.2393156642875577671488, -0.2393156642875577671488, -0.6631226582407952023768, -0.9350162426854148234398, -0.9927088740980539928008, -0.8229838658936563945796, -0.464723172043768545656})
 
+// unit roots for the composite radices (same c/s tables, used as inner twiddles by BflyComp)
+NDFFT_ODDTAB(6, {1.0, 0.5, -0.5, -1.0, -0.5, 0.5})
+NDFFT_ODDTAB_S(6, {0.0, 0.8660254037844386467637, 0.8660254037844386467637, 0.0, -0.8660254037844386467637, -0.8660254037844386467637})
+NDFFT_ODDTAB(9, {1.0, 0.7660444431189780352024, 0.1736481776669303488517, -0.5, -0.9396926207859083840541, -0.9396926207859083840541, -0.5, 0.1736481776669303488517, 0.7660444431189780352024})
+NDFFT_ODDTAB_S(9, {0.0, 0.6427876096865393263226, 0.9848077530122080593667, 0.8660254037844386467637, 0.3420201433256687330441, -0.3420201433256687330441, -0.8660254037844386467637, -0.9848077530122080593667, -0.6427876096865393263226})
+NDFFT_ODDTAB(10, {1.0, 0.8090169943749474241023, 0.3090169943749474241023, -0.3090169943749474241023, -0.8090169943749474241023, -1.0, -0.8090169943749474241023, -0.3090169943749474241023, 0.3090169943749474241023, 0.8090169943749474241023})
+NDFFT_ODDTAB_S(10, {0.0, 0.5877852522924731291687, 0.9510565162951535721164, 0.9510565162951535721164, 0.5877852522924731291687, 0.0, -0.5877852522924731291687, -0.9510565162951535721164, -0.9510565162951535721164, -0.5877852522924731291687})
+NDFFT_ODDTAB(12, {1.0, 0.8660254037844386467637, 0.5, 0.0, -0.5, -0.8660254037844386467637, -1.0, -0.8660254037844386467637, -0.5, 0.0, 0.5, 0.8660254037844386467637})
+NDFFT_ODDTAB_S(12, {0.0, 0.5, 0.8660254037844386467637, 1.0, 0.8660254037844386467637, 0.5, 0.0, -0.5, -0.8660254037844386467637, -1.0, -0.8660254037844386467637, -0.5})
+
 template <typename T> __device__ __forceinline__ void bfly2(cpx<T> &a, cpx<T> &b) {
     cpx<T> t = a; a = cadd(t, b); b = csub(t, b);
 }
@@ -115,5 +125,41 @@ template <typename T> struct Bfly<T, 5> : BflyOdd<T, 5> {};
 template <typename T> struct Bfly<T, 7> : BflyOdd<T, 7> {};
 template <typename T> struct Bfly<T, 11> : BflyOdd<T, 11> {};
 template <typename T> struct Bfly<T, 13> : BflyOdd<T, 13> {};
+
+// composite radix R = R1*R2 in registers (Cooley-Tukey inside one butterfly), natural order in and out:
+//   X[k1 + R1 k2] = sum_{n2} W_R2^{n2 k2} ( W_R^{n2 k1} sum_{n1} x[n1 R2 + n2] W_R1^{n1 k1} )
+// fewer Stockham passes (1000 = 10*10*10 instead of 8*5*5*5) = fewer LDS round trips and barriers
+template <typename T, int R1, int R2> struct BflyComp {
+    static __device__ __forceinline__ void run(cpx<T> *v) {
+        constexpr int R = R1 * R2;
+        cpx<T> a[R];
+#pragma unroll
+        for (int n2 = 0; n2 < R2; ++n2) {
+            cpx<T> t[R1];
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) t[n1] = v[n1 * R2 + n2];
+            Bfly<T, R1>::run(t);
+#pragma unroll
+            for (int k1 = 0; k1 < R1; ++k1) {
+                const int m = (n2 * k1) % R;
+                if (m == 0) a[k1 * R2 + n2] = t[k1];
+                else a[k1 * R2 + n2] = cmul(t[k1], mk<T>((T)OddTab<R>::c(m), -(T)OddTab<R>::s(m)));
+            }
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < R1; ++k1) {
+            cpx<T> t[R2];
+#pragma unroll
+            for (int n2 = 0; n2 < R2; ++n2) t[n2] = a[k1 * R2 + n2];
+            Bfly<T, R2>::run(t);
+#pragma unroll
+            for (int k2 = 0; k2 < R2; ++k2) v[k1 + R1 * k2] = t[k2];
+        }
+    }
+};
+template <typename T> struct Bfly<T, 6> : BflyComp<T, 2, 3> {};
+template <typename T> struct Bfly<T, 9> : BflyComp<T, 3, 3> {};
+template <typename T> struct Bfly<T, 10> : BflyComp<T, 2, 5> {};
+template <typename T> struct Bfly<T, 12> : BflyComp<T, 4, 3> {};
 
 }  // namespace ndfft

@@ -144,7 +144,8 @@ int get_dev_tables(const ndfft_plan *plan, const DevTables **out);
 // kernels_generic.hip
 template <typename T> int launch_generic(const GenArgs<T> &a, int threads, size_t lds_bytes, hipStream_t s);
 size_t generic_lds_bytes(int lpb, int pitch, size_t csize);
-int generic_z_len(int len);   // LDS elements a padded length-`len` complex buffer needs
+int generic_z_len(int len);
+bool generic_needs_big(const int32_t *radix, int npass, const int32_t *radixM, int npassM);   // radices > 10: 512-thread class   // LDS elements a padded length-`len` complex buffer needs
 
 // kernels_pow2.hip : register-resident Stockham for contiguous power-of-two C2C lanes
 struct Pow2Args {

@@ -192,8 +192,9 @@ static int dispatch_generic(const Problem &P, const void *d_in, void *d_out, con
     const size_t lds = generic_lds_bytes(lpb, pitch, csize);
     // power-of-two thread maps: threads per lane in the FFT phases (~ one radix-4 butterfly each) and in row IO
     int fft_tpl = 1; while (fft_tpl < len / 4 && fft_tpl < 1024) fft_tpl <<= 1;
-    int threads = 64; while (threads < lpb * fft_tpl && threads < 1024) threads <<= 1;
-    if (col) while (threads < 4 * lpb && threads < 1024) threads <<= 1;
+    const int maxthr = generic_needs_big(a.radix, a.npass, a.radixM, a.blue ? a.npassM : 0) ? 512 : 1024;
+    int threads = 64; while (threads < lpb * fft_tpl && threads < maxthr) threads <<= 1;
+    if (col) while (threads < 4 * lpb && threads < maxthr) threads <<= 1;
     fft_tpl = std::min(fft_tpl, threads);
     int io_tpl = 1; while (io_tpl < std::max(a.n_in, a.n_out) && io_tpl < threads) io_tpl <<= 1;
     a.fft_tpl_log = 0; while ((1 << a.fft_tpl_log) < fft_tpl) ++a.fft_tpl_log;

@@ -1,217 +1,8 @@
-// kernels_generic.hip -- the any-n, any-op lane kernel (gfx950).
-//
-// One workgroup owns `lpb` whole lanes in LDS and makes ONE pass over HBM:
-//   LOAD   global -> LDS, coalesced either along the lane (IO_ROW) or across adjacent lanes
-//          (IO_COL: the LDS-padded transpose that replaces the reference's per-lane
-//          x.to_vec() gather, src/lib.rs:133, 155);
-//   PRE    op-specific fold of the raw lane into the complex FFT input Z[0..F)
-//          (R2C packing, C2R/DCT-III Hermitian fold, Makhoul permutation, DCT-IV pre-twiddle,
-//          the "before" normalisations of C2R and DCT: src/lib.rs:511-521, 692-696);
-//   FFT    Stockham autosort radix passes ping-ponging two LDS buffers (Bluestein when F has a
-//          prime factor > 13), twiddles from a precomputed HBM table that stays in L1/L2;
-//   STORE  op-specific gather out of the FFT result (R2C split, DCT post-twiddles, the "after"
-//          normalisation of the C2C inverse, src/lib.rs:326-330), LDS -> global coalesced
-//          (replaces y.assign(&outvec), src/lib.rs:134).
-#include "butterflies.h"
-#include "engine.h"
-#include "realops.h"
+// kernels_generic.hip -- host-side pieces of the generic lane kernel: LDS sizing and the dispatch between the
+// two register classes (generic_kernel.h: BIG = radices 11/12/13/16 present).
+#include "generic_kernel.h"
 
 namespace ndfft {
-
-// LDS header: per-lane global offsets, radix lists and per-pass fast-division constants
-struct GenHeader {
-    int64_t off_in[kMaxLpb], off_out[kMaxLpb];
-    int32_t radix[kMaxPasses], radixM[kMaxPasses];
-};
-constexpr size_t kGenHeaderBytes = (sizeof(GenHeader) + 15) & ~size_t(15);
-
-template <typename T> struct GenCtx {
-    GenHeader *h;
-    cpx<T> *buf[2];
-    int lanes;                   // lanes this block really owns (<= lpb)
-    int fl, fj0, fstep, flstep;  // FFT-phase thread map: lane = fl (+= flstep), index = fj0 (+= fstep)
-};
-
-// Z buffers are padded by one element every 8 so that the stride-R writes of the first radix
-// passes (R = 4, 8: addresses 8j+q -> 9j+q) spread over all LDS banks for 8- and 16-byte elements
-__device__ __forceinline__ int zi(int p) { return p + (p >> 3); }
-struct ZiPad8 { static __device__ __forceinline__ int map(int p) { return p + (p >> 3); } };
-
-// j mod d for j < 2^17, d < 2^15, with m = ceil(2^32 / d)
-__device__ __forceinline__ int fast_mod(int j, int d, uint32_t m) {
-    const uint32_t q = (uint32_t)(((uint64_t)(uint32_t)j * m) >> 32);
-    return j - (int)q * d;
-}
-
-// ---------------------------------------------------------------------------------------------
-// one Stockham pass over all lanes of the block
-// ---------------------------------------------------------------------------------------------
-template <typename T, int R>
-__device__ __forceinline__ void stockham_pass(const GenCtx<T> &c, const cpx<T> *__restrict__ src, cpx<T> *__restrict__ dst,
-                                              const cpx<T> *__restrict__ tw, int len, int Ns, int pitch) {
-    const int nb = len / R, tws = len / (Ns * R);
-    const uint32_t magic = Ns > 1 ? (uint32_t)((0x100000000ull + (uint32_t)Ns - 1) / (uint32_t)Ns) : 0u;
-    for (int l = c.fl; l < c.lanes; l += c.flstep) {
-        const cpx<T> *s = src + l * pitch;
-        cpx<T> *d = dst + l * pitch;
-        for (int j = c.fj0; j < nb; j += c.fstep) {
-            cpx<T> v[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) v[r] = s[zi(j + r * nb)];
-            int k = 0;
-            if (Ns > 1) {
-                k = fast_mod(j, Ns, magic);
-                const int kt = k * tws;
-#pragma unroll
-                for (int r = 1; r < R; ++r) v[r] = cmul(v[r], tw[r * kt]);
-            }
-            Bfly<T, R>::run(v);
-            const int o = (j - k) * R + k;
-#pragma unroll
-            for (int q = 0; q < R; ++q) d[zi(o + q * Ns)] = v[q];
-        }
-    }
-}
-
-// runs the radix passes; returns the index of the buffer holding the result
-template <typename T>
-__device__ int run_passes(GenCtx<T> &c, int cur, int len, int npass, const int32_t *radix, const cpx<T> *tw,
-                          int pitch) {
-    int Ns = 1;
-    for (int p = 0; p < npass; ++p) {
-        const int R = radix[p];
-        __syncthreads();
-        const cpx<T> *s = c.buf[cur];
-        cpx<T> *d = c.buf[cur ^ 1];
-        switch (R) {
-            case 2: stockham_pass<T, 2>(c, s, d, tw, len, Ns, pitch); break;
-            case 3: stockham_pass<T, 3>(c, s, d, tw, len, Ns, pitch); break;
-            case 4: stockham_pass<T, 4>(c, s, d, tw, len, Ns, pitch); break;
-            case 5: stockham_pass<T, 5>(c, s, d, tw, len, Ns, pitch); break;
-            case 7: stockham_pass<T, 7>(c, s, d, tw, len, Ns, pitch); break;
-            case 8: stockham_pass<T, 8>(c, s, d, tw, len, Ns, pitch); break;
-            case 11: stockham_pass<T, 11>(c, s, d, tw, len, Ns, pitch); break;
-            default: stockham_pass<T, 13>(c, s, d, tw, len, Ns, pitch); break;
-        }
-        cur ^= 1;
-        Ns *= R;
-    }
-    __syncthreads();
-    return cur;
-}
-
-// ---------------------------------------------------------------------------------------------
-// the kernel
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int64_t lane_offset(const LaneGeom &g, int64_t lane) {
-    int64_t off = 0;
-    for (int d = g.nb - 1; d >= 0; --d) {
-        const int64_t e = g.bshape[d], i = lane % e;
-        lane /= e;
-        off += i * g.bstride[d];
-    }
-    return off;
-}
-
-template <typename T, int OP> __global__ __launch_bounds__(1024) void k_generic(const GenArgs<T> a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    GenCtx<T> c;
-    c.h = (GenHeader *)smem;
-    c.buf[0] = (cpx<T> *)(smem + kGenHeaderBytes);
-    c.buf[1] = c.buf[0] + (size_t)a.lpb * a.pitch;
-    const int64_t lane0 = (int64_t)blockIdx.x * a.lpb;
-    c.lanes = (int)min((int64_t)a.lpb, a.nlanes - lane0);
-    const int tid = threadIdx.x, nthr = blockDim.x, pitch = a.pitch;
-    // division-free thread maps (all counts are powers of two chosen on the host)
-    c.fl = tid >> a.fft_tpl_log; c.fj0 = tid & ((1 << a.fft_tpl_log) - 1);
-    c.fstep = 1 << a.fft_tpl_log; c.flstep = nthr >> a.fft_tpl_log;
-
-    if (tid < kMaxPasses) { c.h->radix[tid] = a.radix[tid]; c.h->radixM[tid] = a.radixM[tid]; }
-    if (tid < c.lanes) {
-        c.h->off_in[tid] = lane_offset(a.gin, lane0 + tid);
-        c.h->off_out[tid] = lane_offset(a.gout, lane0 + tid);
-    }
-    __syncthreads();
-
-    // ---- LOAD ------------------------------------------------------------------------------
-    // ops whose PRE is elementwise load straight into Z (buffer 0); the others stage the raw lane
-    // in buffer 1 and fold it into buffer 0.
-    constexpr bool direct = OP == G_C2C_FWD || OP == G_C2C_INV || OP == G_R2C_EVEN || OP == G_R2C_ODD;
-    constexpr bool in_cplx = OP == G_C2C_FWD || OP == G_C2C_INV || OP == G_C2R_EVEN || OP == G_C2R_ODD;
-    constexpr bool out_cplx = OP == G_C2C_FWD || OP == G_C2C_INV || OP == G_R2C_EVEN || OP == G_R2C_ODD;
-    {
-        int l0, lstep, j0, jstep;
-        if (a.load_mode == IO_ROW) { l0 = tid >> a.io_tpl_log; lstep = nthr >> a.io_tpl_log; j0 = tid & ((1 << a.io_tpl_log) - 1); jstep = 1 << a.io_tpl_log; }
-        else { l0 = tid & ((1 << a.lpb_log) - 1); lstep = 1 << a.lpb_log; j0 = tid >> a.lpb_log; jstep = nthr >> a.lpb_log; }
-        const int n_in = a.n_in;
-        const int64_t as = a.gin.axis_stride;
-        for (int l = l0; l < c.lanes; l += lstep) {
-            const int64_t base = c.h->off_in[l];
-            for (int j = j0; j < n_in; j += jstep) {
-                const int64_t g = base + (int64_t)j * as;
-                if (in_cplx) {
-                    cpx<T> v = ((const cpx<T> *)a.in)[g];
-                    if (OP == G_C2C_INV) v.y = -v.y;
-                    if (direct) c.buf[0][l * pitch + zi(j)] = v; else c.buf[1][l * pitch + j] = v;
-                } else {
-                    const T v = ((const T *)a.in)[g];
-                    if (OP == G_R2C_ODD) c.buf[0][l * pitch + zi(j)] = mk<T>(v, (T)0);
-                    else if (OP == G_R2C_EVEN) ((T *)c.buf[0])[(l * pitch + zi(j >> 1)) * 2 + (j & 1)] = v;   // packs pairs in place
-                    else ((T *)c.buf[1])[l * 2 * pitch + j] = v;
-                }
-            }
-        }
-    }
-    // ---- PRE -------------------------------------------------------------------------------
-    if (!direct) {
-        __syncthreads();
-        const int F = a.F;
-        for (int l = c.fl; l < c.lanes; l += c.flstep)
-            for (int i = c.fj0; i < F; i += c.fstep)
-                c.buf[0][l * pitch + zi(i)] = pre_elem<T, OP, ZiPad8>(a, (const void *)(c.buf[1] + l * pitch), i);
-    }
-    // ---- FFT -------------------------------------------------------------------------------
-    int cur = 0;
-    if (!a.blue) {
-        cur = run_passes<T>(c, 0, a.F, a.npass, c.h->radix, a.tw, pitch);
-    } else {
-        // Bluestein: X[k] = chirp[k] * IFFT_M( FFT_M(z * chirp, zero padded) * bhat )[k]
-        __syncthreads();
-        const int F = a.F, M = a.M;
-        for (int l = c.fl; l < c.lanes; l += c.flstep) {
-            cpx<T> *z = c.buf[0] + l * pitch;
-            for (int i = c.fj0; i < M; i += c.fstep) z[zi(i)] = i < F ? cmul(z[zi(i)], a.chirp[i]) : mk<T>((T)0, (T)0);
-        }
-        cur = run_passes<T>(c, 0, M, a.npassM, c.h->radixM, a.twM, pitch);
-        for (int l = c.fl; l < c.lanes; l += c.flstep) {
-            cpx<T> *z = c.buf[cur] + l * pitch;
-            for (int i = c.fj0; i < M; i += c.fstep) z[zi(i)] = cconj(cmul(z[zi(i)], a.bhat[i]));   // bhat carries 1/M
-        }
-        cur = run_passes<T>(c, cur, M, a.npassM, c.h->radixM, a.twM, pitch);
-        for (int l = c.fl; l < c.lanes; l += c.flstep) {
-            cpx<T> *z = c.buf[cur] + l * pitch;
-            for (int i = c.fj0; i < F; i += c.fstep) z[zi(i)] = cmul(cconj(z[zi(i)]), a.chirp[i]);
-        }
-        __syncthreads();
-    }
-    // ---- STORE (with POST gather) ----------------------------------------------------------
-    {
-        int l0, lstep, j0, jstep;
-        if (a.store_mode == IO_ROW) { l0 = tid >> a.io_tpl_log; lstep = nthr >> a.io_tpl_log; j0 = tid & ((1 << a.io_tpl_log) - 1); jstep = 1 << a.io_tpl_log; }
-        else { l0 = tid & ((1 << a.lpb_log) - 1); lstep = 1 << a.lpb_log; j0 = tid >> a.lpb_log; jstep = nthr >> a.lpb_log; }
-        const int n_out = a.n_out;
-        const int64_t as = a.gout.axis_stride;
-        for (int l = l0; l < c.lanes; l += lstep) {
-            const int64_t base = c.h->off_out[l];
-            const cpx<T> *res = c.buf[cur] + l * pitch;
-            for (int q = j0; q < n_out; q += jstep) {
-                const int64_t g = base + (int64_t)q * as;
-                if (out_cplx) ((cpx<T> *)a.out)[g] = post_cplx<T, OP, ZiPad8>(a, res, q);
-                else ((T *)a.out)[g] = post_real<T, OP, ZiPad8>(a, res, q);
-            }
-        }
-    }
-}
 
 size_t generic_lds_bytes(int lpb, int pitch, size_t csize) {
     return kGenHeaderBytes + 2 * (size_t)lpb * (size_t)pitch * csize;
@@ -223,32 +14,21 @@ size_t generic_max_len(size_t csize) {
     return len;
 }
 
-template <typename T, int OP> static int launch_op(const GenArgs<T> &a, int threads, size_t lds_bytes, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_generic<T, OP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    const int64_t nblk = (a.nlanes + a.lpb - 1) / a.lpb;
-    if (nblk <= 0) return NDFFT_OK;
-    if (nblk > 0x7fffffffLL) return fail(NDFFT_ERR_UNSUPPORTED, "too many lanes for one launch");
-    hipLaunchKernelGGL((k_generic<T, OP>), dim3((unsigned)nblk), dim3(threads), lds_bytes, s, a);
-    NDFFT_HIP(hipGetLastError());
-    return NDFFT_OK;
+extern template int launch_generic_class<float, false>(const GenArgs<float> &, int, size_t, hipStream_t);
+extern template int launch_generic_class<float, true>(const GenArgs<float> &, int, size_t, hipStream_t);
+extern template int launch_generic_class<double, false>(const GenArgs<double> &, int, size_t, hipStream_t);
+extern template int launch_generic_class<double, true>(const GenArgs<double> &, int, size_t, hipStream_t);
+
+bool generic_needs_big(const int32_t *radix, int npass, const int32_t *radixM, int npassM) {
+    for (int i = 0; i < npass; ++i) if (radix[i] > 10) return true;
+    for (int i = 0; i < npassM; ++i) if (radixM[i] > 10) return true;
+    return false;
 }
 
 template <typename T> int launch_generic(const GenArgs<T> &a, int threads, size_t lds_bytes, hipStream_t s) {
-    switch (a.op) {
-#define NDFFT_OPCASE(OP) case OP: return launch_op<T, OP>(a, threads, lds_bytes, s);
-        NDFFT_OPCASE(G_C2C_FWD) NDFFT_OPCASE(G_C2C_INV) NDFFT_OPCASE(G_R2C_EVEN) NDFFT_OPCASE(G_R2C_ODD)
-        NDFFT_OPCASE(G_C2R_EVEN) NDFFT_OPCASE(G_C2R_ODD) NDFFT_OPCASE(G_DCT1) NDFFT_OPCASE(G_DCT2_EVEN)
-        NDFFT_OPCASE(G_DCT2_ODD) NDFFT_OPCASE(G_DCT3_EVEN) NDFFT_OPCASE(G_DCT3_ODD) NDFFT_OPCASE(G_DCT4_EVEN)
-        NDFFT_OPCASE(G_DCT4_ODD)
-#undef NDFFT_OPCASE
-        default: return fail(NDFFT_ERR_INVALID_ARG, "bad generic op");
-    }
+    if (generic_needs_big(a.radix, a.npass, a.radixM, a.blue ? a.npassM : 0)) return launch_generic_class<T, true>(a, threads, lds_bytes, s);
+    return launch_generic_class<T, false>(a, threads, lds_bytes, s);
 }
-
 template int launch_generic<float>(const GenArgs<float> &, int, size_t, hipStream_t);
 template int launch_generic<double>(const GenArgs<double> &, int, size_t, hipStream_t);
 

@@ -1,0 +1,6 @@
+// kernels_generic_big_f32.hip -- one instantiation set of the generic lane kernel (see generic_kernel.h);
+// split into four translation units so they compile in parallel.
+#include "generic_kernel.h"
+namespace ndfft {
+template int launch_generic_class<float, true>(const GenArgs<float> &, int, size_t, hipStream_t);
+}

@@ -28,15 +28,20 @@ static void unit(HostTable &t, unsigned long long num, unsigned long long den) {
     t.im.push_back(-sinl(ang));
 }
 
+// radix list for the LDS Stockham kernel: largest available radix first (composite 16/12/10/9/6 cut the
+// number of passes), primes 7, 11, 13 last; false if a larger prime factor remains
 static bool factorize(int F, std::vector<int> &radix) {
     radix.clear();
     int m = F;
-    while (m % 8 == 0) { radix.push_back(8); m /= 8; }
-    while (m % 4 == 0) { radix.push_back(4); m /= 4; }
-    while (m % 2 == 0) { radix.push_back(2); m /= 2; }
-    const int odd[] = {3, 5, 7, 11, 13};
-    for (int p : odd) while (m % p == 0) { radix.push_back(p); m /= p; }
-    return m == 1 && radix.size() <= (size_t)kMaxPasses;
+    const int cand[] = {16, 12, 10, 9, 8, 6, 5, 4, 3, 2, 7, 11, 13};
+    while (m > 1) {
+        int pick = 0;
+        for (int c : cand) if (m % c == 0) { pick = c; break; }
+        if (!pick) return false;
+        radix.push_back(pick);
+        m /= pick;
+    }
+    return radix.size() <= (size_t)kMaxPasses;
 }
 
 static ndfft_plan *make_plan(int kind, int dtype, size_t n);
