@@ -7,11 +7,15 @@
 namespace ndfft {
 
 template <int R> struct OddTab;
+// cos / sin of 2 pi k / R in constant memory: folded to literals where the index is known after unrolling,
+// a scalar load otherwise (a function-local table would live in scratch)
 #define NDFFT_ODDTAB(R, ...)                                   \
-    template <> struct OddTab<R> {                             \
-        static __device__ inline double c(int k) { const double t[R] = __VA_ARGS__; return t[k]; }
+    static __constant__ const double kUnitCos##R[R] = __VA_ARGS__;
 #define NDFFT_ODDTAB_S(R, ...)                                 \
-        static __device__ inline double s(int k) { const double t[R] = __VA_ARGS__; return t[k]; } \
+    static __constant__ const double kUnitSin##R[R] = __VA_ARGS__; \
+    template <> struct OddTab<R> {                             \
+        static __device__ __forceinline__ double c(int k) { return kUnitCos##R[k]; } \
+        static __device__ __forceinline__ double s(int k) { return kUnitSin##R[k]; } \
     };
 
 NDFFT_ODDTAB(3, {1.0, -0.5, -0.5})

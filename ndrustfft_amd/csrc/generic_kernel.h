@@ -53,22 +53,26 @@ __device__ __forceinline__ int fast_mod(int j, int d, uint32_t m) {
 // ---------------------------------------------------------------------------------------------
 enum PassIO : int { IO_LDS = 0, IO_GLOBAL = 1 };
 
-template <typename T, int OP> __device__ __forceinline__ cpx<T> first_pass_load(const GenArgs<T> &a, int64_t base, int i) {
-    const int64_t as = a.gin.axis_stride;
+// what a fused pass needs from the kernel arguments -- passed BY VALUE: handing `const GenArgs&` to a
+// non-inlined function would force the whole kernarg struct into scratch memory
+template <typename T> struct PassGlobals { const void *in; void *out; int n_out; T scale; };
+
+// (fused passes are only used on unit-stride lanes, so the element index is the memory offset)
+template <typename T, int OP> __device__ __forceinline__ cpx<T> first_pass_load(const PassGlobals<T> &a, int64_t base, int i) {
     if constexpr (OP == G_R2C_EVEN) {          // z[i] = (x[2i], x[2i+1])
         const T *p = (const T *)a.in + base;
-        return mk<T>(p[(int64_t)(2 * i) * as], p[(int64_t)(2 * i + 1) * as]);
+        return mk<T>(p[2 * i], p[2 * i + 1]);
     } else if constexpr (OP == G_R2C_ODD) {
-        return mk<T>(((const T *)a.in)[base + (int64_t)i * as], (T)0);
+        return mk<T>(((const T *)a.in)[base + i], (T)0);
     } else {
-        cpx<T> v = ((const cpx<T> *)a.in)[base + (int64_t)i * as];
+        cpx<T> v = ((const cpx<T> *)a.in)[base + i];
         if (OP == G_C2C_INV) v.y = -v.y;
         return v;
     }
 }
 
 template <typename T, int OP, int R, int SRC, int DST>
-__device__ __forceinline__ void stockham_pass(const GenCtx<T> &c, const GenArgs<T> &a, const cpx<T> *__restrict__ src,
+__device__ __forceinline__ void stockham_pass(const GenCtx<T> &c, const PassGlobals<T> &a, const cpx<T> *__restrict__ src,
                                               cpx<T> *__restrict__ dst, const cpx<T> *__restrict__ tw, int len, int Ns, int pitch) {
     const int nb = len / R, tws = len / (Ns * R);
     const uint32_t magic = Ns > 1 ? (uint32_t)((0x100000000ull + (uint32_t)Ns - 1) / (uint32_t)Ns) : 0u;
@@ -95,14 +99,14 @@ __device__ __forceinline__ void stockham_pass(const GenCtx<T> &c, const GenArgs<
             Bfly<T, R>::run(v);
             const int o = (j - k) * R + k;
             if constexpr (DST == IO_GLOBAL) {   // last pass: Ns = len / R, so o + q Ns = j + q nb
-                const int64_t base = c.h->off_out[l], as = a.gout.axis_stride;
+                cpx<T> *outp = (cpx<T> *)a.out + c.h->off_out[l];
 #pragma unroll
                 for (int q = 0; q < R; ++q) {
                     const int idx = o + q * Ns;
                     if (idx < a.n_out) {
                         cpx<T> w = v[q];
                         if (OP == G_C2C_INV) { w.x *= a.scale; w.y *= -a.scale; }
-                        ((cpx<T> *)a.out)[base + (int64_t)idx * as] = w;
+                        outp[idx] = w;
                     }
                 }
             } else {
@@ -114,7 +118,7 @@ __device__ __forceinline__ void stockham_pass(const GenCtx<T> &c, const GenArgs<
 }
 
 template <typename T, int OP, int SRC, int DST, bool BIG>
-__device__ __forceinline__ void pass_switch(int R, const GenCtx<T> &c, const GenArgs<T> &a, const cpx<T> *s, cpx<T> *d,
+__device__ __forceinline__ void pass_switch(int R, const GenCtx<T> &c, const PassGlobals<T> &a, const cpx<T> *s, cpx<T> *d,
                                             const cpx<T> *tw, int len, int Ns, int pitch) {
     switch (R) {
 #define NDFFT_R(RR) case RR: stockham_pass<T, OP, RR, SRC, DST>(c, a, s, d, tw, len, Ns, pitch); break;
@@ -136,7 +140,7 @@ __device__ __forceinline__ void pass_switch(int R, const GenCtx<T> &c, const Gen
 // runs the radix passes on LDS buffers; returns the index of the buffer holding the result.
 // fuse_in / fuse_out: first pass reads global / last pass writes global (see stockham_pass).
 template <typename T, int OP, bool BIG>
-__device__ int run_passes(GenCtx<T> &c, const GenArgs<T> &a, int cur, int len, int npass, const int32_t *radix,
+__device__ __forceinline__ int run_passes(const GenCtx<T> &c, const PassGlobals<T> &a, int cur, int len, int npass, const int32_t *radix,
                           const cpx<T> *tw, int pitch, bool fuse_in, bool fuse_out) {
     constexpr bool can_in = OP == G_C2C_FWD || OP == G_C2C_INV || OP == G_R2C_EVEN || OP == G_R2C_ODD;
     constexpr bool can_out = OP == G_C2C_FWD || OP == G_C2C_INV || OP == G_R2C_ODD;
@@ -204,8 +208,8 @@ template <typename T, int OP, bool BIG> __global__ __launch_bounds__(BIG ? 512 :
     constexpr bool direct = OP == G_C2C_FWD || OP == G_C2C_INV || OP == G_R2C_EVEN || OP == G_R2C_ODD;
     constexpr bool store_direct = OP == G_C2C_FWD || OP == G_C2C_INV || OP == G_R2C_ODD;
     // row-layout elementwise ops: the first pass loads global memory itself and the last pass stores it
-    const bool fuse_in = direct && a.load_mode == IO_ROW && !a.blue && a.npass > 0;
-    const bool fuse_out = store_direct && a.store_mode == IO_ROW && !a.blue && a.npass > 0;
+    const bool fuse_in = direct && a.load_mode == IO_ROW && a.gin.axis_stride == 1 && !a.blue && a.npass > 0;
+    const bool fuse_out = store_direct && a.store_mode == IO_ROW && a.gout.axis_stride == 1 && !a.blue && a.npass > 0;
     constexpr bool in_cplx = OP == G_C2C_FWD || OP == G_C2C_INV || OP == G_C2R_EVEN || OP == G_C2R_ODD;
     constexpr bool out_cplx = OP == G_C2C_FWD || OP == G_C2C_INV || OP == G_R2C_EVEN || OP == G_R2C_ODD;
     if (!fuse_in) {
@@ -241,27 +245,35 @@ template <typename T, int OP, bool BIG> __global__ __launch_bounds__(BIG ? 512 :
     }
     // ---- FFT -------------------------------------------------------------------------------
     int cur = 0;
-    if (!a.blue) {
-        cur = run_passes<T, OP, BIG>(c, a, 0, a.F, a.npass, c.h->radix, a.tw, pitch, fuse_in, fuse_out);
-    } else {
-        // Bluestein: X[k] = chirp[k] * IFFT_M( FFT_M(z * chirp, zero padded) * bhat )[k]
-        __syncthreads();
-        const int F = a.F, M = a.M;
-        for (int l = c.fl; l < c.lanes; l += c.flstep) {
-            cpx<T> *z = c.buf[0] + l * pitch;
-            for (int i = c.fj0; i < M; i += c.fstep) z[zi(i)] = i < F ? cmul(z[zi(i)], a.chirp[i]) : mk<T>((T)0, (T)0);
+    const PassGlobals<T> pg{a.in, a.out, a.n_out, a.scale};
+    {
+        // one call site for the (force-inlined) pass runner: plain FFT = one round; Bluestein = two rounds
+        // of FFT_M with the chirp / chirp-spectrum multiplies in front:
+        //   X[k] = chirp[k] * IFFT_M( FFT_M(z * chirp, zero padded) * bhat )[k]      (bhat carries 1/M)
+        const int rounds = a.blue ? 2 : 1;
+        const int len = a.blue ? a.M : a.F, np = a.blue ? a.npassM : a.npass;
+        const int32_t *radix = a.blue ? c.h->radixM : c.h->radix;
+        const cpx<T> *tw = a.blue ? a.twM : a.tw;
+        for (int round = 0; round < rounds; ++round) {
+            if (a.blue) {
+                __syncthreads();
+                const int F = a.F, M = a.M;
+                for (int l = c.fl; l < c.lanes; l += c.flstep) {
+                    cpx<T> *z = c.buf[cur] + l * pitch;
+                    if (round == 0) for (int i = c.fj0; i < M; i += c.fstep) z[zi(i)] = i < F ? cmul(z[zi(i)], a.chirp[i]) : mk<T>((T)0, (T)0);
+                    else for (int i = c.fj0; i < M; i += c.fstep) z[zi(i)] = cconj(cmul(z[zi(i)], a.bhat[i]));
+                }
+            }
+            cur = run_passes<T, OP, BIG>(c, pg, cur, len, np, radix, tw, pitch, fuse_in, fuse_out);
         }
-        cur = run_passes<T, OP, BIG>(c, a, 0, M, a.npassM, c.h->radixM, a.twM, pitch, false, false);
-        for (int l = c.fl; l < c.lanes; l += c.flstep) {
-            cpx<T> *z = c.buf[cur] + l * pitch;
-            for (int i = c.fj0; i < M; i += c.fstep) z[zi(i)] = cconj(cmul(z[zi(i)], a.bhat[i]));   // bhat carries 1/M
+        if (a.blue) {
+            const int F = a.F;
+            for (int l = c.fl; l < c.lanes; l += c.flstep) {
+                cpx<T> *z = c.buf[cur] + l * pitch;
+                for (int i = c.fj0; i < F; i += c.fstep) z[zi(i)] = cmul(cconj(z[zi(i)]), a.chirp[i]);
+            }
+            __syncthreads();
         }
-        cur = run_passes<T, OP, BIG>(c, a, cur, M, a.npassM, c.h->radixM, a.twM, pitch, false, false);
-        for (int l = c.fl; l < c.lanes; l += c.flstep) {
-            cpx<T> *z = c.buf[cur] + l * pitch;
-            for (int i = c.fj0; i < F; i += c.fstep) z[zi(i)] = cmul(cconj(z[zi(i)]), a.chirp[i]);
-        }
-        __syncthreads();
     }
     // ---- STORE (with POST gather) ----------------------------------------------------------
     if (!fuse_out) {

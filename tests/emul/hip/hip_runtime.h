@@ -18,6 +18,7 @@
 #define __global__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __shared__
+#define __constant__
 #define __launch_bounds__(...)
 #define __restrict__ __restrict
 
