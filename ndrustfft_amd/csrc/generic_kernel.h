@@ -124,8 +124,8 @@ __device__ __forceinline__ void pass_switch(int R, const GenCtx<T> &c, const Pas
 #define NDFFT_R(RR) case RR: stockham_pass<T, OP, RR, SRC, DST>(c, a, s, d, tw, len, Ns, pitch); break;
         NDFFT_R(2) NDFFT_R(3) NDFFT_R(4) NDFFT_R(5) NDFFT_R(6) NDFFT_R(7) NDFFT_R(8) NDFFT_R(9) NDFFT_R(10)
         default:
-            // the register-hungry radices live only in the BIG instantiation (compiled for <= 512 threads, so the
-            // allocator may use 256 VGPRs); the small one stays under 128 VGPRs without spilling
+            // the register-hungry prime radices live only in the BIG instantiation (compiled for <= 512 threads,
+            // so the allocator may use up to 256 VGPRs instead of spilling: 264 = 8*3*11 runs 566 vs 975 us)
             if constexpr (BIG) {
                 switch (R) {
                     NDFFT_R(11) NDFFT_R(12) NDFFT_R(16)

@@ -28,12 +28,13 @@ static void unit(HostTable &t, unsigned long long num, unsigned long long den) {
     t.im.push_back(-sinl(ang));
 }
 
-// radix list for the LDS Stockham kernel: largest available radix first (composite 16/12/10/9/6 cut the
-// number of passes), primes 7, 11, 13 last; false if a larger prime factor remains
+// radix list for the LDS Stockham kernel: largest available radix first (composite 10/9/6 cut the number
+// of passes; 12 and 16 cost more in registers than they save: measured), primes 7, 11, 13 last; false if a
+// larger prime factor remains
 static bool factorize(int F, std::vector<int> &radix) {
     radix.clear();
     int m = F;
-    const int cand[] = {16, 12, 10, 9, 8, 6, 5, 4, 3, 2, 7, 11, 13};
+    const int cand[] = {10, 9, 8, 6, 5, 4, 3, 2, 7, 11, 13};
     while (m > 1) {
         int pick = 0;
         for (int c : cand) if (m % c == 0) { pick = c; break; }
