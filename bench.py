@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--rows", type=int, default=0, help="lanes per GPU (default: 4096 at 1 GPU, 8192 per GPU otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist", action="store_true", help="initialise torch.distributed (RCCL) even at world size 1 (path check)")
     args = ap.parse_args()
 
     import numpy as np
@@ -64,8 +65,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or args.dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("LOCAL_RANK", "0")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -89,7 +93,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
@@ -99,13 +103,13 @@ def main():
         step()
     ev1.record()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
     path = lib.last_path()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([el, dev_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el, dev_ms = float(t[0]), float(t[1])
@@ -150,7 +154,7 @@ def main():
         if not args.no_cpu_baseline and ngpu == 1:
             out["cpu_baseline"] = cpu_baseline(n, min(rows, 4096))
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
