@@ -70,6 +70,7 @@ template <typename T> struct GenArgs {
     int32_t pitch;           // LDS pitch per lane per buffer, in complex elements
     int32_t load_mode, store_mode;
     int32_t io_tpl_log, fft_tpl_log, lpb_log;   // log2 of the power-of-two thread-map factors
+    int32_t inplace;         // one LDS buffer per lane: every thread owns <= 1 butterfly per pass (elementwise ops only)
     T scale;                 // normalisation scalar, applied where the reference applies it
     const cpx<T> *tw;        // tw[k] = e^{-2 pi i k/F}
     const cpx<T> *aux1, *aux2;
@@ -143,7 +144,7 @@ int get_dev_tables(const ndfft_plan *plan, const DevTables **out);
 
 // kernels_generic.hip
 template <typename T> int launch_generic(const GenArgs<T> &a, int threads, size_t lds_bytes, hipStream_t s);
-size_t generic_lds_bytes(int lpb, int pitch, size_t csize);
+size_t generic_lds_bytes(int lpb, int pitch, size_t csize, int nbuf = 2);
 int generic_z_len(int len);
 bool generic_needs_big(const int32_t *radix, int npass, const int32_t *radixM, int npassM);   // radices > 10: 512-thread class   // LDS elements a padded length-`len` complex buffer needs
 

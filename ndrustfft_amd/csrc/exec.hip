@@ -163,16 +163,29 @@ static int dispatch_generic(const Problem &P, const void *d_in, void *d_out, con
     const int pitch = std::max(generic_z_len(len), in_c) | 1;   // odd: lanes land in different banks for the IO_COL transposes
     const size_t csize = 2 * sizeof(T);
     const size_t lds_cap = 160 * 1024;
-    if (generic_lds_bytes(1, pitch, csize) > lds_cap) {
+    if (generic_lds_bytes(1, pitch, csize, 2) > lds_cap) {
         char m[160];
         snprintf(m, sizeof m, "lane of %d elements needs %zu B of LDS (> %zu): multi-pass path not built yet", n,
                  generic_lds_bytes(1, pitch, csize), lds_cap);
         return fail(NDFFT_ERR_UNSUPPORTED, m);
     }
-    // lanes per block: fill ~64 KiB of LDS (2 blocks/CU), but never more lanes than exist
-    const size_t per_lane = 2 * (size_t)pitch * csize;
-    int lpb = (int)std::min<size_t>((64 * 1024) / per_lane, kMaxLpb);
     const bool col = a.load_mode == IO_COL || a.store_mode == IO_COL;
+    // threads per lane in the FFT phases: one butterfly each in the pass with the most butterflies
+    int nb_max = 1;
+    {
+        const std::vector<int> &rr = c.blue ? c.radixM : c.radix;
+        for (int r : rr) nb_max = std::max(nb_max, len / r);
+    }
+    const int maxthr = generic_needs_big(a.radix, a.npass, a.radixM, a.blue ? a.npassM : 0) ? 512 : 1024;
+    int fft_tpl = 1; while (fft_tpl < nb_max && fft_tpl < maxthr) fft_tpl <<= 1;
+    // in place (one LDS buffer per lane) when the op is elementwise at both ends and a thread never owns more
+    // than one butterfly of a pass: needs fft_tpl >= nb_max and one thread group per lane
+    const bool elementwise = gop == G_C2C_FWD || gop == G_C2C_INV || gop == G_R2C_EVEN || gop == G_R2C_ODD;
+    const bool inplace = elementwise && fft_tpl >= nb_max;
+    const int nbuf = inplace ? 1 : 2;
+    // lanes per block: fill ~64 KiB of LDS (2+ blocks/CU), but never more lanes than exist
+    const size_t per_lane = (size_t)nbuf * (size_t)pitch * csize;
+    int lpb = (int)std::min<size_t>((64 * 1024) / per_lane, kMaxLpb);
     if (col) {
         // want >= 128 B contiguous across lanes per row of the tile; take more LDS if that is what it costs
         const int want = (int)std::min<size_t>(kMaxLpb, std::max<size_t>(128 / sizeof(T) / (a.in_cplx ? 2 : 1), 16));
@@ -180,6 +193,7 @@ static int dispatch_generic(const Problem &P, const void *d_in, void *d_out, con
         lpb = std::max(lpb, std::min(want, fit));
     }
     lpb = std::max(1, lpb);
+    if (inplace) lpb = std::max(1, std::min(lpb, maxthr / fft_tpl));   // one thread group per lane
     if ((int64_t)lpb > P.nlanes) lpb = (int)P.nlanes;
     // keep every CU busy: prefer >= 1024 blocks when lanes allow
     while (lpb > 1 && !col && (P.nlanes + lpb - 1) / lpb < 1024) lpb = (lpb + 1) / 2;
@@ -188,13 +202,11 @@ static int dispatch_generic(const Problem &P, const void *d_in, void *d_out, con
         while ((2 << lpb_log) <= lpb) ++lpb_log;
         lpb = 1 << lpb_log;
     }
-    a.lpb = lpb; a.pitch = pitch; a.lpb_log = lpb_log;
-    const size_t lds = generic_lds_bytes(lpb, pitch, csize);
-    // power-of-two thread maps: threads per lane in the FFT phases (~ one radix-4 butterfly each) and in row IO
-    int fft_tpl = 1; while (fft_tpl < len / 4 && fft_tpl < 1024) fft_tpl <<= 1;
-    const int maxthr = generic_needs_big(a.radix, a.npass, a.radixM, a.blue ? a.npassM : 0) ? 512 : 1024;
+    a.lpb = lpb; a.pitch = pitch; a.lpb_log = lpb_log; a.inplace = inplace;
+    const size_t lds = generic_lds_bytes(lpb, pitch, csize, nbuf);
     int threads = 64; while (threads < lpb * fft_tpl && threads < maxthr) threads <<= 1;
     if (col) while (threads < 4 * lpb && threads < maxthr) threads <<= 1;
+    if (inplace && threads < lpb * fft_tpl) return fail(NDFFT_ERR_INVALID_ARG, "internal: in-place thread map");
     fft_tpl = std::min(fft_tpl, threads);
     int io_tpl = 1; while (io_tpl < std::max(a.n_in, a.n_out) && io_tpl < threads) io_tpl <<= 1;
     a.fft_tpl_log = 0; while ((1 << a.fft_tpl_log) < fft_tpl) ++a.fft_tpl_log;

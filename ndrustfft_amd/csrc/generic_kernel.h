@@ -74,7 +74,7 @@ template <typename T, int OP> __device__ __forceinline__ cpx<T> first_pass_load(
 template <typename T, int OP, int R, int SRC, int DST>
 __device__ __forceinline__ void stockham_pass(const GenCtx<T> &c, const PassGlobals<T> &a, const cpx<T> *__restrict__ src,
                                               cpx<T> *__restrict__ dst, const cpx<T> *__restrict__ tw, int len, int Ns, int pitch) {
-    const int nb = len / R, tws = len / (Ns * R);
+    const int nb = len / R;
     const uint32_t magic = Ns > 1 ? (uint32_t)((0x100000000ull + (uint32_t)Ns - 1) / (uint32_t)Ns) : 0u;
     for (int l = c.fl; l < c.lanes; l += c.flstep) {
         const cpx<T> *s = src + l * pitch;
@@ -92,9 +92,8 @@ __device__ __forceinline__ void stockham_pass(const GenCtx<T> &c, const PassGlob
             int k = 0;
             if (Ns > 1) {
                 k = fast_mod(j, Ns, magic);
-                const int kt = k * tws;
 #pragma unroll
-                for (int r = 1; r < R; ++r) v[r] = cmul(v[r], tw[r * kt]);
+                for (int r = 1; r < R; ++r) v[r] = cmul(v[r], tw[(r - 1) * Ns + k]);   // this pass's transposed block
             }
             Bfly<T, R>::run(v);
             const int o = (j - k) * R + k;
@@ -117,6 +116,75 @@ __device__ __forceinline__ void stockham_pass(const GenCtx<T> &c, const PassGlob
     }
 }
 
+// in-place variant: ONE LDS buffer per lane.  The host guarantees that every thread owns at most one
+// butterfly of the pass, so its R values sit in registers across the barrier that separates "all reads
+// of this pass" from "first write of this pass" -- half the LDS footprint, twice the lanes per CU.
+template <typename T, int OP, int R, int SRC, int DST>
+__device__ __forceinline__ void stockham_pass_inplace(const GenCtx<T> &c, const PassGlobals<T> &a, cpx<T> *__restrict__ buf,
+                                                      const cpx<T> *__restrict__ tw, int len, int Ns, int pitch) {
+    const int nb = len / R, l = c.fl, j = c.fj0;
+    const bool active = l < c.lanes && j < nb;
+    cpx<T> *s = buf + l * pitch;
+    cpx<T> v[R];
+    int k = 0;
+    if (active) {
+        if constexpr (SRC == IO_GLOBAL) {
+            const int64_t base = c.h->off_in[l];
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[r] = first_pass_load<T, OP>(a, base, j + r * nb);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[r] = s[zi(j + r * nb)];
+        }
+        if (Ns > 1) {
+            const uint32_t magic = (uint32_t)((0x100000000ull + (uint32_t)Ns - 1) / (uint32_t)Ns);
+            k = fast_mod(j, Ns, magic);
+#pragma unroll
+            for (int r = 1; r < R; ++r) v[r] = cmul(v[r], tw[(r - 1) * Ns + k]);
+        }
+        Bfly<T, R>::run(v);
+    }
+    const int o = (j - k) * R + k;
+    if constexpr (DST == IO_GLOBAL) {
+        if (active) {
+            cpx<T> *outp = (cpx<T> *)a.out + c.h->off_out[l];
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const int idx = o + q * Ns;
+                if (idx < a.n_out) {
+                    cpx<T> w = v[q];
+                    if (OP == G_C2C_INV) { w.x *= a.scale; w.y *= -a.scale; }
+                    outp[idx] = w;
+                }
+            }
+        }
+    } else {
+        if constexpr (SRC == IO_LDS) __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) s[zi(o + q * Ns)] = v[q];
+        }
+    }
+}
+
+template <typename T, int OP, int SRC, int DST, bool BIG>
+__device__ __forceinline__ void pass_switch_inplace(int R, const GenCtx<T> &c, const PassGlobals<T> &a, cpx<T> *buf,
+                                                    const cpx<T> *tw, int len, int Ns, int pitch) {
+    switch (R) {
+#define NDFFT_R(RR) case RR: stockham_pass_inplace<T, OP, RR, SRC, DST>(c, a, buf, tw, len, Ns, pitch); break;
+        NDFFT_R(2) NDFFT_R(3) NDFFT_R(4) NDFFT_R(5) NDFFT_R(6) NDFFT_R(7) NDFFT_R(8) NDFFT_R(9) NDFFT_R(10)
+        default:
+            if constexpr (BIG) {
+                switch (R) {
+                    NDFFT_R(11)
+                    default: stockham_pass_inplace<T, OP, 13, SRC, DST>(c, a, buf, tw, len, Ns, pitch); break;
+                }
+            }
+            break;
+#undef NDFFT_R
+    }
+}
+
 template <typename T, int OP, int SRC, int DST, bool BIG>
 __device__ __forceinline__ void pass_switch(int R, const GenCtx<T> &c, const PassGlobals<T> &a, const cpx<T> *s, cpx<T> *d,
                                             const cpx<T> *tw, int len, int Ns, int pitch) {
@@ -128,7 +196,7 @@ __device__ __forceinline__ void pass_switch(int R, const GenCtx<T> &c, const Pas
             // so the allocator may use up to 256 VGPRs instead of spilling: 264 = 8*3*11 runs 566 vs 975 us)
             if constexpr (BIG) {
                 switch (R) {
-                    NDFFT_R(11) NDFFT_R(12) NDFFT_R(16)
+                    NDFFT_R(11)
                     default: stockham_pass<T, OP, 13, SRC, DST>(c, a, s, d, tw, len, Ns, pitch); break;
                 }
             }
@@ -141,7 +209,7 @@ __device__ __forceinline__ void pass_switch(int R, const GenCtx<T> &c, const Pas
 // fuse_in / fuse_out: first pass reads global / last pass writes global (see stockham_pass).
 template <typename T, int OP, bool BIG>
 __device__ __forceinline__ int run_passes(const GenCtx<T> &c, const PassGlobals<T> &a, int cur, int len, int npass, const int32_t *radix,
-                          const cpx<T> *tw, int pitch, bool fuse_in, bool fuse_out) {
+                          const cpx<T> *tw, int pitch, bool fuse_in, bool fuse_out, bool inplace) {
     constexpr bool can_in = OP == G_C2C_FWD || OP == G_C2C_INV || OP == G_R2C_EVEN || OP == G_R2C_ODD;
     constexpr bool can_out = OP == G_C2C_FWD || OP == G_C2C_INV || OP == G_R2C_ODD;
     int Ns = 1;
@@ -151,6 +219,23 @@ __device__ __forceinline__ int run_passes(const GenCtx<T> &c, const PassGlobals<
         if (!gin) __syncthreads();
         const cpx<T> *s = c.buf[cur];
         cpx<T> *d = c.buf[cur ^ 1];
+        if constexpr (can_in) {
+            if (inplace) {   // only the elementwise ops are ever launched in place
+                cpx<T> *b = c.buf[0];
+                if constexpr (can_out) {
+                    if (gin && gout) pass_switch_inplace<T, OP, IO_GLOBAL, IO_GLOBAL, BIG>(R, c, a, b, tw, len, Ns, pitch);
+                    else if (gin) pass_switch_inplace<T, OP, IO_GLOBAL, IO_LDS, BIG>(R, c, a, b, tw, len, Ns, pitch);
+                    else if (gout) pass_switch_inplace<T, OP, IO_LDS, IO_GLOBAL, BIG>(R, c, a, b, tw, len, Ns, pitch);
+                    else pass_switch_inplace<T, OP, IO_LDS, IO_LDS, BIG>(R, c, a, b, tw, len, Ns, pitch);
+                } else {
+                    if (gin) pass_switch_inplace<T, OP, IO_GLOBAL, IO_LDS, BIG>(R, c, a, b, tw, len, Ns, pitch);
+                    else pass_switch_inplace<T, OP, IO_LDS, IO_LDS, BIG>(R, c, a, b, tw, len, Ns, pitch);
+                }
+                if (p > 0) tw += (R - 1) * Ns;
+                Ns *= R;
+                continue;
+            }
+        }
         if constexpr (can_in && can_out) {
             if (gin && gout) pass_switch<T, OP, IO_GLOBAL, IO_GLOBAL, BIG>(R, c, a, s, d, tw, len, Ns, pitch);
             else if (gin) pass_switch<T, OP, IO_GLOBAL, IO_LDS, BIG>(R, c, a, s, d, tw, len, Ns, pitch);
@@ -163,6 +248,7 @@ __device__ __forceinline__ int run_passes(const GenCtx<T> &c, const PassGlobals<
             pass_switch<T, OP, IO_LDS, IO_LDS, BIG>(R, c, a, s, d, tw, len, Ns, pitch);
         }
         cur ^= 1;
+        if (p > 0) tw += (R - 1) * Ns;   // next pass's twiddle block (pass 0 has none)
         Ns *= R;
     }
     __syncthreads();
@@ -187,7 +273,7 @@ template <typename T, int OP, bool BIG> __global__ __launch_bounds__(BIG ? 512 :
     GenCtx<T> c;
     c.h = (GenHeader *)smem;
     c.buf[0] = (cpx<T> *)(smem + kGenHeaderBytes);
-    c.buf[1] = c.buf[0] + (size_t)a.lpb * a.pitch;
+    c.buf[1] = a.inplace ? c.buf[0] : c.buf[0] + (size_t)a.lpb * a.pitch;
     const int64_t lane0 = (int64_t)blockIdx.x * a.lpb;
     c.lanes = (int)min((int64_t)a.lpb, a.nlanes - lane0);
     const int tid = threadIdx.x, nthr = blockDim.x, pitch = a.pitch;
@@ -264,7 +350,7 @@ template <typename T, int OP, bool BIG> __global__ __launch_bounds__(BIG ? 512 :
                     else for (int i = c.fj0; i < M; i += c.fstep) z[zi(i)] = cconj(cmul(z[zi(i)], a.bhat[i]));
                 }
             }
-            cur = run_passes<T, OP, BIG>(c, pg, cur, len, np, radix, tw, pitch, fuse_in, fuse_out);
+            cur = run_passes<T, OP, BIG>(c, pg, cur, len, np, radix, tw, pitch, fuse_in, fuse_out, a.inplace != 0);
         }
         if (a.blue) {
             const int F = a.F;

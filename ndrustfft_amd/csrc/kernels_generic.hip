@@ -4,8 +4,8 @@
 
 namespace ndfft {
 
-size_t generic_lds_bytes(int lpb, int pitch, size_t csize) {
-    return kGenHeaderBytes + 2 * (size_t)lpb * (size_t)pitch * csize;
+size_t generic_lds_bytes(int lpb, int pitch, size_t csize, int nbuf) {
+    return kGenHeaderBytes + (size_t)nbuf * (size_t)lpb * (size_t)pitch * csize;
 }
 int generic_z_len(int len) { return len + (len >> 3) + 1; }
 size_t generic_max_len(size_t csize) {

@@ -2,8 +2,10 @@
 // Stands for FftHandler::new / R2cFftHandler::new / DctHandler::new (src/lib.rs:294, 477, 665):
 // plans are built eagerly (DctHandler plans all four types, lib.rs:666-670) and are immutable
 // afterwards, so one plan can be shared by any number of host threads (lib.rs:192-194).
+#include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <tuple>
 
 #include "engine.h"
 
@@ -28,24 +30,60 @@ static void unit(HostTable &t, unsigned long long num, unsigned long long den) {
     t.im.push_back(-sinl(ang));
 }
 
-// radix list for the LDS Stockham kernel: largest available radix first (composite 10/9/6 cut the number
-// of passes; 12 and 16 cost more in registers than they save: measured), primes 7, 11, 13 last; false if a
-// larger prime factor remains
+// radix list for the LDS Stockham kernel.  Allowed radices: 2..10 (6, 9, 10 are composite butterflies that
+// save passes; 12 and 16 cost more in registers than they save: measured) and the primes 11, 13.
+// Among all factorisations the search keeps the one with the fewest passes, then the largest minimum
+// radix (balanced passes keep every thread busy: 96 = 6*4*4, not 8*6*2), then the smallest maximum.
+static void factor_search(int m, int max_r, std::vector<int> &cur, std::vector<int> &best) {
+    if (m == 1) {
+        auto key = [](const std::vector<int> &v) {
+            int mn = 1 << 30, mx = 0;
+            for (int r : v) { mn = std::min(mn, r); mx = std::max(mx, r); }
+            return std::make_tuple((int)v.size(), -mn, mx);
+        };
+        if (best.empty() || key(cur) < key(best)) best = cur;
+        return;
+    }
+    if (!best.empty() && cur.size() + 1 > best.size()) return;
+    static const int cand[] = {13, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
+    for (int c : cand) {
+        if (c > max_r || m % c) continue;
+        cur.push_back(c);
+        factor_search(m / c, c, cur, best);   // non-increasing order: each multiset is visited once
+        cur.pop_back();
+    }
+}
 static bool factorize(int F, std::vector<int> &radix) {
     radix.clear();
-    int m = F;
-    const int cand[] = {10, 9, 8, 6, 5, 4, 3, 2, 7, 11, 13};
-    while (m > 1) {
-        int pick = 0;
-        for (int c : cand) if (m % c == 0) { pick = c; break; }
-        if (!pick) return false;
-        radix.push_back(pick);
-        m /= pick;
-    }
-    return radix.size() <= (size_t)kMaxPasses;
+    if (F <= 1) return true;
+    int m = F;   // reject early if a prime factor > 13 remains
+    for (int p : {2, 3, 5, 7, 11, 13}) while (m % p == 0) m /= p;
+    if (m != 1) return false;
+    std::vector<int> cur;
+    factor_search(F, 13, cur, radix);
+    // largest radix first: the first pass reads global memory directly with R independent loads in flight
+    std::sort(radix.begin(), radix.end(), [](int x, int y) { return x > y; });
+    return !radix.empty() && radix.size() <= (size_t)kMaxPasses;
 }
 
 static ndfft_plan *make_plan(int kind, int dtype, size_t n);
+
+// per-pass transposed twiddles of the LDS Stockham kernel: for pass p (radix R, Ns = product of the
+// earlier radices) the block  tw_p[(r-1) Ns + k] = e^{-2 pi i r k/(Ns R)},  r in [1,R), k in [0,Ns);
+// blocks are concatenated, pass 0 (Ns = 1, all ones) is skipped.  Consecutive butterflies have consecutive
+// k, so a wave reads them coalesced.
+static void build_pass_twiddles(HostTable &t, const std::vector<int> &radix, int len) {
+    (void)len;
+    unsigned long long Ns = 1;
+    for (size_t p = 0; p < radix.size(); ++p) {
+        const unsigned long long R = (unsigned long long)radix[p];
+        if (p > 0)
+            for (unsigned long long r = 1; r < R; ++r)
+                for (unsigned long long k = 0; k < Ns; ++k) unit(t, r * k, Ns * R);
+        Ns *= R;
+    }
+    if (t.re.empty()) unit(t, 0, 1);   // single-pass transforms: keep the table non-empty
+}
 
 static int blue_len(int F) { int M = 1; while (M < 2 * F - 1) M <<= 1; return M; }
 
@@ -65,7 +103,7 @@ static void build_fft(FftConfig &c, int F, int dtype) {
     const size_t maxlen = generic_max_len(dtype == NDFFT_F32 ? 8 : 16);
     const bool smooth = factorize(F, c.radix);
     if (smooth && (size_t)F <= maxlen) {
-        for (int k = 0; k < F; ++k) unit(c.tw, k, F);
+        build_pass_twiddles(c.tw, c.radix, F);
         return;
     }
     if (smooth || (size_t)blue_len(F) > maxlen) {
@@ -92,7 +130,7 @@ static void build_fft(FftConfig &c, int F, int dtype) {
     const int M = blue_len(F);
     c.M = M;
     factorize(M, c.radixM);
-    for (int k = 0; k < M; ++k) unit(c.twM, k, M);
+    build_pass_twiddles(c.twM, c.radixM, M);
     for (int j = 0; j < F; ++j) unit(c.chirp, ((unsigned long long)j * j) % (2ull * F), 2ull * F);
     std::vector<long double> br(M, 0.0L), bi(M, 0.0L);
     for (int j = 0; j < F; ++j) {
