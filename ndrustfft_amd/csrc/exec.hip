@@ -176,12 +176,14 @@ static int dispatch_generic(const Problem &P, const void *d_in, void *d_out, con
         const std::vector<int> &rr = c.blue ? c.radixM : c.radix;
         for (int r : rr) nb_max = std::max(nb_max, len / r);
     }
-    const int maxthr = generic_needs_big(a.radix, a.npass, a.radixM, a.blue ? a.npassM : 0) ? 512 : 1024;
+    const bool elementwise = gop == G_C2C_FWD || gop == G_C2C_INV || gop == G_R2C_EVEN || gop == G_R2C_ODD;
+    // (the in-place and the prime-radix kernels are compiled for <= 512 threads: 256-VGPR budget)
+    const bool want_inplace = elementwise && nb_max <= 512;
+    const int maxthr = (want_inplace || generic_needs_big(a.radix, a.npass, a.radixM, a.blue ? a.npassM : 0)) ? 512 : 1024;
     int fft_tpl = 1; while (fft_tpl < nb_max && fft_tpl < maxthr) fft_tpl <<= 1;
     // in place (one LDS buffer per lane) when the op is elementwise at both ends and a thread never owns more
     // than one butterfly of a pass: needs fft_tpl >= nb_max and one thread group per lane
-    const bool elementwise = gop == G_C2C_FWD || gop == G_C2C_INV || gop == G_R2C_EVEN || gop == G_R2C_ODD;
-    const bool inplace = elementwise && fft_tpl >= nb_max;
+    const bool inplace = want_inplace && fft_tpl >= nb_max;
     const int nbuf = inplace ? 1 : 2;
     // lanes per block: fill ~64 KiB of LDS (2+ blocks/CU), but never more lanes than exist
     const size_t per_lane = (size_t)nbuf * (size_t)pitch * csize;

@@ -207,9 +207,9 @@ __device__ __forceinline__ void pass_switch(int R, const GenCtx<T> &c, const Pas
 
 // runs the radix passes on LDS buffers; returns the index of the buffer holding the result.
 // fuse_in / fuse_out: first pass reads global / last pass writes global (see stockham_pass).
-template <typename T, int OP, bool BIG>
+template <typename T, int OP, bool BIG, bool INPLACE>
 __device__ __forceinline__ int run_passes(const GenCtx<T> &c, const PassGlobals<T> &a, int cur, int len, int npass, const int32_t *radix,
-                          const cpx<T> *tw, int pitch, bool fuse_in, bool fuse_out, bool inplace) {
+                          const cpx<T> *tw, int pitch, bool fuse_in, bool fuse_out) {
     constexpr bool can_in = OP == G_C2C_FWD || OP == G_C2C_INV || OP == G_R2C_EVEN || OP == G_R2C_ODD;
     constexpr bool can_out = OP == G_C2C_FWD || OP == G_C2C_INV || OP == G_R2C_ODD;
     int Ns = 1;
@@ -219,8 +219,8 @@ __device__ __forceinline__ int run_passes(const GenCtx<T> &c, const PassGlobals<
         if (!gin) __syncthreads();
         const cpx<T> *s = c.buf[cur];
         cpx<T> *d = c.buf[cur ^ 1];
-        if constexpr (can_in) {
-            if (inplace) {   // only the elementwise ops are ever launched in place
+        if constexpr (can_in && INPLACE) {
+            {   // only the elementwise ops are ever instantiated in place
                 cpx<T> *b = c.buf[0];
                 if constexpr (can_out) {
                     if (gin && gout) pass_switch_inplace<T, OP, IO_GLOBAL, IO_GLOBAL, BIG>(R, c, a, b, tw, len, Ns, pitch);
@@ -235,8 +235,7 @@ __device__ __forceinline__ int run_passes(const GenCtx<T> &c, const PassGlobals<
                 Ns *= R;
                 continue;
             }
-        }
-        if constexpr (can_in && can_out) {
+        } else if constexpr (can_in && can_out) {
             if (gin && gout) pass_switch<T, OP, IO_GLOBAL, IO_GLOBAL, BIG>(R, c, a, s, d, tw, len, Ns, pitch);
             else if (gin) pass_switch<T, OP, IO_GLOBAL, IO_LDS, BIG>(R, c, a, s, d, tw, len, Ns, pitch);
             else if (gout) pass_switch<T, OP, IO_LDS, IO_GLOBAL, BIG>(R, c, a, s, d, tw, len, Ns, pitch);
@@ -268,12 +267,12 @@ __device__ __forceinline__ int64_t lane_offset(const LaneGeom &g, int64_t lane) 
     return off;
 }
 
-template <typename T, int OP, bool BIG> __global__ __launch_bounds__(BIG ? 512 : 1024) void k_generic(const GenArgs<T> a) {
+template <typename T, int OP, bool BIG, bool INPLACE> __global__ __launch_bounds__((BIG || INPLACE) ? 512 : 1024) void k_generic(const GenArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     GenCtx<T> c;
     c.h = (GenHeader *)smem;
     c.buf[0] = (cpx<T> *)(smem + kGenHeaderBytes);
-    c.buf[1] = a.inplace ? c.buf[0] : c.buf[0] + (size_t)a.lpb * a.pitch;
+    c.buf[1] = INPLACE ? c.buf[0] : c.buf[0] + (size_t)a.lpb * a.pitch;
     const int64_t lane0 = (int64_t)blockIdx.x * a.lpb;
     c.lanes = (int)min((int64_t)a.lpb, a.nlanes - lane0);
     const int tid = threadIdx.x, nthr = blockDim.x, pitch = a.pitch;
@@ -350,7 +349,7 @@ template <typename T, int OP, bool BIG> __global__ __launch_bounds__(BIG ? 512 :
                     else for (int i = c.fj0; i < M; i += c.fstep) z[zi(i)] = cconj(cmul(z[zi(i)], a.bhat[i]));
                 }
             }
-            cur = run_passes<T, OP, BIG>(c, pg, cur, len, np, radix, tw, pitch, fuse_in, fuse_out, a.inplace != 0);
+            cur = run_passes<T, OP, BIG, INPLACE>(c, pg, cur, len, np, radix, tw, pitch, fuse_in, fuse_out);
         }
         if (a.blue) {
             const int F = a.F;
@@ -381,16 +380,20 @@ template <typename T, int OP, bool BIG> __global__ __launch_bounds__(BIG ? 512 :
 }
 
 
-template <typename T, int OP, bool BIG> static int launch_op(const GenArgs<T> &a, int threads, size_t lds_bytes, hipStream_t s) {
+template <typename T, int OP, bool BIG, bool INPLACE = false> static int launch_op(const GenArgs<T> &a, int threads, size_t lds_bytes, hipStream_t s) {
+    constexpr bool elementwise = OP == G_C2C_FWD || OP == G_C2C_INV || OP == G_R2C_EVEN || OP == G_R2C_ODD;
+    if constexpr (elementwise && !INPLACE) {
+        if (a.inplace) return launch_op<T, OP, BIG, true>(a, threads, lds_bytes, s);
+    }
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_generic<T, OP, BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_generic<T, OP, BIG, INPLACE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const int64_t nblk = (a.nlanes + a.lpb - 1) / a.lpb;
     if (nblk <= 0) return NDFFT_OK;
     if (nblk > 0x7fffffffLL) return fail(NDFFT_ERR_UNSUPPORTED, "too many lanes for one launch");
-    hipLaunchKernelGGL((k_generic<T, OP, BIG>), dim3((unsigned)nblk), dim3(threads), lds_bytes, s, a);
+    hipLaunchKernelGGL((k_generic<T, OP, BIG, INPLACE>), dim3((unsigned)nblk), dim3(threads), lds_bytes, s, a);
     NDFFT_HIP(hipGetLastError());
     return NDFFT_OK;
 }
