@@ -96,6 +96,7 @@ struct FftConfig {                 // one complex-FFT-of-length-F recipe + op ta
     bool pow2 = false;             // C2C slot: pow2_kernel.h ; real-op slots: pow2_real.h
     HostTable twp;                 // per-pass transposed twiddles
     HostTable twp_col;             // C2C slot only: twiddles in the radix order of the column kernel (pow2_real.h)
+    HostTable twp_narrow;          // twiddles in the radix order of the narrow (XCD-aware) column kernel
     // long lanes (one lane does not fit LDS): four-step F = F1 * F2 on top of the row kernels
     bool big = false; int F1 = 0, F2 = 0, logB = 0;
     ndfft_plan *sub1 = nullptr, *sub2 = nullptr;   // C2C sub-plans of length F1 / F2 (owned)
@@ -105,7 +106,7 @@ struct FftConfig {                 // one complex-FFT-of-length-F recipe + op ta
 
 struct DevConfig {                 // device copies (typed by dtype) of one FftConfig
     void *tw = nullptr, *twM = nullptr, *chirp = nullptr, *bhat = nullptr, *aux1 = nullptr, *aux2 = nullptr, *twp = nullptr;
-    void *twlo = nullptr, *twhi = nullptr, *twp_col = nullptr;
+    void *twlo = nullptr, *twhi = nullptr, *twp_col = nullptr, *twp_narrow = nullptr;
 };
 
 enum ConfigSlot { CFG_MAIN = 0, CFG_DCT1 = 1, CFG_DCT4 = 2, CFG_COUNT = 3 };
@@ -167,6 +168,9 @@ bool pow2_real_supported(int F);
 void pow2_real_build_twiddles(int F, HostTable &out);
 template <typename T> int launch_pow2_real(int gen_op, const RealArgs<T> &a, bool col, hipStream_t s);
 template <typename T> int pow2_real_col_lanes(int F);   // adjacent lanes per column tile (0: none)
+template <typename T> int pow2_real_narrow_lanes(int F);   // lanes per XCD-aware narrow column tile (0: none)
+void pow2_real_build_narrow_twiddles(int dtype, int F, HostTable &out);
+template <typename T> int launch_pow2_real_narrow(int gen_op, const RealArgs<T> &a, hipStream_t s);
 
 // big.hip : four-step pieces for lanes that do not fit LDS
 template <typename T>

@@ -5,6 +5,7 @@
 // choice, and -- for host arrays -- staging through HBM.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -274,6 +275,12 @@ static int big_fft(const FftConfig &c, const DevConfig &d, const cpx<T> *zin, in
     return transpose_batched(s2, zout, L, F1, F2, F2, F1, F, pitch_out, esz, stream);
 }
 
+// developer switch: NDFFT_NARROW=0 sends long strided lanes through the transpose route instead
+static bool narrow_enabled() {
+    static const bool on = [] { const char *e = getenv("NDFFT_NARROW"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 static int gen_op_of(int op, int n, int *slot) {
     *slot = CFG_MAIN;
     switch (op) {
@@ -368,11 +375,40 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
         const bool odd_variant = gop == G_R2C_ODD || gop == G_C2R_ODD || gop == G_DCT2_ODD || gop == G_DCT3_ODD || gop == G_DCT4_ODD;
         const bool have_tw = is_c2c ? !c.twp_col.re.empty() : c.pow2;
         const bool row = !is_c2c && P.xs == 1 && P.ys == 1 && P.b.size() <= 1;
-        bool col = false;
-        if (!row && have_tw && !odd_variant && P.xlen > 1 && !P.b.empty() && P.b.size() <= 2 && P.b.back().sin == 1 &&
-            P.b.back().sout == 1 && P.b.back().shape >= 8) {
-            const int lanes = plan->dtype == NDFFT_F32 ? pow2_real_col_lanes<float>(c.F) : pow2_real_col_lanes<double>(c.F);
-            col = lanes > 0;
+        bool col = false, narrow = false;
+        if (!row && !odd_variant && P.xlen > 1 && !P.b.empty() && P.b.size() <= 2 && P.b.back().sin == 1 && P.b.back().sout == 1) {
+            if (have_tw && P.b.back().shape >= 8) {
+                const int lanes = plan->dtype == NDFFT_F32 ? pow2_real_col_lanes<float>(c.F) : pow2_real_col_lanes<double>(c.F);
+                col = lanes > 0;
+            }
+            // long lanes: XCD-aware narrow tiles (one HBM pass) instead of the three-pass transpose route
+            if (!col && !c.twp_narrow.re.empty() && P.b.back().shape >= 64 && narrow_enabled()) {
+                const int lanes = plan->dtype == NDFFT_F32 ? pow2_real_narrow_lanes<float>(c.F) : pow2_real_narrow_lanes<double>(c.F);
+                narrow = lanes > 0;
+            }
+        }
+        if (narrow) {
+            auto fill = [&](auto &a) {
+                a.in = d_in; a.out = d_out; a.nlanes = P.nlanes;
+                a.pitch_in = 0; a.pitch_out = 0; a.vec_in = 0;
+                a.n = n; a.F = c.F; a.n_in = (int)P.xlen; a.n_out = (int)P.ylen;
+                a.inner = P.b.back().shape;
+                a.outer_in = P.b.size() == 2 ? P.b[0].sin : 0;
+                a.outer_out = P.b.size() == 2 ? P.b[0].sout : 0;
+                a.elem_in = P.xs; a.elem_out = P.ys;
+            };
+            int rc2;
+            if (plan->dtype == NDFFT_F32) {
+                RealArgs<float> a; fill(a); a.scale = (float)P.scale;
+                a.aux1 = (const float2 *)d.aux1; a.aux2 = (const float2 *)d.aux2; a.twp = (const float2 *)d.twp_narrow;
+                rc2 = launch_pow2_real_narrow<float>(gop, a, stream);
+            } else {
+                RealArgs<double> a; fill(a); a.scale = P.scale;
+                a.aux1 = (const double2 *)d.aux1; a.aux2 = (const double2 *)d.aux2; a.twp = (const double2 *)d.twp_narrow;
+                rc2 = launch_pow2_real_narrow<double>(gop, a, stream);
+            }
+            set_last_path("pow2_col_xcd");
+            return rc2;
         }
         if (have_tw && !odd_variant && (row || col)) {
             auto fill = [&](auto &a) {

@@ -64,6 +64,75 @@ template <typename T, int F> struct ColGeom {
     static constexpr bool OK = LPB >= 8 && LDS <= 160 * 1024;
 };
 
+// narrow (XCD-aware) column tiles for long lanes: 1024 threads, LPB = 2 or 4 lanes
+template <typename T, int F> struct NarrowCfg { static constexpr bool OK = false; };
+#define NDFFT_NARROW(T_, F_, TPL_, LPB_, ...)                                   \
+    template <> struct NarrowCfg<T_, F_> {                                     \
+        static constexpr bool OK = true;                                       \
+        static constexpr int TPL = TPL_, LPB = LPB_;                           \
+        using RL = RadixList<__VA_ARGS__>;                                     \
+    };
+NDFFT_NARROW(float, 2048, 256, 4, 8, 8, 8, 4)
+NDFFT_NARROW(float, 4096, 256, 4, 16, 16, 16)
+NDFFT_NARROW(float, 8192, 512, 2, 16, 16, 8, 4)
+NDFFT_NARROW(double, 2048, 256, 4, 8, 8, 8, 4)
+NDFFT_NARROW(double, 4096, 512, 2, 8, 8, 8, 8)
+
+template <typename T> int pow2_real_narrow_lanes(int F) {
+    switch (F) {
+        case 2048: return NarrowCfg<T, 2048>::OK ? NarrowCfg<T, 2048>::LPB : 0;
+        case 4096: return NarrowCfg<T, 4096>::OK ? NarrowCfg<T, 4096>::LPB : 0;
+        case 8192: if constexpr (NarrowCfg<T, 8192>::OK) return NarrowCfg<T, 8192>::LPB; else return 0;
+        default: return 0;
+    }
+}
+template int pow2_real_narrow_lanes<float>(int);
+template int pow2_real_narrow_lanes<double>(int);
+
+template <typename T, int F> static void narrow_tw(HostTable &out) {
+    if constexpr (NarrowCfg<T, F>::OK) build_tw<typename NarrowCfg<T, F>::RL>(out);
+}
+void pow2_real_build_narrow_twiddles(int dtype, int F, HostTable &out) {
+    switch (F) {
+        case 2048: if (dtype == NDFFT_F32) narrow_tw<float, 2048>(out); else narrow_tw<double, 2048>(out); break;
+        case 4096: if (dtype == NDFFT_F32) narrow_tw<float, 4096>(out); else narrow_tw<double, 4096>(out); break;
+        case 8192: if (dtype == NDFFT_F32) narrow_tw<float, 8192>(out); else narrow_tw<double, 8192>(out); break;
+        default: break;
+    }
+}
+
+template <typename T, int F, int OP> static int launch_narrow_one(const RealArgs<T> &a, hipStream_t s) {
+    if constexpr (NarrowCfg<T, F>::OK) {
+        using C = NarrowCfg<T, F>;
+        return launch_k<RealPow2Kernel<T, F, C::TPL, C::LPB, typename C::RL, OP, true, true>, T>(a, C::LPB, s);
+    } else {
+        return fail(NDFFT_ERR_UNSUPPORTED, "no narrow column kernel for this F");
+    }
+}
+template <typename T, int F> static int launch_narrow_F(int op, const RealArgs<T> &a, hipStream_t s) {
+    switch (op) {
+        case G_C2C_FWD: return launch_narrow_one<T, F, G_C2C_FWD>(a, s);
+        case G_C2C_INV: return launch_narrow_one<T, F, G_C2C_INV>(a, s);
+        case G_R2C_EVEN: return launch_narrow_one<T, F, G_R2C_EVEN>(a, s);
+        case G_C2R_EVEN: return launch_narrow_one<T, F, G_C2R_EVEN>(a, s);
+        case G_DCT1: return launch_narrow_one<T, F, G_DCT1>(a, s);
+        case G_DCT2_EVEN: return launch_narrow_one<T, F, G_DCT2_EVEN>(a, s);
+        case G_DCT3_EVEN: return launch_narrow_one<T, F, G_DCT3_EVEN>(a, s);
+        case G_DCT4_EVEN: return launch_narrow_one<T, F, G_DCT4_EVEN>(a, s);
+        default: return fail(NDFFT_ERR_INVALID_ARG, "narrow kernel: bad op");
+    }
+}
+template <typename T> int launch_pow2_real_narrow(int op, const RealArgs<T> &a, hipStream_t s) {
+    switch (a.F) {
+        case 2048: return launch_narrow_F<T, 2048>(op, a, s);
+        case 4096: return launch_narrow_F<T, 4096>(op, a, s);
+        case 8192: return launch_narrow_F<T, 8192>(op, a, s);
+        default: return fail(NDFFT_ERR_UNSUPPORTED, "narrow kernel: unsupported F");
+    }
+}
+template int launch_pow2_real_narrow<float>(int, const RealArgs<float> &, hipStream_t);
+template int launch_pow2_real_narrow<double>(int, const RealArgs<double> &, hipStream_t);
+
 template <typename T, int F, int OP> static int launch_real_one(const RealArgs<T> &a, bool col, hipStream_t s) {
     constexpr int TPL = RealCfg<F>::TPL;
     if (!col) {

@@ -67,6 +67,7 @@ static bool factorize(int F, std::vector<int> &radix) {
 }
 
 static ndfft_plan *make_plan(int kind, int dtype, size_t n);
+static void add_narrow_tables(ndfft_plan *p);
 
 // per-pass transposed twiddles of the LDS Stockham kernel: for pass p (radix R, Ns = product of the
 // earlier radices) the block  tw_p[(r-1) Ns + k] = e^{-2 pi i r k/(Ns R)},  r in [1,R), k in [0,Ns);
@@ -215,7 +216,13 @@ static ndfft_plan *make_plan(int kind, int dtype, size_t n) {
     ndfft_plan *p = new ndfft_plan();
     p->kind = kind; p->dtype = dtype; p->n = n; p->refcount = 1;
     build_plan_tables(p);
+    add_narrow_tables(p);
     return p;
+}
+
+static void add_narrow_tables(ndfft_plan *p) {
+    for (int i = 0; i < CFG_COUNT; ++i)
+        if (p->has_cfg[i] && !p->cfg[i].blue && !p->cfg[i].big) pow2_real_build_narrow_twiddles(p->dtype, p->cfg[i].F, p->cfg[i].twp_narrow);
 }
 
 template <typename T> static int upload(const HostTable &t, void **dptr) {
@@ -257,6 +264,7 @@ int get_dev_tables(const ndfft_plan *cplan, const DevTables **out) {
         if ((rc = upload_any(plan->dtype, c.twlo, &d.twlo))) return rc;
         if ((rc = upload_any(plan->dtype, c.twhi, &d.twhi))) return rc;
         if ((rc = upload_any(plan->dtype, c.twp_col, &d.twp_col))) return rc;
+        if ((rc = upload_any(plan->dtype, c.twp_narrow, &d.twp_narrow))) return rc;
     }
     auto ins = plan->dev.emplace(dev, t);
     *out = &ins.first->second;
@@ -321,7 +329,7 @@ int ndfft_plan_destroy(ndfft_plan *plan) {
         (void)hipSetDevice(kv.first);
         for (int i = 0; i < CFG_COUNT; ++i) {
             DevConfig &d = kv.second.cfg[i];
-            void *ptrs[] = {d.tw, d.twM, d.chirp, d.bhat, d.aux1, d.aux2, d.twp, d.twlo, d.twhi, d.twp_col};
+            void *ptrs[] = {d.tw, d.twM, d.chirp, d.bhat, d.aux1, d.aux2, d.twp, d.twlo, d.twhi, d.twp_col, d.twp_narrow};
             for (void *q : ptrs) if (q) (void)hipFree(q);
         }
     }

@@ -36,7 +36,12 @@ struct ZiPhi { static __device__ __forceinline__ int map(int p) { return p + (p 
 // ADJACENT LANES are contiguous (strategy ii on a C-layout array): the workgroup stages an LDS tile of
 // LPB lanes x n elements with lanes fastest -- the fused, LDS-padded transpose that replaces the
 // reference's per-lane x.to_vec() / y.assign() (src/lib.rs:133-134) -- and stores the same way.
-template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = false> struct RealPow2Kernel {
+// XCD = true (only with COL): "narrow" column tiles for LONG strided lanes (F >= 2048), LPB = 2 or 4 lanes
+// = 8-16 bytes per row of the tile.  One 128-byte line is then shared by 8 neighbouring tiles; the
+// blockIdx -> tile map puts those 8 tiles on ONE XCD, back to back in dispatch order, so that the line
+// is fetched from HBM once and the other seven reads hit that XCD's L2 (workgroups are dealt round-robin
+// over the 8 XCDs: blocks b and b+8 share one -- MI355X_MICROARCH.md).  Placement only affects speed.
+template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = false, bool XCD = false> struct RealPow2Kernel {
     static constexpr int E = F / TPL;
     static constexpr int THREADS = TPL * LPB;
     // complex elements per lane: padded Z, or F+1 raw complex.  COL: odd, so adjacent lanes spread over the
@@ -76,7 +81,15 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
     static __device__ __forceinline__ void run(const RealArgs<T> &a) {
         extern __shared__ __attribute__((aligned(16))) char smem[];
         const int t = threadIdx.x % TPL, ll = threadIdx.x / TPL;
-        const int64_t lane0 = (int64_t)blockIdx.x * LPB;
+        int64_t tile = blockIdx.x;
+        if constexpr (XCD) {
+            const int64_t nb64 = (int64_t)gridDim.x & ~(int64_t)63;
+            if (tile < nb64) {   // b = 8 q + x  ->  tile = 8 (8 (q / 8) + x) + q % 8
+                const int64_t q = tile >> 3, x = tile & 7;
+                tile = 8 * (8 * (q >> 3) + x) + (q & 7);
+            }
+        }
+        const int64_t lane0 = tile * LPB;
         const int64_t lane = lane0 + ll;
         const bool live = lane < a.nlanes;
         char *lds = smem + (size_t)ll * LANE_LDS * 2 * sizeof(T);

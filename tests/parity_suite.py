@@ -340,6 +340,17 @@ def shared_handler_across_threads(L, nthreads=8):
     assert not errs, errs
 
 
+def narrow_xcd_tiles(L):
+    """Long strided lanes (inner FFT 2048..8192) with >= 64 adjacent lanes: XCD-aware narrow column tiles,
+    incl. ragged tails, 3-D outer dims and every op family."""
+    cases = (("ndfft_r2c", (8192, 128), 0, np.float32), ("ndifft_r2c", (8192, 64), 0, np.float32), ("ndfft", (4096, 72), 0, np.float32),
+             ("ndfft", (4096, 64), 0, np.float64), ("nddct2", (2, 4096, 130), 1, np.float64), ("ndifft", (2048, 200), 0, np.float64),
+             ("nddct1", (4097, 64), 0, np.float32), ("ndfft", (8192, 64), 0, np.float32), ("ndfft_r2c", (16384, 66), 0, np.float32),
+             ("nddct3", (4096, 1000), 0, np.float64), ("nddct4", (8192, 96), 0, np.float32))
+    for name, shape, axis, rdt in cases:
+        assert run_case(L, name, shape, axis, rdt) == "pow2_col_xcd", (name, shape)
+
+
 def handler_clone_shares_plan(L):
     h = handlers.FftHandler(16, _library=L)
     h2 = h.clone()
