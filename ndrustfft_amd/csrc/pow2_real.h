@@ -26,6 +26,7 @@ template <typename T> struct RealArgs {
     // element j of lane L lives at o*outer_* + i + j*elem_*   (adjacent lanes are adjacent in memory)
     int64_t inner, outer_in, outer_out, elem_in, elem_out;
     int32_t vec_in;   // row layout: every lane base is 16-byte aligned -> stage with 16-byte loads
+    int32_t xcd_remap;   // narrow tiles: 1 = XCD-aware blockIdx -> tile map (0 only for A/B measurements)
 };
 
 struct ZiNone { static __device__ __forceinline__ int map(int p) { return p; } };
@@ -84,7 +85,7 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
         int64_t tile = blockIdx.x;
         if constexpr (XCD) {
             const int64_t nb64 = (int64_t)gridDim.x & ~(int64_t)63;
-            if (tile < nb64) {   // b = 8 q + x  ->  tile = 8 (8 (q / 8) + x) + q % 8
+            if (a.xcd_remap && tile < nb64) {   // b = 8 q + x  ->  tile = 8 (8 (q / 8) + x) + q % 8
                 const int64_t q = tile >> 3, x = tile & 7;
                 tile = 8 * (8 * (q >> 3) + x) + (q & 7);
             }
@@ -172,17 +173,22 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
             if constexpr (PAIR) {
                 if constexpr (OUT_CPLX) {
                     cpx<T> *out = (cpx<T> *)a.out + base;
-                    for (int k = j0; k <= F / 2; k += THREADS / LPB) post_pair(a, res, k, [&](int q, cpx<T> v) { gstore<T, true>(out + (int64_t)q * a.elem_out, v); });
+                    for (int k = j0; k <= F / 2; k += THREADS / LPB) post_pair(a, res, k, [&](int q, cpx<T> v) { gstore<T, !XCD>(out + (int64_t)q * a.elem_out, v); });
                 } else {
                     T *out = (T *)a.out + base;
-                    for (int k = j0; k <= F / 2; k += THREADS / LPB) post_pair(a, res, k, [&](int q, T v) { __builtin_nontemporal_store(v, out + (int64_t)q * a.elem_out); });
+                    for (int k = j0; k <= F / 2; k += THREADS / LPB) post_pair(a, res, k, [&](int q, T v) { if constexpr (XCD) out[(int64_t)q * a.elem_out] = v; else __builtin_nontemporal_store(v, out + (int64_t)q * a.elem_out); });
                 }
             } else if constexpr (OUT_CPLX) {
                 cpx<T> *out = (cpx<T> *)a.out + base;
-                for (int q = j0; q < a.n_out; q += THREADS / LPB) gstore<T, true>(out + (int64_t)q * a.elem_out, post_cplx<T, OP, ZiPhi>(a, res, q));
+                for (int q = j0; q < a.n_out; q += THREADS / LPB) gstore<T, !XCD>(out + (int64_t)q * a.elem_out, post_cplx<T, OP, ZiPhi>(a, res, q));
             } else {
                 T *out = (T *)a.out + base;
-                for (int q = j0; q < a.n_out; q += THREADS / LPB) __builtin_nontemporal_store(post_real<T, OP, ZiPhi>(a, res, q), out + (int64_t)q * a.elem_out);
+                for (int q = j0; q < a.n_out; q += THREADS / LPB) {
+                    const T val = post_real<T, OP, ZiPhi>(a, res, q);
+                    // narrow tiles write 8-32 byte pieces of lines shared with neighbouring tiles: keep them
+                    // cacheable so that the XCD's L2 merges whole lines before they go to HBM
+                    if constexpr (XCD) out[(int64_t)q * a.elem_out] = val; else __builtin_nontemporal_store(val, out + (int64_t)q * a.elem_out);
+                }
             }
         } else {
             if (!live) return;
