@@ -276,6 +276,65 @@ void transform(int op, const ArrayView<const In> &input, ArrayView<Out> &output,
 }
 }  // namespace detail
 
+// ---- device-resident arrays: keep `work` arrays in HBM between axis passes ----------
+// DeviceArray<A> owns a C-layout array in device memory.  The nd* overloads on DeviceArray go through
+// ndfft_exec_device (asynchronous on the default stream); upload()/download() are the only PCIe traffic.
+// Normalization::Custom is a host function and is rejected on this path.
+template <typename A> class DeviceArray {
+  public:
+    DeviceArray() = default;
+    explicit DeviceArray(std::vector<std::int64_t> shape) : shape_(std::move(shape)) {
+        strides_.assign(shape_.size(), 1);
+        std::int64_t s = 1;
+        for (std::size_t d = shape_.size(); d-- > 0;) { strides_[d] = s; s *= shape_[d]; }
+        len_ = (std::size_t)s;
+        detail::check(ndfft_dev_alloc(&ptr_, len_ * sizeof(A)));
+    }
+    static DeviceArray from_host(const Array<A> &h) {
+        DeviceArray d(h.shape());
+        auto v = h.to_logical();
+        detail::check(ndfft_dev_upload(d.ptr_, v.data(), v.size() * sizeof(A)));
+        return d;
+    }
+    Array<A> to_host() const {
+        std::vector<A> v(len_);
+        detail::check(ndfft_dev_sync(nullptr));
+        detail::check(ndfft_dev_download(v.data(), ptr_, len_ * sizeof(A)));
+        return Array<A>::from(shape_, v);
+    }
+    DeviceArray(const DeviceArray &) = delete;
+    DeviceArray &operator=(const DeviceArray &) = delete;
+    DeviceArray(DeviceArray &&o) noexcept { *this = std::move(o); }
+    DeviceArray &operator=(DeviceArray &&o) noexcept {
+        if (this != &o) { release(); ptr_ = o.ptr_; shape_ = std::move(o.shape_); strides_ = std::move(o.strides_); len_ = o.len_; o.ptr_ = nullptr; }
+        return *this;
+    }
+    ~DeviceArray() { release(); }
+    void *ptr() const { return ptr_; }
+    const std::vector<std::int64_t> &shape() const { return shape_; }
+    const std::vector<std::int64_t> &strides() const { return strides_; }
+
+  private:
+    void release() { if (ptr_) ndfft_dev_free(ptr_); ptr_ = nullptr; }
+    void *ptr_ = nullptr;
+    std::vector<std::int64_t> shape_, strides_;
+    std::size_t len_ = 0;
+};
+
+namespace detail {
+template <typename In, typename Out, typename NormT>
+void transform_device(int op, const DeviceArray<In> &input, DeviceArray<Out> &output, ndfft_plan *plan,
+                      const Normalization<NormT> &norm, bool norm_applies, std::size_t axis) {
+    if (input.shape().size() != output.shape().size()) throw Error(NDFFT_ERR_INVALID_ARG, "input and output must have the same dimensionality D");
+    if (norm.kind == Normalization<NormT>::Custom && norm_applies)
+        throw Error(NDFFT_ERR_INVALID_ARG, "Normalization::Custom is a host function: not available on device-resident arrays");
+    const int mode = norm.kind == Normalization<NormT>::Default ? NDFFT_NORM_DEFAULT : NDFFT_NORM_NONE;
+    if (axis > 0x7fffffffu) throw Panic(NDFFT_ERR_AXIS, "index out of bounds");
+    check(ndfft_exec_device(plan, op, input.ptr(), output.ptr(), (int)input.shape().size(), input.shape().data(), input.strides().data(),
+                            output.shape().data(), output.strides().data(), (int)axis, mode, 0.0, nullptr));
+}
+}  // namespace detail
+
 #define NDRUSTFFT_DEFINE(NAME, IN, OUT, HANDLER, OP, NORMT, APPLIES, PRE)                                   \
     template <typename T>                                                                                    \
     void NAME(const ArrayView<const IN> &input, ArrayView<OUT> output, const HANDLER<T> &handler, std::size_t axis) { \
@@ -292,6 +351,14 @@ void transform(int op, const ArrayView<const In> &input, ArrayView<Out> &output,
     template <typename T>                                                                                    \
     void NAME##_par(const Array<IN> &input, Array<OUT> &output, const HANDLER<T> &handler, std::size_t axis) { \
         NAME<T>(input.view(), output.view(), handler, axis);                                                 \
+    }                                                                                                        \
+    template <typename T>                                                                                    \
+    void NAME(const DeviceArray<IN> &input, DeviceArray<OUT> &output, const HANDLER<T> &handler, std::size_t axis) { \
+        detail::transform_device<IN, OUT, NORMT>(OP, input, output, handler.plan(), handler.norm(), APPLIES, axis);   \
+    }                                                                                                        \
+    template <typename T>                                                                                    \
+    void NAME##_par(const DeviceArray<IN> &input, DeviceArray<OUT> &output, const HANDLER<T> &handler, std::size_t axis) { \
+        NAME<T>(input, output, handler, axis);                                                               \
     }
 
 NDRUSTFFT_DEFINE(ndfft, Complex<T>, Complex<T>, FftHandler, NDFFT_OP_C2C_FWD, Complex<T>, false, false)       // lib.rs:350-372

@@ -134,6 +134,28 @@ static void readme_r2c_6x4() {                                                  
     ndfft_r2c(data, vhat, handler, 0);
     approx_eq_complex(vhat.to_logical(), refvec::readme_r2c_6x4_re, refvec::readme_r2c_6x4_im, 1e-12);
 }
+static void device_resident_fft2() {   // examples/fft2.rs with the work array kept in HBM
+    auto v = Array<C>::from({3, 3}, cplx_of(refvec::m3x3));
+    FftHandler<double> handler_ax0(3), handler_ax1(3);
+    auto dv = DeviceArray<C>::from_host(v);
+    DeviceArray<C> work({3, 3}), dvhat({3, 3}), back({3, 3});
+    ndfft(dv, work, handler_ax1, 1);
+    ndfft(work, dvhat, handler_ax0, 0);
+    approx_eq_complex(dvhat.to_host().to_logical(), refvec::example_fft2_re, refvec::example_fft2_im, 1e-4);
+    ndifft(dvhat, work, handler_ax0, 0);
+    ndifft(work, back, handler_ax1, 1);
+    approx_eq_complex(back.to_host().to_logical(), refvec::m3x3, refvec::m3x3, 1e-4);
+    // a larger 2-D real transform: rfft2 round trip on 64 x 96
+    const int nx = 64, ny = 96;
+    std::vector<double> d(nx * ny); for (int i = 0; i < nx * ny; ++i) d[i] = std::sin(0.37 * i) + 0.01 * (i % 17);
+    auto x = Array<double>::from({nx, ny}, d);
+    auto dx = DeviceArray<double>::from_host(x);
+    DeviceArray<C> w1({nx, ny / 2 + 1}), w2({nx, ny / 2 + 1}), w3({nx, ny / 2 + 1});
+    DeviceArray<double> dy({nx, ny});
+    R2cFftHandler<double> hr(ny); FftHandler<double> hc(nx);
+    ndfft_r2c(dx, w1, hr, 1); ndfft(w1, w2, hc, 0); ndifft(w2, w3, hc, 0); ndifft_r2c(w3, dy, hr, 1);
+    approx_eq(dy.to_host().to_logical(), d, 1e-10);
+}
 static void panics() {                                                                                              // lib.rs:340-347, 116, 120-121
     auto x = Array<C>::zeros({3, 5}); auto y = Array<C>::zeros({3, 5});
     try { ndfft(x, y, FftHandler<double>(6), 1); EXPECT(!"no panic"); }
@@ -173,6 +195,7 @@ int main(int argc, char **argv) {
         {"test_dct4", test_dct<4, false>}, {"test_dct4_par", test_dct<4, true>},
         {"example_fft2", example_fft2}, {"example_rfft2", example_rfft2}, {"example_fft_norm", example_fft_norm},
         {"readme_r2c_6x4", readme_r2c_6x4}, {"panics", panics}, {"f32_and_clone", f32_and_clone},
+        {"device_resident_fft2", device_resident_fft2},
     };
     int bad = 0;
     for (const T &t : tests) {

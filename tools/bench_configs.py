@@ -98,6 +98,18 @@ def main():
         run("generic nddct2 axis=1 16384x1000 f64", nddct2, x, y, DctHandler(1000), 1, x.numel(), a.steps)
         x = torch.from_numpy(synth.complex_array((16384, 1000), np.complex64)).to(dev); y = torch.empty_like(x)
         run("generic ndfft axis=1 16384x1000 c64", ndfft, x, y, FftHandler(1000, np.float32), 1, x.numel(), a.steps)
+    if want("fft2d"):
+        # two-axis transforms with the work array resident in HBM (examples/fft2.rs, rfft2.rs at scale)
+        for n, cdt, rdt in ((4096, np.complex128, np.float64), (8192, np.complex64, np.float32), (1024, np.complex128, np.float64)):
+            x = torch.from_numpy(synth.complex_array((n, n), cdt)).to(dev); w = torch.empty_like(x); y = torch.empty_like(x)
+            h = FftHandler(n, rdt)
+            def fft2(_x, _y, _h, _ax):
+                ndfft(_x, w, _h, 1); ndfft(w, _y, _h, 0)
+            t = timeit(lambda: fft2(x, y, h, 0), a.steps)
+            nbytes = 4 * x.numel() * x.element_size()
+            print(json.dumps({"workload": f"fft2 {n}x{n} {np.dtype(cdt).name} (axis 1 then axis 0, work array in HBM)", "us": round(t * 1e6, 1),
+                              "GFFT-points/s": round(2 * x.numel() / t / 1e9, 1), "algorithmic_bytes(2 passes)": nbytes,
+                              "GB/s": round(nbytes / t / 1e9, 1), "frac_of_8TBs": round(nbytes / t / 1e9 / PEAK, 4)}), flush=True)
     if want("refbench"):
         for n in (128, 264, 512, 1024):
             x = torch.from_numpy(synth.bench_fill_complex((n, n))).to(dev); y = torch.empty_like(x)
