@@ -5,9 +5,10 @@ f64 array, GFFT-points/s (whole job) + achieved HBM GB/s vs the 8 TB/s roofline.
   python bench.py --gpus N --steps K --warmup W
   (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
 
-Workload: N = 1 -> configs[1]: ndfft axis=1 on 4096x4096 Complex<f64>, device resident.
-          N > 1 -> configs[4]: 65536/8 = 8192 rows x 4096 per GPU (batch-sharded lanes, no data-path
-                   collective: lanes are independent, src/lib.rs:120-124), weak scaling.
+Workload: the configuration BASELINE.json's metric is quoted on -- ndfft axis=1 on a 4096x4096 Complex<f64>
+          array, device resident -- PER GPU, at every N ("scaling": "weak"): N ranks hold the N contiguous
+          4096-row blocks of a (4096 N) x 4096 array (batch-sharded lanes, no data-path collective: lanes are
+          independent, src/lib.rs:120-124).  `--rows 8192` gives configs[4]'s per-GPU shard (65536/8 rows).
 One "step" = one ndfft call over the whole resident array through the C ABI (ndfft_exec_device).
 """
 import argparse
@@ -51,7 +52,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--n", type=int, default=4096)
-    ap.add_argument("--rows", type=int, default=0, help="lanes per GPU (default: 4096 at 1 GPU, 8192 per GPU otherwise)")
+    ap.add_argument("--rows", type=int, default=4096, help="lanes per GPU (4096 = the metric's shape; 8192 = configs[4]'s per-GPU shard)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist", action="store_true", help="initialise torch.distributed (RCCL) even at world size 1 (path check)")
     args = ap.parse_args()
@@ -79,7 +80,7 @@ def main():
     ngpu = max(world, 1)
 
     n = args.n
-    rows = args.rows or (4096 if ngpu == 1 else 8192)
+    rows = args.rows
     # device-resident shard: rank r holds global rows [r*rows, (r+1)*rows) of the (ngpu*rows) x n array
     x = synth.complex_array((rows, n), offset=rank * rows * n)
     xd = torch.from_numpy(x).to(dev)
@@ -142,7 +143,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"ndfft axis=1 on {ngpu * rows}x{n} Complex<f64> "
-                                   f"({'BASELINE configs[1]' if ngpu == 1 and rows == 4096 else 'BASELINE configs[4] shard shape: ' + str(rows) + ' rows per GPU'}), "
+                                   f"({'BASELINE configs[1] per GPU' if rows == 4096 else 'BASELINE configs[4] shard shape: ' + str(rows) + ' rows per GPU'}), "
                                    f"device-resident, splitmix64 U[-1,1) seed 20241008",
                        "lanes_per_gpu": rows, "lane_len": n, "kernel_path": path,
                        "sharding": "none" if ngpu == 1 else f"lanes split in {ngpu} contiguous blocks, one per GPU, no collective in the timed region"},
