@@ -390,7 +390,7 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
         if (narrow) {
             auto fill = [&](auto &a) {
                 a.in = d_in; a.out = d_out; a.nlanes = P.nlanes;
-                a.pitch_in = 0; a.pitch_out = 0; a.vec_in = 0;
+                a.pitch_in = 0; a.pitch_out = 0; a.vec_in = 0; a.vec_out = 0;
                 { const char *e = getenv("NDFFT_XCD_REMAP"); a.xcd_remap = !(e && e[0] == '0'); }
                 a.n = n; a.F = c.F; a.n_in = (int)P.xlen; a.n_out = (int)P.ylen;
                 a.inner = P.b.back().shape;
@@ -424,6 +424,8 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
                 const size_t es_in = (op_in_cplx(P.op) ? 2 : 1) * real_size(plan->dtype);
                 a.vec_in = !col && ((uintptr_t)d_in % 16 == 0) && ((size_t)a.pitch_in * es_in) % 16 == 0;
                 a.xcd_remap = 0;
+                const size_t es_out = (op_out_cplx(P.op) ? 2 : 1) * real_size(plan->dtype);
+                a.vec_out = !col && ((uintptr_t)d_out % 16 == 0) && ((size_t)a.pitch_out * es_out) % 16 == 0;
             };
             int rc2;
             if (plan->dtype == NDFFT_F32) {

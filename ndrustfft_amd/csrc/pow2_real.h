@@ -11,6 +11,8 @@
 // Replaces R2cFftHandler::fft_r2c_lane / ifft_r2c_lane (src/lib.rs:497-523) and
 // DctHandler::dct1..4_lane (src/lib.rs:688-734) together with the strategy-(i) row loop.
 #pragma once
+#include <type_traits>
+
 #include "pow2_kernel.h"
 #include "realops.h"
 
@@ -26,6 +28,7 @@ template <typename T> struct RealArgs {
     // element j of lane L lives at o*outer_* + i + j*elem_*   (adjacent lanes are adjacent in memory)
     int64_t inner, outer_in, outer_out, elem_in, elem_out;
     int32_t vec_in;   // row layout: every lane base is 16-byte aligned -> stage with 16-byte loads
+    int32_t vec_out;  // row layout: output lanes 16-byte aligned -> stage the outputs in LDS and store 16 bytes per lane
     int32_t xcd_remap;   // narrow tiles: 1 = XCD-aware blockIdx -> tile map (0 only for A/B measurements)
 };
 
@@ -55,28 +58,26 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
     // ops whose POST is the real-FFT split: outputs k and F-k share one pair of LDS reads and one twiddle
     static constexpr bool PAIR = OP == G_R2C_EVEN || OP == G_DCT1 || OP == G_DCT2_EVEN;
 
-    // writes every output derived from the spectrum pair (k, F-k); `st(q, value)` stores output element q
-    template <typename Store> static __device__ __forceinline__ void post_pair(const RealArgs<T> &a, const cpx<T> *res, int k, Store st) {
+    // every output derived from the spectrum pair (k, F-k), in four fixed slots (q < 0: slot unused)
+    template <typename OT> struct PairOut { OT v[4]; int q[4]; };
+    template <typename OT> static __device__ __forceinline__ PairOut<OT> post_pair(const RealArgs<T> &a, const cpx<T> *res, int k) {
+        PairOut<OT> r;
         cpx<T> xk, xf;
         r2c_split_pair<T, ZiPhi>(res, k, F, a.aux1[k], xk, xf);
         const int kf = F - k;
+        r.q[0] = k; r.q[1] = -1; r.q[2] = kf != k ? kf : -1; r.q[3] = -1;
         if constexpr (OP == G_R2C_EVEN) {
-            st(k, xk);
-            if (kf != k) st(kf, xf);
+            r.v[0] = xk; r.v[2] = xf; r.v[1] = xk; r.v[3] = xk;
         } else if constexpr (OP == G_DCT1) {
-            st(k, (T)0.5 * xk.x);
-            if (kf != k) st(kf, (T)0.5 * xf.x);
+            r.v[0] = (T)0.5 * xk.x; r.v[2] = (T)0.5 * xf.x; r.v[1] = 0; r.v[3] = 0;
         } else {   // G_DCT2_EVEN: y[k] = Re(X[k] c_k), y[n-k] = -Im(X[k] c_k)
             const int n = 2 * F;
-            cpx<T> tk = cmul(xk, a.aux2[k]);
-            st(k, tk.x);
-            if (k > 0) st(n - k, -tk.y);
-            if (kf != k) {
-                cpx<T> tf = cmul(xf, a.aux2[kf]);
-                st(kf, tf.x);
-                if (kf < F) st(n - kf, -tf.y);
-            }
+            const cpx<T> tk = cmul(xk, a.aux2[k]), tf = cmul(xf, a.aux2[kf]);
+            r.v[0] = tk.x; r.v[1] = -tk.y; r.v[2] = tf.x; r.v[3] = -tf.y;
+            r.q[1] = k > 0 ? n - k : -1;
+            r.q[3] = (kf != k && kf < F) ? n - kf : -1;
         }
+        return r;
     }
 
     static __device__ __forceinline__ void run(const RealArgs<T> &a) {
@@ -173,10 +174,22 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
             if constexpr (PAIR) {
                 if constexpr (OUT_CPLX) {
                     cpx<T> *out = (cpx<T> *)a.out + base;
-                    for (int k = j0; k <= F / 2; k += THREADS / LPB) post_pair(a, res, k, [&](int q, cpx<T> v) { gstore<T, !XCD>(out + (int64_t)q * a.elem_out, v); });
+                    for (int k = j0; k <= F / 2; k += THREADS / LPB) {
+                        const PairOut<cpx<T>> r = post_pair<cpx<T>>(a, res, k);
+#pragma unroll
+                        for (int z = 0; z < 4; ++z) if (r.q[z] >= 0) gstore<T, !XCD>(out + (int64_t)r.q[z] * a.elem_out, r.v[z]);
+                    }
                 } else {
                     T *out = (T *)a.out + base;
-                    for (int k = j0; k <= F / 2; k += THREADS / LPB) post_pair(a, res, k, [&](int q, T v) { if constexpr (XCD) out[(int64_t)q * a.elem_out] = v; else __builtin_nontemporal_store(v, out + (int64_t)q * a.elem_out); });
+                    for (int k = j0; k <= F / 2; k += THREADS / LPB) {
+                        const PairOut<T> r = post_pair<T>(a, res, k);
+#pragma unroll
+                        for (int z = 0; z < 4; ++z)
+                            if (r.q[z] >= 0) {
+                                if constexpr (XCD) out[(int64_t)r.q[z] * a.elem_out] = r.v[z];
+                                else __builtin_nontemporal_store(r.v[z], out + (int64_t)r.q[z] * a.elem_out);
+                            }
+                    }
                 }
             } else if constexpr (OUT_CPLX) {
                 cpx<T> *out = (cpx<T> *)a.out + base;
@@ -191,15 +204,52 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                 }
             }
         } else {
-            if (!live) return;
             const cpx<T> *res = (const cpx<T> *)lds;
-            if constexpr (PAIR) {
-                if constexpr (OUT_CPLX) {
-                    cpx<T> *out = (cpx<T> *)a.out + lane * a.pitch_out;
-                    for (int k = t; k <= F / 2; k += TPL) post_pair(a, res, k, [&](int q, cpx<T> v) { gstore<T, true>(out + q, v); });
+            using OT = typename std::conditional<OUT_CPLX, cpx<T>, T>::type;
+            if (a.vec_out) {
+                // Row layout, 16-byte aligned lanes: outputs go registers -> LDS (raw order) -> 16-byte
+                // non-temporal stores, instead of 4/8-byte stores straight from the POST gather.
+                constexpr int NSLOT = PAIR ? 4 * ((F / 2) / TPL + 1) : 2 * E;
+                OT o[NSLOT];
+                int oq[NSLOT];
+                if constexpr (PAIR) {
+#pragma unroll
+                    for (int i = 0; i < NSLOT / 4; ++i) {
+                        const int k = t + i * TPL;
+                        const PairOut<OT> r = post_pair<OT>(a, res, k <= F / 2 ? k : 0);
+#pragma unroll
+                        for (int z = 0; z < 4; ++z) { o[4 * i + z] = r.v[z]; oq[4 * i + z] = k <= F / 2 ? r.q[z] : -1; }
+                    }
                 } else {
-                    T *out = (T *)a.out + lane * a.pitch_out;
-                    for (int k = t; k <= F / 2; k += TPL) post_pair(a, res, k, [&](int q, T v) { __builtin_nontemporal_store(v, out + q); });
+#pragma unroll
+                    for (int i = 0; i < NSLOT; ++i) {
+                        const int q = t + i * TPL;
+                        oq[i] = q < a.n_out ? q : -1;
+                        if (q < a.n_out) {
+                            if constexpr (OUT_CPLX) o[i] = post_cplx<T, OP, ZiPhi>(a, res, q); else o[i] = post_real<T, OP, ZiPhi>(a, res, q);
+                        }
+                    }
+                }
+                __syncthreads();                       // every read of Z is done: the lane region becomes the raw output
+                OT *stage = (OT *)lds;
+#pragma unroll
+                for (int i = 0; i < NSLOT; ++i) if (oq[i] >= 0) stage[oq[i]] = o[i];
+                __syncthreads();
+                if (!live) return;
+                OT *out = (OT *)a.out + lane * a.pitch_out;
+                constexpr int W = 16 / sizeof(OT);
+                const int nv = a.n_out / W;
+                for (int j = t; j < nv; j += TPL) __builtin_nontemporal_store(((const vec4f *)stage)[j], (vec4f *)out + j);
+                for (int j = W * nv + t; j < a.n_out; j += TPL) out[j] = stage[j];
+                return;
+            }
+            if (!live) return;
+            if constexpr (PAIR) {
+                OT *out = (OT *)a.out + lane * a.pitch_out;
+                for (int k = t; k <= F / 2; k += TPL) {
+                    const PairOut<OT> r = post_pair<OT>(a, res, k);
+#pragma unroll
+                    for (int z = 0; z < 4; ++z) if (r.q[z] >= 0) out[r.q[z]] = r.v[z];
                 }
             } else if constexpr (OUT_CPLX) {
                 cpx<T> *out = (cpx<T> *)a.out + lane * a.pitch_out;
