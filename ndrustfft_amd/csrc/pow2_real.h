@@ -206,7 +206,10 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
         } else {
             const cpx<T> *res = (const cpx<T> *)lds;
             using OT = typename std::conditional<OUT_CPLX, cpx<T>, T>::type;
-            if (a.vec_out) {
+            // DCT-I / DCT-II scatter four real outputs per spectrum pair (k, n-k, F-k, F+k): worth staging.
+            // (measured: 117 -> 104 us on cfg4; the ops with one contiguous output per thread lose 5-20 % to the
+            // two extra barriers, so they keep their direct stores)
+            if (PAIR && !OUT_CPLX && a.vec_out) {
                 // Row layout, 16-byte aligned lanes: outputs go registers -> LDS (raw order) -> 16-byte
                 // non-temporal stores, instead of 4/8-byte stores straight from the POST gather.
                 constexpr int NSLOT = PAIR ? 4 * ((F / 2) / TPL + 1) : 2 * E;
