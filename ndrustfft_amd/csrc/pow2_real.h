@@ -252,7 +252,11 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                 for (int k = t; k <= F / 2; k += TPL) {
                     const PairOut<OT> r = post_pair<OT>(a, res, k);
 #pragma unroll
-                    for (int z = 0; z < 4; ++z) if (r.q[z] >= 0) out[r.q[z]] = r.v[z];
+                    for (int z = 0; z < 4; ++z)
+                        if (r.q[z] >= 0) {
+                            if constexpr (OUT_CPLX) gstore<T, true>((cpx<T> *)out + r.q[z], r.v[z]);
+                            else __builtin_nontemporal_store(r.v[z], out + r.q[z]);
+                        }
                 }
             } else if constexpr (OUT_CPLX) {
                 cpx<T> *out = (cpx<T> *)a.out + lane * a.pitch_out;
