@@ -55,6 +55,10 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
     static constexpr bool IN_CPLX = OP == G_C2R_EVEN || OP == G_C2C_FWD || OP == G_C2C_INV;
     static constexpr bool OUT_CPLX = OP == G_R2C_EVEN || OP == G_C2C_FWD || OP == G_C2C_INV;
     using FFT = Pow2Kernel<T, F, TPL, LPB, false, RL, 0, 1, 0>;
+    // row layout R2C / C2R: the PRE fold reads unit-stride complex elements (ascending, and for C2R also
+    // descending), so it loads global memory directly and the LDS staging pass and its barrier are skipped
+    // (f64 only: 16-byte elements; for f32 the 16-byte vector staging loads measure faster than 8-byte direct ones)
+    static constexpr bool DIRECT_IN = !COL && sizeof(T) == 8 && (OP == G_R2C_EVEN || OP == G_C2R_EVEN);
     // ops whose POST is the real-FFT split: outputs k and F-k share one pair of LDS reads and one twiddle
     static constexpr bool PAIR = OP == G_R2C_EVEN || OP == G_DCT1 || OP == G_DCT2_EVEN;
 
@@ -111,7 +115,7 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                     for (int j = j0; j < a.n_in; j += THREADS / LPB) ((T *)dst)[j] = in[(int64_t)j * a.elem_in];
                 }
             }
-        } else {
+        } else if constexpr (!DIRECT_IN) {
             const int64_t lsafe = live ? lane : 0;
             if constexpr (IN_CPLX) {
                 const cpx<T> *in = (const cpx<T> *)a.in + lsafe * a.pitch_in;
@@ -136,19 +140,25 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                 }
             }
         }
-        __syncthreads();
+        if constexpr (!DIRECT_IN) __syncthreads();
         // ---- PRE into the first pass's register pattern ----
         cpx<T> v[E];
         {
             constexpr int R0 = RL::at(0), NB0 = F / R0, NBF0 = E / R0;
+            const void *raw = (const void *)lds;
+            if constexpr (DIRECT_IN) {
+                const int64_t lsafe = live ? lane : 0;
+                if constexpr (IN_CPLX) raw = (const void *)((const cpx<T> *)a.in + lsafe * a.pitch_in);
+                else raw = (const void *)((const T *)a.in + lsafe * a.pitch_in);
+            }
 #pragma unroll
             for (int q = 0; q < NBF0; ++q)
 #pragma unroll
                 for (int r = 0; r < R0; ++r) {
                     const int i = t + q * TPL + r * NB0;
-                    if constexpr (OP == G_R2C_EVEN || OP == G_C2C_FWD) v[q * R0 + r] = ((const cpx<T> *)lds)[i];   // z[i] = (x[2i], x[2i+1])
-                    else if constexpr (OP == G_C2C_INV) v[q * R0 + r] = cconj(((const cpx<T> *)lds)[i]);
-                    else v[q * R0 + r] = pre_elem<T, OP, ZiNone>(a, (const void *)lds, i);
+                    if constexpr (OP == G_R2C_EVEN || OP == G_C2C_FWD) v[q * R0 + r] = ((const cpx<T> *)raw)[i];   // z[i] = (x[2i], x[2i+1])
+                    else if constexpr (OP == G_C2C_INV) v[q * R0 + r] = cconj(((const cpx<T> *)raw)[i]);
+                    else v[q * R0 + r] = pre_elem<T, OP, ZiNone>(a, raw, i);
                 }
         }
         // (the first exchange inside passes() starts with a barrier, so the raw lane is dead by then)
