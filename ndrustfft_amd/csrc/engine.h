@@ -157,6 +157,9 @@ struct Pow2Args {
     int32_t inverse;
     double scale;
     const void *twp;
+    // four-step second stage: element i of lane L is first multiplied by W_F^{i * (L % f1)} = twhi[m >> logB] * twlo[m & (2^logB - 1)]
+    const void *twlo = nullptr, *twhi = nullptr;
+    int32_t logB = 0, f1 = 1;
 };
 bool pow2_supported(int dtype, int n);
 // layout of the per-pass transposed twiddle table for length n (host builder in plan.cpp)

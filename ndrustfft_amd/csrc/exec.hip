@@ -9,6 +9,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <type_traits>
 
 #include "engine.h"
 #include "pow2_real.h"
@@ -246,6 +247,12 @@ static int transpose_batched(const void *in, void *out, int64_t batch, int64_t r
 }
 
 
+// developer switch: NDFFT_NARROW=0 sends long strided lanes through the transpose route instead
+static bool narrow_enabled() {
+    static const bool on = [] { const char *e = getenv("NDFFT_NARROW"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 // Four-step complex FFT of length F = F1*F2 on L lanes (zin / zout: lane pitches in elements).
 // zin may equal zout.  Sub-FFTs run through dispatch() on the row kernels.
 template <typename T>
@@ -258,6 +265,33 @@ static int big_fft(const FftConfig &c, const DevConfig &d, const cpx<T> *zin, in
     int rc;
     if ((rc = get_scratch(2, stream, (size_t)(L * F) * esz, &s1))) return rc;
     if ((rc = get_scratch(3, stream, (size_t)(L * F) * esz, &s2))) return rc;
+    // Fused three-pass form when both halves run on the register kernels:
+    //   (1) length-F1 FFTs IN PLACE of the layout, on the strided n1 axis, by the column-tile kernels
+    //   (2) length-F2 row FFTs whose load multiplies by the four-step twiddle W_F^{n2 k1}
+    //   (3) one transpose into natural order
+    {
+        const bool row2 = c.sub2->cfg[CFG_MAIN].pow2;
+        const int col_lanes = std::is_same<T, float>::value ? pow2_real_col_lanes<float>(F1) : pow2_real_col_lanes<double>(F1);
+        const int nar_lanes = std::is_same<T, float>::value ? pow2_real_narrow_lanes<float>(F1) : pow2_real_narrow_lanes<double>(F1);
+        const bool col1 = !c.sub1->cfg[CFG_MAIN].twp_col.re.empty() && F2 >= 8 && col_lanes > 0;
+        const bool nar1 = !c.sub1->cfg[CFG_MAIN].twp_narrow.re.empty() && F2 >= 64 && nar_lanes > 0 && narrow_enabled();
+        if (row2 && (col1 || nar1)) {
+            Problem Q;
+            Q.plan = c.sub1; Q.op = inverse ? NDFFT_OP_C2C_INV : NDFFT_OP_C2C_FWD;
+            Q.xlen = Q.ylen = F1; Q.xs = Q.ys = F2; Q.nlanes = L * F2; Q.scale = 1.0;
+            if (L > 1) Q.b.push_back({L, pitch_in, F});
+            Q.b.push_back({(int64_t)F2, 1, 1});
+            if ((rc = dispatch(Q, zin, s1, stream))) return rc;
+            const DevTables *dt2;
+            if ((rc = get_dev_tables(c.sub2, &dt2))) return rc;
+            Pow2Args a;
+            a.in = s1; a.out = s2; a.nlanes = L * F1; a.pitch_in = F2; a.pitch_out = F2;
+            a.inverse = inverse; a.scale = (double)scale; a.twp = dt2->cfg[CFG_MAIN].twp;
+            a.twlo = d.twlo; a.twhi = d.twhi; a.logB = c.logB; a.f1 = F1;
+            if ((rc = launch_pow2(c.sub2->dtype, F2, a, stream))) return rc;
+            return transpose_batched(s2, zout, L, F1, F2, F2, F1, F, pitch_out, esz, stream);
+        }
+    }
     // x[n1][n2] -> s1[n2][n1]
     if ((rc = transpose_batched(zin, s1, L, F1, F2, F2, F1, pitch_in, F, esz, stream))) return rc;
     Problem Q;
@@ -273,12 +307,6 @@ static int big_fft(const FftConfig &c, const DevConfig &d, const cpx<T> *zin, in
     if ((rc = dispatch(Q, s1, s2, stream))) return rc;
     // s2[k1][k2] -> out[k2][k1]  (flat index k1 + F1 k2)
     return transpose_batched(s2, zout, L, F1, F2, F2, F1, F, pitch_out, esz, stream);
-}
-
-// developer switch: NDFFT_NARROW=0 sends long strided lanes through the transpose route instead
-static bool narrow_enabled() {
-    static const bool on = [] { const char *e = getenv("NDFFT_NARROW"); return !(e && e[0] == '0'); }();
-    return on;
 }
 
 static int gen_op_of(int op, int n, int *slot) {

@@ -160,6 +160,18 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
 #pragma unroll
             for (int i = 0; i < E; ++i) v[i].y = -v[i].y;
         }
+        if (a.twlo) {   // fused four-step twiddle (after the conjugation, so the same table serves both directions)
+            constexpr int R0 = RL::at(0), NB0 = N / R0, NBF0 = E / R0;
+            const int k1 = (int)(lane % a.f1), mask = (1 << a.logB) - 1;
+            const cpx<T> *lo = (const cpx<T> *)a.twlo, *hi = (const cpx<T> *)a.twhi;
+#pragma unroll
+            for (int q = 0; q < NBF0; ++q)
+#pragma unroll
+                for (int r = 0; r < R0; ++r) {
+                    const int m = (jof<0>(t, q) + r * NB0) * k1;
+                    v[q * R0 + r] = cmul(v[q * R0 + r], cmul(hi[m >> a.logB], lo[m & mask]));
+                }
+        }
         passes<0>(v, (const cpx<T> *)a.twp, lds, t);
         if (!live) return;
         constexpr int RL_ = RL::at(RL::NP - 1), NBL = N / RL_, NBFL = E / RL_;
