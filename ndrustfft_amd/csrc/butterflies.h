@@ -2,7 +2,7 @@
 // Inverse transforms never need their own butterflies: ifft(x) = conj(fft(conj(x))) and the
 // conjugations are folded into the global load / store of the kernels.
 #pragma once
-#include "engine.h"
+#include "device_common.h"
 
 namespace ndfft {
 

@@ -1,0 +1,48 @@
+// device_common.h -- the device-side vocabulary shared by every kernel header.  It is also the first of
+// the headers handed to hiprtc when a register-resident kernel is specialised at plan time (jit.hip), so it
+// must compile WITHOUT host headers: under __HIPCC_RTC__ nothing is included.
+#pragma once
+#ifndef __HIPCC_RTC__
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#else
+typedef __hip_internal::int64_t int64_t;   // hiprtc has no <stdint.h>; same widths as the host's
+typedef __hip_internal::int32_t int32_t;
+typedef __hip_internal::uint32_t uint32_t;
+typedef __hip_internal::uint64_t uint64_t;
+#endif
+
+namespace ndfft {
+
+// ------------------------------------------------------------------------------------------
+// complex helpers (Complex<T> = {re, im} interleaved = float2 / double2)
+// ------------------------------------------------------------------------------------------
+template <typename T> struct vec2;
+template <> struct vec2<float> { using type = float2; };
+template <> struct vec2<double> { using type = double2; };
+template <typename T> using cpx = typename vec2<T>::type;
+
+template <typename T> __host__ __device__ inline cpx<T> mk(T a, T b) { cpx<T> r; r.x = a; r.y = b; return r; }
+template <typename C> __host__ __device__ inline C cadd(C a, C b) { a.x += b.x; a.y += b.y; return a; }
+template <typename C> __host__ __device__ inline C csub(C a, C b) { a.x -= b.x; a.y -= b.y; return a; }
+template <typename C> __host__ __device__ inline C cmul(C a, C b) {
+    C r; r.x = a.x * b.x - a.y * b.y; r.y = a.x * b.y + a.y * b.x; return r;
+}
+template <typename C> __host__ __device__ inline C cconj(C a) { a.y = -a.y; return a; }
+// multiply by -i (forward quarter turn): (x, y) -> (y, -x)
+template <typename C> __host__ __device__ inline C cmul_mi(C a) { C r; r.x = a.y; r.y = -a.x; return r; }
+
+// arguments of the register-resident C2C row kernels (pow2_kernel.h)
+struct Pow2Args {
+    const void *in; void *out;
+    int64_t nlanes;
+    int64_t pitch_in, pitch_out;   // elements between consecutive lanes
+    int32_t inverse;
+    double scale;
+    const void *twp;
+    // four-step second stage: element i of lane L is first multiplied by W_F^{i * (L % f1)} = twhi[m >> logB] * twlo[m & (2^logB - 1)]
+    const void *twlo = nullptr, *twhi = nullptr;
+    int32_t logB = 0, f1 = 1;
+};
+
+}  // namespace ndfft

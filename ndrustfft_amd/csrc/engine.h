@@ -3,32 +3,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/ndfft_mi355x.h"
+#include "device_common.h"
 
 namespace ndfft {
-
-// ------------------------------------------------------------------------------------------
-// complex helpers (Complex<T> = {re, im} interleaved = float2 / double2)
-// ------------------------------------------------------------------------------------------
-template <typename T> struct vec2;
-template <> struct vec2<float> { using type = float2; };
-template <> struct vec2<double> { using type = double2; };
-template <typename T> using cpx = typename vec2<T>::type;
-
-template <typename T> __host__ __device__ inline cpx<T> mk(T a, T b) { cpx<T> r; r.x = a; r.y = b; return r; }
-template <typename C> __host__ __device__ inline C cadd(C a, C b) { a.x += b.x; a.y += b.y; return a; }
-template <typename C> __host__ __device__ inline C csub(C a, C b) { a.x -= b.x; a.y -= b.y; return a; }
-template <typename C> __host__ __device__ inline C cmul(C a, C b) {
-    C r; r.x = a.x * b.x - a.y * b.y; r.y = a.x * b.y + a.y * b.x; return r;
-}
-template <typename C> __host__ __device__ inline C cconj(C a) { a.y = -a.y; return a; }
-// multiply by -i (forward quarter turn): (x, y) -> (y, -x)
-template <typename C> __host__ __device__ inline C cmul_mi(C a) { C r; r.x = a.y; r.y = -a.x; return r; }
 
 // ------------------------------------------------------------------------------------------
 // lane geometry: where lane `l`, element `j` of an n-d view lives (offsets in ELEMENTS)
@@ -83,6 +67,7 @@ template <typename T> struct GenArgs {
 // plan
 // ------------------------------------------------------------------------------------------
 struct HostTable { std::vector<long double> re, im; };
+struct JitCfg { int n = 0, tpl = 0, e = 0, lpb = 1, vec = 1; std::vector<int> radix; };
 }  // namespace ndfft
 struct ndfft_plan;
 namespace ndfft {   // built once in long double
@@ -101,6 +86,7 @@ struct FftConfig {                 // one complex-FFT-of-length-F recipe + op ta
     bool big = false; int F1 = 0, F2 = 0, logB = 0;
     ndfft_plan *sub1 = nullptr, *sub2 = nullptr;   // C2C sub-plans of length F1 / F2 (owned)
     HostTable twlo, twhi;          // W_F^m = twhi[m >> logB] * twlo[m & (2^logB - 1)]
+    bool jit = false; JitCfg jitcfg;   // C2C slot: smooth non-power-of-two n -> specialised register kernel (jit.hip); twiddles in twp
     bool unsupported = false;      // no single-kernel fit and no usable factorisation (large prime factor)
 };
 
@@ -150,17 +136,6 @@ int generic_z_len(int len);
 bool generic_needs_big(const int32_t *radix, int npass, const int32_t *radixM, int npassM);   // radices > 10: 512-thread class   // LDS elements a padded length-`len` complex buffer needs
 
 // kernels_pow2.hip : register-resident Stockham for contiguous power-of-two C2C lanes
-struct Pow2Args {
-    const void *in; void *out;
-    int64_t nlanes;
-    int64_t pitch_in, pitch_out;   // elements between consecutive lanes
-    int32_t inverse;
-    double scale;
-    const void *twp;
-    // four-step second stage: element i of lane L is first multiplied by W_F^{i * (L % f1)} = twhi[m >> logB] * twlo[m & (2^logB - 1)]
-    const void *twlo = nullptr, *twhi = nullptr;
-    int32_t logB = 0, f1 = 1;
-};
 bool pow2_supported(int dtype, int n);
 // layout of the per-pass transposed twiddle table for length n (host builder in plan.cpp)
 void pow2_build_twiddles(int dtype, int n, HostTable &out);
@@ -184,6 +159,11 @@ int launch_big_pre(int gen_op, const RealArgs<T> &a, cpx<T> *z, hipStream_t s); 
 template <typename T>
 int launch_big_post(int gen_op, const RealArgs<T> &a, const cpx<T> *z, hipStream_t s);   // z[lane][F] -> a.out
 size_t generic_max_len(size_t csize);   // longest complex FFT the single-launch LDS kernel can hold
+
+// jit.hip : hiprtc specialisation of the register-resident kernel for smooth non-power-of-two lengths
+bool jit_choose(int dtype, int n, JitCfg &cfg);
+void jit_build_twiddles(const JitCfg &cfg, HostTable &out);
+int launch_jit_c2c(int dtype, const JitCfg &cfg, int nt, const Pow2Args &a, hipStream_t s);
 
 // transpose.hip : batched LDS-padded 2-D transpose, elem size 4/8/16 bytes
 // out[b][c][r] = in[b][r][c];  in pitch = ld_in elements per row, out pitch = ld_out

@@ -390,6 +390,22 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
         set_last_path("pow2_reg");
         return launch_pow2(plan->dtype, (int)plan->n, a, stream);
     }
+    // smooth non-power-of-two C2C lanes: the same register-resident kernel, specialised at first use (jit.hip);
+    // only worth a compile when there is real work
+    if (plan->kind == NDFFT_KIND_C2C && plan->cfg[CFG_MAIN].jit && P.xs == 1 && P.ys == 1 && P.b.size() <= 1 &&
+        P.nlanes * (int64_t)plan->n >= (1 << 17)) {
+        Pow2Args a;
+        a.in = d_in; a.out = d_out; a.nlanes = P.nlanes;
+        a.pitch_in = P.b.empty() ? (int64_t)plan->n : P.b[0].sin;
+        a.pitch_out = P.b.empty() ? (int64_t)plan->n : P.b[0].sout;
+        a.inverse = P.op == NDFFT_OP_C2C_INV;
+        a.scale = P.scale;
+        a.twp = dt->cfg[CFG_MAIN].twp;
+        const size_t in_bytes = (size_t)P.nlanes * plan->n * 2 * real_size(plan->dtype);
+        const int rcj = launch_jit_c2c(plan->dtype, plan->cfg[CFG_MAIN].jitcfg, in_bytes > ((size_t)256 << 20) ? 3 : 1, a, stream);
+        if (rcj == NDFFT_OK) { set_last_path("jit_reg"); return NDFFT_OK; }
+        if (rcj != NDFFT_ERR_UNSUPPORTED) return rcj;   // a real HIP error; UNSUPPORTED = no hiprtc / compile failed -> LDS kernel
+    }
     // tuned paths on the register-resident real-op engine (pow2_real.h), power-of-two inner FFT:
     //   row: R2C / C2R / DCT on contiguous lanes;  col: the same ops AND C2C on a strided axis whose
     //   adjacent lanes are contiguous (strategy ii), through an LDS tile of adjacent lanes

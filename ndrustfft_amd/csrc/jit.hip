@@ -1,0 +1,172 @@
+// jit.hip -- plan-time specialisation of the register-resident Stockham kernel (pow2_kernel.h) for smooth
+// NON-power-of-two lengths.  The hand-written kernel template is radix- and size-generic but needs n, the
+// threads per lane and the radix list as compile-time constants; power-of-two lengths are instantiated
+// ahead of time (kernels_pow2.hip), every other 2-3-5-7-smooth length is compiled on first use with hiprtc
+// from the SAME header text (embedded at build time: _build/jit_sources.inc) and cached per process.
+// libhiprtc is loaded lazily with dlopen; if it is missing, or a compile fails, the caller falls back to the
+// LDS kernel (generic_kernel.h) -- still on the GPU.
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <string>
+
+#include "engine.h"
+#include "jit_sources.inc"
+
+namespace ndfft {
+
+namespace {
+typedef struct _hiprtcProgram *rtcProgram;
+struct Rtc {
+    void *lib = nullptr;
+    int (*create)(rtcProgram *, const char *, const char *, int, const char **, const char **) = nullptr;
+    int (*compile)(rtcProgram, int, const char **) = nullptr;
+    int (*log_size)(rtcProgram, size_t *) = nullptr;
+    int (*log)(rtcProgram, char *) = nullptr;
+    int (*code_size)(rtcProgram, size_t *) = nullptr;
+    int (*code)(rtcProgram, char *) = nullptr;
+    int (*destroy)(rtcProgram *) = nullptr;
+    bool ok = false;
+};
+Rtc &rtc() {
+    static Rtc r = [] {
+        Rtc x;
+        const char *names[] = {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"};
+        for (const char *n : names) if ((x.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!x.lib) return x;
+        x.create = (decltype(x.create))dlsym(x.lib, "hiprtcCreateProgram");
+        x.compile = (decltype(x.compile))dlsym(x.lib, "hiprtcCompileProgram");
+        x.log_size = (decltype(x.log_size))dlsym(x.lib, "hiprtcGetProgramLogSize");
+        x.log = (decltype(x.log))dlsym(x.lib, "hiprtcGetProgramLog");
+        x.code_size = (decltype(x.code_size))dlsym(x.lib, "hiprtcGetCodeSize");
+        x.code = (decltype(x.code))dlsym(x.lib, "hiprtcGetCode");
+        x.destroy = (decltype(x.destroy))dlsym(x.lib, "hiprtcDestroyProgram");
+        x.ok = x.create && x.compile && x.log_size && x.log && x.code_size && x.code && x.destroy;
+        return x;
+    }();
+    return r;
+}
+
+struct Entry { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; bool failed = false; };
+std::mutex g_mu;
+std::map<std::string, Entry> g_cache;
+
+bool jit_disabled() {
+    static const bool off = [] { const char *e = getenv("NDFFT_JIT"); return e && e[0] == '0'; }();
+    return off;
+}
+}  // namespace
+
+// Picks threads-per-lane and a radix list for a smooth length: every radix divides E = n / TPL (so each
+// thread owns whole butterflies in every pass), fewest passes first, then the smallest E.
+bool jit_choose(int dtype, int n, JitCfg &cfg) {
+    if (jit_disabled() || n < 12 || n > 8192 || pow2_supported(dtype, n)) return false;
+    {   int m = n; for (int p : {2, 3, 5, 7}) while (m % p == 0) m /= p; if (m != 1) return false; }
+    const int emax = dtype == NDFFT_F32 ? 20 : 16;
+    const int cand[] = {16, 10, 9, 8, 7, 6, 5, 4, 3, 2};
+    std::vector<int> best, cur;
+    int best_e = 0;
+    auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
+    std::function<void(int, int, int)> rec = [&](int m, int maxr, int e) {
+        if (e > emax || n % e) return;
+        if (m == 1) {
+            if (best.empty() || cur.size() < best.size() || (cur.size() == best.size() && e < best_e)) { best = cur; best_e = e; }
+            return;
+        }
+        if (!best.empty() && cur.size() + 1 > best.size()) return;
+        for (int c : cand) {
+            if (c > maxr || m % c) continue;
+            cur.push_back(c);
+            rec(m / c, c, e / gcd(e, c) * c);
+            cur.pop_back();
+        }
+    };
+    rec(n, 16, 1);
+    if (best.empty()) return false;
+    cfg.n = n; cfg.e = best_e; cfg.tpl = n / best_e;
+    if (cfg.tpl > 1024) return false;
+    cfg.radix = best;   // non-increasing: the largest radix first (most loads in flight on the global read)
+    cfg.lpb = cfg.tpl >= 256 ? 1 : std::max(1, 256 / cfg.tpl);
+    // f32: 16-byte (two-element) global accesses need an even number of butterflies per thread in the
+    // first and the last pass
+    cfg.vec = (dtype == NDFFT_F32 && (best_e / best.front()) % 2 == 0 && (best_e / best.back()) % 2 == 0) ? 2 : 1;
+    return true;
+}
+
+void jit_build_twiddles(const JitCfg &cfg, HostTable &out) {
+    const long double kPiL = 3.14159265358979323846264338327950288L;
+    unsigned long long Ns = 1;
+    for (size_t p = 0; p < cfg.radix.size(); ++p) {
+        const unsigned long long R = (unsigned long long)cfg.radix[p];
+        if (p > 0)
+            for (unsigned long long r = 1; r < R; ++r)
+                for (unsigned long long k = 0; k < Ns; ++k) {
+                    const unsigned long long num = (r * k) % (Ns * R);
+                    const long double ang = 2.0L * kPiL * (long double)num / (long double)(Ns * R);
+                    out.re.push_back(cosl(ang)); out.im.push_back(-sinl(ang));
+                }
+        Ns *= R;
+    }
+}
+
+// returns NDFFT_OK and launches, or NDFFT_ERR_UNSUPPORTED if no specialised kernel can be had (caller falls back)
+int launch_jit_c2c(int dtype, const JitCfg &cfg, int nt, const Pow2Args &a, hipStream_t s) {
+    Rtc &r = rtc();
+    if (!r.ok) return NDFFT_ERR_UNSUPPORTED;
+    const bool vec_ok = cfg.vec == 2 && a.pitch_in % 2 == 0 && a.pitch_out % 2 == 0 && ((uintptr_t)a.in % 16) == 0 && ((uintptr_t)a.out % 16) == 0;
+    const int vec = vec_ok ? 2 : 1;
+    int dev = 0;
+    NDFFT_HIP(hipGetDevice(&dev));
+    std::string rl;
+    for (size_t i = 0; i < cfg.radix.size(); ++i) rl += (i ? ", " : "") + std::to_string(cfg.radix[i]);
+    const char *tn = dtype == NDFFT_F32 ? "float" : "double";
+    const int threads = cfg.tpl * cfg.lpb;
+    const std::string inst = std::string("Pow2Kernel<") + tn + ", " + std::to_string(cfg.n) + ", " + std::to_string(cfg.tpl) + ", " +
+                             std::to_string(cfg.lpb) + ", true, RadixList<" + rl + ">, 0, 1, " + std::to_string(nt) + ", " + std::to_string(vec) + ">";
+    const std::string key = "dev" + std::to_string(dev) + ":" + inst;
+    Entry e;
+    {
+        std::lock_guard<std::mutex> g(g_mu);
+        auto it = g_cache.find(key);
+        if (it == g_cache.end()) {
+            Entry ne;
+            const std::string src = "#include \"pow2_kernel.h\"\nusing namespace ndfft;\nextern \"C\" __global__ __launch_bounds__(" +
+                                    std::to_string(threads) + ") void k_jit(const Pow2Args a) { " + inst + "::run(a); }\n";
+            const char *hn[] = {"device_common.h", "butterflies.h", "pow2_kernel.h"};
+            const char *hs[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h};
+            rtcProgram prog = nullptr;
+            bool ok = r.create(&prog, src.c_str(), "k_jit.hip", 3, hs, hn) == 0;
+            if (ok) {
+                const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast"};
+                ok = r.compile(prog, 4, opts) == 0;
+                if (!ok && getenv("NDFFT_JIT_VERBOSE")) {
+                    size_t ls = 0; r.log_size(prog, &ls);
+                    std::string log(ls, '\0'); r.log(prog, &log[0]);
+                    fprintf(stderr, "ndfft jit: compile of %s failed:\n%s\n", inst.c_str(), log.c_str());
+                }
+            }
+            std::string code;
+            if (ok) { size_t cs = 0; ok = r.code_size(prog, &cs) == 0 && cs > 0; if (ok) { code.resize(cs); ok = r.code(prog, &code[0]) == 0; } }
+            if (prog) r.destroy(&prog);
+            if (ok) ok = hipModuleLoadData(&ne.mod, code.data()) == hipSuccess && hipModuleGetFunction(&ne.fn, ne.mod, "k_jit") == hipSuccess;
+            if (!ok) { (void)hipGetLastError(); ne.failed = true; }
+            it = g_cache.emplace(key, ne).first;
+        }
+        e = it->second;
+    }
+    if (e.failed) return NDFFT_ERR_UNSUPPORTED;
+    const size_t esz = dtype == NDFFT_F32 ? 4 : 8;
+    const size_t lds = (size_t)cfg.lpb * (size_t)(cfg.n + (cfg.n >> 4) + 1) * esz;   // Pow2Kernel::LDS_BYTES (HALF exchange)
+    const int64_t nblk = (a.nlanes + cfg.lpb - 1) / cfg.lpb;
+    if (nblk <= 0) return NDFFT_OK;
+    if (nblk > 0x7fffffffLL) return NDFFT_ERR_UNSUPPORTED;
+    Pow2Args arg = a;
+    void *params[] = {(void *)&arg};
+    NDFFT_HIP(hipModuleLaunchKernel(e.fn, (unsigned)nblk, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, s, params, nullptr));
+    return NDFFT_OK;
+}
+
+}  // namespace ndfft

@@ -1,8 +1,10 @@
 // pow2_kernel.h -- register-resident Stockham kernel template (see kernels_pow2.hip for the design notes).
 #pragma once
 #include "butterflies.h"
+#ifndef __HIPCC_RTC__
 #include "engine.h"
 #include <cmath>
+#endif
 
 namespace ndfft {
 
@@ -16,6 +18,11 @@ template <int... Rs> struct RadixList {
 };
 
 __device__ __forceinline__ int phi(int p) { return p + (p >> 4); }
+// j mod Ns for a compile-time Ns (a mask when Ns is a power of two, a multiply-shift otherwise)
+template <int Ns> __device__ __forceinline__ int kmod(int j) {
+    if constexpr ((Ns & (Ns - 1)) == 0) return j & (Ns - 1);
+    else return j % Ns;
+}
 
 // Streaming (touch-once) global accesses.  A lane is read once and written once per call, so the
 // output is stored non-temporally: it then neither evicts the still-to-be-read input from the
@@ -76,7 +83,7 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
             const cpx<T> *tw = twp + RL::twoff(P);
 #pragma unroll
             for (int q = 0; q < NBF; ++q) {
-                const int k = jof<P>(t, q) & (Ns - 1);
+                const int k = kmod<Ns>(jof<P>(t, q));
 #pragma unroll
                 for (int r = 1; r < R; ++r) v[q * R + r] = cmul(v[q * R + r], tw[(r - 1) * Ns + k]);
             }
@@ -93,7 +100,7 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
                     __syncthreads();
 #pragma unroll
                     for (int q = 0; q < NBF; ++q) {
-                        const int j = jof<P>(t, q), k = j & (Ns - 1), o = (j - k) * R + k;
+                        const int j = jof<P>(t, q), k = kmod<Ns>(j), o = (j - k) * R + k;
 #pragma unroll
                         for (int r = 0; r < R; ++r) s[phi(o + r * Ns)] = half ? v[q * R + r].y : v[q * R + r].x;
                     }
@@ -113,7 +120,7 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
                 __syncthreads();
 #pragma unroll
                 for (int q = 0; q < NBF; ++q) {
-                    const int j = jof<P>(t, q), k = j & (Ns - 1), o = (j - k) * R + k;
+                    const int j = jof<P>(t, q), k = kmod<Ns>(j), o = (j - k) * R + k;
 #pragma unroll
                     for (int r = 0; r < R; ++r) s[phi(o + r * Ns)] = v[q * R + r];
                 }
@@ -200,6 +207,7 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
 
 template <typename K> __global__ __launch_bounds__(K::THREADS, K::MIN_WAVES) void k_pow2(const Pow2Args a) { K::run(a); }
 
+#ifndef __HIPCC_RTC__
 // host: per-pass transposed twiddles, tw_p[(r-1)*Ns + k] = e^{-2 pi i r k/(Ns R)}, long double
 template <typename RL> inline void build_tw(HostTable &out) {
     const long double kPiL = 3.14159265358979323846264338327950288L;
@@ -215,5 +223,7 @@ template <typename RL> inline void build_tw(HostTable &out) {
     }
 }
 
+
+#endif
 
 }  // namespace ndfft

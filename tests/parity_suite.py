@@ -351,6 +351,23 @@ def narrow_xcd_tiles(L):
         assert run_case(L, name, shape, axis, rdt) == "pow2_col_xcd", (name, shape)
 
 
+def jit_specialised_sizes(L):
+    """Smooth non-power-of-two C2C lanes: the register-resident kernel specialised with hiprtc at first use."""
+    for n in (96, 100, 144, 384, 500, 768, 1000, 1296, 1536, 2000, 2187, 3072, 3125):
+        rows = max(4, (1 << 17) // n + 3)
+        for rdt in (np.float64, np.float32):
+            for name, norm in (("ndfft", "Default"), ("ndifft", "Default"), ("ndifft", "None")):
+                assert run_case(L, name, (rows, n), 1, rdt, norm=norm, offset=n) == "jit_reg", (name, n, rdt)
+    # odd lane pitch / unaligned base -> the scalar-access variant is compiled
+    n = 1000
+    big = synth.complex_array((140, n + 1), np.complex64); x = big[:, 1:]; y = np.zeros((140, n + 1), np.complex64)[:, 1:]
+    h = handlers.FftHandler(n, np.float32, _library=L); api.ndfft(x, y, h, 1)
+    assert L.last_path() == "jit_reg"
+    assert_close(y, np.fft.fft(x.astype(np.complex128), axis=1), 1, 1e-4, "jit unaligned")
+    # small problems are not worth a compile: LDS kernel
+    assert run_case(L, "ndfft", (3, 1000), 1, np.float64) == "generic_row"
+
+
 def handler_clone_shares_plan(L):
     h = handlers.FftHandler(16, _library=L)
     h2 = h.clone()

@@ -32,6 +32,7 @@ def test_long_strided_lanes(L): ps.long_strided_lanes(L)
 def test_narrow_xcd_tiles(L): ps.narrow_xcd_tiles(L)
 def test_long_lanes_four_step(L): ps.long_lanes_four_step(L, full=True)
 def test_pow2_real_sizes(L): ps.pow2_real_sizes(L)
+def test_jit_specialised_sizes(L): ps.jit_specialised_sizes(L)
 def test_pow2_col_sizes(L): ps.pow2_col_sizes(L)
 def test_reference_bench_shapes(L): ps.reference_bench_shapes(L)
 
