@@ -32,6 +32,15 @@ template <typename C> __host__ __device__ inline C cconj(C a) { a.y = -a.y; retu
 // multiply by -i (forward quarter turn): (x, y) -> (y, -x)
 template <typename C> __host__ __device__ inline C cmul_mi(C a) { C r; r.x = a.y; r.y = -a.x; return r; }
 
+// internal op codes of the generic kernel = public ndfft_op, with parity variants resolved on host
+enum GenOp : int {
+    G_C2C_FWD = 0, G_C2C_INV,
+    G_R2C_EVEN, G_R2C_ODD, G_C2R_EVEN, G_C2R_ODD,
+    G_DCT1,               // n >= 2, F = n-1
+    G_DCT2_EVEN, G_DCT2_ODD, G_DCT3_EVEN, G_DCT3_ODD,
+    G_DCT4_EVEN, G_DCT4_ODD
+};
+
 // arguments of the register-resident C2C row kernels (pow2_kernel.h)
 struct Pow2Args {
     const void *in; void *out;

@@ -26,14 +26,6 @@ struct LaneGeom {
     int64_t bstride[kMaxBatchDims];
 };
 
-// internal op codes of the generic kernel = public ndfft_op, with parity variants resolved on host
-enum GenOp : int {
-    G_C2C_FWD = 0, G_C2C_INV,
-    G_R2C_EVEN, G_R2C_ODD, G_C2R_EVEN, G_C2R_ODD,
-    G_DCT1,               // n >= 2, F = n-1
-    G_DCT2_EVEN, G_DCT2_ODD, G_DCT3_EVEN, G_DCT3_ODD,
-    G_DCT4_EVEN, G_DCT4_ODD
-};
 
 constexpr int kMaxPasses = 16;
 constexpr int kMaxLpb = 64;
@@ -164,6 +156,8 @@ size_t generic_max_len(size_t csize);   // longest complex FFT the single-launch
 bool jit_choose(int dtype, int n, JitCfg &cfg);
 void jit_build_twiddles(const JitCfg &cfg, HostTable &out);
 int launch_jit_c2c(int dtype, const JitCfg &cfg, int nt, const Pow2Args &a, hipStream_t s);
+int jit_col_lanes(int dtype, const JitCfg &cfg);
+template <typename T> int launch_jit_real(int gen_op, const JitCfg &cfg, bool col, const RealArgs<T> &a, hipStream_t s);
 
 // transpose.hip : batched LDS-padded 2-D transpose, elem size 4/8/16 bytes
 // out[b][c][r] = in[b][r][c];  in pitch = ld_in elements per row, out pitch = ld_out

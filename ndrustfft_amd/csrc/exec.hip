@@ -417,12 +417,14 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
         const DevConfig &d = dt->cfg[slot];
         const bool is_c2c = plan->kind == NDFFT_KIND_C2C;
         const bool odd_variant = gop == G_R2C_ODD || gop == G_C2R_ODD || gop == G_DCT2_ODD || gop == G_DCT3_ODD || gop == G_DCT4_ODD;
-        const bool have_tw = is_c2c ? !c.twp_col.re.empty() : c.pow2;
+        const bool use_jit = c.jit && !c.pow2 && P.nlanes * (int64_t)c.F >= (1 << 16);
+        const bool have_tw = use_jit || (is_c2c ? !c.twp_col.re.empty() : c.pow2);
         const bool row = !is_c2c && P.xs == 1 && P.ys == 1 && P.b.size() <= 1;
         bool col = false, narrow = false;
         if (!row && !odd_variant && P.xlen > 1 && !P.b.empty() && P.b.size() <= 2 && P.b.back().sin == 1 && P.b.back().sout == 1) {
             if (have_tw && P.b.back().shape >= 8) {
-                const int lanes = plan->dtype == NDFFT_F32 ? pow2_real_col_lanes<float>(c.F) : pow2_real_col_lanes<double>(c.F);
+                const int lanes = use_jit ? jit_col_lanes(plan->dtype, c.jitcfg)
+                                          : plan->dtype == NDFFT_F32 ? pow2_real_col_lanes<float>(c.F) : pow2_real_col_lanes<double>(c.F);
                 col = lanes > 0;
             }
             // long lanes: XCD-aware narrow tiles (one HBM pass) instead of the three-pass transpose route
@@ -474,15 +476,17 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
             int rc2;
             if (plan->dtype == NDFFT_F32) {
                 RealArgs<float> a; fill(a); a.scale = (float)P.scale;
-                a.aux1 = (const float2 *)d.aux1; a.aux2 = (const float2 *)d.aux2; a.twp = (const float2 *)(is_c2c ? d.twp_col : d.twp);
-                rc2 = launch_pow2_real<float>(gop, a, col, stream);
+                a.aux1 = (const float2 *)d.aux1; a.aux2 = (const float2 *)d.aux2; a.twp = (const float2 *)((is_c2c && !use_jit) ? d.twp_col : d.twp);
+                rc2 = use_jit ? launch_jit_real<float>(gop, c.jitcfg, col, a, stream) : launch_pow2_real<float>(gop, a, col, stream);
             } else {
                 RealArgs<double> a; fill(a); a.scale = P.scale;
-                a.aux1 = (const double2 *)d.aux1; a.aux2 = (const double2 *)d.aux2; a.twp = (const double2 *)(is_c2c ? d.twp_col : d.twp);
-                rc2 = launch_pow2_real<double>(gop, a, col, stream);
+                a.aux1 = (const double2 *)d.aux1; a.aux2 = (const double2 *)d.aux2; a.twp = (const double2 *)((is_c2c && !use_jit) ? d.twp_col : d.twp);
+                rc2 = use_jit ? launch_jit_real<double>(gop, c.jitcfg, col, a, stream) : launch_pow2_real<double>(gop, a, col, stream);
             }
-            set_last_path(col ? "pow2_col" : "pow2_real");
-            return rc2;
+            if (!(use_jit && rc2 == NDFFT_ERR_UNSUPPORTED)) {   // UNSUPPORTED from the JIT = no hiprtc / compile failed: fall through to the LDS kernel
+                set_last_path(use_jit ? (col ? "jit_col" : "jit_real") : (col ? "pow2_col" : "pow2_real"));
+                return rc2;
+            }
         }
     }
     {   // long lanes: four-step on the row kernels (contiguous lanes) -- strided ones reach here via the transpose route

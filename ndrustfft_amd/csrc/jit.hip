@@ -14,6 +14,7 @@
 #include <string>
 
 #include "engine.h"
+#include "pow2_real.h"
 #include "jit_sources.inc"
 
 namespace ndfft {
@@ -112,51 +113,56 @@ void jit_build_twiddles(const JitCfg &cfg, HostTable &out) {
     }
 }
 
+namespace {
+// compiles `src` (which defines extern "C" kernel k_jit) once per key; returns the cached entry
+Entry get_or_compile(const std::string &key, const std::string &src, const std::string &what) {
+    Rtc &r = rtc();
+    std::lock_guard<std::mutex> g(g_mu);
+    auto it = g_cache.find(key);
+    if (it != g_cache.end()) return it->second;
+    Entry ne;
+    const char *hn[] = {"device_common.h", "butterflies.h", "pow2_kernel.h", "realops.h", "pow2_real.h"};
+    const char *hs[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h, jit_src_realops_h, jit_src_pow2_real_h};
+    rtcProgram prog = nullptr;
+    bool ok = r.ok && r.create(&prog, src.c_str(), "k_jit.hip", 5, hs, hn) == 0;
+    if (ok) {
+        const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast"};
+        ok = r.compile(prog, 4, opts) == 0;
+        if (!ok && getenv("NDFFT_JIT_VERBOSE")) {
+            size_t ls = 0; r.log_size(prog, &ls);
+            std::string log(ls, '\0'); r.log(prog, &log[0]);
+            fprintf(stderr, "ndfft jit: compile of %s failed:\n%s\n", what.c_str(), log.c_str());
+        }
+    }
+    std::string code;
+    if (ok) { size_t cs = 0; ok = r.code_size(prog, &cs) == 0 && cs > 0; if (ok) { code.resize(cs); ok = r.code(prog, &code[0]) == 0; } }
+    if (prog) r.destroy(&prog);
+    if (ok) ok = hipModuleLoadData(&ne.mod, code.data()) == hipSuccess && hipModuleGetFunction(&ne.fn, ne.mod, "k_jit") == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); ne.failed = true; }
+    g_cache.emplace(key, ne);
+    return ne;
+}
+std::string radix_list(const JitCfg &cfg) {
+    std::string rl;
+    for (size_t i = 0; i < cfg.radix.size(); ++i) rl += (i ? ", " : "") + std::to_string(cfg.radix[i]);
+    return rl;
+}
+}  // namespace
+
 // returns NDFFT_OK and launches, or NDFFT_ERR_UNSUPPORTED if no specialised kernel can be had (caller falls back)
 int launch_jit_c2c(int dtype, const JitCfg &cfg, int nt, const Pow2Args &a, hipStream_t s) {
-    Rtc &r = rtc();
-    if (!r.ok) return NDFFT_ERR_UNSUPPORTED;
+    if (!rtc().ok) return NDFFT_ERR_UNSUPPORTED;
     const bool vec_ok = cfg.vec == 2 && a.pitch_in % 2 == 0 && a.pitch_out % 2 == 0 && ((uintptr_t)a.in % 16) == 0 && ((uintptr_t)a.out % 16) == 0;
     const int vec = vec_ok ? 2 : 1;
     int dev = 0;
     NDFFT_HIP(hipGetDevice(&dev));
-    std::string rl;
-    for (size_t i = 0; i < cfg.radix.size(); ++i) rl += (i ? ", " : "") + std::to_string(cfg.radix[i]);
     const char *tn = dtype == NDFFT_F32 ? "float" : "double";
     const int threads = cfg.tpl * cfg.lpb;
     const std::string inst = std::string("Pow2Kernel<") + tn + ", " + std::to_string(cfg.n) + ", " + std::to_string(cfg.tpl) + ", " +
-                             std::to_string(cfg.lpb) + ", true, RadixList<" + rl + ">, 0, 1, " + std::to_string(nt) + ", " + std::to_string(vec) + ">";
-    const std::string key = "dev" + std::to_string(dev) + ":" + inst;
-    Entry e;
-    {
-        std::lock_guard<std::mutex> g(g_mu);
-        auto it = g_cache.find(key);
-        if (it == g_cache.end()) {
-            Entry ne;
-            const std::string src = "#include \"pow2_kernel.h\"\nusing namespace ndfft;\nextern \"C\" __global__ __launch_bounds__(" +
-                                    std::to_string(threads) + ") void k_jit(const Pow2Args a) { " + inst + "::run(a); }\n";
-            const char *hn[] = {"device_common.h", "butterflies.h", "pow2_kernel.h"};
-            const char *hs[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h};
-            rtcProgram prog = nullptr;
-            bool ok = r.create(&prog, src.c_str(), "k_jit.hip", 3, hs, hn) == 0;
-            if (ok) {
-                const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast"};
-                ok = r.compile(prog, 4, opts) == 0;
-                if (!ok && getenv("NDFFT_JIT_VERBOSE")) {
-                    size_t ls = 0; r.log_size(prog, &ls);
-                    std::string log(ls, '\0'); r.log(prog, &log[0]);
-                    fprintf(stderr, "ndfft jit: compile of %s failed:\n%s\n", inst.c_str(), log.c_str());
-                }
-            }
-            std::string code;
-            if (ok) { size_t cs = 0; ok = r.code_size(prog, &cs) == 0 && cs > 0; if (ok) { code.resize(cs); ok = r.code(prog, &code[0]) == 0; } }
-            if (prog) r.destroy(&prog);
-            if (ok) ok = hipModuleLoadData(&ne.mod, code.data()) == hipSuccess && hipModuleGetFunction(&ne.fn, ne.mod, "k_jit") == hipSuccess;
-            if (!ok) { (void)hipGetLastError(); ne.failed = true; }
-            it = g_cache.emplace(key, ne).first;
-        }
-        e = it->second;
-    }
+                             std::to_string(cfg.lpb) + ", true, RadixList<" + radix_list(cfg) + ">, 0, 1, " + std::to_string(nt) + ", " + std::to_string(vec) + ">";
+    const std::string src = "#include \"pow2_kernel.h\"\nusing namespace ndfft;\nextern \"C\" __global__ __launch_bounds__(" +
+                            std::to_string(threads) + ") void k_jit(const Pow2Args a) { " + inst + "::run(a); }\n";
+    const Entry e = get_or_compile("dev" + std::to_string(dev) + ":" + inst, src, inst);
     if (e.failed) return NDFFT_ERR_UNSUPPORTED;
     const size_t esz = dtype == NDFFT_F32 ? 4 : 8;
     const size_t lds = (size_t)cfg.lpb * (size_t)(cfg.n + (cfg.n >> 4) + 1) * esz;   // Pow2Kernel::LDS_BYTES (HALF exchange)
@@ -168,5 +174,45 @@ int launch_jit_c2c(int dtype, const JitCfg &cfg, int nt, const Pow2Args &a, hipS
     NDFFT_HIP(hipModuleLaunchKernel(e.fn, (unsigned)nblk, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, s, params, nullptr));
     return NDFFT_OK;
 }
+
+// lanes per column tile of the specialised real-op / column kernel (0: no useful tile)
+int jit_col_lanes(int dtype, const JitCfg &cfg) {
+    int thr = cfg.tpl * 32;
+    thr = thr > 1024 ? 1024 : (thr < 256 ? 256 : thr);
+    const int lpb = thr / cfg.tpl;
+    const size_t lane = (size_t)((cfg.n + (cfg.n >> 4) + 2) | 1) * 2 * (dtype == NDFFT_F32 ? 4 : 8);
+    return (lpb >= 8 && lpb * lane <= 160 * 1024) ? lpb : 0;
+}
+
+// RealPow2Kernel (pow2_real.h) specialised for a smooth inner FFT length cfg.n: R2C / C2R / DCT rows, and
+// every op incl. C2C on column tiles
+template <typename T> int launch_jit_real(int gop, const JitCfg &cfg, bool col, const RealArgs<T> &a, hipStream_t s) {
+    if (!rtc().ok) return NDFFT_ERR_UNSUPPORTED;
+    const int dtype = sizeof(T) == 4 ? NDFFT_F32 : NDFFT_F64;
+    const int lpb = col ? jit_col_lanes(dtype, cfg) : (cfg.tpl >= 256 ? 1 : std::max(1, 256 / cfg.tpl));
+    if (lpb <= 0) return NDFFT_ERR_UNSUPPORTED;
+    int dev = 0;
+    NDFFT_HIP(hipGetDevice(&dev));
+    const char *tn = sizeof(T) == 4 ? "float" : "double";
+    const int threads = cfg.tpl * lpb;
+    const std::string inst = std::string("RealPow2Kernel<") + tn + ", " + std::to_string(cfg.n) + ", " + std::to_string(cfg.tpl) + ", " +
+                             std::to_string(lpb) + ", RadixList<" + radix_list(cfg) + ">, " + std::to_string(gop) + ", " + (col ? "true" : "false") + ", false>";
+    const std::string src = std::string("#include \"pow2_real.h\"\nusing namespace ndfft;\nextern \"C\" __global__ __launch_bounds__(") +
+                            std::to_string(threads) + ") void k_jit(const RealArgs<" + tn + "> a) { " + inst + "::run(a); }\n";
+    const Entry e = get_or_compile("dev" + std::to_string(dev) + ":" + inst, src, inst);
+    if (e.failed) return NDFFT_ERR_UNSUPPORTED;
+    const int F = cfg.n;
+    const size_t lane_lds = col ? (size_t)((F + (F >> 4) + 2) | 1) : (size_t)((F + (F >> 4) + 3) & ~1);
+    const size_t lds = (size_t)lpb * lane_lds * 2 * sizeof(T);
+    const int64_t nblk = (a.nlanes + lpb - 1) / lpb;
+    if (nblk <= 0) return NDFFT_OK;
+    if (nblk > 0x7fffffffLL) return NDFFT_ERR_UNSUPPORTED;
+    RealArgs<T> arg = a;
+    void *params[] = {(void *)&arg};
+    NDFFT_HIP(hipModuleLaunchKernel(e.fn, (unsigned)nblk, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, s, params, nullptr));
+    return NDFFT_OK;
+}
+template int launch_jit_real<float>(int, const JitCfg &, bool, const RealArgs<float> &, hipStream_t);
+template int launch_jit_real<double>(int, const JitCfg &, bool, const RealArgs<double> &, hipStream_t);
 
 }  // namespace ndfft

@@ -11,12 +11,13 @@
 // Replaces R2cFftHandler::fft_r2c_lane / ifft_r2c_lane (src/lib.rs:497-523) and
 // DctHandler::dct1..4_lane (src/lib.rs:688-734) together with the strategy-(i) row loop.
 #pragma once
-#include <type_traits>
-
 #include "pow2_kernel.h"
 #include "realops.h"
 
 namespace ndfft {
+
+template <bool C, typename A, typename B> struct cond_type { typedef A type; };
+template <typename A, typename B> struct cond_type<false, A, B> { typedef B type; };
 
 template <typename T> struct RealArgs {
     const void *in; void *out;
@@ -215,7 +216,7 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
             }
         } else {
             const cpx<T> *res = (const cpx<T> *)lds;
-            using OT = typename std::conditional<OUT_CPLX, cpx<T>, T>::type;
+            using OT = typename cond_type<OUT_CPLX, cpx<T>, T>::type;
             // DCT-I / DCT-II scatter four real outputs per spectrum pair (k, n-k, F-k, F+k): worth staging.
             // (measured: 117 -> 104 us on cfg4; the ops with one contiguous output per thread lose 5-20 % to the
             // two extra barriers, so they keep their direct stores)

@@ -5,7 +5,7 @@
 //   R2C  (realfft forward)            lib.rs:497-503      C2R (scale, zero DC/Nyquist imag, inverse) lib.rs:506-531
 //   DCT-I..IV (x2 pre-scale, rustdct) lib.rs:688-741      C2C inverse scale after                    lib.rs:321-338
 #pragma once
-#include "engine.h"
+#include "device_common.h"
 
 namespace ndfft {
 

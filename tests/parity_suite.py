@@ -366,6 +366,19 @@ def jit_specialised_sizes(L):
     assert_close(y, np.fft.fft(x.astype(np.complex128), axis=1), 1, 1e-4, "jit unaligned")
     # small problems are not worth a compile: LDS kernel
     assert run_case(L, "ndfft", (3, 1000), 1, np.float64) == "generic_row"
+    # real-data ops with a smooth inner FFT (rows) and every op on column tiles (strategy ii)
+    for n, F in ((1000, 500), (192, 96), (2000, 1000), (600, 300)):
+        rows = max(8, (1 << 17) // n + 3)
+        for rdt in (np.float64, np.float32):
+            for name in ("ndfft_r2c", "ndifft_r2c", "nddct2", "nddct3", "nddct4"):
+                assert run_case(L, name, (rows, n), 1, rdt, offset=n) == "jit_real", (name, n)
+            assert run_case(L, "nddct1", (rows, F + 1), 1, rdt, offset=n) == "jit_real", ("nddct1", F)
+    for n in (100, 300, 600):
+        for rdt in (np.float64, np.float32):
+            for name in OPS:
+                m = n if name in ("ndfft", "ndifft") else (n + 1 if name == "nddct1" else 2 * n)
+                assert run_case(L, name, (m, 1500), 0, rdt, offset=n) == "jit_col", (name, m)
+                assert run_case(L, name, (3, m, 700), 1, rdt, offset=n + 1) == "jit_col", (name, m)
 
 
 def handler_clone_shares_plan(L):
