@@ -367,13 +367,13 @@ def jit_specialised_sizes(L):
     # small problems are not worth a compile: LDS kernel
     assert run_case(L, "ndfft", (3, 1000), 1, np.float64) == "generic_row"
     # real-data ops with a smooth inner FFT (rows) and every op on column tiles (strategy ii)
-    for n, F in ((1000, 500), (192, 96), (2000, 1000), (600, 300)):
+    for n, F in ((1000, 500), (192, 96), (2000, 1000), (288, 144), (500, 250)):
         rows = max(8, (1 << 17) // n + 3)
         for rdt in (np.float64, np.float32):
             for name in ("ndfft_r2c", "ndifft_r2c", "nddct2", "nddct3", "nddct4"):
                 assert run_case(L, name, (rows, n), 1, rdt, offset=n) == "jit_real", (name, n)
             assert run_case(L, "nddct1", (rows, F + 1), 1, rdt, offset=n) == "jit_real", ("nddct1", F)
-    for n in (100, 300, 600):
+    for n in (100, 250, 144):
         for rdt in (np.float64, np.float32):
             for name in OPS:
                 m = n if name in ("ndfft", "ndifft") else (n + 1 if name == "nddct1" else 2 * n)
