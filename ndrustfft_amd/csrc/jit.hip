@@ -65,9 +65,10 @@ bool jit_disabled() {
 // thread owns whole butterflies in every pass), fewest passes first, then the smallest E.
 bool jit_choose(int dtype, int n, JitCfg &cfg) {
     if (jit_disabled() || n < 12 || n > 8192 || pow2_supported(dtype, n)) return false;
-    {   int m = n; for (int p : {2, 3, 5, 7}) while (m % p == 0) m /= p; if (m != 1) return false; }
-    const int emax = dtype == NDFFT_F32 ? 20 : 16;
-    const int cand[] = {16, 10, 9, 8, 7, 6, 5, 4, 3, 2};
+    {   int m = n; for (int p : {2, 3, 5, 7, 11, 13}) while (m % p == 0) m /= p; if (m != 1) return false; }
+    // E complex registers per thread: 2E (f32) / 4E (f64) VGPRs of data.  Mixed 2-3-5 lengths need E = 30.
+    const int emax = dtype == NDFFT_F32 ? 32 : 30;
+    const int cand[] = {16, 13, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
     std::vector<int> best, cur;
     int best_e = 0;
     auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
