@@ -167,6 +167,7 @@ int launch_jit_c2c(int dtype, const JitCfg &cfg, int nt, const Pow2Args &a, hipS
     if (e.failed) return NDFFT_ERR_UNSUPPORTED;
     const size_t esz = dtype == NDFFT_F32 ? 4 : 8;
     const size_t lds = (size_t)cfg.lpb * (size_t)(cfg.n + (cfg.n >> 4) + 1) * esz;   // Pow2Kernel::LDS_BYTES (HALF exchange)
+    if (lds > 64 * 1024) return NDFFT_ERR_UNSUPPORTED;   // module functions get the default dynamic-LDS limit
     const int64_t nblk = (a.nlanes + cfg.lpb - 1) / cfg.lpb;
     if (nblk <= 0) return NDFFT_OK;
     if (nblk > 0x7fffffffLL) return NDFFT_ERR_UNSUPPORTED;
@@ -182,7 +183,9 @@ int jit_col_lanes(int dtype, const JitCfg &cfg) {
     thr = thr > 1024 ? 1024 : (thr < 256 ? 256 : thr);
     const int lpb = thr / cfg.tpl;
     const size_t lane = (size_t)((cfg.n + (cfg.n >> 4) + 2) | 1) * 2 * (dtype == NDFFT_F32 ? 4 : 8);
-    return (lpb >= 8 && lpb * lane <= 160 * 1024) ? lpb : 0;
+    int l = lpb;
+    while (l >= 8 && (size_t)l * lane > 64 * 1024) l /= 2;   // module functions: 64 KiB of dynamic LDS
+    return l >= 8 ? l : 0;
 }
 
 // RealPow2Kernel (pow2_real.h) specialised for a smooth inner FFT length cfg.n: R2C / C2R / DCT rows, and
@@ -205,6 +208,7 @@ template <typename T> int launch_jit_real(int gop, const JitCfg &cfg, bool col, 
     const int F = cfg.n;
     const size_t lane_lds = col ? (size_t)((F + (F >> 4) + 2) | 1) : (size_t)((F + (F >> 4) + 3) & ~1);
     const size_t lds = (size_t)lpb * lane_lds * 2 * sizeof(T);
+    if (lds > 64 * 1024) return NDFFT_ERR_UNSUPPORTED;
     const int64_t nblk = (a.nlanes + lpb - 1) / lpb;
     if (nblk <= 0) return NDFFT_OK;
     if (nblk > 0x7fffffffLL) return NDFFT_ERR_UNSUPPORTED;
