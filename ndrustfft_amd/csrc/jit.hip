@@ -160,7 +160,7 @@ int launch_jit_c2c(int dtype, const JitCfg &cfg, int nt, const Pow2Args &a, hipS
     const char *tn = dtype == NDFFT_F32 ? "float" : "double";
     const int threads = cfg.tpl * cfg.lpb;
     const std::string inst = std::string("Pow2Kernel<") + tn + ", " + std::to_string(cfg.n) + ", " + std::to_string(cfg.tpl) + ", " +
-                             std::to_string(cfg.lpb) + ", true, RadixList<" + radix_list(cfg) + ">, 0, 1, " + std::to_string(nt) + ", " + std::to_string(vec) + ">";
+                             std::to_string(cfg.lpb) + ", true, RadixList<" + radix_list(cfg) + ">, " + (a.twlo ? "8" : "0") + ", 1, " + std::to_string(nt) + ", " + std::to_string(vec) + ">";
     const std::string src = "#include \"pow2_kernel.h\"\nusing namespace ndfft;\nextern \"C\" __global__ __launch_bounds__(" +
                             std::to_string(threads) + ") void k_jit(const Pow2Args a) { " + inst + "::run(a); }\n";
     const Entry e = get_or_compile("dev" + std::to_string(dev) + ":" + inst, src, inst);

@@ -79,9 +79,9 @@ void pow2_build_twiddles(int dtype, int n, HostTable &out) {
     }
 }
 
-template <typename T, int N, int NT, int VEC> static int launch_one(const Pow2Args &a, hipStream_t s) {
+template <typename T, int N, int NT, int VEC, int FL = 0> static int launch_one(const Pow2Args &a, hipStream_t s) {
     constexpr int TPL = Pow2Cfg<T, N>::TPL, LPB = lpb_for(TPL);
-    using K = Pow2Kernel<T, N, TPL, LPB, true, typename Pow2Cfg<T, N>::RL, 0, 1, NT, VEC>;
+    using K = Pow2Kernel<T, N, TPL, LPB, true, typename Pow2Cfg<T, N>::RL, FL, 1, NT, VEC>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)k_pow2<K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -95,22 +95,22 @@ template <typename T, int N, int NT, int VEC> static int launch_one(const Pow2Ar
     return NDFFT_OK;
 }
 
-// Cache policy by footprint (measured, tools/kbench.hip): the output is always stored
-// non-temporally; once the input no longer fits the 256 MiB Infinity Cache it is also loaded
-// non-temporally (16384x4096 c64: 354 us vs 377 us), while a smaller input is loaded with the
-// default policy so that a copy left in the Infinity Cache by its producer is used (4096x4096 c64:
-// 84 us vs 93 us).
+// Cache policy (measured, tools/kbench.hip f64_4096 sweep over 4096..16384 lanes): the output is
+// always stored non-temporally (4096x4096 c128: 84 us vs 105 us with plain stores); the input is
+// loaded with the default policy at every size -- non-temporal loads cost 9 % while the input still
+// fits the 256 MiB Infinity Cache and are within +-2 % of plain loads beyond it.
+// The fused four-step twiddle (Pow2Args::twlo) is its own instantiation (FLAGS bit 3): as a
+// run-time branch it cost the plain kernel 23-70 VGPRs (n=8192 f64: 122 -> 194, one block per CU).
 int launch_pow2(int dtype, int n, const Pow2Args &a, hipStream_t s) {
-    const size_t in_bytes = (size_t)a.nlanes * (size_t)n * (dtype == NDFFT_F32 ? 8 : 16);
-    const bool big = in_bytes > ((size_t)256 << 20);
     // 16-byte accesses for f32 need even pitches and 16-byte aligned bases
     const bool vec_ok = a.pitch_in % 2 == 0 && a.pitch_out % 2 == 0 && ((uintptr_t)a.in % 16) == 0 && ((uintptr_t)a.out % 16) == 0;
+    const bool fused = a.twlo != nullptr;
     switch (n) {
 #define NDFFT_CASE(N_, TPL_, ...)                                                               \
     case N_:                                                                                    \
-        if (dtype == NDFFT_F64) return big ? launch_one<double, N_, 3, 1>(a, s) : launch_one<double, N_, 1, 1>(a, s); \
-        if (vec_ok) return big ? launch_one<float, N_, 3, 2>(a, s) : launch_one<float, N_, 1, 2>(a, s);              \
-        return big ? launch_one<float, N_, 3, 1>(a, s) : launch_one<float, N_, 1, 1>(a, s);
+        if (dtype == NDFFT_F64) return fused ? launch_one<double, N_, 1, 1, 8>(a, s) : launch_one<double, N_, 1, 1>(a, s); \
+        if (vec_ok) return fused ? launch_one<float, N_, 1, 2, 8>(a, s) : launch_one<float, N_, 1, 2>(a, s);              \
+        return fused ? launch_one<float, N_, 1, 1, 8>(a, s) : launch_one<float, N_, 1, 1>(a, s);
         NDFFT_POW2_CONFIGS_F64(NDFFT_CASE)
 #undef NDFFT_CASE
         default: return fail(NDFFT_ERR_UNSUPPORTED, "pow2 kernel: unsupported n");

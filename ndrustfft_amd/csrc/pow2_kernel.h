@@ -167,7 +167,7 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
 #pragma unroll
             for (int i = 0; i < E; ++i) v[i].y = -v[i].y;
         }
-        if (a.twlo) {   // fused four-step twiddle (after the conjugation, so the same table serves both directions)
+        if constexpr ((FLAGS & 8) != 0) {   // fused four-step twiddle (after the conjugation, so the same table serves both directions)
             constexpr int R0 = RL::at(0), NB0 = N / R0, NBF0 = E / R0;
             const int k1 = (int)(lane % a.f1), mask = (1 << a.logB) - 1;
             const cpx<T> *lo = (const cpx<T> *)a.twlo, *hi = (const cpx<T> *)a.twhi;

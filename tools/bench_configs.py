@@ -19,10 +19,16 @@ from ndrustfft_amd import (DctHandler, FftHandler, R2cFftHandler, _lib, nddct1, 
 PEAK = 8000.0
 
 
-def timeit(fn, steps, warmup=5):
-    for _ in range(warmup):
-        fn()
-    torch.cuda.synchronize()
+def timeit(fn, steps, warmup=5, ramp_ms=150.0):
+    # keep the device busy for ramp_ms first: the clocks take ~30-40 ms of sustained work to settle
+    import time
+    t0 = time.perf_counter()
+    while True:
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        if (time.perf_counter() - t0) * 1e3 >= ramp_ms:
+            break
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(steps):

@@ -3,6 +3,7 @@
 // pattern on one MI355X, interleaved rounds in ONE process (guide rule 24), HIP events.
 //   build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -I ndrustfft_amd/csrc tools/kbench.hip -o tools/kbench
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -153,6 +154,38 @@ int main(int argc, char **argv) {
         V(b, double, 8192, "half 512x16 8.8.8.16", 512, true, 1, 1, 8, 8, 8, 16);
         V(b, double, 8192, "half 512x16 16.8.8.8", 512, true, 1, 1, 16, 8, 8, 8);
         V(b, double, 8192, "half 256x32 16.16.32?no 16.16.8.4", 256, true, 1, 1, 16, 16, 8, 4);
+        b.run(1e-12);
+    } else if (what == "creep") {
+        // does the per-launch time drift under sustained back-to-back launches? (clock / power management)
+        Bench<double> b{4096, 4096, 1}; b.init();
+        V(b, double, 4096, "fft 512x8 nt1", 512, true, 1, 1, 8, 8, 8, 8);
+        {
+            Variant v; v.name = "copy_lane 512x8"; const double2 *i2 = (const double2 *)b.din; double2 *o2 = (double2 *)b.dout;
+            v.launch = [=]() { hipLaunchKernelGGL((k_copy_lane<512, 8>), dim3(4096), dim3(512), 0, 0, i2, o2); };
+            v.bytes = 2.0 * 4096 * 4096 * 16; v.check = false; b.vs.push_back(v);
+        }
+        const int groups = argc > 2 ? atoi(argv[2]) : 40, per = 25;
+        std::vector<hipEvent_t> ev(groups + 1);
+        for (auto &e : ev) CK(hipEventCreate(&e));
+        for (auto &v : b.vs) {
+            CK(hipDeviceSynchronize());
+            usleep(300000);
+            CK(hipEventRecord(ev[0], 0));
+            for (int g = 0; g < groups; ++g) { for (int k = 0; k < per; ++k) v.launch(); CK(hipEventRecord(ev[g + 1], 0)); }
+            CK(hipDeviceSynchronize());
+            printf("%s: us/launch per group of %d:", v.name.c_str(), per);
+            for (int g = 0; g < groups; ++g) { float ms; CK(hipEventElapsedTime(&ms, ev[g], ev[g + 1])); printf(" %.1f", ms * 1000.f / per); }
+            printf("\n");
+        }
+    } else if (what == "f64_4096") {
+        const int64_t lanes = argc > 3 ? atoll(argv[3]) : 8192;
+        Bench<double> b{4096, lanes, rounds}; b.init();
+        V(b, double, 4096, "half 512x8 8.8.8.8 nt1 (st)", 512, true, 1, 1, 8, 8, 8, 8);
+        V(b, double, 4096, "half 512x8 8.8.8.8 nt3 (ld+st)", 512, true, 3, 1, 8, 8, 8, 8);
+        V(b, double, 4096, "half 512x8 8.8.8.8 nt0", 512, true, 0, 1, 8, 8, 8, 8);
+        V(b, double, 4096, "half 512x8 8.8.8.8 nt2 (ld)", 512, true, 2, 1, 8, 8, 8, 8);
+        V(b, double, 4096, "half 256x16 16.16.16 nt1", 256, true, 1, 1, 16, 16, 16);
+        V(b, double, 4096, "half 256x16 16.16.16 nt3", 256, true, 3, 1, 16, 16, 16);
         b.run(1e-12);
     } else if (what == "f64_16384") {
         Bench<double> b{16384, 1024, rounds}; b.init();
