@@ -127,3 +127,76 @@ def transform_sharded(fn, full_in, in_shape, in_dtype, out_shape, out_dtype, han
     if x.numel() and y.numel():
         fn(x, y, handler, axis)
     return gather_lanes(y, tuple(out_shape), d, root, None, group)
+
+
+# ---- multi-axis transforms on a sharded array ----------------------------------------
+#
+# A 2-D / n-D transform (the reference's examples/fft2.rs, rfft2.rs: axis 1, then axis 0 through a
+# `work` array) on an array that is sharded along dimension `d` needs ONE exchange when the next
+# transform axis IS `d`: re-shard from slabs along `d` to slabs along another dimension `e`.  That is
+# an all-to-all: rank r sends the block (its rows of `d`) x (rank q's range of `e`) to every q.  On
+# MI355X xGMI is a full point-to-point mesh (7 links per GPU), so the exchange is issued as ONE group
+# of pairwise isend/irecv (RCCL groups them into a single launch; every link carries exactly one
+# block in each direction) -- no ring, no staging through a root.  Uneven extents are allowed.
+
+def reshard(local, global_shape, d_from, d_to, group=None):
+    """`local` is this rank's slab of a `global_shape` array sharded along `d_from` (bounds from
+    shard_bounds).  Returns this rank's slab of the SAME array sharded along `d_to`."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if d_from == d_to:
+        return local
+    bf = shard_bounds(global_shape[d_from], world)
+    bt = shard_bounds(global_shape[d_to], world)
+    oshape = list(global_shape); oshape[d_to] = bt[rank][1] - bt[rank][0]
+    out = torch.empty(oshape, dtype=local.dtype, device=local.device)
+    ops, recvs, keep = [], [], []
+    for q in range(world):
+        # block that stays on / goes to q: my d_from rows, q's d_to range
+        piece = _slice(local, d_to, bt[q][0], bt[q][1])
+        if q == rank:
+            _slice(out, d_from, bf[rank][0], bf[rank][1]).copy_(piece)
+            continue
+        if piece.numel():
+            piece = piece.contiguous(); keep.append(piece)
+            ops.append(dist.P2POp(dist.isend, piece, q, group))
+        rshape = list(oshape); rshape[d_from] = bf[q][1] - bf[q][0]
+        buf = torch.empty(rshape, dtype=local.dtype, device=local.device)
+        if buf.numel():
+            recvs.append((buf, bf[q][0], bf[q][1]))
+            ops.append(dist.P2POp(dist.irecv, buf, q, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    for buf, lo, hi in recvs:
+        _slice(out, d_from, lo, hi).copy_(buf)
+    return out
+
+
+def transform_axes_sharded(steps, local, global_shape, sharded_dim, group=None, alloc=None):
+    """Apply a sequence of single-axis transforms to an array that lives sharded across the ranks.
+
+    steps         list of (fn, handler, axis, out_extent, out_dtype): fn is an nd* function,
+                  out_extent the output length along `axis` (n, or n/2+1 for R2C, ...)
+    local         this rank's slab (sharded along `sharded_dim`)
+    Returns (local_out, out_global_shape, out_sharded_dim).  Whenever the next axis is the sharded
+    dimension the array is first re-sharded (one all-to-all, `reshard`) to the outermost other
+    dimension; otherwise the step runs on the local slab with no communication.  The result is left
+    in whatever sharding the last step used (callers that need the original sharding call
+    `reshard` once more) -- the same choice pencil/slab FFT codes make to save an exchange."""
+    shape = list(global_shape)
+    d = sharded_dim
+    x = local
+    for fn, handler, axis, out_extent, out_dtype in steps:
+        if axis == d:
+            e = next((k for k, ext in enumerate(shape) if k != axis and ext > 1), None)
+            if e is None:
+                raise ValueError("array has a single lane: nothing to re-shard to")
+            x = reshard(x, tuple(shape), d, e, group)
+            d = e
+        oshape = list(x.shape); oshape[axis] = out_extent
+        y = (alloc or torch.zeros)(oshape, dtype=out_dtype, device=x.device)
+        if x.numel() and y.numel():
+            fn(x.contiguous(), y, handler, axis)
+        shape[axis] = out_extent
+        x = y
+    return x, tuple(shape), d

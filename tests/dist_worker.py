@@ -54,6 +54,53 @@ def main():
             err = np.abs(out.numpy() - ref).max()
             print(f"case {name} {shape} axis={axis}: max abs diff {err:.2e}")
             ok &= err == 0.0
+    # ---- sharded multi-axis transforms: slab -> all-to-all re-shard -> slab ----
+    cdt, rdt = torch.complex128, torch.float64
+    def shard_of(a, d):
+        lo, hi = nd_dist.shard_bounds(a.shape[d], world)[rank]
+        idx = [slice(None)] * a.ndim; idx[d] = slice(lo, hi)
+        return torch.from_numpy(np.ascontiguousarray(a[tuple(idx)]))
+    def unshard(t, gshape, d):
+        bufs = []
+        for r, (lo, hi) in enumerate(nd_dist.shard_bounds(gshape[d], world)):
+            s_ = list(gshape); s_[d] = hi - lo
+            bufs.append(torch.empty(s_, dtype=t.dtype))
+        for r in range(world):                                  # slabs may be uneven: one broadcast per rank
+            if r == rank:
+                bufs[r].copy_(t)
+            dist.broadcast(bufs[r], r)
+        return torch.cat(bufs, dim=d).numpy()
+    # fft2 (examples/fft2.rs): axis 1 then axis 0, array sharded by rows (dim 0)
+    for (nx, ny) in ((8, 6), (7, 5), (6, 9)):
+        a = synth.complex_array((nx, ny))
+        hx, hy = orc.FftHandler(nx), orc.FftHandler(ny)
+        steps = [(wrap(orc.ndfft), hy, 1, ny, cdt), (wrap(orc.ndfft), hx, 0, nx, cdt)]
+        y, gshape, d = nd_dist.transform_axes_sharded(steps, shard_of(a, 0), (nx, ny), 0)
+        got = unshard(y, gshape, d)
+        w = np.zeros((nx, ny), np.complex128); ref = np.zeros((nx, ny), np.complex128)
+        orc.ndfft(a, w, hy, 1); orc.ndfft(w, ref, hx, 0)
+        err = np.abs(got - ref).max()
+        if rank == 0:
+            print(f"fft2 sharded {nx}x{ny}: final shard dim {d}, max abs diff {err:.2e}")
+        ok &= err == 0.0 and d == 1
+        # and back to the original row sharding
+        back = nd_dist.reshard(y, gshape, d, 0)
+        ok &= np.array_equal(unshard(back, gshape, 0), ref)
+    # rfft2 (examples/rfft2.rs): R2C along axis 1, C2C along axis 0; 3-D with the sharded dim in the middle
+    for shape, sd in (((6, 10), 0), ((5, 4, 6), 1)):
+        a = synth.real_array(shape)
+        n_last, n0 = shape[-1], shape[sd]
+        hr, h0 = orc.R2cFftHandler(n_last), orc.FftHandler(n0)
+        steps = [(wrap(orc.ndfft_r2c), hr, len(shape) - 1, n_last // 2 + 1, cdt), (wrap(orc.ndfft), h0, sd, n0, cdt)]
+        y, gshape, d = nd_dist.transform_axes_sharded(steps, shard_of(a, sd), shape, sd)
+        got = unshard(y, gshape, d)
+        ws = list(shape); ws[-1] = n_last // 2 + 1
+        w = np.zeros(ws, np.complex128); ref = np.zeros(ws, np.complex128)
+        orc.ndfft_r2c(a, w, hr, len(shape) - 1); orc.ndfft(w, ref, h0, sd)
+        err = np.abs(got - ref).max()
+        if rank == 0:
+            print(f"rfft sharded {shape} sharded dim {sd}: final shard dim {d}, max abs diff {err:.2e}")
+        ok &= err == 0.0
     # shard bounds are a partition
     for ext in (1, 2, 7, 8, 65536):
         for w in (1, 2, 3, 8):

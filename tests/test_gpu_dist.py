@@ -45,3 +45,31 @@ print("RCCL_OK")
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_sharded_fft2_rccl_world1():
+    """transform_axes_sharded (slab -> re-shard -> slab) with the HIP kernels as the local executor."""
+    code = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import synth
+from ndrustfft_amd import FftHandler, R2cFftHandler, ndfft, ndfft_r2c, distributed as nd
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+x = synth.real_array((96, 128))
+loc = torch.from_numpy(x).cuda()
+steps = [(ndfft_r2c, R2cFftHandler(128), 1, 65, torch.complex128), (ndfft, FftHandler(96), 0, 96, torch.complex128)]
+y, gshape, d = nd.transform_axes_sharded(steps, loc, x.shape, 0)
+torch.cuda.synchronize()
+ref = np.fft.fft(np.fft.rfft(x, axis=1), axis=0)
+err = np.abs(y.cpu().numpy() - ref).max() / np.abs(ref).max()
+assert gshape == (96, 65) and d == 1 and err < 1e-10, (gshape, d, err)
+back = nd.reshard(y, gshape, d, 0)
+assert torch.equal(back, y)
+dist.destroy_process_group()
+print("RCCL_OK")
+''' % (ROOT, ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29535", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
