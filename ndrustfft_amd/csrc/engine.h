@@ -78,6 +78,11 @@ struct FftConfig {                 // one complex-FFT-of-length-F recipe + op ta
     bool big = false; int F1 = 0, F2 = 0, logB = 0;
     ndfft_plan *sub1 = nullptr, *sub2 = nullptr;   // C2C sub-plans of length F1 / F2 (owned)
     HostTable twlo, twhi;          // W_F^m = twhi[m >> logB] * twlo[m & (2^logB - 1)]
+    // long STRIDED lanes (pow2 n, C2C and R2C/C2R slots): column four-step n = cs_F1 * cs_F2 in two passes of
+    // wide column tiles (exec.hip col_split); cs_sub1 has the kind of the owning plan, cs_sub2 is C2C
+    bool cs = false; int cs_F1 = 0, cs_F2 = 0, cs_logB = 0;
+    ndfft_plan *cs_sub1 = nullptr, *cs_sub2 = nullptr;
+    HostTable cs_twlo, cs_twhi;    // W_n^m for m < n, split like twlo / twhi
     bool jit = false; JitCfg jitcfg;   // C2C slot: smooth non-power-of-two n -> specialised register kernel (jit.hip); twiddles in twp
     bool unsupported = false;      // no single-kernel fit and no usable factorisation (large prime factor)
 };
@@ -85,6 +90,7 @@ struct FftConfig {                 // one complex-FFT-of-length-F recipe + op ta
 struct DevConfig {                 // device copies (typed by dtype) of one FftConfig
     void *tw = nullptr, *twM = nullptr, *chirp = nullptr, *bhat = nullptr, *aux1 = nullptr, *aux2 = nullptr, *twp = nullptr;
     void *twlo = nullptr, *twhi = nullptr, *twp_col = nullptr, *twp_narrow = nullptr;
+    void *cs_twlo = nullptr, *cs_twhi = nullptr;
 };
 
 enum ConfigSlot { CFG_MAIN = 0, CFG_DCT1 = 1, CFG_DCT4 = 2, CFG_COUNT = 3 };
@@ -141,6 +147,10 @@ template <typename T> int pow2_real_col_lanes(int F);   // adjacent lanes per co
 template <typename T> int pow2_real_narrow_lanes(int F);   // lanes per XCD-aware narrow column tile (0: none)
 void pow2_real_build_narrow_twiddles(int dtype, int F, HostTable &out);
 template <typename T> int launch_pow2_real_narrow(int gen_op, const RealArgs<T> &a, hipStream_t s);
+// column four-step, twiddled stage (kernels_colsplit.hip): cs = 1 C2C, 2 = R2C second stage, 3 = C2R first stage
+int colsplit_inner_len();
+int colsplit_tile_lanes();
+template <typename T> int launch_colsplit(int cs, bool inverse, const RealArgs<T> &a, hipStream_t s);
 
 // big.hip : four-step pieces for lanes that do not fit LDS
 template <typename T>

@@ -26,6 +26,7 @@ struct Problem {
     std::vector<BatchDim> b;     // merged batch dims, slowest first
     int64_t nlanes;
     double scale;
+    int keep_out = 0;            // column kernels: cache-allocating stores (the output is re-read right away, col_split)
 };
 
 static size_t real_size(int dtype) { return dtype == NDFFT_F32 ? 4 : 8; }
@@ -221,7 +222,7 @@ static int dispatch_generic(const Problem &P, const void *d_in, void *d_out, con
 
 // per-(host thread, stream) scratch for the transpose route; grows, never shrinks
 struct Scratch { void *p = nullptr; size_t cap = 0; };
-static thread_local std::map<hipStream_t, Scratch> g_scratch[5];
+static thread_local std::map<hipStream_t, Scratch> g_scratch[6];
 static int get_scratch(int which, hipStream_t s, size_t bytes, void **out) {
     Scratch &sc = g_scratch[which][s];
     if (bytes > sc.cap) {
@@ -251,6 +252,92 @@ static int transpose_batched(const void *in, void *out, int64_t batch, int64_t r
 static bool narrow_enabled() {
     static const bool on = [] { const char *e = getenv("NDFFT_NARROW"); return !(e && e[0] == '0'); }();
     return on;
+}
+
+// developer switch: NDFFT_COLSPLIT=0 keeps long strided lanes on the narrow-tile / transpose routes
+static bool colsplit_enabled() {   // read per call: the parity tests toggle it to reach the narrow-tile kernels
+    const char *e = getenv("NDFFT_COLSPLIT");
+    return !(e && e[0] == '0');
+}
+
+// Column four-step (pow2_real.h, CS kernels): a long STRIDED power-of-two lane, n = F1 * F2, as two passes
+// of wide column tiles over a dense C-layout block [O][n][I] -- no transpose, no narrow tiles:
+//   C2C      A: column C2C of length F1 over a = row / F2 (lanes (b, i): F2*I contiguous)  -> S[o][k1][b][i]
+//            B: CS=1 kernel of length F2 over b, twiddle on load, rows k1 + F1 k2            -> out
+//   R2C      A: column R2C of length F1 (k1 = 0..F1/2); B: CS=2 kernel (Hermitian row map)   -> out rows 0..n/2
+//   C2R      A: CS=3 kernel (Hermitian gather, inverse F2, conj twiddle) -> S; B: column C2R of length F1 -> out
+// Cost: two reads + two writes of the array at 60-80 % of the HBM roofline each, against one pass of
+// 16-32 byte row segments at 15-25 % (8192-long f32 lanes).
+template <typename T>
+static int col_split(const Problem &P, const void *d_in, void *d_out, const FftConfig &c, const DevConfig &d, hipStream_t stream) {
+    const int64_t I = P.b.back().shape;
+    const int64_t O = P.b.size() == 2 ? P.b[0].shape : 1;
+    const int64_t sin_o = P.b.size() == 2 ? P.b[0].sin : 0, sout_o = P.b.size() == 2 ? P.b[0].sout : 0;
+    const int F1 = c.cs_F1, F2 = c.cs_F2;
+    const bool r2c = P.op == NDFFT_OP_R2C, c2r = P.op == NDFFT_OP_C2R, inv = P.op == NDFFT_OP_C2C_INV;
+    const int K1 = (r2c || c2r) ? F1 / 2 + 1 : F1;
+    // Column chunks: the intermediate of one chunk (K1*F2*C complex, <= 128 MiB) is written by stage A with
+    // cache-allocating stores and re-read by stage B before much of it has left the 256 MiB Infinity Cache.
+    // Measured (8192x8192 f32 R2C axis 0): one chunk 241 us, 128 MiB chunks 226 us; smaller chunks LOSE
+    // (32 MiB: 293 us, 8 MiB: 628 us) because every chunk costs two launches of a few microseconds each.
+    int64_t C = I;
+    {
+        const char *e = getenv("NDFFT_CS_CHUNK_MB");   // developer / test switch (0 = one chunk)
+        const int64_t target = (int64_t)(e ? atoi(e) : 128) << 20;
+        const int64_t per_col = (int64_t)K1 * F2 * (int64_t)sizeof(cpx<T>);
+        if (target > 0 && O == 1 && per_col * I > target) C = std::max<int64_t>(64, (target / per_col) & ~(int64_t)63);
+        if (C > I) C = I;
+    }
+    const bool chunked = C < I;
+    void *S;
+    int rc = get_scratch(5, stream, (size_t)O * K1 * F2 * C * sizeof(cpx<T>), &S);
+    if (rc) return rc;
+    const DevTables *dt2;
+    if ((rc = get_dev_tables(c.cs_sub2, &dt2))) return rc;
+    const size_t ein = (op_in_cplx(P.op) ? 2 : 1) * sizeof(T), eout = (op_out_cplx(P.op) ? 2 : 1) * sizeof(T);
+    for (int64_t c0 = 0; c0 < I; c0 += C) {
+        const int64_t Cc = std::min(C, I - c0);
+        const char *in_c = (const char *)d_in + (size_t)c0 * ein;
+        char *out_c = (char *)d_out + (size_t)c0 * eout;
+        RealArgs<T> a;
+        a.nlanes = O * K1 * Cc; a.pitch_in = 0; a.pitch_out = 0; a.vec_in = 0; a.vec_out = 0; a.xcd_remap = 0; a.keep_out = 0;
+        a.n = F2; a.F = F2; a.n_in = F2; a.n_out = F2; a.scale = (T)P.scale;
+        a.aux1 = nullptr; a.aux2 = nullptr; a.twp = (const cpx<T> *)dt2->cfg[CFG_MAIN].twp_col;
+        a.inner = Cc;
+        a.cs_twlo = (const cpx<T> *)d.cs_twlo; a.cs_twhi = (const cpx<T> *)d.cs_twhi; a.cs_logB = c.cs_logB;
+        a.cs_k1n = K1; a.cs_f1 = F1; a.cs_n = (int)P.plan->n; a.cs_outer_in = sin_o; a.cs_outer_out = sout_o; a.cs_pitch = I;
+        Problem Q;
+        Q.plan = c.cs_sub1; Q.nlanes = O * F2 * Cc; Q.scale = 1.0;
+        if (!c2r) {
+            // A: column transform of length F1 over a = row / F2; lanes (b, i)
+            Q.op = P.op; Q.xlen = F1; Q.ylen = K1; Q.xs = (int64_t)F2 * I; Q.ys = (int64_t)F2 * Cc; Q.keep_out = chunked;
+            if (chunked) { Q.b.push_back({(int64_t)F2, I, Cc}); Q.b.push_back({Cc, 1, 1}); }
+            else {
+                if (O > 1) Q.b.push_back({O, sin_o, (int64_t)K1 * F2 * I});
+                Q.b.push_back({(int64_t)F2 * I, 1, 1});
+            }
+            if ((rc = dispatch(Q, in_c, S, stream))) return rc;
+            // B: twiddle on load, length F2 over b, rows k1 + F1 k2 (R2C: Hermitian row map)
+            a.in = S; a.out = out_c;
+            a.outer_in = (int64_t)F2 * Cc; a.outer_out = 0; a.elem_in = Cc; a.elem_out = (int64_t)F1 * I;
+            if ((rc = launch_colsplit<T>(r2c ? 2 : 1, inv, a, stream))) return rc;
+        } else {
+            // A: Hermitian gather, inverse of length F2 over k2, conj twiddle -> S[o][k1][b][i]
+            a.in = in_c; a.out = S;
+            a.outer_in = 0; a.outer_out = (int64_t)F2 * Cc; a.elem_in = I; a.elem_out = Cc;
+            if ((rc = launch_colsplit<T>(3, true, a, stream))) return rc;
+            // B: column C2R of length F1 over k1
+            Q.op = NDFFT_OP_C2R; Q.xlen = K1; Q.ylen = F1; Q.xs = (int64_t)F2 * Cc; Q.ys = (int64_t)F2 * I;
+            if (chunked) { Q.b.push_back({(int64_t)F2, Cc, I}); Q.b.push_back({Cc, 1, 1}); }
+            else {
+                if (O > 1) Q.b.push_back({O, (int64_t)K1 * F2 * I, sout_o});
+                Q.b.push_back({(int64_t)F2 * I, 1, 1});
+            }
+            if ((rc = dispatch(Q, S, out_c, stream))) return rc;
+        }
+    }
+    set_last_path("col_split");
+    return NDFFT_OK;
 }
 
 // Four-step complex FFT of length F = F1*F2 on L lanes (zin / zout: lane pitches in elements).
@@ -432,11 +519,18 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
                 narrow = lanes > 0;
             }
         }
+        // long strided power-of-two lanes on a dense C-layout block: column four-step (two wide-tile passes)
+        if (c.cs && slot == CFG_MAIN && colsplit_enabled() && !row && !P.b.empty() && P.b.size() <= 2 && P.b.back().sin == 1 &&
+            P.b.back().sout == 1 && P.xs == P.b.back().shape && P.ys == P.b.back().shape && P.b.back().shape >= 16 &&
+            (P.op == NDFFT_OP_C2C_FWD || P.op == NDFFT_OP_C2C_INV || P.op == NDFFT_OP_R2C || P.op == NDFFT_OP_C2R)) {
+            return plan->dtype == NDFFT_F32 ? col_split<float>(P, d_in, d_out, c, d, stream) : col_split<double>(P, d_in, d_out, c, d, stream);
+        }
         if (narrow) {
             auto fill = [&](auto &a) {
                 a.in = d_in; a.out = d_out; a.nlanes = P.nlanes;
                 a.pitch_in = 0; a.pitch_out = 0; a.vec_in = 0; a.vec_out = 0;
                 { const char *e = getenv("NDFFT_XCD_REMAP"); a.xcd_remap = !(e && e[0] == '0'); }
+                a.keep_out = 0;
                 a.n = n; a.F = c.F; a.n_in = (int)P.xlen; a.n_out = (int)P.ylen;
                 a.inner = P.b.back().shape;
                 a.outer_in = P.b.size() == 2 ? P.b[0].sin : 0;
@@ -468,7 +562,7 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
                 a.elem_in = P.xs; a.elem_out = P.ys;
                 const size_t es_in = (op_in_cplx(P.op) ? 2 : 1) * real_size(plan->dtype);
                 a.vec_in = !col && ((uintptr_t)d_in % 16 == 0) && ((size_t)a.pitch_in * es_in) % 16 == 0;
-                a.xcd_remap = 0;
+                a.xcd_remap = 0; a.keep_out = P.keep_out;
                 const size_t es_out = (op_out_cplx(P.op) ? 2 : 1) * real_size(plan->dtype);
                 a.vec_out = !col && ((uintptr_t)d_out % 16 == 0) && ((size_t)a.pitch_out * es_out) % 16 == 0;
             };

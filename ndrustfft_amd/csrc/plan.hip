@@ -68,6 +68,7 @@ static bool factorize(int F, std::vector<int> &radix) {
 
 static ndfft_plan *make_plan(int kind, int dtype, size_t n);
 static void add_narrow_tables(ndfft_plan *p);
+static void add_colsplit(ndfft_plan *p);
 
 // per-pass transposed twiddles of the LDS Stockham kernel: for pass p (radix R, Ns = product of the
 // earlier radices) the block  tw_p[(r-1) Ns + k] = e^{-2 pi i r k/(Ns R)},  r in [1,R), k in [0,Ns);
@@ -218,7 +219,30 @@ static ndfft_plan *make_plan(int kind, int dtype, size_t n) {
     p->kind = kind; p->dtype = dtype; p->n = n; p->refcount = 1;
     build_plan_tables(p);
     add_narrow_tables(p);
+    add_colsplit(p);
     return p;
+}
+
+// Column four-step for long strided power-of-two lanes (C2C n >= 4096, R2C n >= 8192): n = F1 * 64.
+// Only the MAIN slot of C2C / R2C plans; F1 (or its inner real FFT F1/2) must have a wide column kernel.
+static void add_colsplit(ndfft_plan *p) {
+    if (p->kind != NDFFT_KIND_C2C && p->kind != NDFFT_KIND_R2C) return;
+    const size_t n = p->n;
+    if (n == 0 || (n & (n - 1))) return;
+    const int F2 = colsplit_inner_len();
+    if (n % F2) return;
+    const size_t F1 = n / F2;
+    const size_t lo = p->kind == NDFFT_KIND_C2C ? 64 : 128, hi = p->kind == NDFFT_KIND_C2C ? 1024 : 2048;
+    if (F1 < lo || F1 > hi) return;
+    FftConfig &c = p->cfg[CFG_MAIN];
+    c.cs = true; c.cs_F1 = (int)F1; c.cs_F2 = F2;
+    c.cs_sub1 = make_plan(p->kind, p->dtype, F1);
+    c.cs_sub2 = make_plan(NDFFT_KIND_C2C, p->dtype, (size_t)F2);
+    int logn = 0; while (((size_t)1 << logn) < n) ++logn;
+    c.cs_logB = (logn + 1) / 2;
+    const int64_t B = 1ll << c.cs_logB;
+    for (int64_t k = 0; k < B && k < (int64_t)n; ++k) unit(c.cs_twlo, k, n);
+    for (int64_t k = 0; k * B < (int64_t)n; ++k) unit(c.cs_twhi, k * B, n);
 }
 
 static void add_narrow_tables(ndfft_plan *p) {
@@ -270,6 +294,8 @@ int get_dev_tables(const ndfft_plan *cplan, const DevTables **out) {
         if ((rc = upload_any(plan->dtype, c.twp, &d.twp))) return rc;
         if ((rc = upload_any(plan->dtype, c.twlo, &d.twlo))) return rc;
         if ((rc = upload_any(plan->dtype, c.twhi, &d.twhi))) return rc;
+        if ((rc = upload_any(plan->dtype, c.cs_twlo, &d.cs_twlo))) return rc;
+        if ((rc = upload_any(plan->dtype, c.cs_twhi, &d.cs_twhi))) return rc;
         if ((rc = upload_any(plan->dtype, c.twp_col, &d.twp_col))) return rc;
         if ((rc = upload_any(plan->dtype, c.twp_narrow, &d.twp_narrow))) return rc;
     }
@@ -336,12 +362,13 @@ int ndfft_plan_destroy(ndfft_plan *plan) {
         (void)hipSetDevice(kv.first);
         for (int i = 0; i < CFG_COUNT; ++i) {
             DevConfig &d = kv.second.cfg[i];
-            void *ptrs[] = {d.tw, d.twM, d.chirp, d.bhat, d.aux1, d.aux2, d.twp, d.twlo, d.twhi, d.twp_col, d.twp_narrow};
+            void *ptrs[] = {d.tw, d.twM, d.chirp, d.bhat, d.aux1, d.aux2, d.twp, d.twlo, d.twhi, d.twp_col, d.twp_narrow, d.cs_twlo, d.cs_twhi};
             for (void *q : ptrs) if (q) (void)hipFree(q);
         }
     }
     (void)hipSetDevice(cur);
-    for (int i = 0; i < CFG_COUNT; ++i) { ndfft_plan_destroy(plan->cfg[i].sub1); ndfft_plan_destroy(plan->cfg[i].sub2); }
+    for (int i = 0; i < CFG_COUNT; ++i) { ndfft_plan_destroy(plan->cfg[i].sub1); ndfft_plan_destroy(plan->cfg[i].sub2);
+                                          ndfft_plan_destroy(plan->cfg[i].cs_sub1); ndfft_plan_destroy(plan->cfg[i].cs_sub2); }
     delete plan;
     return NDFFT_OK;
 }

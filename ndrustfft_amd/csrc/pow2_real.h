@@ -31,6 +31,13 @@ template <typename T> struct RealArgs {
     int32_t vec_in;   // row layout: every lane base is 16-byte aligned -> stage with 16-byte loads
     int32_t vec_out;  // row layout: output lanes 16-byte aligned -> stage the outputs in LDS and store 16 bytes per lane
     int32_t xcd_remap;   // narrow tiles: 1 = XCD-aware blockIdx -> tile map (0 only for A/B measurements)
+    // column four-step (CS kernels, see below): lane L = (o, k1, i) with (o, k1) = divmod(L / inner, cs_k1n)
+    const cpx<T> *cs_twlo, *cs_twhi;     // W_N^m = cs_twhi[m >> cs_logB] * cs_twlo[m & (2^cs_logB - 1)], N = cs_n
+    int32_t cs_logB, cs_k1n, cs_f1, cs_n;
+    int64_t cs_outer_in, cs_outer_out;   // stride of o on the side that is NOT the dense scratch array
+    int64_t cs_pitch;                    // row pitch of that side (= inner unless the block is processed in column chunks)
+    int32_t keep_out;                    // COL kernels: 1 = plain (cache-allocating) stores instead of non-temporal ones: the
+                                         // output is an intermediate that the next launch re-reads from the Infinity Cache
 };
 
 struct ZiNone { static __device__ __forceinline__ int map(int p) { return p; } };
@@ -46,7 +53,38 @@ struct ZiPhi { static __device__ __forceinline__ int map(int p) { return p + (p 
 // blockIdx -> tile map puts those 8 tiles on ONE XCD, back to back in dispatch order, so that the line
 // is fetched from HBM once and the other seven reads hit that XCD's L2 (workgroups are dealt round-robin
 // over the 8 XCDs: blocks b and b+8 share one -- MI355X_MICROARCH.md).  Placement only affects speed.
-template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = false, bool XCD = false> struct RealPow2Kernel {
+//
+// CS != 0 (COL, C2C ops only): the twiddled stage of a COLUMN FOUR-STEP.  A long strided lane of length
+// N = F1 * F (F = this kernel's length, the inner factor) is transformed in two passes of wide column
+// tiles instead of one pass of narrow ones: stage A runs the ordinary column kernel of length F1 over
+// a = row / F (rows b, b + F, ...), stage B is this kernel over b for every k1, with the twiddle
+// W_N^(b k1) fused into its load and the output row k1 + F1 k2 (no transpose anywhere: both stages see
+// >= 128-byte row segments).  The intermediate lives in a dense scratch array [o][k1][b][i].
+//   CS = 1  C2C: twiddle on load (conjugated for the inverse), rows k1 + F1 k2 on store
+//   CS = 2  second stage of R2C (OP = C2C_FWD): k1 = 0..F1/2 only (stage A was a real FFT); every row of
+//           the half spectrum is written once, either as Z[k1 + F1 k2] or as conj at the mirrored row
+//           N - (k1 + F1 k2) = (F1 - k1) + F1 (F - 1 - k2)
+//   CS = 3  first stage of C2R (OP = C2C_INV): the Hermitian gather of CS = 2 on load (imaginary parts of
+//           DC and Nyquist dropped, src/lib.rs:514-518), conj twiddle on store into the scratch array
+template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = false, bool XCD = false, int CS = 0> struct RealPow2Kernel {
+    static_assert(CS == 0 || (COL && !XCD && (OP == G_C2C_FWD || OP == G_C2C_INV)), "CS kernels are column C2C kernels");
+    // strided staging loop with U independent global loads in flight per thread before the first LDS store
+    // (a plain `for (j) dst[j] = in[j * stride]` leaves one or two loads outstanding: latency-bound)
+    template <int STEP, typename LD, typename ST> static __device__ __forceinline__ void stage_loop(int j0, int n, LD ld, ST st) {
+        constexpr int U = 8;
+        int j = j0;
+        for (; j + (U - 1) * STEP < n; j += U * STEP) {
+            decltype(ld(0)) tmp[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) tmp[u] = ld(j + u * STEP);
+#pragma unroll
+            for (int u = 0; u < U; ++u) st(j + u * STEP, tmp[u]);
+        }
+        for (; j < n; j += STEP) st(j, ld(j));
+    }
+    static __device__ __forceinline__ cpx<T> cs_tw(const RealArgs<T> &a, int m) {
+        return cmul(a.cs_twhi[m >> a.cs_logB], a.cs_twlo[m & ((1 << a.cs_logB) - 1)]);
+    }
     static constexpr int E = F / TPL;
     static constexpr int THREADS = TPL * LPB;
     // complex elements per lane: padded Z, or F+1 raw complex.  COL: odd, so adjacent lanes spread over the
@@ -108,12 +146,32 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
             if (L < a.nlanes) {
                 const int64_t base = (L / a.inner) * a.outer_in + (L % a.inner);
                 char *dst = smem + (size_t)cl * LANE_LDS * 2 * sizeof(T);
-                if constexpr (IN_CPLX) {
+                constexpr int STEP = THREADS / LPB;
+                if constexpr (CS == 1 || CS == 2) {
                     const cpx<T> *in = (const cpx<T> *)a.in + base;
-                    for (int j = j0; j < a.n_in; j += THREADS / LPB) ((cpx<T> *)dst)[j] = in[(int64_t)j * a.elem_in];
+                    const int k1 = (int)((L / a.inner) % a.cs_k1n);
+                    struct VW { cpx<T> v, w; };
+                    stage_loop<STEP>(j0, a.n_in,
+                        [&](int j) { VW r; r.v = in[(int64_t)j * a.elem_in]; r.w = cs_tw(a, j * k1); return r; },
+                        [&](int j, VW r) { if constexpr (OP == G_C2C_INV) r.w = cconj(r.w); ((cpx<T> *)dst)[j] = cmul(r.v, r.w); });
+                } else if constexpr (CS == 3) {
+                    const int64_t ok = L / a.inner;
+                    const int k1 = (int)(ok % a.cs_k1n);
+                    const cpx<T> *in = (const cpx<T> *)a.in + (ok / a.cs_k1n) * a.cs_outer_in + (L % a.inner);
+                    stage_loop<STEP>(j0, a.n_in,
+                        [&](int j) { const int row = k1 + a.cs_f1 * j; return in[(int64_t)(2 * row > a.cs_n ? a.cs_n - row : row) * a.elem_in]; },
+                        [&](int j, cpx<T> v) {
+                            const int row = k1 + a.cs_f1 * j;
+                            if (2 * row > a.cs_n) v.y = -v.y;
+                            if (row == 0 || 2 * row == a.cs_n) v.y = 0;
+                            ((cpx<T> *)dst)[j] = v;
+                        });
+                } else if constexpr (IN_CPLX) {
+                    const cpx<T> *in = (const cpx<T> *)a.in + base;
+                    stage_loop<STEP>(j0, a.n_in, [&](int j) { return in[(int64_t)j * a.elem_in]; }, [&](int j, cpx<T> v) { ((cpx<T> *)dst)[j] = v; });
                 } else {
                     const T *in = (const T *)a.in + base;
-                    for (int j = j0; j < a.n_in; j += THREADS / LPB) ((T *)dst)[j] = in[(int64_t)j * a.elem_in];
+                    stage_loop<STEP>(j0, a.n_in, [&](int j) { return in[(int64_t)j * a.elem_in]; }, [&](int j, T v) { ((T *)dst)[j] = v; });
                 }
             }
         } else if constexpr (!DIRECT_IN) {
@@ -123,10 +181,10 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                 cpx<T> *raw = (cpx<T> *)lds;
                 if (sizeof(T) == 4 && a.vec_in) {   // two c64 per 16-byte load
                     const int nv = a.n_in >> 1;
-                    for (int j = t; j < nv; j += TPL) ((vec4f *)raw)[j] = ((const vec4f *)in)[j];
+                    stage_loop<TPL>(t, nv, [&](int j) { return ((const vec4f *)in)[j]; }, [&](int j, vec4f v) { ((vec4f *)raw)[j] = v; });
                     for (int j = 2 * nv + t; j < a.n_in; j += TPL) raw[j] = in[j];
                 } else {
-                    for (int j = t; j < a.n_in; j += TPL) raw[j] = in[j];
+                    stage_loop<TPL>(t, a.n_in, [&](int j) { return in[j]; }, [&](int j, cpx<T> v) { raw[j] = v; });
                 }
             } else {
                 const T *in = (const T *)a.in + lsafe * a.pitch_in;
@@ -134,10 +192,10 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                 if (a.vec_in) {                      // 2 doubles / 4 floats per 16-byte load
                     constexpr int W = 16 / sizeof(T);
                     const int nv = a.n_in / W;
-                    for (int j = t; j < nv; j += TPL) ((vec4f *)raw)[j] = ((const vec4f *)in)[j];
+                    stage_loop<TPL>(t, nv, [&](int j) { return ((const vec4f *)in)[j]; }, [&](int j, vec4f v) { ((vec4f *)raw)[j] = v; });
                     for (int j = W * nv + t; j < a.n_in; j += TPL) raw[j] = in[j];
                 } else {
-                    for (int j = t; j < a.n_in; j += TPL) raw[j] = in[j];
+                    stage_loop<TPL>(t, a.n_in, [&](int j) { return in[j]; }, [&](int j, T v) { raw[j] = v; });
                 }
             }
         }
@@ -188,7 +246,10 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                     for (int k = j0; k <= F / 2; k += THREADS / LPB) {
                         const PairOut<cpx<T>> r = post_pair<cpx<T>>(a, res, k);
 #pragma unroll
-                        for (int z = 0; z < 4; ++z) if (r.q[z] >= 0) gstore<T, !XCD>(out + (int64_t)r.q[z] * a.elem_out, r.v[z]);
+                        for (int z = 0; z < 4; ++z)
+                            if (r.q[z] >= 0) {
+                                if (XCD || a.keep_out) out[(int64_t)r.q[z] * a.elem_out] = r.v[z]; else gstore<T, true>(out + (int64_t)r.q[z] * a.elem_out, r.v[z]);
+                            }
                     }
                 } else {
                     T *out = (T *)a.out + base;
@@ -202,9 +263,32 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                             }
                     }
                 }
+            } else if constexpr (CS == 1 || CS == 2) {
+                const int64_t ok = L / a.inner;
+                const int k1 = (int)(ok % a.cs_k1n);
+                cpx<T> *out = (cpx<T> *)a.out + (ok / a.cs_k1n) * a.cs_outer_out + (L % a.inner);   // row 0 of (o, i)
+                for (int q = j0; q < F; q += THREADS / LPB) {
+                    cpx<T> val = post_cplx<T, OP, ZiPhi>(a, res, q);
+                    int kk = k1, r2 = q;
+                    bool skip = false;
+                    if constexpr (CS == 2) {
+                        if (k1 == 0) skip = q > F / 2;
+                        else if (2 * k1 == a.cs_f1) skip = q >= F / 2;
+                        else if (q >= F / 2) { kk = a.cs_f1 - k1; r2 = F - 1 - q; val.y = -val.y; }
+                    }
+                    if (!skip) gstore<T, true>(out + (int64_t)kk * a.cs_pitch + (int64_t)r2 * a.elem_out, val);
+                }
+            } else if constexpr (CS == 3) {
+                const int k1 = (int)((L / a.inner) % a.cs_k1n);
+                cpx<T> *out = (cpx<T> *)a.out + base;
+                for (int q = j0; q < F; q += THREADS / LPB)
+                    out[(int64_t)q * a.elem_out] = cmul(post_cplx<T, OP, ZiPhi>(a, res, q), cconj(cs_tw(a, q * k1)));
             } else if constexpr (OUT_CPLX) {
                 cpx<T> *out = (cpx<T> *)a.out + base;
-                for (int q = j0; q < a.n_out; q += THREADS / LPB) gstore<T, !XCD>(out + (int64_t)q * a.elem_out, post_cplx<T, OP, ZiPhi>(a, res, q));
+                for (int q = j0; q < a.n_out; q += THREADS / LPB) {
+                    const cpx<T> val = post_cplx<T, OP, ZiPhi>(a, res, q);
+                    if (XCD || a.keep_out) out[(int64_t)q * a.elem_out] = val; else gstore<T, true>(out + (int64_t)q * a.elem_out, val);
+                }
             } else {
                 T *out = (T *)a.out + base;
                 for (int q = j0; q < a.n_out; q += THREADS / LPB) {

@@ -2,6 +2,8 @@
 through the C ABI) and tests/test_emul_parity.py (the same sources compiled for the host through
 tests/emul, CPU container).  Every case compares against the CPU oracle on the same seeded inputs
 and/or the committed golden vectors.  Tolerances are BASELINE.json's: 1e-10 (f64), 1e-4 (f32)."""
+import os
+
 import numpy as np
 
 import synth
@@ -269,8 +271,12 @@ def long_strided_lanes(L):
              ("ndfft_r2c", (8192, 40), 0, np.float32, "transpose+pow2_real"), ("ndifft_r2c", (8192, 20), 0, np.float32, "transpose+pow2_real"),
              ("nddct2", (3, 4096, 17), 1, np.float64, "transpose+pow2_real"), ("ndfft", (3000, 33), 0, np.float64, "transpose+generic_row"),
              ("nddct3", (2, 4000, 16), 1, np.float32, "transpose+generic_row"))
-    for name, shape, axis, rdt, want in cases:
-        assert run_case(L, name, shape, axis, rdt) == want, (name, shape)
+    os.environ["NDFFT_COLSPLIT"] = "0"          # (the column four-step would take the first four)
+    try:
+        for name, shape, axis, rdt, want in cases:
+            assert run_case(L, name, shape, axis, rdt) == want, (name, shape)
+    finally:
+        del os.environ["NDFFT_COLSPLIT"]
 
 
 def pow2_real_sizes(L, sizes=(64, 128, 256, 512, 1024, 2048, 4096, 8192), dtypes=(np.float64, np.float32)):
@@ -347,8 +353,37 @@ def narrow_xcd_tiles(L):
              ("ndfft", (4096, 64), 0, np.float64), ("nddct2", (2, 4096, 130), 1, np.float64), ("ndifft", (2048, 200), 0, np.float64),
              ("nddct1", (4097, 64), 0, np.float32), ("ndfft", (8192, 64), 0, np.float32), ("ndfft_r2c", (16384, 66), 0, np.float32),
              ("nddct3", (4096, 1000), 0, np.float64), ("nddct4", (8192, 96), 0, np.float32))
-    for name, shape, axis, rdt in cases:
-        assert run_case(L, name, shape, axis, rdt) == "pow2_col_xcd", (name, shape)
+    os.environ["NDFFT_COLSPLIT"] = "0"          # the column four-step would take the C2C / R2C / C2R cases
+    try:
+        for name, shape, axis, rdt in cases:
+            assert run_case(L, name, shape, axis, rdt) == "pow2_col_xcd", (name, shape)
+    finally:
+        del os.environ["NDFFT_COLSPLIT"]
+
+
+def column_four_step(L):
+    """Long strided power-of-two lanes on a dense C-layout block: two passes of wide column tiles
+    (C2C n >= 4096, R2C / C2R n >= 8192), incl. 3-D outer dims, ragged inner extents and both norms."""
+    cases = (("ndfft", (4096, 48), 0, np.float64, "Default"), ("ndifft", (4096, 40), 0, np.float32, "Default"),
+             ("ndifft", (4096, 16), 0, np.float64, "None"), ("ndfft", (8192, 33), 0, np.float32, "Default"),
+             ("ndfft", (2, 4096, 24), 1, np.float64, "Default"), ("ndifft", (3, 4096, 17), 1, np.float32, "Default"),
+             ("ndfft_r2c", (8192, 64), 0, np.float32, "Default"), ("ndfft_r2c", (8192, 21), 0, np.float64, "Default"),
+             ("ndifft_r2c", (8192, 48), 0, np.float64, "Default"), ("ndifft_r2c", (8192, 40), 0, np.float32, "None"),
+             ("ndfft_r2c", (2, 8192, 20), 1, np.float32, "Default"), ("ndifft_r2c", (3, 8192, 16), 1, np.float32, "Default"),
+             ("ndfft_r2c", (16384, 35), 0, np.float64, "Default"), ("ndifft_r2c", (16384, 32), 0, np.float32, "Default"),
+             ("ndfft", (16384, 19), 0, np.float32, "Default"))
+    for name, shape, axis, rdt, norm in cases:
+        assert run_case(L, name, shape, axis, rdt, norm=norm) == "col_split", (name, shape)
+    # too few adjacent lanes for a wide tile: narrow tiles / transpose route as before
+    assert run_case(L, "ndfft", (4096, 8), 0, np.float64) != "col_split"
+    # column chunks (Infinity-Cache-resident intermediate): force small chunks so that these shapes split
+    os.environ["NDFFT_CS_CHUNK_MB"] = "1"
+    try:
+        for name, shape, rdt in (("ndfft_r2c", (8192, 200), np.float32), ("ndifft_r2c", (8192, 136), np.float32),
+                                 ("ndfft", (4096, 100), np.float64), ("ndifft", (8192, 150), np.float32)):
+            assert run_case(L, name, shape, 0, rdt) == "col_split", (name, shape)
+    finally:
+        del os.environ["NDFFT_CS_CHUNK_MB"]
 
 
 def jit_specialised_sizes(L):

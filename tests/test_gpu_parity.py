@@ -30,6 +30,7 @@ def test_clone(L): ps.handler_clone_shares_plan(L)
 def test_shared_handler_across_threads(L): ps.shared_handler_across_threads(L)
 def test_long_strided_lanes(L): ps.long_strided_lanes(L)
 def test_narrow_xcd_tiles(L): ps.narrow_xcd_tiles(L)
+def test_column_four_step(L): ps.column_four_step(L)
 def test_long_lanes_four_step(L): ps.long_lanes_four_step(L, full=True)
 def test_pow2_real_sizes(L): ps.pow2_real_sizes(L)
 def test_jit_specialised_sizes(L): ps.jit_specialised_sizes(L)
