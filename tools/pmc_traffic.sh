@@ -6,7 +6,7 @@ TAG=${1:-pmc}; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $C --output-format csv -d $OUT/$C -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/$C.log 2>&1
+  timeout 600 rocprofv3 --pmc $C --output-format csv -d $OUT/$C -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --ramp-ms 0 --no-cpu-baseline > $OUT/$C.log 2>&1
   echo "$C pass exit $?"
 done
 cd $GRAFT_REPO_ROOT
