@@ -83,6 +83,9 @@ struct FftConfig {                 // one complex-FFT-of-length-F recipe + op ta
     bool cs = false; int cs_F1 = 0, cs_F2 = 0, cs_logB = 0;
     ndfft_plan *cs_sub1 = nullptr, *cs_sub2 = nullptr;
     HostTable cs_twlo, cs_twhi;    // W_n^m for m < n, split like twlo / twhi
+    bool blue_reg_only = false;    // M exceeds the LDS kernel's reach: only the register kernel can run it
+    bool bluereg = false;          // blue && M has a register-kernel configuration: blue_kernel.h, specialised with hiprtc
+                                   // (jitcfg = configuration for M, twp = its per-pass twiddles)
     bool jit = false; JitCfg jitcfg;   // C2C slot: smooth non-power-of-two n -> specialised register kernel (jit.hip); twiddles in twp
     bool unsupported = false;      // no single-kernel fit and no usable factorisation (large prime factor)
 };
@@ -148,6 +151,8 @@ template <typename T> int pow2_real_narrow_lanes(int F);   // lanes per XCD-awar
 void pow2_real_build_narrow_twiddles(int dtype, int F, HostTable &out);
 template <typename T> int launch_pow2_real_narrow(int gen_op, const RealArgs<T> &a, hipStream_t s);
 // column four-step, twiddled stage (kernels_colsplit.hip): cs = 1 C2C, 2 = R2C second stage, 3 = C2R first stage
+bool pow2_real_config(int F, JitCfg &cfg);
+template <typename T> int launch_jit_blue(int gen_op, const JitCfg &cfgM, bool col, const RealArgs<T> &a, hipStream_t s);
 int colsplit_inner_len();
 int colsplit_tile_lanes();
 template <typename T> int launch_colsplit(int cs, bool inverse, const RealArgs<T> &a, hipStream_t s);

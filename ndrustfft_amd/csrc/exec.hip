@@ -254,6 +254,12 @@ static bool narrow_enabled() {
     return on;
 }
 
+// developer switch: NDFFT_BLUE=0 keeps Bluestein lengths on the LDS kernel
+static bool blue_enabled() {
+    const char *e = getenv("NDFFT_BLUE");
+    return !(e && e[0] == '0');
+}
+
 // developer switch: NDFFT_COLSPLIT=0 keeps long strided lanes on the narrow-tile / transpose routes
 static bool colsplit_enabled() {   // read per call: the parity tests toggle it to reach the narrow-tile kernels
     const char *e = getenv("NDFFT_COLSPLIT");
@@ -504,12 +510,14 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
         const bool is_c2c = plan->kind == NDFFT_KIND_C2C;
         const bool odd_variant = gop == G_R2C_ODD || gop == G_C2R_ODD || gop == G_DCT2_ODD || gop == G_DCT3_ODD || gop == G_DCT4_ODD;
         const bool use_jit = c.jit && !c.pow2 && P.nlanes * (int64_t)c.F >= (1 << 16);
-        const bool have_tw = use_jit || (is_c2c ? !c.twp_col.re.empty() : c.pow2);
-        const bool row = !is_c2c && P.xs == 1 && P.ys == 1 && P.b.size() <= 1;
+        // Bluestein lengths on the register kernel (blue_kernel.h), every op incl. the odd-n variants and row C2C
+        const bool use_blue = c.bluereg && ((P.nlanes * (int64_t)c.M >= (1 << 16) && blue_enabled()) || c.blue_reg_only);
+        const bool have_tw = use_jit || use_blue || (is_c2c ? !c.twp_col.re.empty() : c.pow2);
+        const bool row = (!is_c2c || use_blue) && P.xs == 1 && P.ys == 1 && P.b.size() <= 1;
         bool col = false, narrow = false;
-        if (!row && !odd_variant && P.xlen > 1 && !P.b.empty() && P.b.size() <= 2 && P.b.back().sin == 1 && P.b.back().sout == 1) {
+        if (!row && (!odd_variant || use_blue) && P.xlen > 1 && !P.b.empty() && P.b.size() <= 2 && P.b.back().sin == 1 && P.b.back().sout == 1) {
             if (have_tw && P.b.back().shape >= 8) {
-                const int lanes = use_jit ? jit_col_lanes(plan->dtype, c.jitcfg)
+                const int lanes = (use_jit || use_blue) ? jit_col_lanes(plan->dtype, c.jitcfg)
                                           : plan->dtype == NDFFT_F32 ? pow2_real_col_lanes<float>(c.F) : pow2_real_col_lanes<double>(c.F);
                 col = lanes > 0;
             }
@@ -550,7 +558,7 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
             set_last_path("pow2_col_xcd");
             return rc2;
         }
-        if (have_tw && !odd_variant && (row || col)) {
+        if (have_tw && (!odd_variant || use_blue) && (row || col)) {
             auto fill = [&](auto &a) {
                 a.in = d_in; a.out = d_out; a.nlanes = P.nlanes;
                 a.pitch_in = P.b.empty() ? P.xlen : P.b[0].sin;
@@ -569,15 +577,19 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
             int rc2;
             if (plan->dtype == NDFFT_F32) {
                 RealArgs<float> a; fill(a); a.scale = (float)P.scale;
-                a.aux1 = (const float2 *)d.aux1; a.aux2 = (const float2 *)d.aux2; a.twp = (const float2 *)((is_c2c && !use_jit) ? d.twp_col : d.twp);
-                rc2 = use_jit ? launch_jit_real<float>(gop, c.jitcfg, col, a, stream) : launch_pow2_real<float>(gop, a, col, stream);
+                a.aux1 = (const float2 *)d.aux1; a.aux2 = (const float2 *)d.aux2; a.twp = (const float2 *)((is_c2c && !use_jit && !use_blue) ? d.twp_col : d.twp);
+                a.chirp = (const float2 *)d.chirp; a.bhat = (const float2 *)d.bhat;
+                rc2 = use_blue ? launch_jit_blue<float>(gop, c.jitcfg, col, a, stream)
+                      : use_jit ? launch_jit_real<float>(gop, c.jitcfg, col, a, stream) : launch_pow2_real<float>(gop, a, col, stream);
             } else {
                 RealArgs<double> a; fill(a); a.scale = P.scale;
-                a.aux1 = (const double2 *)d.aux1; a.aux2 = (const double2 *)d.aux2; a.twp = (const double2 *)((is_c2c && !use_jit) ? d.twp_col : d.twp);
-                rc2 = use_jit ? launch_jit_real<double>(gop, c.jitcfg, col, a, stream) : launch_pow2_real<double>(gop, a, col, stream);
+                a.aux1 = (const double2 *)d.aux1; a.aux2 = (const double2 *)d.aux2; a.twp = (const double2 *)((is_c2c && !use_jit && !use_blue) ? d.twp_col : d.twp);
+                a.chirp = (const double2 *)d.chirp; a.bhat = (const double2 *)d.bhat;
+                rc2 = use_blue ? launch_jit_blue<double>(gop, c.jitcfg, col, a, stream)
+                      : use_jit ? launch_jit_real<double>(gop, c.jitcfg, col, a, stream) : launch_pow2_real<double>(gop, a, col, stream);
             }
-            if (!(use_jit && rc2 == NDFFT_ERR_UNSUPPORTED)) {   // UNSUPPORTED from the JIT = no hiprtc / compile failed: fall through to the LDS kernel
-                set_last_path(use_jit ? (col ? "jit_col" : "jit_real") : (col ? "pow2_col" : "pow2_real"));
+            if (!((use_jit || use_blue) && rc2 == NDFFT_ERR_UNSUPPORTED)) {   // UNSUPPORTED from the JIT = no hiprtc / compile failed: fall through to the LDS kernel
+                set_last_path(use_blue ? (col ? "blue_col" : "blue_reg") : use_jit ? (col ? "jit_col" : "jit_real") : (col ? "pow2_col" : "pow2_real"));
                 return rc2;
             }
         }
@@ -586,6 +598,8 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
         int slot;
         (void)gen_op_of(P.op, (int)plan->n, &slot);
         const FftConfig &c = plan->cfg[slot];
+        if (c.blue_reg_only && P.xs == 1 && P.ys == 1 && P.b.size() <= 1)
+            return fail(NDFFT_ERR_UNSUPPORTED, "this lane length needs the hiprtc-specialised Bluestein kernel (libhiprtc missing or NDFFT_JIT=0)");
         if (c.unsupported)
             return fail(NDFFT_ERR_UNSUPPORTED, "lane length has a prime factor too large for the single-launch Bluestein and no usable "
                                                "four-step split (DESIGN.md section 9)");
@@ -616,6 +630,13 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
             }
             return rc2;
         }
+    }
+    {
+        int slot;
+        (void)gen_op_of(P.op, (int)plan->n, &slot);
+        if (plan->cfg[slot].blue_reg_only)
+            return fail(NDFFT_ERR_UNSUPPORTED, "this lane length runs only on the hiprtc-specialised Bluestein kernel, which needs unit-stride "
+                                               "lanes or a C-layout column tile (libhiprtc missing, NDFFT_JIT=0, or an unusual layout)");
     }
     return plan->dtype == NDFFT_F32 ? dispatch_generic<float>(P, d_in, d_out, *dt, stream)
                                     : dispatch_generic<double>(P, d_in, d_out, *dt, stream);

@@ -98,6 +98,13 @@ bool jit_choose(int dtype, int n, JitCfg &cfg) {
     return true;
 }
 
+// dynamic LDS a module (hiprtc) function may be launched with: the full 160 KiB of a gfx950 CU -- no
+// opt-in attribute is needed for module functions (checked on the MI355X: a 136 KiB launch runs and is correct)
+static size_t jit_lds_limit() {
+    static const size_t v = [] { const char *e = getenv("NDFFT_JIT_LDS_KB"); return (size_t)(e ? atoi(e) : 160) * 1024; }();
+    return v;
+}
+
 void jit_build_twiddles(const JitCfg &cfg, HostTable &out) {
     const long double kPiL = 3.14159265358979323846264338327950288L;
     unsigned long long Ns = 1;
@@ -122,10 +129,10 @@ Entry get_or_compile(const std::string &key, const std::string &src, const std::
     auto it = g_cache.find(key);
     if (it != g_cache.end()) return it->second;
     Entry ne;
-    const char *hn[] = {"device_common.h", "butterflies.h", "pow2_kernel.h", "realops.h", "pow2_real.h"};
-    const char *hs[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h, jit_src_realops_h, jit_src_pow2_real_h};
+    const char *hn[] = {"device_common.h", "butterflies.h", "pow2_kernel.h", "realops.h", "pow2_real.h", "blue_kernel.h"};
+    const char *hs[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h, jit_src_realops_h, jit_src_pow2_real_h, jit_src_blue_kernel_h};
     rtcProgram prog = nullptr;
-    bool ok = r.ok && r.create(&prog, src.c_str(), "k_jit.hip", 5, hs, hn) == 0;
+    bool ok = r.ok && r.create(&prog, src.c_str(), "k_jit.hip", 6, hs, hn) == 0;
     if (ok) {
         const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast"};
         ok = r.compile(prog, 4, opts) == 0;
@@ -167,7 +174,7 @@ int launch_jit_c2c(int dtype, const JitCfg &cfg, int nt, const Pow2Args &a, hipS
     if (e.failed) return NDFFT_ERR_UNSUPPORTED;
     const size_t esz = dtype == NDFFT_F32 ? 4 : 8;
     const size_t lds = (size_t)cfg.lpb * (size_t)(cfg.n + (cfg.n >> 4) + 1) * esz;   // Pow2Kernel::LDS_BYTES (HALF exchange)
-    if (lds > 64 * 1024) return NDFFT_ERR_UNSUPPORTED;   // module functions get the default dynamic-LDS limit
+    if (lds > jit_lds_limit()) return NDFFT_ERR_UNSUPPORTED;
     const int64_t nblk = (a.nlanes + cfg.lpb - 1) / cfg.lpb;
     if (nblk <= 0) return NDFFT_OK;
     if (nblk > 0x7fffffffLL) return NDFFT_ERR_UNSUPPORTED;
@@ -183,8 +190,7 @@ int jit_col_lanes(int dtype, const JitCfg &cfg) {
     thr = thr > 1024 ? 1024 : (thr < 256 ? 256 : thr);
     const int lpb = thr / cfg.tpl;
     const size_t lane = (size_t)((cfg.n + (cfg.n >> 4) + 2) | 1) * 2 * (dtype == NDFFT_F32 ? 4 : 8);
-    int l = lpb;
-    while (l >= 8 && (size_t)l * lane > 64 * 1024) l /= 2;   // module functions: 64 KiB of dynamic LDS
+    const int l = (int)std::min<size_t>((size_t)lpb, jit_lds_limit() / lane);
     return l >= 8 ? l : 0;
 }
 
@@ -208,7 +214,7 @@ template <typename T> int launch_jit_real(int gop, const JitCfg &cfg, bool col, 
     const int F = cfg.n;
     const size_t lane_lds = col ? (size_t)((F + (F >> 4) + 2) | 1) : (size_t)((F + (F >> 4) + 3) & ~1);
     const size_t lds = (size_t)lpb * lane_lds * 2 * sizeof(T);
-    if (lds > 64 * 1024) return NDFFT_ERR_UNSUPPORTED;
+    if (lds > jit_lds_limit()) return NDFFT_ERR_UNSUPPORTED;
     const int64_t nblk = (a.nlanes + lpb - 1) / lpb;
     if (nblk <= 0) return NDFFT_OK;
     if (nblk > 0x7fffffffLL) return NDFFT_ERR_UNSUPPORTED;
@@ -217,6 +223,37 @@ template <typename T> int launch_jit_real(int gop, const JitCfg &cfg, bool col, 
     NDFFT_HIP(hipModuleLaunchKernel(e.fn, (unsigned)nblk, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, s, params, nullptr));
     return NDFFT_OK;
 }
+// BlueKernel (blue_kernel.h) for Bluestein length cfgM.n = M: every op, rows and column tiles
+template <typename T> int launch_jit_blue(int gop, const JitCfg &cfg, bool col, const RealArgs<T> &a, hipStream_t s) {
+    if (!rtc().ok) return NDFFT_ERR_UNSUPPORTED;
+    const int dtype = sizeof(T) == 4 ? NDFFT_F32 : NDFFT_F64;
+    const int lpb = col ? jit_col_lanes(dtype, cfg) : (cfg.tpl >= 256 ? 1 : std::max(1, 256 / cfg.tpl));
+    if (lpb <= 0) return NDFFT_ERR_UNSUPPORTED;
+    int dev = 0;
+    NDFFT_HIP(hipGetDevice(&dev));
+    const char *tn = sizeof(T) == 4 ? "float" : "double";
+    const int threads = cfg.tpl * lpb;
+    const std::string inst = std::string("BlueKernel<") + tn + ", " + std::to_string(cfg.n) + ", " + std::to_string(cfg.tpl) + ", " +
+                             std::to_string(lpb) + ", RadixList<" + radix_list(cfg) + ">, " + std::to_string(gop) + ", " + (col ? "true" : "false") + ">";
+    const std::string src = std::string("#include \"blue_kernel.h\"\nusing namespace ndfft;\nextern \"C\" __global__ __launch_bounds__(") +
+                            std::to_string(threads) + ") void k_jit(const RealArgs<" + tn + "> a) { " + inst + "::run(a); }\n";
+    const Entry e = get_or_compile("dev" + std::to_string(dev) + ":" + inst, src, inst);
+    if (e.failed) return NDFFT_ERR_UNSUPPORTED;
+    const int M = cfg.n;
+    const size_t lane_lds = col ? (size_t)((M + (M >> 4) + 2) | 1) : (size_t)((M + (M >> 4) + 3) & ~1);
+    const size_t lds = (size_t)lpb * lane_lds * 2 * sizeof(T);
+    if (lds > jit_lds_limit()) return NDFFT_ERR_UNSUPPORTED;
+    const int64_t nblk = (a.nlanes + lpb - 1) / lpb;
+    if (nblk <= 0) return NDFFT_OK;
+    if (nblk > 0x7fffffffLL) return NDFFT_ERR_UNSUPPORTED;
+    RealArgs<T> arg = a;
+    void *params[] = {(void *)&arg};
+    NDFFT_HIP(hipModuleLaunchKernel(e.fn, (unsigned)nblk, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, s, params, nullptr));
+    return NDFFT_OK;
+}
+template int launch_jit_blue<float>(int, const JitCfg &, bool, const RealArgs<float> &, hipStream_t);
+template int launch_jit_blue<double>(int, const JitCfg &, bool, const RealArgs<double> &, hipStream_t);
+
 template int launch_jit_real<float>(int, const JitCfg &, bool, const RealArgs<float> &, hipStream_t);
 template int launch_jit_real<double>(int, const JitCfg &, bool, const RealArgs<double> &, hipStream_t);
 

@@ -32,6 +32,17 @@ bool pow2_real_supported(int F) {
     }
 }
 
+// threads per lane + radix list of the E = 8 configuration for inner length F (also used to specialise
+// blue_kernel.h for M = F with hiprtc)
+bool pow2_real_config(int F, JitCfg &cfg) {
+    switch (F) {
+#define NDFFT_CASE(F_, TPL_, ...) case F_: cfg.n = F_; cfg.tpl = TPL_; cfg.e = F_ / TPL_; cfg.radix = {__VA_ARGS__}; return true;
+        NDFFT_REAL_CONFIGS(NDFFT_CASE)
+#undef NDFFT_CASE
+        default: return false;
+    }
+}
+
 void pow2_real_build_twiddles(int F, HostTable &out) {
     switch (F) {
 #define NDFFT_CASE(F_, TPL_, ...) case F_: build_tw<RealCfg<F_>::RL>(out); break;

@@ -108,7 +108,11 @@ static void build_fft(FftConfig &c, int F, int dtype) {
         build_pass_twiddles(c.tw, c.radix, F);
         return;
     }
-    if (smooth || (size_t)blue_len(F) > maxlen) {
+    // Bluestein needs M = blue_len(F) in ONE launch: the LDS kernel up to `maxlen`, the register kernel
+    // (blue_kernel.h, hiprtc) wherever M has a register configuration (M <= 8192)
+    JitCfg regcfg;
+    const bool blue_lds = (size_t)blue_len(F) <= maxlen, blue_reg = pow2_real_config(blue_len(F), regcfg);
+    if (smooth || !(blue_lds || blue_reg)) {
         // long lane: F = F1 * F2 with both halves inside one launch, as square as possible
         c.radix.clear();
         int best = 0;
@@ -128,6 +132,7 @@ static void build_fft(FftConfig &c, int F, int dtype) {
     // Bluestein: chirp[j] = e^{-i pi j^2/F}; bhat = FFT_M(conj chirp wrapped)/M computed here in
     // long double by a direct radix-2 recursion so the device table is correctly rounded.
     c.blue = true;
+    c.blue_reg_only = !blue_lds;
     c.radix.clear();
     const int M = blue_len(F);
     c.M = M;
@@ -246,6 +251,11 @@ static void add_colsplit(ndfft_plan *p) {
 }
 
 static void add_narrow_tables(ndfft_plan *p) {
+    // Bluestein lengths: the register-kernel form (blue_kernel.h) when M has an E = 8 configuration
+    for (int i = 0; i < CFG_COUNT; ++i) {
+        FftConfig &c = p->cfg[i];
+        if (p->has_cfg[i] && c.blue && pow2_real_config(c.M, c.jitcfg)) { c.bluereg = true; c.twp = HostTable(); pow2_real_build_twiddles(c.M, c.twp); }
+    }
     // specialised (hiprtc) register kernels for the real-data ops with a smooth non-power-of-two inner FFT
     if (p->kind != NDFFT_KIND_C2C)
         for (int i = 0; i < CFG_COUNT; ++i) {

@@ -36,6 +36,7 @@ template <typename T> struct RealArgs {
     int32_t cs_logB, cs_k1n, cs_f1, cs_n;
     int64_t cs_outer_in, cs_outer_out;   // stride of o on the side that is NOT the dense scratch array
     int64_t cs_pitch;                    // row pitch of that side (= inner unless the block is processed in column chunks)
+    const cpx<T> *chirp, *bhat;          // Bluestein kernels (blue_kernel.h): e^{-i pi j^2/F}, FFT_M(conj chirp)/M
     int32_t keep_out;                    // COL kernels: 1 = plain (cache-allocating) stores instead of non-temporal ones: the
                                          // output is an intermediate that the next launch re-reads from the Infinity Cache
 };

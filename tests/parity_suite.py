@@ -386,6 +386,30 @@ def column_four_step(L):
         del os.environ["NDFFT_CS_CHUNK_MB"]
 
 
+def bluestein_register_kernel(L, sizes=((17, 64), (31, 64), (97, 256), (127, 256)), col_max_M=256):
+    """Lengths with a prime factor > 13 on the register-resident Bluestein kernel (blue_kernel.h): every op
+    family incl. the odd-n variants, rows and column tiles.  `sizes` = (F, M): inner FFT length F, M = 2^k >= 2F-1."""
+    for F, M in sizes:
+        rows = (1 << 16) // M + 5
+        for rdt in (np.float64, np.float32):
+            # C2C (n = F), odd-n real ops (inner FFT n = F; DCT-IV odd uses 2n, so it is not in this list)
+            for name in ("ndfft", "ndifft", "ndfft_r2c", "ndifft_r2c", "nddct2", "nddct3"):
+                for norm in ("Default", "None"):
+                    assert run_case(L, name, (rows, F), 1, rdt, norm=norm, offset=F) == "blue_reg", (name, F, rdt)
+            # even-n real ops: inner FFT n/2 = F;  DCT-I: n - 1 = F
+            for name in ("ndfft_r2c", "ndifft_r2c", "nddct2", "nddct3", "nddct4"):
+                assert run_case(L, name, (rows, 2 * F), 1, rdt, offset=F + 1) == "blue_reg", (name, 2 * F, rdt)
+            assert run_case(L, "nddct1", (rows, F + 1), 1, rdt, offset=F) == "blue_reg", ("nddct1", F + 1, rdt)
+            if M > col_max_M:
+                continue
+            # column tiles (strategy ii)
+            for name, n in (("ndfft", F), ("ndifft_r2c", 2 * F), ("nddct1", F + 1), ("nddct2", F), ("ndfft_r2c", F)):
+                assert run_case(L, name, (n, rows + 3), 0, rdt, offset=n) == "blue_col", (name, n, rdt)
+                assert run_case(L, name, (3, n, rows // 2), 1, rdt, offset=n + 1) == "blue_col", (name, n, rdt)
+    # few lanes: not worth a compile
+    assert run_case(L, "ndfft", (3, 97), 1, np.float64) == "generic_row"
+
+
 def jit_specialised_sizes(L):
     """Smooth non-power-of-two C2C lanes: the register-resident kernel specialised with hiprtc at first use."""
     for n in (96, 100, 144, 384, 500, 768, 1000, 1296, 1536, 2000, 2187, 3072, 3125):
