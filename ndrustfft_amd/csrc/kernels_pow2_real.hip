@@ -66,11 +66,15 @@ template <typename K, typename T> static int launch_k(const RealArgs<T> &a, int 
     return NDFFT_OK;
 }
 
+#ifndef NDFFT_COL_LANES_F32
+#define NDFFT_COL_LANES_F32 32
+#endif
 // threads of a COL workgroup: aim at 32 adjacent lanes per tile row, at most 1024 threads
-static constexpr int col_threads(int tpl) { return tpl * 32 > 1024 ? 1024 : (tpl * 32 < 256 ? 256 : tpl * 32); }
+static constexpr int col_threads(int tpl, int lanes) { return tpl * lanes > 1024 ? 1024 : (tpl * lanes < 256 ? 256 : tpl * lanes); }
 template <typename T, int F> struct ColGeom {
     static constexpr int TPL = RealCfg<F>::TPL;
-    static constexpr int LPB = col_threads(TPL) / TPL;
+    static constexpr int WANT = sizeof(T) == 4 ? NDFFT_COL_LANES_F32 : 32;   // f32 rows of a real tile are 4 B per lane
+    static constexpr int LPB = col_threads(TPL, WANT) / TPL;
     static constexpr size_t LDS = (size_t)LPB * (((F + (F >> 4) + 2) | 1)) * 2 * sizeof(T);
     static constexpr bool OK = LPB >= 8 && LDS <= 160 * 1024;
 };
