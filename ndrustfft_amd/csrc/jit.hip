@@ -63,7 +63,48 @@ bool jit_disabled() {
 
 // Picks threads-per-lane and a radix list for a smooth length: every radix divides E = n / TPL (so each
 // thread owns whole butterflies in every pass), fewest passes first, then the smallest E.
-bool jit_choose(int dtype, int n, JitCfg &cfg) {
+// Partial-round configurations (pow2_kernel.h: slots / full): any radix list whose product is n, any TPL.
+// Cost ~ passes x (work incl. idle threads of partial rounds): minimise NP / utilisation; ties -> E nearest 16.
+static bool jit_choose_partial(int dtype, int n, JitCfg &cfg) {
+    const int emax = dtype == NDFFT_F32 ? 32 : 30;
+    const int cand[] = {16, 13, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
+    std::vector<int> cur, best;
+    int best_tpl = 0, best_e = 0;
+    double best_cost = 1e30;
+    auto eval = [&]() {
+        const int np = (int)cur.size();
+        for (int tpl = std::max(1, (n + emax - 1) / emax / 2); tpl <= std::min(1024, n / 2); ++tpl) {
+            int e = 0; double work = 0;
+            for (int r : cur) {
+                const int nb = n / r, sl = (nb + tpl - 1) / tpl;
+                e = std::max(e, sl * r);
+                work += (double)sl * tpl * r;
+            }
+            if (e > emax) continue;
+            const double cost = work / n + 0.02 * std::abs(e - 16) / 16.0 + (tpl % 4 ? 0.05 : 0.0);   // work/n = NP / utilisation
+            (void)np;
+            if (cost < best_cost) { best_cost = cost; best = cur; best_tpl = tpl; best_e = e; }
+        }
+    };
+    std::function<void(int, int)> rec = [&](int m, int maxr) {
+        if (m == 1) { eval(); return; }
+        if (cur.size() >= 6) return;
+        for (int c : cand) {
+            if (c > maxr || m % c) continue;
+            cur.push_back(c);
+            rec(m / c, c);
+            cur.pop_back();
+        }
+    };
+    rec(n, 16);
+    if (best.empty()) return false;
+    cfg.n = n; cfg.e = best_e; cfg.tpl = best_tpl; cfg.radix = best;
+    cfg.lpb = cfg.tpl >= 256 ? 1 : std::max(1, 256 / cfg.tpl);
+    cfg.vec = 1; cfg.partial = true;
+    return true;
+}
+
+bool jit_choose(int dtype, int n, JitCfg &cfg, bool allow_partial) {
     if (jit_disabled() || n < 12 || n > 8192 || pow2_supported(dtype, n)) return false;
     {   int m = n; for (int p : {2, 3, 5, 7, 11, 13}) while (m % p == 0) m /= p; if (m != 1) return false; }
     // E complex registers per thread: 2E (f32) / 4E (f64) VGPRs of data.  Mixed 2-3-5 lengths need E = 30.
@@ -87,9 +128,8 @@ bool jit_choose(int dtype, int n, JitCfg &cfg) {
         }
     };
     rec(n, 16, 1);
-    if (best.empty()) return false;
+    if (best.empty() || n / best_e > 1024) return allow_partial && jit_choose_partial(dtype, n, cfg);
     cfg.n = n; cfg.e = best_e; cfg.tpl = n / best_e;
-    if (cfg.tpl > 1024) return false;
     cfg.radix = best;   // non-increasing: the largest radix first (most loads in flight on the global read)
     cfg.lpb = cfg.tpl >= 256 ? 1 : std::max(1, 256 / cfg.tpl);
     // f32: 16-byte (two-element) global accesses need an even number of butterflies per thread in the

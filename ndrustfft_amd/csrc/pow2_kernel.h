@@ -65,7 +65,14 @@ template <typename T, bool NT> __device__ __forceinline__ void gstore(cpx<T> *p,
 //   Needs E/R >= 2 in those passes, even lane pitches and 16-byte aligned bases (checked on the host).
 template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS = 0, int MINW = 1, int NT = 1, int VEC = 1> struct Pow2Kernel {
     static constexpr int MIN_WAVES = MINW;
-    static constexpr int E = N / TPL;
+    // Pass p has N / R_p butterflies, dealt to the TPL threads of the lane in SLOTS(p) rounds: j = t + q TPL.
+    // When TPL does not divide N / R_p the last round is PARTIAL (threads with j >= N / R_p idle): that is what
+    // lets radix lists like 840 = 8.7.5.3 run here although no E is a multiple of every radix.
+    static constexpr int nbfly(int p) { return N / RL::at(p); }
+    static constexpr int slots(int p) { return (nbfly(p) + TPL - 1) / TPL; }
+    static constexpr bool full(int p) { return nbfly(p) % TPL == 0; }
+    static constexpr int calc_e() { int e = 0; for (int p = 0; p < RL::NP; ++p) { const int x = slots(p) * RL::at(p); if (x > e) e = x; } return e; }
+    static constexpr int E = calc_e();                                     // = N / TPL when every pass is full
     static constexpr int THREADS = TPL * LPB;
     static constexpr int LANE_LDS = N + (N >> 4) + 1;                      // padded elements per lane
     static constexpr size_t LDS_BYTES = (size_t)LPB * LANE_LDS * (HALF ? sizeof(T) : 2 * sizeof(T));
@@ -78,20 +85,24 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
 
     template <int P>
     static __device__ __forceinline__ void passes(cpx<T> (&v)[E], const cpx<T> *__restrict__ twp, char *lds, int t) {
-        constexpr int R = RL::at(P), Ns = RL::ns(P), NBF = E / R;
+        constexpr int R = RL::at(P), Ns = RL::ns(P), NBF = slots(P), NB = nbfly(P);
+        constexpr bool FULL = full(P);
         if constexpr (P > 0 && !(FLAGS & 1)) {
             const cpx<T> *tw = twp + RL::twoff(P);
 #pragma unroll
             for (int q = 0; q < NBF; ++q) {
-                const int k = kmod<Ns>(jof<P>(t, q));
+                const int j = jof<P>(t, q), k = kmod<Ns>(j);
+                if (FULL || j < NB) {
 #pragma unroll
-                for (int r = 1; r < R; ++r) v[q * R + r] = cmul(v[q * R + r], tw[(r - 1) * Ns + k]);
+                    for (int r = 1; r < R; ++r) v[q * R + r] = cmul(v[q * R + r], tw[(r - 1) * Ns + k]);
+                }
             }
         }
 #pragma unroll
-        for (int q = 0; q < NBF; ++q) if constexpr (!(FLAGS & 4)) Bfly<T, R>::run(&v[q * R]);
+        for (int q = 0; q < NBF; ++q) if constexpr (!(FLAGS & 4)) { if (FULL || jof<P>(t, q) < NB) Bfly<T, R>::run(&v[q * R]); }
         if constexpr (P + 1 < RL::NP) {
-            constexpr int R2 = RL::at(P + 1), NB2 = N / R2, NBF2 = E / R2;
+            constexpr int R2 = RL::at(P + 1), NB2 = N / R2, NBF2 = slots(P + 1);
+            constexpr bool FULL2 = full(P + 1);
             if constexpr (FLAGS & 2) {
             } else if constexpr (HALF) {
                 T *s = (T *)lds;
@@ -101,17 +112,21 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
 #pragma unroll
                     for (int q = 0; q < NBF; ++q) {
                         const int j = jof<P>(t, q), k = kmod<Ns>(j), o = (j - k) * R + k;
+                        if (FULL || j < NB) {
 #pragma unroll
-                        for (int r = 0; r < R; ++r) s[phi(o + r * Ns)] = half ? v[q * R + r].y : v[q * R + r].x;
+                            for (int r = 0; r < R; ++r) s[phi(o + r * Ns)] = half ? v[q * R + r].y : v[q * R + r].x;
+                        }
                     }
                     __syncthreads();
 #pragma unroll
                     for (int q = 0; q < NBF2; ++q) {
                         const int j = jof<P + 1>(t, q);
+                        if (FULL2 || j < NB2) {
 #pragma unroll
-                        for (int r = 0; r < R2; ++r) {
-                            const T x = s[phi(j + r * NB2)];
-                            if (half) v[q * R2 + r].y = x; else v[q * R2 + r].x = x;
+                            for (int r = 0; r < R2; ++r) {
+                                const T x = s[phi(j + r * NB2)];
+                                if (half) v[q * R2 + r].y = x; else v[q * R2 + r].x = x;
+                            }
                         }
                     }
                 }
@@ -121,15 +136,19 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
 #pragma unroll
                 for (int q = 0; q < NBF; ++q) {
                     const int j = jof<P>(t, q), k = kmod<Ns>(j), o = (j - k) * R + k;
+                    if (FULL || j < NB) {
 #pragma unroll
-                    for (int r = 0; r < R; ++r) s[phi(o + r * Ns)] = v[q * R + r];
+                        for (int r = 0; r < R; ++r) s[phi(o + r * Ns)] = v[q * R + r];
+                    }
                 }
                 __syncthreads();
 #pragma unroll
                 for (int q = 0; q < NBF2; ++q) {
                     const int j = jof<P + 1>(t, q);
+                    if (FULL2 || j < NB2) {
 #pragma unroll
-                    for (int r = 0; r < R2; ++r) v[q * R2 + r] = s[phi(j + r * NB2)];
+                        for (int r = 0; r < R2; ++r) v[q * R2 + r] = s[phi(j + r * NB2)];
+                    }
                 }
             }
             passes<P + 1>(v, twp, lds, t);
@@ -146,9 +165,9 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
         char *lds = smem + (size_t)ll * LANE_LDS * (HALF ? sizeof(T) : 2 * sizeof(T));
         cpx<T> v[E];
         {
-            constexpr int R0 = RL::at(0), NB0 = N / R0, NBF0 = E / R0;
+            constexpr int R0 = RL::at(0), NB0 = N / R0, NBF0 = slots(0);
             if constexpr (VEC == 2) {
-                static_assert(NBF0 % 2 == 0, "VEC=2 needs an even number of butterflies per thread in pass 0");
+                static_assert(NBF0 % 2 == 0 && full(0) && full(RL::NP - 1), "VEC=2 needs an even number of whole butterfly rounds in the first and last pass");
 #pragma unroll
                 for (int q = 0; q < NBF0; q += 2)
 #pragma unroll
@@ -159,8 +178,10 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
             } else {
 #pragma unroll
                 for (int q = 0; q < NBF0; ++q)
+                    if (full(0) || t + q * TPL < NB0) {
 #pragma unroll
-                    for (int r = 0; r < R0; ++r) v[q * R0 + r] = gload<T, (NT & 2) != 0>(in + t + q * TPL + r * NB0);
+                        for (int r = 0; r < R0; ++r) v[q * R0 + r] = gload<T, (NT & 2) != 0>(in + t + q * TPL + r * NB0);
+                    }
             }
         }
         if (a.inverse) {
@@ -168,20 +189,22 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
             for (int i = 0; i < E; ++i) v[i].y = -v[i].y;
         }
         if constexpr ((FLAGS & 8) != 0) {   // fused four-step twiddle (after the conjugation, so the same table serves both directions)
-            constexpr int R0 = RL::at(0), NB0 = N / R0, NBF0 = E / R0;
+            constexpr int R0 = RL::at(0), NB0 = N / R0, NBF0 = slots(0);
             const int k1 = (int)(lane % a.f1), mask = (1 << a.logB) - 1;
             const cpx<T> *lo = (const cpx<T> *)a.twlo, *hi = (const cpx<T> *)a.twhi;
 #pragma unroll
             for (int q = 0; q < NBF0; ++q)
+                if (full(0) || jof<0>(t, q) < NB0) {
 #pragma unroll
-                for (int r = 0; r < R0; ++r) {
-                    const int m = (jof<0>(t, q) + r * NB0) * k1;
-                    v[q * R0 + r] = cmul(v[q * R0 + r], cmul(hi[m >> a.logB], lo[m & mask]));
+                    for (int r = 0; r < R0; ++r) {
+                        const int m = (jof<0>(t, q) + r * NB0) * k1;
+                        v[q * R0 + r] = cmul(v[q * R0 + r], cmul(hi[m >> a.logB], lo[m & mask]));
+                    }
                 }
         }
         passes<0>(v, (const cpx<T> *)a.twp, lds, t);
         if (!live) return;
-        constexpr int RL_ = RL::at(RL::NP - 1), NBL = N / RL_, NBFL = E / RL_;
+        constexpr int RL_ = RL::at(RL::NP - 1), NBL = N / RL_, NBFL = slots(RL::NP - 1);
         if (a.inverse) {
             const T sc = (T)a.scale;
 #pragma unroll
@@ -199,8 +222,10 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
         } else {
 #pragma unroll
             for (int q = 0; q < NBFL; ++q)
+                if (full(RL::NP - 1) || t + q * TPL < NBL) {
 #pragma unroll
-                for (int r = 0; r < RL_; ++r) gstore<T, (NT & 1) != 0>(out + t + q * TPL + r * NBL, v[q * RL_ + r]);
+                    for (int r = 0; r < RL_; ++r) gstore<T, (NT & 1) != 0>(out + t + q * TPL + r * NBL, v[q * RL_ + r]);
+                }
         }
     }
 };

@@ -5,9 +5,29 @@
 #include "engine.h"
 #include "blue_kernel.h"
 namespace ndfft {
-bool jit_choose(int, int, JitCfg &) { return false; }
-void jit_build_twiddles(const JitCfg &, HostTable &) {}
-int launch_jit_c2c(int, const JitCfg &, int, const Pow2Args &, hipStream_t) { return NDFFT_ERR_UNSUPPORTED; }
+// two PARTIAL-round configurations of the C2C row kernel (pow2_kernel.h: slots / full) instantiated ahead of
+// time, so that the predicated passes are exercised on the CPU: 264 = 11.8.3 on 12 threads, 210 = 7.6.5 on 14
+using PRL264 = RadixList<11, 8, 3>;
+using PRL210 = RadixList<7, 6, 5>;
+bool jit_choose(int, int n, JitCfg &cfg, bool allow_partial) {
+    if (!allow_partial || (n != 264 && n != 210)) return false;
+    cfg.n = n; cfg.partial = true; cfg.vec = 1;
+    if (n == 264) { cfg.tpl = 12; cfg.radix = {11, 8, 3}; cfg.lpb = 21; } else { cfg.tpl = 14; cfg.radix = {7, 6, 5}; cfg.lpb = 18; }
+    return true;
+}
+void jit_build_twiddles(const JitCfg &cfg, HostTable &out) { if (cfg.n == 264) build_tw<PRL264>(out); else if (cfg.n == 210) build_tw<PRL210>(out); }
+template <typename K> __global__ void k_c2c_emul(const Pow2Args a) { K::run(a); }
+template <typename T, int N, int TPL, int LPB, typename RL> static int c2c_one(const Pow2Args &a, hipStream_t s) {
+    using K = Pow2Kernel<T, N, TPL, LPB, true, RL, 0, 1, 1, 1>;
+    hipLaunchKernelGGL((k_c2c_emul<K>), dim3((unsigned)((a.nlanes + LPB - 1) / LPB)), dim3(K::THREADS), K::LDS_BYTES, s, a);
+    return NDFFT_OK;
+}
+int launch_jit_c2c(int dtype, const JitCfg &cfg, int, const Pow2Args &a, hipStream_t s) {
+    if (a.nlanes <= 0) return NDFFT_OK;
+    if (cfg.n == 264) return dtype == NDFFT_F32 ? c2c_one<float, 264, 12, 21, PRL264>(a, s) : c2c_one<double, 264, 12, 21, PRL264>(a, s);
+    if (cfg.n == 210) return dtype == NDFFT_F32 ? c2c_one<float, 210, 14, 18, PRL210>(a, s) : c2c_one<double, 210, 14, 18, PRL210>(a, s);
+    return NDFFT_ERR_UNSUPPORTED;
+}
 int jit_col_lanes(int, const JitCfg &cfg) { return (cfg.n == 64 || cfg.n == 256) ? 8 : 0; }
 template <typename T> int launch_jit_real(int, const JitCfg &, bool, const RealArgs<T> &, hipStream_t) { return NDFFT_ERR_UNSUPPORTED; }
 template int launch_jit_real<float>(int, const JitCfg &, bool, const RealArgs<float> &, hipStream_t);

@@ -410,6 +410,21 @@ def bluestein_register_kernel(L, sizes=((17, 64), (31, 64), (97, 256), (127, 256
     assert run_case(L, "ndfft", (3, 97), 1, np.float64) == "generic_row"
 
 
+def partial_round_configs(L, sizes=(264, 210)):
+    """Smooth lengths whose radix list does not divide any E (264 = 11.8.3, 210 = 7.6.5, 840, ...): the C2C row
+    kernel with PARTIAL butterfly rounds (pow2_kernel.h: slots / full)."""
+    for n in sizes:
+        rows = (1 << 17) // n + 7
+        for rdt in (np.float64, np.float32):
+            for name, norm in (("ndfft", "Default"), ("ndifft", "Default"), ("ndifft", "None")):
+                assert run_case(L, name, (rows, n), 1, rdt, norm=norm, offset=n) == "jit_reg", (name, n, rdt)
+        # padded lane pitch
+        big = synth.complex_array((rows, n + 3), np.complex128); x = big[:, :n]; y = np.zeros((rows, n + 5), np.complex128)[:, 2:n + 2]
+        h = handlers.FftHandler(n, _library=L); api.ndfft(x, y, h, 1)
+        assert L.last_path() == "jit_reg"
+        assert_close(y, np.fft.fft(x, axis=1), 1, 1e-10, f"partial-round {n} padded")
+
+
 def jit_specialised_sizes(L):
     """Smooth non-power-of-two C2C lanes: the register-resident kernel specialised with hiprtc at first use."""
     for n in (96, 100, 144, 384, 500, 768, 1000, 1296, 1536, 2000, 2187, 3072, 3125):

@@ -30,6 +30,7 @@ def test_long_strided_lanes(L): ps.long_strided_lanes(L)
 def test_narrow_xcd_tiles(L): ps.narrow_xcd_tiles(L)
 def test_column_four_step(L): ps.column_four_step(L)
 def test_bluestein_register_kernel(L): ps.bluestein_register_kernel(L)
+def test_partial_round_configs(L): ps.partial_round_configs(L)
 def test_long_lanes_four_step(L): ps.long_lanes_four_step(L, full=False)
 
 
