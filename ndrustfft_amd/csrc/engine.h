@@ -59,7 +59,7 @@ template <typename T> struct GenArgs {
 // plan
 // ------------------------------------------------------------------------------------------
 struct HostTable { std::vector<long double> re, im; };
-struct JitCfg { int n = 0, tpl = 0, e = 0, lpb = 1, vec = 1; bool partial = false; std::vector<int> radix; };   // partial: some pass has an incomplete last round (C2C row kernel only)
+struct JitCfg { int n = 0, tpl = 0, e = 0, lpb = 1, vec = 1; bool partial = false; std::vector<int> radix; };   // partial: some pass has an incomplete last round
 }  // namespace ndfft
 struct ndfft_plan;
 namespace ndfft {   // built once in long double
@@ -168,7 +168,7 @@ int launch_big_post(int gen_op, const RealArgs<T> &a, const cpx<T> *z, hipStream
 size_t generic_max_len(size_t csize);   // longest complex FFT the single-launch LDS kernel can hold
 
 // jit.hip : hiprtc specialisation of the register-resident kernel for smooth non-power-of-two lengths
-bool jit_choose(int dtype, int n, JitCfg &cfg, bool allow_partial = false);   // allow_partial: C2C row kernel only
+bool jit_choose(int dtype, int n, JitCfg &cfg, bool allow_partial = false);
 void jit_build_twiddles(const JitCfg &cfg, HostTable &out);
 int launch_jit_c2c(int dtype, const JitCfg &cfg, int nt, const Pow2Args &a, hipStream_t s);
 int jit_col_lanes(int dtype, const JitCfg &cfg);

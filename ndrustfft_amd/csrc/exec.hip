@@ -509,7 +509,7 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
         const DevConfig &d = dt->cfg[slot];
         const bool is_c2c = plan->kind == NDFFT_KIND_C2C;
         const bool odd_variant = gop == G_R2C_ODD || gop == G_C2R_ODD || gop == G_DCT2_ODD || gop == G_DCT3_ODD || gop == G_DCT4_ODD;
-        const bool use_jit = c.jit && !c.jitcfg.partial && !c.pow2 && P.nlanes * (int64_t)c.F >= (1 << 16);
+        const bool use_jit = c.jit && !c.pow2 && P.nlanes * (int64_t)c.F >= (1 << 16);
         // Bluestein lengths on the register kernel (blue_kernel.h), every op incl. the odd-n variants and row C2C
         const bool use_blue = c.bluereg && ((P.nlanes * (int64_t)c.M >= (1 << 16) && blue_enabled()) || c.blue_reg_only);
         const bool have_tw = use_jit || use_blue || (is_c2c ? !c.twp_col.re.empty() : c.pow2);

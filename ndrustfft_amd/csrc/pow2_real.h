@@ -86,7 +86,6 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
     static __device__ __forceinline__ cpx<T> cs_tw(const RealArgs<T> &a, int m) {
         return cmul(a.cs_twhi[m >> a.cs_logB], a.cs_twlo[m & ((1 << a.cs_logB) - 1)]);
     }
-    static constexpr int E = F / TPL;
     static constexpr int THREADS = TPL * LPB;
     // complex elements per lane: padded Z, or F+1 raw complex.  COL: odd, so adjacent lanes spread over the
     // banks; row: even, so every lane base stays 16-byte aligned for the vector staging stores.
@@ -95,6 +94,7 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
     static constexpr bool IN_CPLX = OP == G_C2R_EVEN || OP == G_C2C_FWD || OP == G_C2C_INV;
     static constexpr bool OUT_CPLX = OP == G_R2C_EVEN || OP == G_C2C_FWD || OP == G_C2C_INV;
     using FFT = Pow2Kernel<T, F, TPL, LPB, false, RL, 0, 1, 0>;
+    static constexpr int E = FFT::E;       // = F / TPL unless some pass has a partial last round (pow2_kernel.h)
     // row layout R2C / C2R: the PRE fold reads unit-stride complex elements (ascending, and for C2R also
     // descending), so it loads global memory directly and the LDS staging pass and its barrier are skipped
     // (f64 only: 16-byte elements; for f32 the 16-byte vector staging loads measure faster than 8-byte direct ones)
@@ -204,7 +204,7 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
         // ---- PRE into the first pass's register pattern ----
         cpx<T> v[E];
         {
-            constexpr int R0 = RL::at(0), NB0 = F / R0, NBF0 = E / R0;
+            constexpr int R0 = RL::at(0), NB0 = F / R0, NBF0 = FFT::slots(0);
             const void *raw = (const void *)lds;
             if constexpr (DIRECT_IN) {
                 const int64_t lsafe = live ? lane : 0;
@@ -213,12 +213,14 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
             }
 #pragma unroll
             for (int q = 0; q < NBF0; ++q)
+                if (FFT::full(0) || t + q * TPL < NB0) {
 #pragma unroll
-                for (int r = 0; r < R0; ++r) {
-                    const int i = t + q * TPL + r * NB0;
-                    if constexpr (OP == G_R2C_EVEN || OP == G_C2C_FWD) v[q * R0 + r] = ((const cpx<T> *)raw)[i];   // z[i] = (x[2i], x[2i+1])
-                    else if constexpr (OP == G_C2C_INV) v[q * R0 + r] = cconj(((const cpx<T> *)raw)[i]);
-                    else v[q * R0 + r] = pre_elem<T, OP, ZiNone>(a, raw, i);
+                    for (int r = 0; r < R0; ++r) {
+                        const int i = t + q * TPL + r * NB0;
+                        if constexpr (OP == G_R2C_EVEN || OP == G_C2C_FWD) v[q * R0 + r] = ((const cpx<T> *)raw)[i];   // z[i] = (x[2i], x[2i+1])
+                        else if constexpr (OP == G_C2C_INV) v[q * R0 + r] = cconj(((const cpx<T> *)raw)[i]);
+                        else v[q * R0 + r] = pre_elem<T, OP, ZiNone>(a, raw, i);
+                    }
                 }
         }
         // (the first exchange inside passes() starts with a barrier, so the raw lane is dead by then)
@@ -226,12 +228,14 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
         // ---- Z in natural order ----
         __syncthreads();
         {
-            constexpr int RL_ = RL::at(RL::NP - 1), NBL = F / RL_, NBFL = E / RL_;
+            constexpr int RL_ = RL::at(RL::NP - 1), NBL = F / RL_, NBFL = FFT::slots(RL::NP - 1);
             cpx<T> *z = (cpx<T> *)lds;
 #pragma unroll
             for (int q = 0; q < NBFL; ++q)
+                if (FFT::full(RL::NP - 1) || t + q * TPL < NBL) {
 #pragma unroll
-                for (int r = 0; r < RL_; ++r) z[ZiPhi::map(t + q * TPL + r * NBL)] = v[q * RL_ + r];
+                    for (int r = 0; r < RL_; ++r) z[ZiPhi::map(t + q * TPL + r * NBL)] = v[q * RL_ + r];
+                }
         }
         __syncthreads();
         // ---- POST gather + store ----

@@ -28,8 +28,35 @@ int launch_jit_c2c(int dtype, const JitCfg &cfg, int, const Pow2Args &a, hipStre
     if (cfg.n == 210) return dtype == NDFFT_F32 ? c2c_one<float, 210, 14, 18, PRL210>(a, s) : c2c_one<double, 210, 14, 18, PRL210>(a, s);
     return NDFFT_ERR_UNSUPPORTED;
 }
-int jit_col_lanes(int, const JitCfg &cfg) { return (cfg.n == 64 || cfg.n == 256) ? 8 : 0; }
-template <typename T> int launch_jit_real(int, const JitCfg &, bool, const RealArgs<T> &, hipStream_t) { return NDFFT_ERR_UNSUPPORTED; }
+int jit_col_lanes(int, const JitCfg &cfg) { return (cfg.n == 64 || cfg.n == 256 || cfg.n == 264 || cfg.n == 210) ? 8 : 0; }
+// the same two partial-round configurations on the real-op / column kernel (pow2_real.h)
+template <typename K, typename T> __global__ void k_real_emul(const RealArgs<T> a) { K::run(a); }
+template <typename T, int F, int TPL, int LPBR, typename RL, int OP> static int real_one(bool col, const RealArgs<T> &a, hipStream_t s) {
+    if (col) {
+        using K = RealPow2Kernel<T, F, TPL, 8, RL, OP, true>;
+        hipLaunchKernelGGL((k_real_emul<K, T>), dim3((unsigned)((a.nlanes + 7) / 8)), dim3(K::THREADS), K::LDS_BYTES, s, a);
+    } else if constexpr (OP != G_C2C_FWD && OP != G_C2C_INV) {
+        using K = RealPow2Kernel<T, F, TPL, LPBR, RL, OP, false>;
+        hipLaunchKernelGGL((k_real_emul<K, T>), dim3((unsigned)((a.nlanes + LPBR - 1) / LPBR)), dim3(K::THREADS), K::LDS_BYTES, s, a);
+    } else {
+        return NDFFT_ERR_UNSUPPORTED;
+    }
+    return NDFFT_OK;
+}
+template <typename T, int F, int TPL, int LPBR, typename RL> static int real_F(int gop, bool col, const RealArgs<T> &a, hipStream_t s) {
+    switch (gop) {
+#define B(OP_) case OP_: return real_one<T, F, TPL, LPBR, RL, OP_>(col, a, s);
+        B(G_C2C_FWD) B(G_C2C_INV) B(G_R2C_EVEN) B(G_C2R_EVEN) B(G_DCT1) B(G_DCT2_EVEN) B(G_DCT3_EVEN) B(G_DCT4_EVEN)
+#undef B
+        default: return NDFFT_ERR_UNSUPPORTED;
+    }
+}
+template <typename T> int launch_jit_real(int gop, const JitCfg &cfg, bool col, const RealArgs<T> &a, hipStream_t s) {
+    if (a.nlanes <= 0) return NDFFT_OK;
+    if (cfg.n == 264) return real_F<T, 264, 12, 21, PRL264>(gop, col, a, s);
+    if (cfg.n == 210) return real_F<T, 210, 14, 18, PRL210>(gop, col, a, s);
+    return NDFFT_ERR_UNSUPPORTED;
+}
 template int launch_jit_real<float>(int, const JitCfg &, bool, const RealArgs<float> &, hipStream_t);
 template int launch_jit_real<double>(int, const JitCfg &, bool, const RealArgs<double> &, hipStream_t);
 

@@ -423,6 +423,15 @@ def partial_round_configs(L, sizes=(264, 210)):
         h = handlers.FftHandler(n, _library=L); api.ndfft(x, y, h, 1)
         assert L.last_path() == "jit_reg"
         assert_close(y, np.fft.fft(x, axis=1), 1, 1e-10, f"partial-round {n} padded")
+    # the real-op / column kernel with the same configurations: inner FFT F = n (R2C / DCT of length 2F, DCT-I of F + 1)
+    for F in sizes[:2]:
+        rows = (1 << 16) // F + 5
+        for rdt in (np.float64, np.float32):
+            for name in ("ndfft_r2c", "ndifft_r2c", "nddct2", "nddct3", "nddct4"):
+                assert run_case(L, name, (rows, 2 * F), 1, rdt, offset=F) == "jit_real", (name, F, rdt)
+            assert run_case(L, "nddct1", (rows, F + 1), 1, rdt, offset=F) == "jit_real", ("nddct1", F, rdt)
+            for name, n in (("ndfft", F), ("ndifft", F), ("ndfft_r2c", 2 * F), ("nddct2", 2 * F), ("nddct1", F + 1)):
+                assert run_case(L, name, (n, rows + 3), 0, rdt, offset=n) == "jit_col", (name, n, rdt)
 
 
 def jit_specialised_sizes(L):
