@@ -24,6 +24,25 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU box
+    shows 256 logical CPUs but grants 16 -- 128 OpenMP threads on 16 CPUs ran 5x SLOWER than 16)."""
+    import math
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                       # cgroup v2
+        if q != "max":
+            n = min(n, max(1, math.ceil(int(q) / int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, math.ceil(q / per)))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(n, rows, budget_s=12.0):
     """The CPU oracle's restatement of ndfft_par (create_transform_par!, src/lib.rs:169-238, OpenMP
     standing in for rayon) on the host cores; bounded sample of the same workload."""
@@ -57,6 +76,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist", action="store_true", help="initialise torch.distributed (RCCL) even at world size 1 (path check)")
     args = ap.parse_args()
+    if "OMP_NUM_THREADS" not in os.environ:        # before libgomp is loaded (torch, the oracle): see usable_cpus()
+        os.environ["OMP_NUM_THREADS"] = str(usable_cpus())
 
     import numpy as np
     import torch
