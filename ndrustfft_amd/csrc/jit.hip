@@ -65,6 +65,7 @@ bool jit_disabled() {
 // thread owns whole butterflies in every pass), fewest passes first, then the smallest E.
 // Partial-round configurations (pow2_kernel.h: slots / full): any radix list whose product is n, any TPL.
 // Cost ~ passes x (work incl. idle threads of partial rounds): minimise NP / utilisation; ties -> E nearest 16.
+static size_t jit_lds_limit();
 static bool jit_choose_partial(int dtype, int n, JitCfg &cfg) {
     const int emax = dtype == NDFFT_F32 ? 32 : 30;
     const int cand[] = {16, 13, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
@@ -105,7 +106,9 @@ static bool jit_choose_partial(int dtype, int n, JitCfg &cfg) {
 }
 
 bool jit_choose(int dtype, int n, JitCfg &cfg, bool allow_partial) {
-    if (jit_disabled() || n < 12 || n > 8192 || pow2_supported(dtype, n)) return false;
+    // one lane's half exchange (n reals, padded) must fit the 160 KiB of LDS: n <= 19274 (f64) / 32768 (f32, capped)
+    const size_t lane_lds = ((size_t)n + ((size_t)n >> 4) + 1) * (dtype == NDFFT_F32 ? 4 : 8);
+    if (jit_disabled() || n < 12 || n > 32768 || lane_lds > jit_lds_limit() || pow2_supported(dtype, n)) return false;
     {   int m = n; for (int p : {2, 3, 5, 7, 11, 13}) while (m % p == 0) m /= p; if (m != 1) return false; }
     // E complex registers per thread: 2E (f32) / 4E (f64) VGPRs of data.  Mixed 2-3-5 lengths need E = 30.
     const int emax = dtype == NDFFT_F32 ? 32 : 30;

@@ -434,6 +434,17 @@ def partial_round_configs(L, sizes=(264, 210)):
                 assert run_case(L, name, (n, rows + 3), 0, rdt, offset=n) == "jit_col", (name, n, rdt)
 
 
+def long_smooth_lanes(L):
+    """Smooth non-power-of-two lanes beyond the LDS kernel's reach but within one lane's half exchange
+    (n <= 19274 f64 / 32768 f32): one specialised launch instead of the four-step."""
+    for n, rdt in ((10000, np.float64), (18000, np.float64), (19200, np.float64), (24576, np.float32), (30000, np.float32)):
+        rows = (1 << 17) // n + 9
+        for name, norm in (("ndfft", "Default"), ("ndifft", "Default")):
+            assert run_case(L, name, (rows, n), 1, rdt, norm=norm, offset=n) == "jit_reg", (name, n, rdt)
+    for name, n, rdt in (("nddct2", 12000, np.float64), ("ndfft_r2c", 16000, np.float64), ("ndifft_r2c", 20000, np.float32), ("nddct4", 20000, np.float32)):
+        assert run_case(L, name, ((1 << 16) // n + 9, n), 1, rdt, offset=n) == "jit_real", (name, n, rdt)
+
+
 def jit_specialised_sizes(L):
     """Smooth non-power-of-two C2C lanes: the register-resident kernel specialised with hiprtc at first use."""
     for n in (96, 100, 144, 384, 500, 768, 1000, 1296, 1536, 2000, 2187, 3072, 3125):

@@ -32,6 +32,7 @@ def test_long_strided_lanes(L): ps.long_strided_lanes(L)
 def test_narrow_xcd_tiles(L): ps.narrow_xcd_tiles(L)
 def test_column_four_step(L): ps.column_four_step(L)
 def test_partial_round_configs(L): ps.partial_round_configs(L, sizes=(264, 210, 840, 1008, 630, 2520, 3003, 6006, 33, 66))
+def test_long_smooth_lanes(L): ps.long_smooth_lanes(L)
 def test_bluestein_register_kernel(L):
     ps.bluestein_register_kernel(L, sizes=((17, 64), (31, 64), (97, 256), (127, 256), (511, 1024), (1009, 2048), (2039, 4096), (4093, 8192)), col_max_M=1024)
 def test_long_lanes_four_step(L): ps.long_lanes_four_step(L, full=True)
