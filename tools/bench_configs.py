@@ -19,7 +19,11 @@ from ndrustfft_amd import (DctHandler, FftHandler, R2cFftHandler, _lib, nddct1, 
 PEAK = 8000.0
 
 
-def timeit(fn, steps, warmup=5, ramp_ms=150.0):
+RAMP_MS = 150.0
+
+
+def timeit(fn, steps, warmup=5, ramp_ms=None):
+    ramp_ms = RAMP_MS if ramp_ms is None else ramp_ms
     # keep the device busy for ramp_ms first: the clocks take ~30-40 ms of sustained work to settle
     import time
     t0 = time.perf_counter()
@@ -47,8 +51,10 @@ def run(name, fn, x, y, h, axis, points, steps):
 
 
 def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=50); ap.add_argument("--only", default="")
+    ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=50); ap.add_argument("--only", default=""); ap.add_argument("--ramp-ms", type=float, default=150.0)
     a = ap.parse_args()
+    global RAMP_MS
+    RAMP_MS = a.ramp_ms
     dev = torch.device("cuda:0")
     want = lambda k: (not a.only) or a.only in k
     if want("cfg2"):
