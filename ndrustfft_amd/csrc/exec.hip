@@ -282,16 +282,19 @@ static int col_split(const Problem &P, const void *d_in, void *d_out, const FftC
     const int F1 = c.cs_F1, F2 = c.cs_F2;
     const bool r2c = P.op == NDFFT_OP_R2C, c2r = P.op == NDFFT_OP_C2R, inv = P.op == NDFFT_OP_C2C_INV;
     const int K1 = (r2c || c2r) ? F1 / 2 + 1 : F1;
-    // Column chunks: the intermediate of one chunk (K1*F2*C complex, <= 128 MiB) is written by stage A with
+    // Column chunks: the intermediate of one chunk (K1*F2*C complex, <= 144 MiB) is written by stage A with
     // cache-allocating stores and re-read by stage B before much of it has left the 256 MiB Infinity Cache.
-    // Measured (8192x8192 f32 R2C axis 0): one chunk 241 us, 128 MiB chunks 226 us; smaller chunks LOSE
-    // (32 MiB: 293 us, 8 MiB: 628 us) because every chunk costs two launches of a few microseconds each.
+    // Measured (8192x8192 f32 R2C axis 0): one chunk 248 us, two chunks (136 MiB each) 212 us, three 228 us;
+    // small chunks LOSE (32 MiB: 293 us, 8 MiB: 628 us): every chunk costs two launches of a few microseconds.
     int64_t C = I;
     {
         const char *e = getenv("NDFFT_CS_CHUNK_MB");   // developer / test switch (0 = one chunk)
-        const int64_t target = (int64_t)(e ? atoi(e) : 128) << 20;
+        const int64_t target = (int64_t)(e ? atoi(e) : 144) << 20;
         const int64_t per_col = (int64_t)K1 * F2 * (int64_t)sizeof(cpx<T>);
-        if (target > 0 && O == 1 && per_col * I > target) C = std::max<int64_t>(64, (target / per_col) & ~(int64_t)63);
+        if (target > 0 && O == 1 && per_col * I > target) {   // equal chunks, a multiple of 64 columns each
+            const int64_t nchunk = (per_col * I + target - 1) / target;
+            C = std::max<int64_t>(64, (((I + nchunk - 1) / nchunk) + 63) & ~(int64_t)63);
+        }
         if (C > I) C = I;
     }
     const bool chunked = C < I;
