@@ -6,6 +6,11 @@
 // libhiprtc is loaded lazily with dlopen; if it is missing, or a compile fails, the caller falls back to the
 // LDS kernel (generic_kernel.h) -- still on the GPU.
 #include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <cerrno>
+#include <cstdint>
+#include <cstring>
 
 #include <cstdio>
 #include <cstdlib>
@@ -166,19 +171,75 @@ void jit_build_twiddles(const JitCfg &cfg, HostTable &out) {
 
 namespace {
 // compiles `src` (which defines extern "C" kernel k_jit) once per key; returns the cached entry
+// ---- on-disk cache of the compiled code objects ------------------------------------------------------
+// $NDFFT_JIT_CACHE (a directory; "0" disables), else $XDG_CACHE_HOME/ndfft_mi355x, else ~/.cache/ndfft_mi355x.
+// File name = FNV-1a hash of the kernel source, every embedded header and the compile options, so a rebuilt
+// library with different kernel text never picks up a stale object.  Written to a temp file and renamed.
+const char *const kJitOpts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast"};
+std::string cache_dir() {
+    const char *e = getenv("NDFFT_JIT_CACHE");
+    std::string d;
+    if (e) { if (!e[0] || !strcmp(e, "0")) return ""; d = e; }
+    else if (const char *x = getenv("XDG_CACHE_HOME")) d = std::string(x) + "/ndfft_mi355x";
+    else if (const char *h = getenv("HOME")) { const std::string c = std::string(h) + "/.cache"; (void)mkdir(c.c_str(), 0755); d = c + "/ndfft_mi355x"; }
+    else return "";
+    if (mkdir(d.c_str(), 0755) != 0 && errno != EEXIST) return "";
+    return d;
+}
+uint64_t fnv1a(uint64_t h, const char *p, size_t n) { for (size_t i = 0; i < n; ++i) { h ^= (unsigned char)p[i]; h *= 1099511628211ull; } return h; }
+std::string cache_path(const std::string &src, const char *const *hs, int nh) {
+    const std::string d = cache_dir();
+    if (d.empty()) return "";
+    uint64_t h = 1469598103934665603ull;
+    h = fnv1a(h, src.data(), src.size());
+    for (int i = 0; i < nh; ++i) h = fnv1a(h, hs[i], strlen(hs[i]));
+    for (const char *o : kJitOpts) h = fnv1a(h, o, strlen(o));
+    char name[40];
+    snprintf(name, sizeof name, "/%016llx.hsaco", (unsigned long long)h);
+    return d + name;
+}
+bool read_file(const std::string &path, std::string &out) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END); const long n = ftell(f); fseek(f, 0, SEEK_SET);
+    bool ok = n > 0;
+    if (ok) { out.resize((size_t)n); ok = fread(&out[0], 1, (size_t)n, f) == (size_t)n; }
+    fclose(f);
+    return ok;
+}
+void write_file_atomic(const std::string &path, const std::string &data) {
+    const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return;
+    const bool ok = fwrite(data.data(), 1, data.size(), f) == data.size();
+    fclose(f);
+    if (!ok || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());
+}
+
 Entry get_or_compile(const std::string &key, const std::string &src, const std::string &what) {
     Rtc &r = rtc();
     std::lock_guard<std::mutex> g(g_mu);
     auto it = g_cache.find(key);
     if (it != g_cache.end()) return it->second;
     Entry ne;
+    {   // a code object compiled by an earlier process?
+        const char *hs0[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h, jit_src_realops_h, jit_src_pow2_real_h, jit_src_blue_kernel_h};
+        const std::string path = cache_path(src, hs0, 6);
+        std::string code;
+        if (!path.empty() && read_file(path, code) && hipModuleLoadData(&ne.mod, code.data()) == hipSuccess &&
+            hipModuleGetFunction(&ne.fn, ne.mod, "k_jit") == hipSuccess) {
+            g_cache.emplace(key, ne);
+            return ne;
+        }
+        (void)hipGetLastError();
+        ne = Entry();
+    }
     const char *hn[] = {"device_common.h", "butterflies.h", "pow2_kernel.h", "realops.h", "pow2_real.h", "blue_kernel.h"};
     const char *hs[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h, jit_src_realops_h, jit_src_pow2_real_h, jit_src_blue_kernel_h};
     rtcProgram prog = nullptr;
     bool ok = r.ok && r.create(&prog, src.c_str(), "k_jit.hip", 6, hs, hn) == 0;
     if (ok) {
-        const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast"};
-        ok = r.compile(prog, 4, opts) == 0;
+        ok = r.compile(prog, 4, (const char **)kJitOpts) == 0;
         if (!ok && getenv("NDFFT_JIT_VERBOSE")) {
             size_t ls = 0; r.log_size(prog, &ls);
             std::string log(ls, '\0'); r.log(prog, &log[0]);
@@ -189,6 +250,7 @@ Entry get_or_compile(const std::string &key, const std::string &src, const std::
     if (ok) { size_t cs = 0; ok = r.code_size(prog, &cs) == 0 && cs > 0; if (ok) { code.resize(cs); ok = r.code(prog, &code[0]) == 0; } }
     if (prog) r.destroy(&prog);
     if (ok) ok = hipModuleLoadData(&ne.mod, code.data()) == hipSuccess && hipModuleGetFunction(&ne.fn, ne.mod, "k_jit") == hipSuccess;
+    if (ok) { const std::string path = cache_path(src, hs, 6); if (!path.empty()) write_file_atomic(path, code); }
     if (!ok) { (void)hipGetLastError(); ne.failed = true; }
     g_cache.emplace(key, ne);
     return ne;

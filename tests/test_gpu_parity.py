@@ -2,6 +2,8 @@
 (include/ndfft_mi355x.h) via the thin ctypes host layer, compared with the CPU oracle on the same
 seeded inputs, with the committed golden vectors, and -- at BASELINE.json's full sizes -- through
 size-independent properties plus oracle checks on sampled lanes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -12,6 +14,7 @@ from ndrustfft_amd import _lib, api, handlers
 from oracle import oracle_ctypes as orc
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -176,3 +179,28 @@ def test_hip_graph_capture_and_replay(L):
     assert_close(y.cpu().numpy(), np.fft.fft2(x), 1, 1e-10, "graph replay fft2")
     xd.copy_(torch.from_numpy(x * 2)); g.replay(); torch.cuda.synchronize()
     assert_close(y.cpu().numpy(), np.fft.fft2(2 * x), 1, 1e-10, "graph replay on new data")
+
+
+def test_jit_disk_cache(tmp_path):
+    """Specialised kernels are written to $NDFFT_JIT_CACHE and a second process loads them instead of compiling."""
+    import subprocess, sys, time
+    code = r'''
+import sys, os, time, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import synth
+from ndrustfft_amd import FftHandler, ndfft, _lib
+x = synth.complex_array((200, 1000)); y = np.zeros_like(x)
+t0 = time.perf_counter(); ndfft(x, y, FftHandler(1000), 1); dt = time.perf_counter() - t0
+assert _lib.default().last_path() == "jit_reg"
+assert np.abs(y - np.fft.fft(x, axis=1)).max() / np.abs(y).max() < 1e-12
+print("CALL_S", dt)
+''' % (ROOT, ROOT)
+    env = dict(os.environ, NDFFT_JIT_CACHE=str(tmp_path))
+    times = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        times.append(float([l for l in r.stdout.splitlines() if l.startswith("CALL_S")][0].split()[1]))
+        files = [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]
+        assert len(files) == 1, files
+    assert times[1] < times[0], times          # no hiprtc compile the second time
