@@ -2,6 +2,8 @@
 #include <ucontext.h>
 
 #include <cstdio>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "hip/hip_runtime.h"
@@ -24,6 +26,43 @@ void entry() {
     swapcontext(&g_f[g_cur].ctx, &g_main);
 }
 }  // namespace
+
+// ---- guarded "device" memory: kernels must not write outside what the host allocated ----------------------
+namespace {
+constexpr size_t kGuard = 256;
+// (never destroyed: plans may be freed from Python finalisers after static destructors have run)
+std::map<char *, size_t> &g_allocs = *new std::map<char *, size_t>;      // user pointer -> user size
+std::mutex &g_alloc_mu = *new std::mutex;
+void check_guards(const char *when) {
+    std::lock_guard<std::mutex> g(g_alloc_mu);
+    for (auto &kv : g_allocs) {
+        const unsigned char *lo = (const unsigned char *)kv.first - kGuard, *hi = (const unsigned char *)kv.first + kv.second;
+        for (size_t i = 0; i < kGuard; ++i)
+            if (lo[i] != 0xC3 || hi[i] != 0xC3) {
+                fprintf(stderr, "emul: %s: write outside a device allocation of %zu bytes (%s guard, offset %zu)\n", when, kv.second,
+                        lo[i] != 0xC3 ? "lower" : "upper", i);
+                abort();
+            }
+    }
+}
+}  // namespace
+hipError_t hipMalloc(void **p, size_t n) {
+    char *raw = (char *)malloc(n + 2 * kGuard);
+    if (!raw) return 2;
+    memset(raw, 0xC3, kGuard); memset(raw + kGuard + n, 0xC3, kGuard);
+    std::lock_guard<std::mutex> g(g_alloc_mu);
+    g_allocs[raw + kGuard] = n;
+    *p = raw + kGuard;
+    return 0;
+}
+hipError_t hipFree(void *p) {
+    if (!p) return 0;
+    check_guards("hipFree");
+    std::lock_guard<std::mutex> g(g_alloc_mu);
+    g_allocs.erase((char *)p);
+    free((char *)p - kGuard);
+    return 0;
+}
 
 void __syncthreads() {
     // yield; the scheduler resumes fibers round-robin, so returning here means every live fiber
@@ -60,5 +99,12 @@ void emul::launch(void (*fn)(void *), void *arg, dim3 grid, dim3 block, size_t l
                 swapcontext(&g_main, &g_f[t].ctx);
             }
         }
+        // a workgroup may only touch the dynamic LDS it asked for: everything past it must still be poison
+        for (size_t i = lds_bytes; i < sizeof ndfft::smem; ++i)
+            if ((unsigned char)ndfft::smem[i] != 0xA5) {
+                fprintf(stderr, "emul: block (%u,%u,%u) wrote LDS byte %zu, beyond the %zu bytes requested at launch\n", b, by, bz, i, lds_bytes);
+                abort();
+            }
     }
+    check_guards("kernel launch");
 }

@@ -40,8 +40,9 @@ inline hipError_t hipGetLastError() { return 0; }
 inline hipError_t hipGetDevice(int *d) { *d = 0; return 0; }
 inline hipError_t hipSetDevice(int) { return 0; }
 inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return 0; }
-inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
-inline hipError_t hipFree(void *p) { free(p); return 0; }
+// "device" allocations carry 256-byte guard zones that are checked after every kernel launch (emul_runtime.cpp)
+hipError_t hipMalloc(void **p, size_t n);
+hipError_t hipFree(void *p);
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return 0; }
