@@ -37,6 +37,44 @@ int launch_big_twiddle(cpx<T> *data, int64_t lanes, int F1, int F2, const cpx<T>
 template int launch_big_twiddle<float>(float2 *, int64_t, int, int, const float2 *, const float2 *, int, int, float, hipStream_t);
 template int launch_big_twiddle<double>(double2 *, int64_t, int, int, const double2 *, const double2 *, int, int, double, hipStream_t);
 
+// Bluestein over global memory (FftConfig::bigblue), the three elementwise stages around two FFT_M:
+//   0: a[l][j] = z[l][j] * chirp[j] (j < F; conj(z) for the inverse), 0 for F <= j < M
+//   1: b[l][k] = conj(a[l][k] * bhat[k])                                  (in place)
+//   2: out[l][k] = conj(b[l][k]) * chirp[k], k < F  (inverse: its conjugate, * scale)
+template <typename T>
+__global__ __launch_bounds__(256) void k_blue_stage(int stage, cpx<T> *dst, int64_t pitch_dst, const cpx<T> *src, int64_t pitch_src, int64_t lanes,
+                                                    int F, int M, const cpx<T> *chirp, const cpx<T> *bhat, int inverse, T scale) {
+    const int len = stage == 2 ? F : M;
+    const int64_t total = lanes * len;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t l = i / len; const int j = (int)(i - l * len);
+        if (stage == 0) {
+            cpx<T> v = mk<T>((T)0, (T)0);
+            if (j < F) { v = src[l * pitch_src + j]; if (inverse) v.y = -v.y; v = cmul(v, chirp[j]); }
+            dst[l * pitch_dst + j] = v;
+        } else if (stage == 1) {
+            dst[l * pitch_dst + j] = cconj(cmul(src[l * pitch_src + j], bhat[j]));
+        } else {
+            cpx<T> v = cmul(cconj(src[l * pitch_src + j]), chirp[j]);
+            if (inverse) v.y = -v.y;
+            v.x *= scale; v.y *= scale;
+            dst[l * pitch_dst + j] = v;
+        }
+    }
+}
+template <typename T>
+int launch_blue_stage(int stage, cpx<T> *dst, int64_t pitch_dst, const cpx<T> *src, int64_t pitch_src, int64_t lanes, int F, int M,
+                      const cpx<T> *chirp, const cpx<T> *bhat, int inverse, T scale, hipStream_t s) {
+    const int64_t total = lanes * (stage == 2 ? F : M);
+    if (total <= 0) return NDFFT_OK;
+    const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 16384);
+    hipLaunchKernelGGL(k_blue_stage<T>, dim3(grid), dim3(256), 0, s, stage, dst, pitch_dst, src, pitch_src, lanes, F, M, chirp, bhat, inverse, scale);
+    NDFFT_HIP(hipGetLastError());
+    return NDFFT_OK;
+}
+template int launch_blue_stage<float>(int, float2 *, int64_t, const float2 *, int64_t, int64_t, int, int, const float2 *, const float2 *, int, float, hipStream_t);
+template int launch_blue_stage<double>(int, double2 *, int64_t, const double2 *, int64_t, int64_t, int, int, const double2 *, const double2 *, int, double, hipStream_t);
+
 template <typename T, int OP> __global__ __launch_bounds__(256) void k_big_pre(const RealArgs<T> a, cpx<T> *z) {
     constexpr bool in_cplx = OP == G_C2R_EVEN || OP == G_C2R_ODD;
     const int64_t total = a.nlanes * a.F;
@@ -59,6 +97,30 @@ template <typename T, int OP> __global__ __launch_bounds__(256) void k_big_post(
         if constexpr (out_cplx) ((cpx<T> *)a.out)[lane * a.pitch_out + q] = post_cplx<T, OP, ZiNone>(a, res, q);
         else ((T *)a.out)[lane * a.pitch_out + q] = post_real<T, OP, ZiNone>(a, res, q);
     }
+}
+
+// Long lanes in an arbitrary strided layout (neither unit-stride lanes nor a C-layout block): pack the lanes into
+// a dense [lane][len] scratch array / unpack them from one.  Element size esz = 4, 8 or 16 bytes.
+template <typename E>
+__global__ __launch_bounds__(256) void k_pack_lanes(const E *strided, E *dense, LaneGeom g, int64_t lanes, int64_t len, int64_t pitch, int unpack) {
+    const int64_t total = lanes * len;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t lane = i / len; const int64_t j = i - lane * len;
+        int64_t off = j * g.axis_stride;
+        const int64_t d0 = lane * pitch + j;
+        for (int b = g.nb - 1; b >= 0; --b) { const int64_t c = lane % g.bshape[b]; lane /= g.bshape[b]; off += c * g.bstride[b]; }
+        if (unpack) ((E *)strided)[off] = dense[d0]; else dense[d0] = strided[off];
+    }
+}
+int launch_pack_lanes(const void *strided, void *dense, const LaneGeom &g, int64_t lanes, int64_t len, int64_t pitch, int esz, int unpack, hipStream_t s) {
+    const int64_t total = lanes * len;
+    if (total <= 0) return NDFFT_OK;
+    const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 16384);
+    if (esz == 4) hipLaunchKernelGGL(k_pack_lanes<float>, dim3(grid), dim3(256), 0, s, (const float *)strided, (float *)dense, g, lanes, len, pitch, unpack);
+    else if (esz == 8) hipLaunchKernelGGL(k_pack_lanes<double>, dim3(grid), dim3(256), 0, s, (const double *)strided, (double *)dense, g, lanes, len, pitch, unpack);
+    else hipLaunchKernelGGL(k_pack_lanes<double2>, dim3(grid), dim3(256), 0, s, (const double2 *)strided, (double2 *)dense, g, lanes, len, pitch, unpack);
+    NDFFT_HIP(hipGetLastError());
+    return NDFFT_OK;
 }
 
 #define NDFFT_BIG_OPS(X) X(G_R2C_EVEN) X(G_R2C_ODD) X(G_C2R_EVEN) X(G_C2R_ODD) X(G_DCT1) X(G_DCT2_EVEN) X(G_DCT2_ODD) \

@@ -76,6 +76,7 @@ struct FftConfig {                 // one complex-FFT-of-length-F recipe + op ta
     HostTable twp_narrow;          // twiddles in the radix order of the narrow (XCD-aware) column kernel
     // long lanes (one lane does not fit LDS): four-step F = F1 * F2 on top of the row kernels
     bool big = false; int F1 = 0, F2 = 0, logB = 0;
+    bool bigblue = false;          // big && no usable split (huge prime factor): Bluestein over global memory, sub1 = C2C plan of length M
     ndfft_plan *sub1 = nullptr, *sub2 = nullptr;   // C2C sub-plans of length F1 / F2 (owned)
     HostTable twlo, twhi;          // W_F^m = twhi[m >> logB] * twlo[m & (2^logB - 1)]
     // long STRIDED lanes (pow2 n, C2C and R2C/C2R slots): column four-step n = cs_F1 * cs_F2 in two passes of
@@ -153,6 +154,7 @@ template <typename T> int launch_pow2_real_narrow(int gen_op, const RealArgs<T> 
 // column four-step, twiddled stage (kernels_colsplit.hip): cs = 1 C2C, 2 = R2C second stage, 3 = C2R first stage
 bool pow2_real_config(int F, JitCfg &cfg);
 template <typename T> int launch_jit_blue(int gen_op, const JitCfg &cfgM, bool col, const RealArgs<T> &a, hipStream_t s);
+int launch_pack_lanes(const void *strided, void *dense, const LaneGeom &g, int64_t lanes, int64_t len, int64_t pitch, int esz, int unpack, hipStream_t s);   // big.hip
 int colsplit_inner_len();
 int colsplit_tile_lanes();
 template <typename T> int launch_colsplit(int cs, bool inverse, const RealArgs<T> &a, hipStream_t s);
@@ -161,6 +163,9 @@ template <typename T> int launch_colsplit(int cs, bool inverse, const RealArgs<T
 template <typename T>
 int launch_big_twiddle(cpx<T> *data, int64_t lanes, int F1, int F2, const cpx<T> *twlo, const cpx<T> *twhi, int logB, int conj,
                        T scale, hipStream_t s);
+template <typename T>
+int launch_blue_stage(int stage, cpx<T> *dst, int64_t pitch_dst, const cpx<T> *src, int64_t pitch_src, int64_t lanes, int F, int M,
+                      const cpx<T> *chirp, const cpx<T> *bhat, int inverse, T scale, hipStream_t s);   // 0 pre, 1 mid, 2 post (big.hip)
 template <typename T>
 int launch_big_pre(int gen_op, const RealArgs<T> &a, cpx<T> *z, hipStream_t s);    // raw lanes (a.in, a.pitch_in) -> z[lane][F]
 template <typename T>

@@ -222,7 +222,7 @@ static int dispatch_generic(const Problem &P, const void *d_in, void *d_out, con
 
 // per-(host thread, stream) scratch for the transpose route; grows, never shrinks
 struct Scratch { void *p = nullptr; size_t cap = 0; };
-static thread_local std::map<hipStream_t, Scratch> g_scratch[6];
+static thread_local std::map<hipStream_t, Scratch> g_scratch[8];
 static int get_scratch(int which, hipStream_t s, size_t bytes, void **out) {
     Scratch &sc = g_scratch[which][s];
     if (bytes > sc.cap) {
@@ -354,6 +354,24 @@ static int col_split(const Problem &P, const void *d_in, void *d_out, const FftC
 template <typename T>
 static int big_fft(const FftConfig &c, const DevConfig &d, const cpx<T> *zin, int64_t pitch_in, cpx<T> *zout, int64_t pitch_out,
                    int64_t L, bool inverse, T scale, hipStream_t stream) {
+    if (c.bigblue) {
+        // Bluestein over global memory: two FFT_M through dispatch() (pow2 row kernel, or its own four-step for
+        // M > 16384 -- which uses scratch slots 2 / 3, hence 6 / 7 here) between three elementwise stages
+        const int Fl = c.F, M = c.M;
+        void *a1, *a2;
+        int rcb;
+        if ((rcb = get_scratch(6, stream, (size_t)L * M * sizeof(cpx<T>), &a1))) return rcb;
+        if ((rcb = get_scratch(7, stream, (size_t)L * M * sizeof(cpx<T>), &a2))) return rcb;
+        const cpx<T> *chirp = (const cpx<T> *)d.chirp, *bhat = (const cpx<T> *)d.bhat;
+        if ((rcb = launch_blue_stage<T>(0, (cpx<T> *)a1, M, zin, pitch_in, L, Fl, M, chirp, bhat, inverse ? 1 : 0, (T)1, stream))) return rcb;
+        Problem Q;
+        Q.plan = c.sub1; Q.op = NDFFT_OP_C2C_FWD; Q.xlen = Q.ylen = M; Q.xs = Q.ys = 1; Q.nlanes = L; Q.scale = 1.0;
+        Q.b.push_back({L, (int64_t)M, (int64_t)M});
+        if ((rcb = dispatch(Q, a1, a2, stream))) return rcb;
+        if ((rcb = launch_blue_stage<T>(1, (cpx<T> *)a2, M, (const cpx<T> *)a2, M, L, Fl, M, chirp, bhat, 0, (T)1, stream))) return rcb;
+        if ((rcb = dispatch(Q, a2, a1, stream))) return rcb;
+        return launch_blue_stage<T>(2, zout, pitch_out, (const cpx<T> *)a1, M, L, Fl, M, chirp, bhat, inverse ? 1 : 0, inverse ? scale : (T)1, stream);
+    }
     const int F1 = c.F1, F2 = c.F2;
     const int64_t F = (int64_t)F1 * F2;
     const int esz = (int)sizeof(cpx<T>);
@@ -430,7 +448,7 @@ static int dispatch_big(const Problem &P, const void *d_in, void *d_out, const D
     const int64_t pin = P.b.empty() ? P.xlen : P.b[0].sin, pout = P.b.empty() ? P.ylen : P.b[0].sout;
     if (gop == G_C2C_FWD || gop == G_C2C_INV) {
         int rc0 = big_fft<T>(c, d, (const cpx<T> *)d_in, pin, (cpx<T> *)d_out, pout, P.nlanes, gop == G_C2C_INV, (T)P.scale, stream);
-        set_last_path("four_step");
+        set_last_path(c.bigblue ? "blue_global" : "four_step");
         return rc0;
     }
     RealArgs<T> a;
@@ -443,7 +461,7 @@ static int dispatch_big(const Problem &P, const void *d_in, void *d_out, const D
     if ((rc = launch_big_pre<T>(gop, a, (cpx<T> *)z, stream))) return rc;
     if ((rc = big_fft<T>(c, d, (const cpx<T> *)z, c.F, (cpx<T> *)z, c.F, P.nlanes, false, (T)1, stream))) return rc;
     rc = launch_big_post<T>(gop, a, (const cpx<T> *)z, stream);
-    set_last_path("four_step");
+    set_last_path(c.bigblue ? "blue_global" : "four_step");
     return rc;
 }
 
@@ -601,8 +619,6 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
         int slot;
         (void)gen_op_of(P.op, (int)plan->n, &slot);
         const FftConfig &c = plan->cfg[slot];
-        if (c.blue_reg_only && P.xs == 1 && P.ys == 1 && P.b.size() <= 1)
-            return fail(NDFFT_ERR_UNSUPPORTED, "this lane length needs the hiprtc-specialised Bluestein kernel (libhiprtc missing or NDFFT_JIT=0)");
         if (c.unsupported)
             return fail(NDFFT_ERR_UNSUPPORTED, "lane length has a prime factor too large for the single-launch Bluestein and no usable "
                                                "four-step split (DESIGN.md section 9)");
@@ -637,9 +653,27 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
     {
         int slot;
         (void)gen_op_of(P.op, (int)plan->n, &slot);
-        if (plan->cfg[slot].blue_reg_only)
-            return fail(NDFFT_ERR_UNSUPPORTED, "this lane length runs only on the hiprtc-specialised Bluestein kernel, which needs unit-stride "
-                                               "lanes or a C-layout column tile (libhiprtc missing, NDFFT_JIT=0, or an unusual layout)");
+        if (plan->cfg[slot].big) {
+            // long lanes in an arbitrary strided layout: pack -> row path on dense lanes -> unpack
+            const size_t r = real_size(plan->dtype);
+            const size_t ein = op_in_cplx(P.op) ? 2 * r : r, eout = op_out_cplx(P.op) ? 2 * r : r;
+            void *s1, *s2;
+            int rc2;
+            if ((rc2 = get_scratch(0, stream, (size_t)(P.nlanes * P.xlen) * ein, &s1))) return rc2;
+            if ((rc2 = get_scratch(1, stream, (size_t)(P.nlanes * P.ylen) * eout, &s2))) return rc2;
+            LaneGeom gi, go;
+            gi.axis_stride = P.xs; go.axis_stride = P.ys; gi.nb = go.nb = (int32_t)P.b.size(); gi.pad_ = go.pad_ = 0;
+            for (size_t k = 0; k < P.b.size(); ++k) { gi.bshape[k] = go.bshape[k] = P.b[k].shape; gi.bstride[k] = P.b[k].sin; go.bstride[k] = P.b[k].sout; }
+            if ((rc2 = launch_pack_lanes(d_in, s1, gi, P.nlanes, P.xlen, P.xlen, (int)ein, 0, stream))) return rc2;
+            Problem Q = P;
+            Q.xs = Q.ys = 1; Q.b.clear(); Q.b.push_back({P.nlanes, P.xlen, P.ylen});
+            if ((rc2 = dispatch(Q, s1, s2, stream))) return rc2;
+            if ((rc2 = launch_pack_lanes(d_out, s2, go, P.nlanes, P.ylen, P.ylen, (int)eout, 1, stream))) return rc2;
+            static thread_local std::string path;
+            path = std::string("pack+") + last_path();
+            set_last_path(path.c_str());
+            return NDFFT_OK;
+        }
     }
     return plan->dtype == NDFFT_F32 ? dispatch_generic<float>(P, d_in, d_out, *dt, stream)
                                     : dispatch_generic<double>(P, d_in, d_out, *dt, stream);

@@ -98,6 +98,37 @@ static bool single_kernel_ok(int len, int dtype) {
     return (size_t)blue_len(len) <= maxlen;
 }
 
+// chirp[j] = e^{-i pi j^2/F} (j < F) and bhat = FFT_M(conj chirp, wrapped) / M, computed in long double by an
+// iterative radix-2 FFT (per-stage twiddle tables) so that the device tables are correctly rounded
+static void build_bluestein_tables(FftConfig &c, int F, int M) {
+    for (int j = 0; j < F; ++j) unit(c.chirp, ((unsigned long long)j * j) % (2ull * F), 2ull * F);
+    std::vector<long double> br(M, 0.0L), bi(M, 0.0L);
+    for (int j = 0; j < F; ++j) {
+        br[j] = c.chirp.re[j]; bi[j] = -c.chirp.im[j];
+        if (j) { br[M - j] = br[j]; bi[M - j] = bi[j]; }
+    }
+    for (int i = 1, j = 0; i < M; ++i) {
+        int bit = M >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { std::swap(br[i], br[j]); std::swap(bi[i], bi[j]); }
+    }
+    std::vector<long double> wr, wi;
+    for (int len = 2; len <= M; len <<= 1) {
+        const int h = len / 2;
+        wr.resize(h); wi.resize(h);
+        for (int k = 0; k < h; ++k) { const long double ang = -2.0L * kPiL * (long double)k / (long double)len; wr[k] = cosl(ang); wi[k] = sinl(ang); }
+        for (int i = 0; i < M; i += len)
+            for (int k = 0; k < h; ++k) {
+                const int a = i + k, b = i + k + h;
+                const long double tr = br[b] * wr[k] - bi[b] * wi[k], ti = br[b] * wi[k] + bi[b] * wr[k];
+                br[b] = br[a] - tr; bi[b] = bi[a] - ti; br[a] += tr; bi[a] += ti;
+            }
+    }
+    c.bhat.re.reserve(M); c.bhat.im.reserve(M);
+    for (int k = 0; k < M; ++k) { c.bhat.re.push_back(br[k] / M); c.bhat.im.push_back(bi[k] / M); }
+}
+
 // fills F, radix / Bluestein, tw (and twM, chirp, bhat); or the four-step split for long lanes
 static void build_fft(FftConfig &c, int F, int dtype) {
     c.F = F;
@@ -118,7 +149,16 @@ static void build_fft(FftConfig &c, int F, int dtype) {
         int best = 0;
         for (int d = 2; (int64_t)d * d <= F; ++d)
             if (F % d == 0 && single_kernel_ok(d, dtype) && single_kernel_ok(F / d, dtype)) best = d;
-        if (!best) { c.unsupported = true; return; }
+        if (!best) {
+            // a prime factor too large for any single launch: Bluestein over global memory -- chirp multiply,
+            // FFT_M through the power-of-two row path (its own four-step when M > 16384), * bhat, FFT_M, chirp
+            const int M = blue_len(F);
+            if (M > (1 << 21)) { c.unsupported = true; return; }
+            c.big = true; c.bigblue = true; c.M = M;
+            c.sub1 = make_plan(NDFFT_KIND_C2C, dtype, (size_t)M);
+            build_bluestein_tables(c, F, M);
+            return;
+        }
         c.big = true; c.F2 = best; c.F1 = F / best;           // F1 >= F2
         c.sub1 = make_plan(NDFFT_KIND_C2C, dtype, (size_t)c.F1);
         c.sub2 = make_plan(NDFFT_KIND_C2C, dtype, (size_t)c.F2);
@@ -138,30 +178,11 @@ static void build_fft(FftConfig &c, int F, int dtype) {
     c.M = M;
     factorize(M, c.radixM);
     build_pass_twiddles(c.twM, c.radixM, M);
-    for (int j = 0; j < F; ++j) unit(c.chirp, ((unsigned long long)j * j) % (2ull * F), 2ull * F);
-    std::vector<long double> br(M, 0.0L), bi(M, 0.0L);
-    for (int j = 0; j < F; ++j) {
-        br[j] = c.chirp.re[j]; bi[j] = -c.chirp.im[j];
-        if (j) { br[M - j] = br[j]; bi[M - j] = bi[j]; }
+    build_bluestein_tables(c, F, M);
+    if (c.blue_reg_only) {   // without hiprtc the register kernel is not available: Bluestein over global memory instead
+        c.big = true; c.bigblue = true;
+        c.sub1 = make_plan(NDFFT_KIND_C2C, dtype, (size_t)M);
     }
-    // iterative radix-2 DIT FFT in long double
-    for (int i = 1, j = 0; i < M; ++i) {
-        int bit = M >> 1;
-        for (; j & bit; bit >>= 1) j ^= bit;
-        j ^= bit;
-        if (i < j) { std::swap(br[i], br[j]); std::swap(bi[i], bi[j]); }
-    }
-    for (int len = 2; len <= M; len <<= 1) {
-        for (int i = 0; i < M; i += len)
-            for (int k = 0; k < len / 2; ++k) {
-                long double ang = -2.0L * kPiL * (long double)k / (long double)len;
-                long double wr = cosl(ang), wi = sinl(ang);
-                int a = i + k, b = i + k + len / 2;
-                long double tr = br[b] * wr - bi[b] * wi, ti = br[b] * wi + bi[b] * wr;
-                br[b] = br[a] - tr; bi[b] = bi[a] - ti; br[a] += tr; bi[a] += ti;
-            }
-    }
-    for (int k = 0; k < M; ++k) { c.bhat.re.push_back(br[k] / M); c.bhat.im.push_back(bi[k] / M); }
 }
 
 static void build_plan_tables(ndfft_plan *p) {

@@ -193,6 +193,58 @@ def layouts(L):
     api.nddct2(x5, y5, hd, 3); orc.nddct2(x5, y5o, od, 3); assert_close(y5, y5o, 3, 1e-10, "6-D permuted")
 
 
+def fuzz(L, seed, count, max_points=1 << 17, lengths=None):
+    """Random op x lane length x shape x axis x dtype x norm x layout (C / F / stepped and reversed views, padded
+    output views) against the oracle.  The lane lengths mix every dispatch class: powers of two, smooth,
+    partial-round smooth, prime / Bluestein, DCT-I n - 1 classes, tiny and long."""
+    rng = np.random.default_rng(seed)
+    lengths = lengths or (1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 16, 17, 30, 31, 32, 33, 64, 65, 96, 97, 100, 127, 128, 129, 210, 243, 256,
+                          257, 264, 343, 500, 512, 513, 1000, 1009, 1024, 1025, 2048, 2187, 3000, 4096, 4097, 5000, 8192)
+    names = list(OPS)
+    paths = {}
+    for it in range(count):
+        name = names[rng.integers(len(names))]
+        n = int(lengths[rng.integers(len(lengths))])
+        if name == "nddct1" and n < 2:
+            n = 2
+        rdt = (np.float64, np.float32)[rng.integers(2)]
+        ndim = int(rng.integers(1, 4))
+        axis = int(rng.integers(ndim))
+        other = max(1, max_points // max(n, 1))
+        shape = [0] * ndim
+        for d in range(ndim):
+            if d == axis:
+                shape[d] = n
+            else:
+                cap = max(1, int(round(other ** (1.0 / max(ndim - 1, 1)))))
+                shape[d] = int(rng.integers(1, min(cap, 300) + 1))
+        norm = ("Default", "None")[rng.integers(2)]
+        sin, sout = shapes_for(name, tuple(shape), axis)
+        view = int(rng.integers(4))          # 0 C, 1 F, 2 stepped / reversed input view, 3 padded output view
+        x = make_input(name, sin, rdt, offset=it)
+        odt = cdt_of(rdt) if OPS[name][4] else np.dtype(rdt)
+        if view == 1:
+            x = np.asfortranarray(x)
+        if view == 2:
+            big = make_input(name, tuple(2 * e for e in sin), rdt, offset=it)
+            x = big[tuple(slice(None, None, -2) if rng.integers(2) else slice(0, None, 2) for _ in sin)]
+        if view == 3:
+            ybig = np.full(tuple(e + 2 for e in sout), 3.25, odt); y = ybig[tuple(slice(1, e + 1) for e in sout)]
+        else:
+            y = np.zeros(sout, odt, order="F" if view == 1 else "C")
+        yo = np.zeros(sout, odt)
+        h, o = handlers_for(name, n, rdt, L, norm)
+        OPS[name][0](x, y, h, axis)
+        path = L.last_path()
+        OPS[name][1](np.ascontiguousarray(x), yo, o, axis)
+        assert_close(np.ascontiguousarray(y), yo, axis, TOL[np.dtype(rdt)], f"fuzz #{it} seed={seed} {name} shape={shape} axis={axis} {np.dtype(rdt)} norm={norm} view={view} path={path}")
+        if view == 3:
+            edge = ybig.copy(); edge[tuple(slice(1, e + 1) for e in sout)] = 3.25
+            assert np.all(edge == 3.25), f"fuzz #{it}: wrote outside the output view ({name} {shape} axis={axis} path={path})"
+        paths[path] = paths.get(path, 0) + 1
+    return paths
+
+
 # ---- normalisation: None / Default / Custom at the reference's three application points --------
 def normalization_modes(L):
     for name in OPS:
@@ -306,10 +358,22 @@ def long_lanes_four_step(L, full=True):
                   ("nddct2", (3, 1 << 18), 1, np.float64, "four_step"), ("ndfft_r2c", (2, 3 * (1 << 17)), 1, np.float32, "four_step")]
     for name, shape, axis, rdt, want in cases:
         assert run_case(L, name, shape, axis, rdt) == want, (name, shape)
-    # a lane length with a huge prime factor and no usable split is refused, never computed on a CPU
-    with pytest.raises(_lib.NdfftError) as e:
-        run_case(L, "ndfft", (2, 2 * 10007), 1, np.float64)
-    assert e.value.status == _lib.ERR_UNSUPPORTED
+    # long lanes in an arbitrary strided layout (stepped + reversed input view, padded output view): pack -> rows -> unpack
+    n = 1 << 15
+    big = synth.complex_array((3, 2 * n)); x = big[::-1, ::2]
+    ybig = np.full((3, n + 4), 1.5 + 0j); y = ybig[:, 2:n + 2]
+    h = handlers.FftHandler(n, _library=L); api.ndfft(x, y, h, 1)
+    assert L.last_path() == "pack+four_step", L.last_path()
+    assert_close(np.ascontiguousarray(y), np.fft.fft(np.ascontiguousarray(x), axis=1), 1, 1e-10, "packed long lanes")
+    assert np.all(ybig[:, :2] == 1.5) and np.all(ybig[:, n + 2:] == 1.5)
+    # a huge prime factor with no usable split: Bluestein over global memory (see huge_prime_factors)
+    assert run_case(L, "ndfft", (2, 2 * 10007), 1, np.float64) == "blue_global"
+    # ... beyond M = 2^21 it is refused, never computed on a CPU
+    if full:
+        with pytest.raises(_lib.NdfftError) as e:
+            h = handlers.FftHandler(1048583, np.float32, _library=L)          # prime; M would be 2^22
+            x = np.zeros((1, 1048583), np.complex64); api.ndfft(x, np.zeros_like(x), h, 1)
+        assert e.value.status == _lib.ERR_UNSUPPORTED
 
 
 def pow2_col_sizes(L, sizes=(64, 128, 256, 512, 1024), dtypes=(np.float64, np.float32)):
@@ -443,6 +507,19 @@ def long_smooth_lanes(L):
             assert run_case(L, name, (rows, n), 1, rdt, norm=norm, offset=n) == "jit_reg", (name, n, rdt)
     for name, n, rdt in (("nddct2", 12000, np.float64), ("ndfft_r2c", 16000, np.float64), ("ndifft_r2c", 20000, np.float32), ("nddct4", 20000, np.float32)):
         assert run_case(L, name, ((1 << 16) // n + 9, n), 1, rdt, offset=n) == "jit_real", (name, n, rdt)
+
+
+def huge_prime_factors(L, full=True):
+    """Lane lengths whose prime factor is too large for any single-launch Bluestein (FftHandler::new(n) is
+    infallible for any n, src/lib.rs:294): Bluestein over global memory around the power-of-two row path."""
+    cases = [("ndfft", 4099, np.float64), ("ndifft", 4099, np.float64), ("nddct1", 8192, np.float64), ("ndfft_r2c", 2 * 4099, np.float64),
+             ("ndifft_r2c", 2 * 4099, np.float64), ("nddct2", 4099, np.float64)]
+    if full:
+        cases += [("ndfft", 10007, np.float64), ("ndfft", 20011, np.float32), ("ndifft", 65537, np.float32), ("nddct4", 10007, np.float32),
+                  ("nddct3", 2 * 8209, np.float64)]
+    for name, n, rdt in cases:
+        assert run_case(L, name, (3, n), 1, rdt, offset=n) == "blue_global", (name, n, rdt)
+    assert run_case(L, "ndfft", (4099, 20), 0, np.float64) == "transpose+blue_global"
 
 
 def jit_specialised_sizes(L):

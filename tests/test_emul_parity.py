@@ -29,6 +29,8 @@ def test_clone(L): ps.handler_clone_shares_plan(L)
 def test_long_strided_lanes(L): ps.long_strided_lanes(L)
 def test_narrow_xcd_tiles(L): ps.narrow_xcd_tiles(L)
 def test_column_four_step(L): ps.column_four_step(L)
+def test_huge_prime_factors(L): ps.huge_prime_factors(L, full=False)
+def test_fuzz(L): ps.fuzz(L, seed=11, count=120, max_points=1 << 13)
 def test_bluestein_register_kernel(L): ps.bluestein_register_kernel(L)
 def test_partial_round_configs(L): ps.partial_round_configs(L)
 def test_long_lanes_four_step(L): ps.long_lanes_four_step(L, full=False)

@@ -34,6 +34,10 @@ def test_shared_handler_across_threads(L): ps.shared_handler_across_threads(L)
 def test_long_strided_lanes(L): ps.long_strided_lanes(L)
 def test_narrow_xcd_tiles(L): ps.narrow_xcd_tiles(L)
 def test_column_four_step(L): ps.column_four_step(L)
+def test_huge_prime_factors(L): ps.huge_prime_factors(L)
+def test_fuzz(L):
+    paths = ps.fuzz(L, seed=7, count=400)
+    assert len(paths) >= 8, paths
 def test_partial_round_configs(L): ps.partial_round_configs(L, sizes=(264, 210, 840, 1008, 630, 2520, 3003, 6006, 33, 66))
 def test_long_smooth_lanes(L): ps.long_smooth_lanes(L)
 def test_bluestein_register_kernel(L):
