@@ -34,7 +34,7 @@ typedef enum {
     NDFFT_ERR_SIZE_MISMATCH = 2,  /* lane length != handler n / n/2+1: lib.rs:340-347, 533-540, 743-750 */
     NDFFT_ERR_SHAPE_MISMATCH = 3, /* a non-axis dimension differs between in and out (ndarray Zip panic, lib.rs:120-121) */
     NDFFT_ERR_AXIS = 4,           /* axis >= ndim: the index panic at lib.rs:116                         */
-    NDFFT_ERR_UNSUPPORTED = 5,    /* lane too long for the single-pass LDS kernels       */
+    NDFFT_ERR_UNSUPPORTED = 5,    /* prime factor beyond the global Bluestein (M > 2^21) or n > 2^24     */
     NDFFT_ERR_HIP = 6,            /* a HIP runtime call failed; message carries hipGetErrorString        */
     NDFFT_ERR_NO_DEVICE = 7,      /* no gfx950 device visible -- there is NO CPU fallback                */
     NDFFT_ERR_ALLOC = 8
