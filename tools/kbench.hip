@@ -187,6 +187,15 @@ int main(int argc, char **argv) {
         V(b, double, 4096, "half 256x16 16.16.16 nt1", 256, true, 1, 1, 16, 16, 16);
         V(b, double, 4096, "half 256x16 16.16.16 nt3", 256, true, 3, 1, 16, 16, 16);
         b.run(1e-12);
+    } else if (what == "f32_16384") {
+        Bench<float> b{16384, 2048, rounds}; b.init();
+        V(b, float, 16384, "half 1024x16 8.16.16.8 vec2 (product)", 1024, true, 1, 2, 8, 16, 16, 8);
+        V(b, float, 16384, "half 512x32 16.16.8.8 vec2", 512, true, 1, 2, 16, 16, 8, 8);
+        V(b, float, 16384, "half 512x32 8.16.16.8 vec2", 512, true, 1, 2, 8, 16, 16, 8);
+        V(b, float, 16384, "half 512x32 16.8.8.16 vec2", 512, true, 1, 2, 16, 8, 8, 16);
+        V(b, float, 16384, "full 512x32 16.16.8.8 vec2", 512, false, 1, 2, 16, 16, 8, 8);
+        V(b, float, 16384, "half 1024x16 16.16.16.4 vec1", 1024, true, 1, 1, 16, 16, 16, 4);
+        b.run(1e-5);
     } else if (what == "f64_16384") {
         Bench<double> b{16384, 1024, rounds}; b.init();
         V(b, double, 16384, "half 1024x16 16.16.16.4 (product)", 1024, true, 1, 1, 16, 16, 16, 4);
