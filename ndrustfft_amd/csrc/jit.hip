@@ -40,6 +40,7 @@ struct Rtc {
 Rtc &rtc() {
     static Rtc r = [] {
         Rtc x;
+        { const char *e = getenv("NDFFT_JIT"); if (e && e[0] == '0') return x; }   // NDFFT_JIT=0: behave like a host without libhiprtc
         const char *names[] = {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"};
         for (const char *n : names) if ((x.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
         if (!x.lib) return x;

@@ -208,3 +208,20 @@ print("CALL_S", dt)
         files = [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]
         assert len(files) == 1, files
     assert times[1] < times[0], times          # no hiprtc compile the second time
+
+
+def test_fuzz_without_hiprtc():
+    """NDFFT_JIT=0 (= a host without libhiprtc): every length still runs, on the LDS kernel, the four-step or the
+    global-memory Bluestein -- same parity bar."""
+    import subprocess, sys
+    code = r'''
+import sys, os
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import parity_suite as ps
+from ndrustfft_amd import _lib
+paths = ps.fuzz(_lib.default(), seed=23, count=200)
+assert not any(p.startswith(("jit_", "blue_reg", "blue_col")) for p in paths), paths
+print("NOJIT_OK", sorted(paths))
+''' % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, NDFFT_JIT="0"), timeout=1200)
+    assert r.returncode == 0 and "NOJIT_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
