@@ -136,6 +136,12 @@ int ndfft_dev_upload(void *d_dst, const void *h_src, size_t bytes);   /* synchro
 int ndfft_dev_download(void *h_dst, const void *d_src, size_t bytes); /* synchronous */
 int ndfft_dev_sync(void *stream);                                     /* hipStreamSynchronize */
 
+/* Frees the CALLING THREAD's device workspace: the scratch arrays of the multi-pass paths (transpose route,
+ * four-step, column four-step, global Bluestein) and the staging buffers of ndfft_exec.  They are otherwise
+ * kept per thread and per stream for reuse (HIP-graph capture needs them stable).  Synchronises the device.
+ * No reference counterpart: rustfft allocates its scratch inside every process() call (src/lib.rs:317). */
+int ndfft_release_workspace(void);
+
 #ifdef __cplusplus
 }
 #endif

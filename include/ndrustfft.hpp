@@ -371,4 +371,7 @@ NDRUSTFFT_DEFINE(nddct3, T, T, DctHandler, NDFFT_OP_DCT3, T, true, true)        
 NDRUSTFFT_DEFINE(nddct4, T, T, DctHandler, NDFFT_OP_DCT4, T, true, true)                                      // lib.rs:827-834
 #undef NDRUSTFFT_DEFINE
 
+/// Frees the calling thread's device scratch and staging buffers (the engine keeps them for reuse).
+inline void release_workspace() { detail::check(ndfft_release_workspace()); }
+
 }  // namespace ndrustfft

@@ -23,6 +23,7 @@ SYMBOLS = [
     "ndfft_plan_dtype", "ndfft_plan_lane_len_in", "ndfft_plan_lane_len_out",
     "ndfft_exec", "ndfft_exec_device", "ndfft_last_path",
     "ndfft_dev_alloc", "ndfft_dev_free", "ndfft_dev_upload", "ndfft_dev_download", "ndfft_dev_sync",
+    "ndfft_release_workspace",
 ]
 
 
@@ -66,6 +67,7 @@ class Library:
         L.ndfft_dev_upload.argtypes = [vp, vp, sz]
         L.ndfft_dev_download.argtypes = [vp, vp, sz]
         L.ndfft_dev_sync.argtypes = [vp]
+        L.ndfft_release_workspace.argtypes = []; L.ndfft_release_workspace.restype = ctypes.c_int
 
     def check(self, status):
         if status == OK:

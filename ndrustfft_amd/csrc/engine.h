@@ -5,6 +5,7 @@
 
 #include <functional>
 #include <map>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -123,6 +124,20 @@ int fail(int code, const std::string &msg);
         hipError_t e_ = (call);                                                                  \
         if (e_ != hipSuccess)                                                                    \
             return ::ndfft::fail(NDFFT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// opt a kernel into more than 64 KiB of dynamic LDS once per DEVICE (the attribute is per device; a process may
+// drive several through ndfft_set_device).  `mask` is a function-local static of the calling launcher.
+#define NDFFT_ENSURE_LDS_ATTR(fn)                                                                                   \
+    do {                                                                                                            \
+        static std::atomic<unsigned long long> mask_{0};                                                            \
+        int dev_ = 0;                                                                                               \
+        (void)hipGetDevice(&dev_);                                                                                  \
+        const unsigned long long bit_ = 1ull << (dev_ & 63);                                                        \
+        if (!(mask_.load(std::memory_order_relaxed) & bit_)) {                                                      \
+            (void)hipFuncSetAttribute((const void *)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+            mask_.fetch_or(bit_, std::memory_order_relaxed);                                                        \
+        }                                                                                                           \
     } while (0)
 
 void set_last_path(const char *p);

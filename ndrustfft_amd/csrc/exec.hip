@@ -767,4 +767,15 @@ int ndfft_exec(const ndfft_plan *plan, int op, const void *in, void *out, int nd
     return NDFFT_OK;
 }
 
+int ndfft_release_workspace(void) {
+    clear_err();
+    NDFFT_HIP(hipDeviceSynchronize());
+    for (auto &m : g_scratch) {
+        for (auto &kv : m) if (kv.second.p) (void)hipFree(kv.second.p);
+        m.clear();
+    }
+    for (Staging *st : {&g_stage_in, &g_stage_out}) { if (st->p) (void)hipFree(st->p); st->p = nullptr; st->cap = 0; }
+    return NDFFT_OK;
+}
+
 }  // extern "C"

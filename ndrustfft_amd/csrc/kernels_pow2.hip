@@ -82,11 +82,7 @@ void pow2_build_twiddles(int dtype, int n, HostTable &out) {
 template <typename T, int N, int NT, int VEC, int FL = 0> static int launch_one(const Pow2Args &a, hipStream_t s) {
     constexpr int TPL = Pow2Cfg<T, N>::TPL, LPB = lpb_for(TPL);
     using K = Pow2Kernel<T, N, TPL, LPB, true, typename Pow2Cfg<T, N>::RL, FL, 1, NT, VEC>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_pow2<K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    NDFFT_ENSURE_LDS_ATTR((k_pow2<K>));
     const int64_t nblk = (a.nlanes + LPB - 1) / LPB;
     if (nblk <= 0) return NDFFT_OK;
     if (nblk > 0x7fffffffLL) return fail(NDFFT_ERR_UNSUPPORTED, "too many lanes for one launch");

@@ -53,11 +53,7 @@ void pow2_real_build_twiddles(int F, HostTable &out) {
 }
 
 template <typename K, typename T> static int launch_k(const RealArgs<T> &a, int lpb, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_pow2_real<K, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    NDFFT_ENSURE_LDS_ATTR((k_pow2_real<K, T>));
     const int64_t nblk = (a.nlanes + lpb - 1) / lpb;
     if (nblk <= 0) return NDFFT_OK;
     if (nblk > 0x7fffffffLL) return fail(NDFFT_ERR_UNSUPPORTED, "too many lanes for one launch");

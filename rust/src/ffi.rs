@@ -43,4 +43,6 @@ extern "C" {
         shape_in: *const i64, stride_in: *const i64, shape_out: *const i64, stride_out: *const i64,
         axis: c_int, norm: c_int, scale: c_double,
     ) -> c_int;
+    /// frees the calling thread's device scratch / staging buffers (kept for reuse otherwise)
+    pub fn ndfft_release_workspace() -> c_int;
 }

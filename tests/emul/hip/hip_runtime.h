@@ -45,6 +45,7 @@ hipError_t hipMalloc(void **p, size_t n);
 hipError_t hipFree(void *p);
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+inline hipError_t hipDeviceSynchronize() { return 0; }
 inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return 0; }
 
 void __syncthreads();

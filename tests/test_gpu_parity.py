@@ -225,3 +225,13 @@ print("NOJIT_OK", sorted(paths))
 ''' % (ROOT, ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, NDFFT_JIT="0"), timeout=1200)
     assert r.returncode == 0 and "NOJIT_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_release_workspace(L):
+    """ndfft_release_workspace frees the per-thread scratch; the next call simply allocates it again."""
+    x = synth.real_array((4096, 96), np.float32); y = np.zeros((2049, 96), np.complex64)
+    h = handlers.R2cFftHandler(4096, np.float32, _library=L)
+    api.ndfft_r2c(x, y, h, 0); first = y.copy()
+    assert L.c.ndfft_release_workspace() == 0
+    y[:] = 0; api.ndfft_r2c(x, y, h, 0)
+    assert np.array_equal(y, first)
