@@ -14,6 +14,10 @@
 #include "pow2_kernel.h"
 #include "realops.h"
 
+#ifndef NDFFT_ROW_NT_MIN_F
+#define NDFFT_ROW_NT_MIN_F 1024
+#endif
+
 namespace ndfft {
 
 template <bool C, typename A, typename B> struct cond_type { typedef A type; };
@@ -101,6 +105,9 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
     static constexpr bool DIRECT_IN = !COL && sizeof(T) == 8 && (OP == G_R2C_EVEN || OP == G_C2R_EVEN);
     // ops whose POST is the real-FFT split: outputs k and F-k share one pair of LDS reads and one twiddle
     static constexpr bool PAIR = OP == G_R2C_EVEN || OP == G_DCT1 || OP == G_DCT2_EVEN;
+    // R2C rows are F + 1 complex long: short lanes start and end mid-line, and non-temporal stores of partial lines
+    // cost more than they save (262144x128 f32: 132 us non-temporal, 50 us plain; from F = 1024 up non-temporal wins) -- let L2 merge them
+    static constexpr bool ROW_NT = F >= NDFFT_ROW_NT_MIN_F;
 
     // every output derived from the spectrum pair (k, F-k), in four fixed slots (q < 0: slot unused)
     template <typename OT> struct PairOut { OT v[4]; int q[4]; };
@@ -354,7 +361,7 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
 #pragma unroll
                     for (int z = 0; z < 4; ++z)
                         if (r.q[z] >= 0) {
-                            if constexpr (OUT_CPLX) gstore<T, true>((cpx<T> *)out + r.q[z], r.v[z]);
+                            if constexpr (OUT_CPLX) gstore<T, ROW_NT>((cpx<T> *)out + r.q[z], r.v[z]);
                             else __builtin_nontemporal_store(r.v[z], out + r.q[z]);
                         }
                 }
@@ -363,6 +370,14 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                 for (int q = t; q < a.n_out; q += TPL) gstore<T, true>(out + q, post_cplx<T, OP, ZiPhi>(a, res, q));
             } else {
                 T *out = (T *)a.out + lane * a.pitch_out;
+                if constexpr (OP == G_C2R_EVEN) {
+                    // x[2k] = Re, x[2k+1] = -Im of the conj-trick result: one LDS read and one 8/16-byte store per pair
+                    // (realops.h post_real would read each element twice and store 4/8 bytes at a time)
+                    if (a.vec_out) {
+                        for (int k = t; k < F; k += TPL) { const cpx<T> c = res[ZiPhi::map(k)]; gstore<T, true>((cpx<T> *)out + k, mk<T>(c.x, -c.y)); }
+                        return;
+                    }
+                }
                 for (int q = t; q < a.n_out; q += TPL) __builtin_nontemporal_store(post_real<T, OP, ZiPhi>(a, res, q), out + q);
             }
         }
