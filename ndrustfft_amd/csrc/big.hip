@@ -34,7 +34,7 @@ int launch_big_twiddle(cpx<T> *data, int64_t lanes, int F1, int F2, const cpx<T>
     NDFFT_HIP(hipGetLastError());
     return NDFFT_OK;
 }
-template int launch_big_twiddle<float>(float2 *, int64_t, int, int, const float2 *, const float2 *, int, int, float, hipStream_t);
+template int launch_big_twiddle<float>(cpx<float> *, int64_t, int, int, const cpx<float> *, const cpx<float> *, int, int, float, hipStream_t);
 template int launch_big_twiddle<double>(double2 *, int64_t, int, int, const double2 *, const double2 *, int, int, double, hipStream_t);
 
 // Bluestein over global memory (FftConfig::bigblue), the three elementwise stages around two FFT_M:
@@ -72,7 +72,7 @@ int launch_blue_stage(int stage, cpx<T> *dst, int64_t pitch_dst, const cpx<T> *s
     NDFFT_HIP(hipGetLastError());
     return NDFFT_OK;
 }
-template int launch_blue_stage<float>(int, float2 *, int64_t, const float2 *, int64_t, int64_t, int, int, const float2 *, const float2 *, int, float, hipStream_t);
+template int launch_blue_stage<float>(int, cpx<float> *, int64_t, const cpx<float> *, int64_t, int64_t, int, int, const cpx<float> *, const cpx<float> *, int, float, hipStream_t);
 template int launch_blue_stage<double>(int, double2 *, int64_t, const double2 *, int64_t, int64_t, int, int, const double2 *, const double2 *, int, double, hipStream_t);
 
 template <typename T, int OP> __global__ __launch_bounds__(256) void k_big_pre(const RealArgs<T> a, cpx<T> *z) {
@@ -148,9 +148,9 @@ template <typename T> int launch_big_post(int op, const RealArgs<T> &a, const cp
     NDFFT_HIP(hipGetLastError());
     return NDFFT_OK;
 }
-template int launch_big_pre<float>(int, const RealArgs<float> &, float2 *, hipStream_t);
+template int launch_big_pre<float>(int, const RealArgs<float> &, cpx<float> *, hipStream_t);
 template int launch_big_pre<double>(int, const RealArgs<double> &, double2 *, hipStream_t);
-template int launch_big_post<float>(int, const RealArgs<float> &, const float2 *, hipStream_t);
+template int launch_big_post<float>(int, const RealArgs<float> &, const cpx<float> *, hipStream_t);
 template int launch_big_post<double>(int, const RealArgs<double> &, const double2 *, hipStream_t);
 
 }  // namespace ndfft

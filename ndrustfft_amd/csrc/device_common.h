@@ -18,7 +18,11 @@ namespace ndfft {
 // complex helpers (Complex<T> = {re, im} interleaved = float2 / double2)
 // ------------------------------------------------------------------------------------------
 template <typename T> struct vec2;
-template <> struct vec2<float> { using type = float2; };
+// f32 complex is a NATIVE 2-vector (same layout as float2): component-wise arithmetic then compiles to packed
+// math (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32, two floats per lane per issue).  A wave64 VALU instruction
+// takes 4 cycles on the 16-lane SIMDs and the f32 kernels are issue-bound before they are HBM-bound.
+typedef float ndfft_c32 __attribute__((ext_vector_type(2)));
+template <> struct vec2<float> { using type = ndfft_c32; };
 template <> struct vec2<double> { using type = double2; };
 template <typename T> using cpx = typename vec2<T>::type;
 
@@ -28,6 +32,9 @@ template <typename C> __host__ __device__ inline C csub(C a, C b) { a.x -= b.x; 
 template <typename C> __host__ __device__ inline C cmul(C a, C b) {
     C r; r.x = a.x * b.x - a.y * b.y; r.y = a.x * b.y + a.y * b.x; return r;
 }
+__host__ __device__ inline ndfft_c32 cadd(ndfft_c32 a, ndfft_c32 b) { return a + b; }
+__host__ __device__ inline ndfft_c32 csub(ndfft_c32 a, ndfft_c32 b) { return a - b; }
+__host__ __device__ inline ndfft_c32 cmul(ndfft_c32 a, ndfft_c32 b) { const ndfft_c32 bs = {-b.y, b.x}; return a.xx * b + a.yy * bs; }
 template <typename C> __host__ __device__ inline C cconj(C a) { a.y = -a.y; return a; }
 // multiply by -i (forward quarter turn): (x, y) -> (y, -x)
 template <typename C> __host__ __device__ inline C cmul_mi(C a) { C r; r.x = a.y; r.y = -a.x; return r; }

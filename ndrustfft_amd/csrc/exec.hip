@@ -569,7 +569,7 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
             int rc2;
             if (plan->dtype == NDFFT_F32) {
                 RealArgs<float> a; fill(a); a.scale = (float)P.scale;
-                a.aux1 = (const float2 *)d.aux1; a.aux2 = (const float2 *)d.aux2; a.twp = (const float2 *)d.twp_narrow;
+                a.aux1 = (const cpx<float> *)d.aux1; a.aux2 = (const cpx<float> *)d.aux2; a.twp = (const cpx<float> *)d.twp_narrow;
                 rc2 = launch_pow2_real_narrow<float>(gop, a, stream);
             } else {
                 RealArgs<double> a; fill(a); a.scale = P.scale;
@@ -598,8 +598,8 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
             int rc2;
             if (plan->dtype == NDFFT_F32) {
                 RealArgs<float> a; fill(a); a.scale = (float)P.scale;
-                a.aux1 = (const float2 *)d.aux1; a.aux2 = (const float2 *)d.aux2; a.twp = (const float2 *)((is_c2c && !use_jit && !use_blue) ? d.twp_col : d.twp);
-                a.chirp = (const float2 *)d.chirp; a.bhat = (const float2 *)d.bhat;
+                a.aux1 = (const cpx<float> *)d.aux1; a.aux2 = (const cpx<float> *)d.aux2; a.twp = (const cpx<float> *)((is_c2c && !use_jit && !use_blue) ? d.twp_col : d.twp);
+                a.chirp = (const cpx<float> *)d.chirp; a.bhat = (const cpx<float> *)d.bhat;
                 rc2 = use_blue ? launch_jit_blue<float>(gop, c.jitcfg, col, a, stream)
                       : use_jit ? launch_jit_real<float>(gop, c.jitcfg, col, a, stream) : launch_pow2_real<float>(gop, a, col, stream);
             } else {

@@ -87,14 +87,30 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
     static __device__ __forceinline__ void passes(cpx<T> (&v)[E], const cpx<T> *__restrict__ twp, char *lds, int t) {
         constexpr int R = RL::at(P), Ns = RL::ns(P), NBF = slots(P), NB = nbfly(P);
         constexpr bool FULL = full(P);
+        constexpr bool TW_POWERS = (FLAGS & 16) != 0 && (size_t)(R - 1) * Ns * sizeof(cpx<T>) > 32 * 1024;
         if constexpr (P > 0 && !(FLAGS & 1)) {
             const cpx<T> *tw = twp + RL::twoff(P);
 #pragma unroll
             for (int q = 0; q < NBF; ++q) {
                 const int j = jof<P>(t, q), k = kmod<Ns>(j);
                 if (FULL || j < NB) {
+                    if constexpr (TW_POWERS && (R == 8 || R == 16)) {
+                        // big late-pass tables (> 32 KiB) miss L1: load W^k, W^2k, W^4k (, W^8k) only and build the other
+                        // powers with at most two (three) complex multiplications each -- 3-4 L2 loads instead of 7-15
+                        cpx<T> w[R];
+                        w[1] = tw[k]; w[2] = tw[Ns + k]; w[4] = tw[3 * Ns + k];
+                        w[3] = cmul(w[1], w[2]); w[5] = cmul(w[1], w[4]); w[6] = cmul(w[2], w[4]); w[7] = cmul(w[3], w[4]);
+                        if constexpr (R == 16) {
+                            w[8] = tw[7 * Ns + k];
 #pragma unroll
-                    for (int r = 1; r < R; ++r) v[q * R + r] = cmul(v[q * R + r], tw[(r - 1) * Ns + k]);
+                            for (int r = 9; r < 16; ++r) w[r] = cmul(w[r - 8], w[8]);
+                        }
+#pragma unroll
+                        for (int r = 1; r < R; ++r) v[q * R + r] = cmul(v[q * R + r], w[r]);
+                    } else {
+#pragma unroll
+                        for (int r = 1; r < R; ++r) v[q * R + r] = cmul(v[q * R + r], tw[(r - 1) * Ns + k]);
+                    }
                 }
             }
         }

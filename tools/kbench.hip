@@ -195,6 +195,13 @@ int main(int argc, char **argv) {
         V(b, float, 16384, "half 512x32 16.8.8.16 vec2", 512, true, 1, 2, 16, 8, 8, 16);
         V(b, float, 16384, "full 512x32 16.16.8.8 vec2", 512, false, 1, 2, 16, 16, 8, 8);
         V(b, float, 16384, "half 1024x16 16.16.16.4 vec1", 1024, true, 1, 1, 16, 16, 16, 4);
+        b.template add<Pow2Kernel<float, 16384, 1024, 1, true, RadixList<8, 16, 16, 8>, 0, 8, 1, 2>, RadixList<8, 16, 16, 8>>("half 1024x16 8.16.16.8 vec2 MINW=8");
+        b.template add<Pow2Kernel<float, 16384, 1024, 1, true, RadixList<8, 16, 16, 8>, 0, 8, 1, 1>, RadixList<8, 16, 16, 8>>("half 1024x16 8.16.16.8 vec1 MINW=8");
+        b.template add<Pow2Kernel<float, 16384, 1024, 1, true, RadixList<8, 16, 16, 8>, 16, 1, 1, 2>, RadixList<8, 16, 16, 8>>("TW_POWERS 8.16.16.8");
+        b.template add<Pow2Kernel<float, 16384, 1024, 1, true, RadixList<8, 16, 16, 8>, 2, 1, 1, 2>, RadixList<8, 16, 16, 8>>("ABLATE no LDS exchange");
+        b.template add<Pow2Kernel<float, 16384, 1024, 1, true, RadixList<8, 16, 16, 8>, 4, 1, 1, 2>, RadixList<8, 16, 16, 8>>("ABLATE no butterflies");
+        b.template add<Pow2Kernel<float, 16384, 1024, 1, true, RadixList<8, 16, 16, 8>, 7, 1, 1, 2>, RadixList<8, 16, 16, 8>>("ABLATE load+store only");
+        b.template add<Pow2Kernel<float, 16384, 1024, 1, true, RadixList<8, 16, 16, 8>, 1, 1, 1, 2>, RadixList<8, 16, 16, 8>>("ABLATE no twiddles");
         b.run(1e-5);
     } else if (what == "f64_16384") {
         Bench<double> b{16384, 1024, rounds}; b.init();
@@ -202,6 +209,8 @@ int main(int argc, char **argv) {
         V(b, double, 16384, "half 1024x16 8.8.16.16", 1024, true, 1, 1, 8, 8, 16, 16);
         V(b, double, 16384, "half 512x32 16.16.16.4", 512, true, 1, 1, 16, 16, 16, 4);
         V(b, double, 16384, "half 1024x16 8.8.8.8.4", 1024, true, 1, 1, 8, 8, 8, 8, 4);
+        b.template add<Pow2Kernel<double, 16384, 1024, 1, true, RadixList<16, 16, 16, 4>, 16, 1, 1, 1>, RadixList<16, 16, 16, 4>>("TW_POWERS 16.16.16.4");
+        b.template add<Pow2Kernel<double, 16384, 1024, 1, true, RadixList<8, 8, 16, 16>, 16, 1, 1, 1>, RadixList<8, 8, 16, 16>>("TW_POWERS 8.8.16.16");
         b.run(1e-12);
     }
     return 0;
