@@ -47,7 +47,7 @@ namespace ndfft {
     X(2048, 128, 8, 4, 8, 8)  \
     X(4096, 256, 8, 8, 8, 8)  \
     X(8192, 512, 8, 16, 8, 8) \
-    X(16384, 1024, 8, 16, 16, 8)
+    X(16384, 512, 16, 16, 8, 8)
 
 static constexpr int lpb_for(int tpl) { return tpl >= 256 ? 1 : 256 / tpl; }
 
@@ -58,6 +58,16 @@ template <typename T, int N> struct Pow2Cfg;
     template <> struct Pow2Cfg<float, N_> { static constexpr int TPL = TPL_; using RL = RadixList<__VA_ARGS__>; };
 NDFFT_POW2_CONFIGS_F64(NDFFT_DEF_CFG64)
 NDFFT_POW2_CONFIGS_F32(NDFFT_DEF_CFG32)
+
+// LDS exchange: HALF (real parts, then imaginary parts, through one real-sized buffer) halves the footprint and
+// wins for f64 (occupancy).  f32 from n = 2048 up exchanges whole complex elements with 64-bit LDS accesses: half
+// the LDS instructions, and the footprint is that of the f64 half exchange anyway (measured after the packed-math
+// change, tools/kbench f32_halffull: 2048 83 -> 78 us, 4096 86 -> 80, 8192 93 -> 89, 16384 146 -> 126)
+template <typename T, int N> struct Pow2Half { static constexpr bool value = true; };
+template <> struct Pow2Half<float, 2048> { static constexpr bool value = false; };
+template <> struct Pow2Half<float, 4096> { static constexpr bool value = false; };
+template <> struct Pow2Half<float, 8192> { static constexpr bool value = false; };
+template <> struct Pow2Half<float, 16384> { static constexpr bool value = false; };
 
 bool pow2_supported(int dtype, int n) {
     (void)dtype;
@@ -81,7 +91,7 @@ void pow2_build_twiddles(int dtype, int n, HostTable &out) {
 
 template <typename T, int N, int NT, int VEC, int FL = 0> static int launch_one(const Pow2Args &a, hipStream_t s) {
     constexpr int TPL = Pow2Cfg<T, N>::TPL, LPB = lpb_for(TPL);
-    using K = Pow2Kernel<T, N, TPL, LPB, true, typename Pow2Cfg<T, N>::RL, FL, 1, NT, VEC>;
+    using K = Pow2Kernel<T, N, TPL, LPB, Pow2Half<T, N>::value, typename Pow2Cfg<T, N>::RL, FL, 1, NT, VEC>;
     NDFFT_ENSURE_LDS_ATTR((k_pow2<K>));
     const int64_t nblk = (a.nlanes + LPB - 1) / LPB;
     if (nblk <= 0) return NDFFT_OK;

@@ -187,6 +187,18 @@ int main(int argc, char **argv) {
         V(b, double, 4096, "half 256x16 16.16.16 nt1", 256, true, 1, 1, 16, 16, 16);
         V(b, double, 4096, "half 256x16 16.16.16 nt3", 256, true, 3, 1, 16, 16, 16);
         b.run(1e-12);
+    } else if (what == "f32_halffull") {
+        { Bench<float> b{1024, 32768, rounds}; b.init();
+          V(b, float, 1024, "1024 half 64x16 8.16.8 (product)", 64, true, 1, 2, 8, 16, 8);
+          V(b, float, 1024, "1024 full 64x16 8.16.8", 64, false, 1, 2, 8, 16, 8); b.run(1e-5); }
+        { Bench<float> b{2048, 16384, rounds}; b.init();
+          V(b, float, 2048, "2048 half 128x16 8.4.8.8 (product)", 128, true, 1, 2, 8, 4, 8, 8);
+          V(b, float, 2048, "2048 full 128x16 8.4.8.8", 128, false, 1, 2, 8, 4, 8, 8);
+          V(b, float, 2048, "2048 full 128x16 16.16.8 vec1", 128, false, 1, 1, 16, 16, 8); b.run(1e-5); }
+        { Bench<float> b{4096, 8192, rounds}; b.init();
+          V(b, float, 4096, "4096 half 256x16 8.8.8.8 (product)", 256, true, 1, 2, 8, 8, 8, 8);
+          V(b, float, 4096, "4096 full 256x16 8.8.8.8", 256, false, 1, 2, 8, 8, 8, 8);
+          V(b, float, 4096, "4096 full 256x16 8.16.8?  8.8.8.8->16.16.16 no vec", 256, false, 1, 1, 16, 16, 16); b.run(1e-5); }
     } else if (what == "f32_16384") {
         Bench<float> b{16384, 2048, rounds}; b.init();
         V(b, float, 16384, "half 1024x16 8.16.16.8 vec2 (product)", 1024, true, 1, 2, 8, 16, 16, 8);
