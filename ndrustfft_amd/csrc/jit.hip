@@ -72,6 +72,7 @@ bool jit_disabled() {
 // Partial-round configurations (pow2_kernel.h: slots / full): any radix list whose product is n, any TPL.
 // Cost ~ passes x (work incl. idle threads of partial rounds): minimise NP / utilisation; ties -> E nearest 16.
 static size_t jit_lds_limit();
+static int jit_full_min() { static const int v = [] { const char *e = getenv("NDFFT_JIT_FULL_MIN"); return e ? atoi(e) : 256; }(); return v; }
 static bool jit_choose_partial(int dtype, int n, JitCfg &cfg) {
     const int emax = dtype == NDFFT_F32 ? 32 : 30;
     const int cand[] = {16, 13, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
@@ -272,14 +273,20 @@ int launch_jit_c2c(int dtype, const JitCfg &cfg, int nt, const Pow2Args &a, hipS
     NDFFT_HIP(hipGetDevice(&dev));
     const char *tn = dtype == NDFFT_F32 ? "float" : "double";
     const int threads = cfg.tpl * cfg.lpb;
+    // f32 lanes exchange whole complex elements (64-bit LDS accesses, half the LDS instructions) as long as two
+    // workgroups still fit a CU, like the ahead-of-time f32 configurations (kernels_pow2.hip: Pow2Half).  Measured on
+    // 2^25 points (tools/probes/jit_f32_full.py): n = 1000 102 -> 96 us, 3000 141 -> 133, 6000 177 -> 137; but
+    // n = 10000 (85 KiB: one workgroup per CU) 149 -> 172, hence the 80 KiB bound.
+    const bool half = !(dtype == NDFFT_F32 && cfg.n >= jit_full_min() &&
+                        (size_t)cfg.lpb * (size_t)(cfg.n + (cfg.n >> 4) + 1) * 8 <= (size_t)80 * 1024);
     const std::string inst = std::string("Pow2Kernel<") + tn + ", " + std::to_string(cfg.n) + ", " + std::to_string(cfg.tpl) + ", " +
-                             std::to_string(cfg.lpb) + ", true, RadixList<" + radix_list(cfg) + ">, " + (a.twlo ? "8" : "0") + ", 1, " + std::to_string(nt) + ", " + std::to_string(vec) + ">";
+                             std::to_string(cfg.lpb) + (half ? ", true" : ", false") + ", RadixList<" + radix_list(cfg) + ">, " + (a.twlo ? "8" : "0") + ", 1, " + std::to_string(nt) + ", " + std::to_string(vec) + ">";
     const std::string src = "#include \"pow2_kernel.h\"\nusing namespace ndfft;\nextern \"C\" __global__ __launch_bounds__(" +
                             std::to_string(threads) + ") void k_jit(const Pow2Args a) { " + inst + "::run(a); }\n";
     const Entry e = get_or_compile("dev" + std::to_string(dev) + ":" + inst, src, inst);
     if (e.failed) return NDFFT_ERR_UNSUPPORTED;
     const size_t esz = dtype == NDFFT_F32 ? 4 : 8;
-    const size_t lds = (size_t)cfg.lpb * (size_t)(cfg.n + (cfg.n >> 4) + 1) * esz;   // Pow2Kernel::LDS_BYTES (HALF exchange)
+    const size_t lds = (size_t)cfg.lpb * (size_t)(cfg.n + (cfg.n >> 4) + 1) * esz * (half ? 1 : 2);   // Pow2Kernel::LDS_BYTES
     if (lds > jit_lds_limit()) return NDFFT_ERR_UNSUPPORTED;
     const int64_t nblk = (a.nlanes + cfg.lpb - 1) / cfg.lpb;
     if (nblk <= 0) return NDFFT_OK;
