@@ -187,6 +187,24 @@ int main(int argc, char **argv) {
         V(b, double, 4096, "half 256x16 16.16.16 nt1", 256, true, 1, 1, 16, 16, 16);
         V(b, double, 4096, "half 256x16 16.16.16 nt3", 256, true, 3, 1, 16, 16, 16);
         b.run(1e-12);
+    } else if (what == "f32_small") {
+        { Bench<float> b{64, 524288, rounds}; b.init();
+          V(b, float, 64, "64 half 4x16 8.8 vec2 (product)", 4, true, 1, 2, 8, 8);
+          V(b, float, 64, "64 full 4x16 8.8 vec2", 4, false, 1, 2, 8, 8);
+          V(b, float, 64, "64 half 8x8 8.8 vec1", 8, true, 1, 1, 8, 8);
+          V(b, float, 64, "64 full 8x8 8.8 vec1", 8, false, 1, 1, 8, 8);
+          V(b, float, 64, "64 full 2x32 16.4?no 8.8 vec2", 2, false, 1, 2, 8, 8); b.run(1e-5); }
+        { Bench<float> b{128, 262144, rounds}; b.init();
+          V(b, float, 128, "128 half 8x16 8.2.8 vec2 (product)", 8, true, 1, 2, 8, 2, 8);
+          V(b, float, 128, "128 full 8x16 8.2.8 vec2", 8, false, 1, 2, 8, 2, 8);
+          V(b, float, 128, "128 full 8x16 8.16 vec1", 8, false, 1, 1, 8, 16); b.run(1e-5); }
+        { Bench<float> b{256, 131072, rounds}; b.init();
+          V(b, float, 256, "256 half 16x16 8.4.8 vec2 (product)", 16, true, 1, 2, 8, 4, 8);
+          V(b, float, 256, "256 full 16x16 8.4.8 vec2", 16, false, 1, 2, 8, 4, 8);
+          V(b, float, 256, "256 full 16x16 16.16 vec1", 16, false, 1, 1, 16, 16); b.run(1e-5); }
+        { Bench<float> b{512, 65536, rounds}; b.init();
+          V(b, float, 512, "512 half 32x16 8.8.8 vec2 (product)", 32, true, 1, 2, 8, 8, 8);
+          V(b, float, 512, "512 full 32x16 8.8.8 vec2", 32, false, 1, 2, 8, 8, 8); b.run(1e-5); }
     } else if (what == "f32_halffull") {
         { Bench<float> b{1024, 32768, rounds}; b.init();
           V(b, float, 1024, "1024 half 64x16 8.16.8 (product)", 64, true, 1, 2, 8, 16, 8);
