@@ -18,6 +18,12 @@ template <int... Rs> struct RadixList {
 };
 
 __device__ __forceinline__ int phi(int p) { return p + (p >> 4); }
+// phi(base + r * STRIDE): when STRIDE is a multiple of 16 the padding term splits, phi(base) + r * (STRIDE + STRIDE/16),
+// i.e. a compile-time offset per r that folds into the LDS instruction's immediate
+template <int STRIDE> __device__ __forceinline__ int phi_at(int base, int pbase, int r) {
+    if constexpr (STRIDE % 16 == 0) return pbase + r * (STRIDE + STRIDE / 16);
+    else return phi(base + r * STRIDE);
+}
 // j mod Ns for a compile-time Ns (a mask when Ns is a power of two, a multiply-shift otherwise)
 template <int Ns> __device__ __forceinline__ int kmod(int j) {
     if constexpr ((Ns & (Ns - 1)) == 0) return j & (Ns - 1);
@@ -127,20 +133,20 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
                     __syncthreads();
 #pragma unroll
                     for (int q = 0; q < NBF; ++q) {
-                        const int j = jof<P>(t, q), k = kmod<Ns>(j), o = (j - k) * R + k;
+                        const int j = jof<P>(t, q), k = kmod<Ns>(j), o = (j - k) * R + k, po = phi(o);
                         if (FULL || j < NB) {
 #pragma unroll
-                            for (int r = 0; r < R; ++r) s[phi(o + r * Ns)] = half ? v[q * R + r].y : v[q * R + r].x;
+                            for (int r = 0; r < R; ++r) s[phi_at<Ns>(o, po, r)] = half ? v[q * R + r].y : v[q * R + r].x;
                         }
                     }
                     __syncthreads();
 #pragma unroll
                     for (int q = 0; q < NBF2; ++q) {
-                        const int j = jof<P + 1>(t, q);
+                        const int j = jof<P + 1>(t, q), pj = phi(j);
                         if (FULL2 || j < NB2) {
 #pragma unroll
                             for (int r = 0; r < R2; ++r) {
-                                const T x = s[phi(j + r * NB2)];
+                                const T x = s[phi_at<NB2>(j, pj, r)];
                                 if (half) v[q * R2 + r].y = x; else v[q * R2 + r].x = x;
                             }
                         }
@@ -151,19 +157,19 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
                 __syncthreads();
 #pragma unroll
                 for (int q = 0; q < NBF; ++q) {
-                    const int j = jof<P>(t, q), k = kmod<Ns>(j), o = (j - k) * R + k;
+                    const int j = jof<P>(t, q), k = kmod<Ns>(j), o = (j - k) * R + k, po = phi(o);
                     if (FULL || j < NB) {
 #pragma unroll
-                        for (int r = 0; r < R; ++r) s[phi(o + r * Ns)] = v[q * R + r];
+                        for (int r = 0; r < R; ++r) s[phi_at<Ns>(o, po, r)] = v[q * R + r];
                     }
                 }
                 __syncthreads();
 #pragma unroll
                 for (int q = 0; q < NBF2; ++q) {
-                    const int j = jof<P + 1>(t, q);
+                    const int j = jof<P + 1>(t, q), pj = phi(j);
                     if (FULL2 || j < NB2) {
 #pragma unroll
-                        for (int r = 0; r < R2; ++r) v[q * R2 + r] = s[phi(j + r * NB2)];
+                        for (int r = 0; r < R2; ++r) v[q * R2 + r] = s[phi_at<NB2>(j, pj, r)];
                     }
                 }
             }
