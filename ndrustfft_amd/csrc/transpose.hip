@@ -39,13 +39,15 @@ __global__ __launch_bounds__(256) void k_transpose(const E *__restrict__ in, E *
     const int tx = threadIdx.x % TILE, ty = threadIdx.x / TILE;
     constexpr int RSTEP = 256 / TILE;
 #pragma unroll
-    for (int i = ty; i < TILE; i += RSTEP) {
+    for (int ii = 0; ii < TILE / RSTEP; ++ii) {          // (trip count known at compile time: all loads in flight)
+        const int i = ty + ii * RSTEP;
         const int64_t r = r0 + i, c = c0 + tx;
         if (r < rows && c < cols) tile[i][tx] = src[r * ld_in + c];
     }
     __syncthreads();
 #pragma unroll
-    for (int i = ty; i < TILE; i += RSTEP) {
+    for (int ii = 0; ii < TILE / RSTEP; ++ii) {
+        const int i = ty + ii * RSTEP;
         const int64_t c = c0 + i, r = r0 + tx;
         if (r < rows && c < cols) __builtin_nontemporal_store(tile[tx][i], &dst[c * ld_out + r]);
     }
