@@ -65,6 +65,7 @@ template <typename T, bool NT> __device__ __forceinline__ void gstore(cpx<T> *p,
 
 // FLAGS is for ablation builds in tools/kbench.hip only (product kernels use 0):
 //   1 = skip twiddle multiplies, 2 = skip the LDS exchange, 4 = skip butterflies
+// product flags: 8 = fused four-step twiddle on load (Pow2Args::twlo), 16 = derive twiddle powers for big late-pass tables
 // NT: bit 0 = non-temporal stores, bit 1 = non-temporal loads
 // VEC = 2 (f32 only): global loads/stores move TWO adjacent complex elements (16 B) per lane; the
 //   first and last pass then own adjacent butterfly pairs j = 2t, 2t+1 instead of j = t, t+TPL.
