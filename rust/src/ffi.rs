@@ -45,4 +45,15 @@ extern "C" {
     ) -> c_int;
     /// frees the calling thread's device scratch / staging buffers (kept for reuse otherwise)
     pub fn ndfft_release_workspace() -> c_int;
+    // device-resident arrays (no reference counterpart)
+    pub fn ndfft_exec_device(
+        plan: *const ndfft_plan, op: c_int, d_input: *const c_void, d_output: *mut c_void, ndim: c_int,
+        shape_in: *const i64, stride_in: *const i64, shape_out: *const i64, stride_out: *const i64,
+        axis: c_int, norm: c_int, scale: c_double, stream: *mut c_void,
+    ) -> c_int;
+    pub fn ndfft_dev_alloc(d_ptr: *mut *mut c_void, bytes: usize) -> c_int;
+    pub fn ndfft_dev_free(d_ptr: *mut c_void) -> c_int;
+    pub fn ndfft_dev_upload(d_dst: *mut c_void, h_src: *const c_void, bytes: usize) -> c_int;
+    pub fn ndfft_dev_download(h_dst: *mut c_void, d_src: *const c_void, bytes: usize) -> c_int;
+    pub fn ndfft_dev_sync(stream: *mut c_void) -> c_int;
 }

@@ -190,3 +190,80 @@ transform!(/// DCT-III along `axis`.
     nddct3, nddct3_par, T, T, DctHandler, ffi::NDFFT_OP_DCT3, NormPoint::Before);
 transform!(/// DCT-IV along `axis`.
     nddct4, nddct4_par, T, T, DctHandler, ffi::NDFFT_OP_DCT4, NormPoint::Before);
+
+/// Device-resident arrays: keep the `work` array of a multi-axis transform (examples/fft2.rs:23-27 in the
+/// reference) in HBM between the axis passes instead of crossing PCIe twice per call.
+/// No counterpart in ndrustfft; the functions mirror the host ones (same names, same handlers, same axis
+/// semantics) on `DeviceArray`s.  `Normalization::Custom` needs host lanes and is rejected here.
+pub mod device {
+    use super::*;
+
+    /// A C-layout n-d array in device memory (owned).
+    pub struct DeviceArray<A> {
+        ptr: *mut c_void,
+        shape: Vec<usize>,
+        _elem: std::marker::PhantomData<A>,
+    }
+    unsafe impl<A: Send> Send for DeviceArray<A> {}
+
+    impl<A: Copy> DeviceArray<A> {
+        /// Uninitialised device array of `shape` (C layout).
+        pub fn new(shape: &[usize]) -> Self {
+            let len: usize = shape.iter().product();
+            let mut p = std::ptr::null_mut();
+            check(unsafe { ffi::ndfft_dev_alloc(&mut p, len.max(1) * std::mem::size_of::<A>()) });
+            DeviceArray { ptr: p, shape: shape.to_vec(), _elem: std::marker::PhantomData }
+        }
+        /// Copies a host array (any layout) to the device in C layout.
+        pub fn from_host<S: Data<Elem = A>, D: Dimension>(a: &ArrayBase<S, D>) -> Self {
+            let d = Self::new(a.shape());
+            let c = a.as_standard_layout();
+            check(unsafe { ffi::ndfft_dev_upload(d.ptr, c.as_ptr() as *const c_void, c.len() * std::mem::size_of::<A>()) });
+            d
+        }
+        /// Copies back into a C-layout host array of the same shape.
+        pub fn to_host<S: DataMut<Elem = A>, D: Dimension>(&self, out: &mut ArrayBase<S, D>) {
+            assert_eq!(out.shape(), &self.shape[..], "shape mismatch in to_host");
+            assert!(out.is_standard_layout(), "to_host needs a C-layout destination");
+            check(unsafe { ffi::ndfft_dev_sync(std::ptr::null_mut()) });
+            check(unsafe { ffi::ndfft_dev_download(out.as_mut_ptr() as *mut c_void, self.ptr, out.len() * std::mem::size_of::<A>()) });
+        }
+        pub fn shape(&self) -> &[usize] { &self.shape }
+        fn geom(&self) -> (Vec<i64>, Vec<i64>) {
+            let shape: Vec<i64> = self.shape.iter().map(|&s| s as i64).collect();
+            let mut stride = vec![1i64; shape.len()];
+            for d in (0..shape.len().saturating_sub(1)).rev() { stride[d] = stride[d + 1] * shape[d + 1]; }
+            (shape, stride)
+        }
+    }
+    impl<A> Drop for DeviceArray<A> {
+        fn drop(&mut self) { unsafe { ffi::ndfft_dev_free(self.ptr) }; }
+    }
+
+    macro_rules! device_transform {
+        ($name:ident, $a:ty, $b:ty, $h:ident, $op:expr) => {
+            /// Device-resident twin of the host function of the same name (asynchronous on the null stream).
+            pub fn $name<T: GpuFloat>(input: &DeviceArray<$a>, output: &mut DeviceArray<$b>, handler: &$h<T>, axis: usize) {
+                let mode = match handler.norm {
+                    Normalization::None => ffi::NDFFT_NORM_NONE,
+                    Normalization::Default => ffi::NDFFT_NORM_DEFAULT,
+                    Normalization::Custom(_) => panic!("Normalization::Custom needs host lanes: use the host functions"),
+                };
+                let (si, sti) = input.geom();
+                let (so, sto) = output.geom();
+                check(unsafe {
+                    ffi::ndfft_exec_device(handler.plan.0, $op, input.ptr, output.ptr, si.len() as c_int, si.as_ptr(), sti.as_ptr(),
+                                           so.as_ptr(), sto.as_ptr(), axis as c_int, mode, 0.0, std::ptr::null_mut())
+                });
+            }
+        };
+    }
+    device_transform!(ndfft, Complex<T>, Complex<T>, FftHandler, ffi::NDFFT_OP_C2C_FWD);
+    device_transform!(ndifft, Complex<T>, Complex<T>, FftHandler, ffi::NDFFT_OP_C2C_INV);
+    device_transform!(ndfft_r2c, T, Complex<T>, R2cFftHandler, ffi::NDFFT_OP_R2C);
+    device_transform!(ndifft_r2c, Complex<T>, T, R2cFftHandler, ffi::NDFFT_OP_C2R);
+    device_transform!(nddct1, T, T, DctHandler, ffi::NDFFT_OP_DCT1);
+    device_transform!(nddct2, T, T, DctHandler, ffi::NDFFT_OP_DCT2);
+    device_transform!(nddct3, T, T, DctHandler, ffi::NDFFT_OP_DCT3);
+    device_transform!(nddct4, T, T, DctHandler, ffi::NDFFT_OP_DCT4);
+}
