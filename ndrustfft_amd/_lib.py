@@ -23,7 +23,7 @@ SYMBOLS = [
     "ndfft_plan_dtype", "ndfft_plan_lane_len_in", "ndfft_plan_lane_len_out",
     "ndfft_exec", "ndfft_exec_device", "ndfft_last_path",
     "ndfft_dev_alloc", "ndfft_dev_free", "ndfft_dev_upload", "ndfft_dev_download", "ndfft_dev_sync",
-    "ndfft_release_workspace",
+    "ndfft_release_workspace", "ndfft_host_alloc", "ndfft_host_free",
 ]
 
 
@@ -68,6 +68,8 @@ class Library:
         L.ndfft_dev_download.argtypes = [vp, vp, sz]
         L.ndfft_dev_sync.argtypes = [vp]
         L.ndfft_release_workspace.argtypes = []; L.ndfft_release_workspace.restype = ctypes.c_int
+        L.ndfft_host_alloc.argtypes = [ctypes.POINTER(vp), ctypes.c_size_t]; L.ndfft_host_alloc.restype = ctypes.c_int
+        L.ndfft_host_free.argtypes = [vp]; L.ndfft_host_free.restype = ctypes.c_int
 
     def check(self, status):
         if status == OK:

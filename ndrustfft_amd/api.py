@@ -132,3 +132,19 @@ def nddct4(input, output, handler, axis): _transform(_lib.OP_DCT4, input, output
 ndfft_par, ndifft_par = ndfft, ndifft
 ndfft_r2c_par, ndifft_r2c_par = ndfft_r2c, ndifft_r2c
 nddct1_par, nddct2_par, nddct3_par, nddct4_par = nddct1, nddct2, nddct3, nddct4
+
+
+def pinned_empty(shape, dtype, _library=None):
+    """A C-layout numpy array in page-locked host memory from ndfft_host_alloc: ndfft_exec on such arrays overlaps
+    upload, transform and download (include/ndfft_mi355x.h).  The memory is released when the array (and every
+    view of it) is garbage-collected."""
+    import weakref
+    L = _library or _lib.default()
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape, dtype=np.int64)) if len(shape) else 1
+    p = ctypes.c_void_p()
+    L.check(L.c.ndfft_host_alloc(ctypes.byref(p), max(n * dt.itemsize, 1)))
+    buf = (ctypes.c_char * max(n * dt.itemsize, 1)).from_address(p.value)
+    arr = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+    weakref.finalize(buf, L.c.ndfft_host_free, p)
+    return arr

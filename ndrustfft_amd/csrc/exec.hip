@@ -721,6 +721,75 @@ static thread_local Staging g_stage_in, g_stage_out;
 
 using namespace ndfft;
 
+namespace {
+// ---- pinned host arrays: H2D || kernel || D2H over row chunks --------------------------------------------
+// Pageable host memory is staged by the runtime and the two PCIe directions do not overlap (tools/h2d_bench.hip:
+// 9.7 ms for 2 x 256 MiB whatever the threading); arrays allocated with ndfft_host_alloc are pinned, their copies
+// are real DMA and the directions overlap (5.6 ms).  A dense C-layout call whose slowest dimension is a batch
+// dimension is therefore split into row chunks: chunk c+1 uploads while chunk c transforms and chunk c-1 downloads.
+bool is_pinned(const void *p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+struct Pipe { hipStream_t h2d = nullptr, cmp = nullptr, d2h = nullptr; std::vector<hipEvent_t> up, done; bool ok = false; };
+thread_local Pipe g_pipe;
+int pipe_init(int chunks) {
+    Pipe &p = g_pipe;
+    if (!p.ok) {
+        NDFFT_HIP(hipStreamCreate(&p.h2d)); NDFFT_HIP(hipStreamCreate(&p.cmp)); NDFFT_HIP(hipStreamCreate(&p.d2h));
+        p.ok = true;
+    }
+    while ((int)p.up.size() < chunks) {
+        hipEvent_t a, b;
+        NDFFT_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming)); NDFFT_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        p.up.push_back(a); p.done.push_back(b);
+    }
+    return NDFFT_OK;
+}
+// span (in elements) of one index of dimension 0, i.e. of the sub-view shape[1:], or -1 if it has negative strides
+int64_t inner_span(int ndim, const int64_t *shape, const int64_t *stride) {
+    int64_t hi = 0;
+    for (int d = 1; d < ndim; ++d) {
+        if (shape[d] <= 0) return 0;
+        if (stride[d] < 0) return -1;
+        hi += (shape[d] - 1) * stride[d];
+    }
+    return hi + 1;
+}
+}  // namespace
+
+static int exec_pinned_pipeline(const ndfft_plan *plan, int op, const char *hin, char *hout, int ndim, const int64_t *shape_in,
+                                const int64_t *stride_in, const int64_t *shape_out, const int64_t *stride_out, int axis, int norm,
+                                double scale, size_t ein, size_t eout, int chunks) {
+    int rc;
+    if ((rc = pipe_init(chunks))) return rc;
+    Pipe &pp = g_pipe;
+    const int64_t R = shape_in[0];
+    const int64_t isp = inner_span(ndim, shape_in, stride_in), osp = inner_span(ndim, shape_out, stride_out);
+    std::vector<int64_t> si(shape_in, shape_in + ndim), so(shape_out, shape_out + ndim);
+    for (int c = 0; c < chunks; ++c) {
+        const int64_t r0 = R * c / chunks, r1 = R * (c + 1) / chunks;
+        if (r1 <= r0) continue;
+        si[0] = so[0] = r1 - r0;
+        const size_t off_in = (size_t)(r0 * stride_in[0]) * ein, off_out = (size_t)(r0 * stride_out[0]) * eout;
+        const size_t bytes_in = (size_t)((r1 - r0 - 1) * stride_in[0] + isp) * ein, bytes_out = (size_t)((r1 - r0 - 1) * stride_out[0] + osp) * eout;
+        NDFFT_HIP(hipMemcpyAsync((char *)g_stage_in.p + off_in, hin + off_in, bytes_in, hipMemcpyHostToDevice, pp.h2d));
+        NDFFT_HIP(hipEventRecord(pp.up[c], pp.h2d));
+        NDFFT_HIP(hipStreamWaitEvent(pp.cmp, pp.up[c], 0));
+        Problem P;
+        bool nothing;
+        if ((rc = prepare(plan, op, ndim, si.data(), stride_in, so.data(), stride_out, axis, norm, scale, P, nothing))) return rc;
+        if (!nothing && (rc = dispatch_peeled(P, (const char *)g_stage_in.p + off_in, (char *)g_stage_out.p + off_out, ein, eout, pp.cmp))) return rc;
+        NDFFT_HIP(hipEventRecord(pp.done[c], pp.cmp));
+        NDFFT_HIP(hipStreamWaitEvent(pp.d2h, pp.done[c], 0));
+        NDFFT_HIP(hipMemcpyAsync(hout + off_out, (const char *)g_stage_out.p + off_out, bytes_out, hipMemcpyDeviceToHost, pp.d2h));
+    }
+    NDFFT_HIP(hipStreamSynchronize(pp.d2h));
+    NDFFT_HIP(hipStreamSynchronize(pp.cmp));
+    return NDFFT_OK;
+}
+
 extern "C" {
 
 int ndfft_exec_device(const ndfft_plan *plan, int op, const void *d_in, void *d_out, int ndim,
@@ -735,6 +804,18 @@ int ndfft_exec_device(const ndfft_plan *plan, int op, const void *d_in, void *d_
     const size_t r = real_size(plan->dtype);
     return dispatch_peeled(P, (const char *)d_in, (char *)d_out, op_in_cplx(op) ? 2 * r : r, op_out_cplx(op) ? 2 * r : r,
                            (hipStream_t)stream);
+}
+
+int ndfft_host_alloc(void **h_ptr, size_t bytes) {
+    clear_err();
+    if (!h_ptr) return fail(NDFFT_ERR_INVALID_ARG, "h_ptr is null");
+    NDFFT_HIP(hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return NDFFT_OK;
+}
+int ndfft_host_free(void *h_ptr) {
+    clear_err();
+    if (h_ptr) NDFFT_HIP(hipHostFree(h_ptr));
+    return NDFFT_OK;
 }
 
 int ndfft_exec(const ndfft_plan *plan, int op, const void *in, void *out, int ndim, const int64_t *shape_in,
@@ -756,6 +837,16 @@ int ndfft_exec(const ndfft_plan *plan, int op, const void *in, void *out, int nd
     if ((rc = g_stage_out.reserve(obytes))) return rc;
     const char *hin = (const char *)in + ilo * (int64_t)ein;
     char *hout = (char *)out + olo * (int64_t)eout;
+    // pinned, dense, C-ordered in dimension 0, transform along another axis: pipelined row chunks
+    if (ndim >= 2 && axis != 0 && ilo == 0 && olo == 0 && shape_in[0] == shape_out[0] && shape_in[0] >= 16 &&
+        (int64_t)(ohi + 1) == ocnt && ibytes + obytes >= ((size_t)8 << 20) && is_pinned(in) && is_pinned(out)) {
+        const int64_t isp = inner_span(ndim, shape_in, stride_in), osp = inner_span(ndim, shape_out, stride_out);
+        if (isp > 0 && osp > 0 && stride_in[0] >= isp && stride_out[0] >= osp) {
+            const char *e = getenv("NDFFT_PIPE_CHUNKS");
+            const int chunks = (int)std::min<int64_t>(shape_in[0], e ? std::max(1, atoi(e)) : 8);
+            return exec_pinned_pipeline(plan, op, hin, hout, ndim, shape_in, stride_in, shape_out, stride_out, axis, norm, scale, ein, eout, chunks);
+        }
+    }
     NDFFT_HIP(hipMemcpy(g_stage_in.p, hin, ibytes, hipMemcpyHostToDevice));
     // a strided output view has holes that belong to the caller: carry them through the round trip
     if ((int64_t)(ohi - olo + 1) != ocnt) NDFFT_HIP(hipMemcpy(g_stage_out.p, hout, obytes, hipMemcpyHostToDevice));

@@ -56,4 +56,7 @@ extern "C" {
     pub fn ndfft_dev_upload(d_dst: *mut c_void, h_src: *const c_void, bytes: usize) -> c_int;
     pub fn ndfft_dev_download(h_dst: *mut c_void, d_src: *const c_void, bytes: usize) -> c_int;
     pub fn ndfft_dev_sync(stream: *mut c_void) -> c_int;
+    /// pinned host memory: ndfft_exec on arrays that both live in it overlaps upload, transform and download
+    pub fn ndfft_host_alloc(h_ptr: *mut *mut c_void, bytes: usize) -> c_int;
+    pub fn ndfft_host_free(h_ptr: *mut c_void) -> c_int;
 }

@@ -46,6 +46,18 @@ hipError_t hipFree(void *p);
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline hipError_t hipDeviceSynchronize() { return 0; }
+// pinned-host pipeline of ndfft_exec: never taken in the emulation (no pointer is ever "pinned"), stubs only
+typedef void *hipEvent_t;
+enum { hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipMemoryTypeHost = 1 };
+struct hipPointerAttribute_t { int type; };
+inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *, const void *) { return 1; }
+inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return 0; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = nullptr; return 0; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return 0; }
+inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
+inline hipError_t hipHostFree(void *p) { free(p); return 0; }
 inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return 0; }
 
 void __syncthreads();

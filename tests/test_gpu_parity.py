@@ -235,3 +235,22 @@ def test_release_workspace(L):
     assert L.c.ndfft_release_workspace() == 0
     y[:] = 0; api.ndfft_r2c(x, y, h, 0)
     assert np.array_equal(y, first)
+
+
+def test_pinned_host_pipeline(L):
+    """Arrays from ndfft_host_alloc: ndfft_exec runs as overlapped row chunks; same results as the plain host path."""
+    from ndrustfft_amd import pinned_empty
+    for name, shape, axis, rdt in (("ndfft", (512, 4096), 1, np.float64), ("ndfft_r2c", (300, 8, 1000), 2, np.float32),
+                                   ("nddct2", (64, 96, 512), 1, np.float64), ("ndifft_r2c", (257, 2049), 1, np.float64)):
+        sin, sout = ps.shapes_for(name, shape, axis)
+        src = ps.make_input(name, sin, rdt)
+        x = pinned_empty(sin, src.dtype, _library=L); x[...] = src
+        odt = (np.complex64 if rdt == np.float32 else np.complex128) if ps.OPS[name][4] else np.dtype(rdt)
+        y = pinned_empty(sout, odt, _library=L); y[...] = 0
+        y2 = np.zeros(sout, odt)
+        h, o = ps.handlers_for(name, shape[axis], rdt, L)
+        ps.OPS[name][0](x, y, h, axis)
+        ps.OPS[name][0](src, y2, h, axis)
+        assert np.array_equal(y, y2), (name, shape)
+        yo = np.zeros(sout, odt); ps.OPS[name][1](src, yo, o, axis)
+        assert_close(y, yo, axis, TOL[np.dtype(rdt)], f"pinned {name} {shape}")

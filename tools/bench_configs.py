@@ -92,6 +92,16 @@ def main():
         t = (time.perf_counter() - t0) / reps
         print(json.dumps({"workload": "hostpath ndfft_exec (pageable host arrays, PCIe both ways) 4096x4096 c128", "us": round(t * 1e6, 1),
                           "GFFT-points/s": round(x.size / t / 1e9, 3), "host_GB/s": round(2 * x.nbytes / t / 1e9, 2)}), flush=True)
+        from ndrustfft_amd import pinned_empty
+        xp = pinned_empty(x.shape, x.dtype); xp[...] = x; yp = pinned_empty(y.shape, y.dtype)
+        ndfft(xp, yp, h, 1)
+        assert np.array_equal(yp, y)
+        t0 = time.perf_counter(); reps = 5
+        for _ in range(reps):
+            ndfft(xp, yp, h, 1)
+        t = (time.perf_counter() - t0) / reps
+        print(json.dumps({"workload": "hostpath ndfft_exec (PINNED host arrays from ndfft_host_alloc: upload || transform || download over 8 row chunks) 4096x4096 c128",
+                          "us": round(t * 1e6, 1), "GFFT-points/s": round(x.size / t / 1e9, 3), "host_GB/s": round(2 * x.nbytes / t / 1e9, 2)}), flush=True)
     if want("longlanes"):
         for n, rows, cdt, rdt in ((1 << 16, 256, np.complex128, np.float64), (1 << 20, 16, np.complex128, np.float64), (6000, 2048, np.complex128, np.float64),
                                   (1 << 20, 32, np.complex64, np.float32)):
