@@ -314,8 +314,38 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
             const cpx<T> *res = (const cpx<T> *)lds;
             using OT = typename cond_type<OUT_CPLX, cpx<T>, T>::type;
             // DCT-I / DCT-II scatter four real outputs per spectrum pair (k, n-k, F-k, F+k): worth staging.
+            // (DCT-III was tried the same way as DCT-IV above: 88 -> 94 us on cfg4 -- its cost is the PRE fold, not the POST)
             // (measured: 117 -> 104 us on cfg4; the ops with one contiguous output per thread lose 5-20 % to the
             // two extra barriers, so they keep their direct stores)
+            if constexpr (OP == G_DCT4_EVEN) {
+                // DCT-IV: y[2k] = Re(Z[k] c_k), y[n-1-2k] = -Im(Z[k] c_k) -- one LDS read and one twiddle per PAIR of
+                // outputs (realops.h post_real reads and multiplies once per output), staged through LDS for 16-byte stores
+                if (a.vec_out) {
+                    constexpr int NK = (F + TPL - 1) / TPL;
+                    T o0[NK], o1[NK];
+#pragma unroll
+                    for (int i = 0; i < NK; ++i) {
+                        const int k = t + i * TPL;
+                        if (k < F) { const cpx<T> u = cmul(res[ZiPhi::map(k)], a.aux2[k]); o0[i] = u.x; o1[i] = -u.y; }
+                    }
+                    __syncthreads();
+                    T *stage = (T *)lds;
+                    const int n = 2 * F;
+#pragma unroll
+                    for (int i = 0; i < NK; ++i) {
+                        const int k = t + i * TPL;
+                        if (k < F) { stage[2 * k] = o0[i]; stage[n - 1 - 2 * k] = o1[i]; }
+                    }
+                    __syncthreads();
+                    if (!live) return;
+                    T *out = (T *)a.out + lane * a.pitch_out;
+                    constexpr int W = 16 / sizeof(T);
+                    const int nv = n / W;
+                    for (int j = t; j < nv; j += TPL) __builtin_nontemporal_store(((const vec4f *)stage)[j], (vec4f *)out + j);
+                    for (int j = W * nv + t; j < n; j += TPL) out[j] = stage[j];
+                    return;
+                }
+            }
             if (PAIR && !OUT_CPLX && a.vec_out) {
                 // Row layout, 16-byte aligned lanes: outputs go registers -> LDS (raw order) -> 16-byte
                 // non-temporal stores, instead of 4/8-byte stores straight from the POST gather.
