@@ -208,6 +208,28 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
             }
         }
         if constexpr (!DIRECT_IN) __syncthreads();
+        if constexpr (OP == G_DCT3_EVEN) {
+            // DCT-III: V[k] = 0.5 s (x[k] - i x[n-k]) e^{+i pi k/(2n)}, k = 0..F (x[n] := 0), computed ONCE per k into the lane
+            // region (over the raw lane); the PRE fold below then needs V[i] and V[F-i] only.  pre_elem would build both
+            // from four raw reads, two table loads and two complex multiplies per element -- each V[k] twice.
+            constexpr int NK = (F + 1 + TPL - 1) / TPL;
+            cpx<T> vk[NK];
+            const T *xr = (const T *)lds;
+            const int n = 2 * F;
+            const T hs = (T)0.5 * a.scale;
+#pragma unroll
+            for (int i = 0; i < NK; ++i) {
+                const int k = t + i * TPL;
+                if (k <= F) vk[i] = cmul(mk<T>(xr[k] * hs, k ? -xr[n - k] * hs : (T)0), cconj(a.aux2[k]));
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NK; ++i) {
+                const int k = t + i * TPL;
+                if (k <= F) ((cpx<T> *)lds)[k] = vk[i];
+            }
+            __syncthreads();
+        }
         // ---- PRE into the first pass's register pattern ----
         cpx<T> v[E];
         {
@@ -226,6 +248,7 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                         const int i = t + q * TPL + r * NB0;
                         if constexpr (OP == G_R2C_EVEN || OP == G_C2C_FWD) v[q * R0 + r] = ((const cpx<T> *)raw)[i];   // z[i] = (x[2i], x[2i+1])
                         else if constexpr (OP == G_C2C_INV) v[q * R0 + r] = cconj(((const cpx<T> *)raw)[i]);
+                        else if constexpr (OP == G_DCT3_EVEN) v[q * R0 + r] = herm_fold<T>(((const cpx<T> *)raw)[i], cconj(((const cpx<T> *)raw)[F - i]), a.aux1[i]);
                         else v[q * R0 + r] = pre_elem<T, OP, ZiNone>(a, raw, i);
                     }
                 }
