@@ -235,6 +235,9 @@ Entry get_or_compile(const std::string &key, const std::string &src, const std::
         }
         (void)hipGetLastError();
         ne = Entry();
+        if (const char *e = getenv("NDFFT_JIT_NOCOMPILE")) {      // test switch: cached code objects only
+            if (e[0] == '1') { ne.failed = true; g_cache.emplace(key, ne); return ne; }
+        }
     }
     const char *hn[] = {"device_common.h", "butterflies.h", "pow2_kernel.h", "realops.h", "pow2_real.h", "blue_kernel.h"};
     const char *hs[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h, jit_src_realops_h, jit_src_pow2_real_h, jit_src_blue_kernel_h};

@@ -200,14 +200,16 @@ assert np.abs(y - np.fft.fft(x, axis=1)).max() / np.abs(y).max() < 1e-12
 print("CALL_S", dt)
 ''' % (ROOT, ROOT)
     env = dict(os.environ, NDFFT_JIT_CACHE=str(tmp_path))
-    times = []
-    for _ in range(2):
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    # second process: compiling is forbidden (NDFFT_JIT_NOCOMPILE=1), so "jit_reg" can only come from the cached code object
+    for extra in ({}, {"NDFFT_JIT_NOCOMPILE": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, **extra), timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-        times.append(float([l for l in r.stdout.splitlines() if l.startswith("CALL_S")][0].split()[1]))
         files = [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]
         assert len(files) == 1, files
-    assert times[1] < times[0], times          # no hiprtc compile the second time
+    # and without a cache the same switch sends the call to the LDS kernel (the assert inside the child fails)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                       env=dict(os.environ, NDFFT_JIT_CACHE="0", NDFFT_JIT_NOCOMPILE="1"), timeout=600)
+    assert r.returncode != 0 and "AssertionError" in r.stderr, r.stdout[-500:] + r.stderr[-1500:]
 
 
 def test_fuzz_without_hiprtc():
