@@ -253,6 +253,7 @@ def test_pinned_host_pipeline(L):
         h, o = ps.handlers_for(name, shape[axis], rdt, L)
         ps.OPS[name][0](x, y, h, axis)
         ps.OPS[name][0](src, y2, h, axis)
-        assert np.array_equal(y, y2), (name, shape)
+        # (same kernels, but a chunk may fall on the other side of a specialisation threshold: compare to rounding)
+        assert np.abs(y - y2).max() <= 50 * np.finfo(rdt).eps * np.abs(y2).max(), (name, shape)
         yo = np.zeros(sout, odt); ps.OPS[name][1](src, yo, o, axis)
         assert_close(y, yo, axis, TOL[np.dtype(rdt)], f"pinned {name} {shape}")

@@ -95,7 +95,7 @@ def main():
         from ndrustfft_amd import pinned_empty
         xp = pinned_empty(x.shape, x.dtype); xp[...] = x; yp = pinned_empty(y.shape, y.dtype)
         ndfft(xp, yp, h, 1)
-        assert np.array_equal(yp, y)
+        assert np.abs(yp - y).max() <= 1e-12 * np.abs(y).max()
         t0 = time.perf_counter(); reps = 5
         for _ in range(reps):
             ndfft(xp, yp, h, 1)
