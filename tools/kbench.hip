@@ -187,6 +187,17 @@ int main(int argc, char **argv) {
         V(b, double, 4096, "half 256x16 16.16.16 nt1", 256, true, 1, 1, 16, 16, 16);
         V(b, double, 4096, "half 256x16 16.16.16 nt3", 256, true, 3, 1, 16, 16, 16);
         b.run(1e-12);
+    } else if (what == "f64_full") {
+        { Bench<double> b{4096, 4096, rounds}; b.init();
+          V(b, double, 4096, "4096 half 512x8 8.8.8.8 (product)", 512, true, 1, 1, 8, 8, 8, 8);
+          V(b, double, 4096, "4096 full 512x8 8.8.8.8", 512, false, 1, 1, 8, 8, 8, 8);
+          V(b, double, 4096, "4096 full 256x16 16.16.16", 256, false, 1, 1, 16, 16, 16); b.run(1e-12); }
+        { Bench<double> b{8192, 2048, rounds}; b.init();
+          V(b, double, 8192, "8192 half 512x16 8.8.8.16 (product)", 512, true, 1, 1, 8, 8, 8, 16);
+          V(b, double, 8192, "8192 full 512x16 8.8.8.16", 512, false, 1, 1, 8, 8, 8, 16); b.run(1e-12); }
+        { Bench<double> b{2048, 8192, rounds}; b.init();
+          V(b, double, 2048, "2048 half 128x16 16.16.8 (product)", 128, true, 1, 1, 16, 16, 8);
+          V(b, double, 2048, "2048 full 128x16 16.16.8", 128, false, 1, 1, 16, 16, 8); b.run(1e-12); }
     } else if (what == "f32_small") {
         { Bench<float> b{64, 524288, rounds}; b.init();
           V(b, float, 64, "64 half 4x16 8.8 vec2 (product)", 4, true, 1, 2, 8, 8);
