@@ -91,9 +91,9 @@ void pow2_build_twiddles(int dtype, int n, HostTable &out) {
 
 template <typename T, int N, int NT, int VEC, int FL = 0> static int launch_one(const Pow2Args &a, hipStream_t s) {
     constexpr int TPL = Pow2Cfg<T, N>::TPL, LPB = lpb_for(TPL);
-    // FLAGS bit 4 from n = 8192: late passes whose twiddle table exceeds 32 KiB load W^k, W^2k, W^4k (, W^8k) and build
+    // FLAGS bit 4 from n = 4096: late passes whose twiddle table exceeds 32 KiB load W^k, W^2k, W^4k (, W^8k) and build
     // the other powers (2-4 % on the instruction-bound long kernels; two extra roundings on those twiddles)
-    using K = Pow2Kernel<T, N, TPL, LPB, Pow2Half<T, N>::value, typename Pow2Cfg<T, N>::RL, FL | (N >= 8192 ? 16 : 0), 1, NT, VEC>;
+    using K = Pow2Kernel<T, N, TPL, LPB, Pow2Half<T, N>::value, typename Pow2Cfg<T, N>::RL, FL | (N >= 4096 ? 16 : 0), 1, NT, VEC>;
     NDFFT_ENSURE_LDS_ATTR((k_pow2<K>));
     const int64_t nblk = (a.nlanes + LPB - 1) / LPB;
     if (nblk <= 0) return NDFFT_OK;

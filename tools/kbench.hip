@@ -191,7 +191,8 @@ int main(int argc, char **argv) {
         { Bench<double> b{4096, 4096, rounds}; b.init();
           V(b, double, 4096, "4096 half 512x8 8.8.8.8 (product)", 512, true, 1, 1, 8, 8, 8, 8);
           V(b, double, 4096, "4096 full 512x8 8.8.8.8", 512, false, 1, 1, 8, 8, 8, 8);
-          V(b, double, 4096, "4096 full 256x16 16.16.16", 256, false, 1, 1, 16, 16, 16); b.run(1e-12); }
+          b.template add<Pow2Kernel<double, 4096, 512, 1, true, RadixList<8, 8, 8, 8>, 16, 1, 1, 1>, RadixList<8, 8, 8, 8>>("4096 half 512x8 8.8.8.8 TW_POWERS");
+          b.run(1e-12); }
         { Bench<double> b{8192, 2048, rounds}; b.init();
           V(b, double, 8192, "8192 half 512x16 8.8.8.16 (product)", 512, true, 1, 1, 8, 8, 8, 16);
           V(b, double, 8192, "8192 full 512x16 8.8.8.16", 512, false, 1, 1, 8, 8, 8, 16); b.run(1e-12); }
