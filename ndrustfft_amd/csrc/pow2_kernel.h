@@ -17,11 +17,16 @@ template <int... Rs> struct RadixList {
     static constexpr int twoff(int i) { int o = 0; for (int p = 1; p < i; ++p) o += (at(p) - 1) * ns(p); return o; }
 };
 
-__device__ __forceinline__ int phi(int p) { return p + (p >> 4); }
+// LDS padding of the exchange: one element per 2^NDFFT_PHI_SHIFT (16).  One per 8 makes the stride-8 writes of the
+// first passes conflict-free but measured no faster, so 16 stays the default.
+#ifndef NDFFT_PHI_SHIFT
+#define NDFFT_PHI_SHIFT 4
+#endif
+__device__ __forceinline__ int phi(int p) { return p + (p >> NDFFT_PHI_SHIFT); }
 // phi(base + r * STRIDE): when STRIDE is a multiple of 16 the padding term splits, phi(base) + r * (STRIDE + STRIDE/16),
 // i.e. a compile-time offset per r that folds into the LDS instruction's immediate
 template <int STRIDE> __device__ __forceinline__ int phi_at(int base, int pbase, int r) {
-    if constexpr (STRIDE % 16 == 0) return pbase + r * (STRIDE + STRIDE / 16);
+    if constexpr (STRIDE % (1 << NDFFT_PHI_SHIFT) == 0) return pbase + r * (STRIDE + (STRIDE >> NDFFT_PHI_SHIFT));
     else return phi(base + r * STRIDE);
 }
 // j mod Ns for a compile-time Ns (a mask when Ns is a power of two, a multiply-shift otherwise)
@@ -81,7 +86,7 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
     static constexpr int calc_e() { int e = 0; for (int p = 0; p < RL::NP; ++p) { const int x = slots(p) * RL::at(p); if (x > e) e = x; } return e; }
     static constexpr int E = calc_e();                                     // = N / TPL when every pass is full
     static constexpr int THREADS = TPL * LPB;
-    static constexpr int LANE_LDS = N + (N >> 4) + 1;                      // padded elements per lane
+    static constexpr int LANE_LDS = N + (N >> NDFFT_PHI_SHIFT) + 1;                      // padded elements per lane
     static constexpr size_t LDS_BYTES = (size_t)LPB * LANE_LDS * (HALF ? sizeof(T) : 2 * sizeof(T));
 
     // butterfly index owned by thread t, slot q, in pass P
