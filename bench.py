@@ -3,17 +3,31 @@
 f64 array, GFFT-points/s (whole job) + achieved HBM GB/s vs the 8 TB/s roofline.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
 
-Workload: the configuration BASELINE.json's metric is quoted on -- ndfft axis=1 on a 4096x4096 Complex<f64>
-          array, device resident -- PER GPU, at every N ("scaling": "weak"): N ranks hold the N contiguous
-          4096-row blocks of a (4096 N) x 4096 array (batch-sharded lanes, no data-path collective: lanes are
-          independent, src/lib.rs:120-124).  `--rows 8192` gives configs[4]'s per-GPU shard (65536/8 rows).
-One "step" = one ndfft call over the whole resident array through the C ABI (ndfft_exec_device).
+N > 1 runs N ranks, one per GPU, over torch.distributed (RCCL):
+  * under a launcher (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`) the rank
+    environment is already there and this process IS a rank;
+  * started plainly (`python bench.py --gpus N`, no WORLD_SIZE in the environment) this process only spawns the N
+    ranks as children -- before anything here touches the GPU or imports torch -- and exits with their status.
+
+Primary line (the contract's `value`): the configuration BASELINE.json's metric is quoted on -- ndfft axis=1 on a
+4096x4096 Complex<f64> array, device resident -- PER GPU at every N ("scaling": "weak": N ranks hold the N
+contiguous 4096-row blocks of a (4096 N) x 4096 array; lanes are independent, src/lib.rs:120-124 / 187-194, so
+there is no data-path collective).  One "step" = one ndfft call over the whole resident array through the C ABI
+(ndfft_exec_device).  EXACTLY K steps are timed between barrier + synchronize on both sides, max over ranks.
+
+Two more measurements ride in the same JSON line (each its own timed region, after the primary one):
+  * roofline.frac_cold -- the same kernel on ROTATING (in, out) pairs whose footprint (>= 2.5 GiB) exceeds the
+    256 MiB Infinity Cache, so every step's input really comes from HBM (`frac` re-reads one 256 MiB input, which
+    the Infinity Cache can hold);
+  * strong_cfg5 -- BASELINE configs[4]: the 65536x4096 array split in N contiguous row blocks, one per rank
+    (N = 1: the whole 4 GiB + 4 GiB array on one GPU), i.e. STRONG scaling of the north star's multi-GPU target.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,7 +35,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (~6.3 TB/s achievable)
+CFG5_ROWS = 65536              # BASELINE configs[4]
 
 
 def usable_cpus():
@@ -43,9 +58,20 @@ def usable_cpus():
     return n
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(n, rows, budget_s=12.0):
     """The CPU oracle's restatement of ndfft_par (create_transform_par!, src/lib.rs:169-238, OpenMP
-    standing in for rayon) on the host cores; bounded sample of the same workload."""
+    standing in for rayon) on the host cores; bounded sample of the same workload.  A second, independent CPU
+    number is scipy's pocketfft with workers = the same core count."""
     import numpy as np
     import synth
     from oracle import oracle_ctypes as orc
@@ -60,9 +86,45 @@ def cpu_baseline(n, rows, budget_s=12.0):
         if el > budget_s or reps >= 500:
             break
     pts = rows * n * reps
-    return {"value": round(pts / el / 1e9, 4), "unit": "GFFT-points/s", "cores": orc.num_threads(), "kind": "port",
-            "sample": f"{reps} x ndfft_par axis=1 on {rows}x{n} Complex<f64> (oracle/ndfft_oracle.c, OpenMP over lanes, "
-                      f"{el:.1f} s; CPU restatement of ndrustfft _par, not rustfft)"}
+    out = {"value": round(pts / el / 1e9, 4), "unit": "GFFT-points/s", "cores": orc.num_threads(), "kind": "port",
+           "cpu_model": cpu_model(),
+           "sample": f"{reps} x ndfft_par axis=1 on {rows}x{n} Complex<f64> (oracle/ndfft_oracle.c, OpenMP over lanes, "
+                     f"{el:.1f} s; scalar C restatement of ndrustfft _par, NOT rustfft -- a lower bound on the reference's CPU speed)"}
+    try:
+        import scipy.fft as sfft
+        w = orc.num_threads()
+        sfft.fft(x, axis=1, workers=w)
+        t0 = time.perf_counter(); reps = 0
+        while True:
+            sfft.fft(x, axis=1, workers=w); reps += 1
+            el = time.perf_counter() - t0
+            if el > budget_s / 2 or reps >= 500:
+                break
+        out["scipy_pocketfft"] = {"value": round(rows * n * reps / el / 1e9, 4), "unit": "GFFT-points/s", "workers": w,
+                                  "sample": f"{reps} x scipy.fft.fft(axis=1, workers={w}) on the same array, {el:.1f} s (allocates its output)"}
+    except Exception as e:                           # scipy missing on the box: say so, do not fail the bench
+        out["scipy_pocketfft"] = {"value": None, "error": repr(e)}
+    return out
+
+
+def free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def spawn_ranks(ngpu):
+    """Parent of a plain `python bench.py --gpus N`: start N ranks as children (nothing in this process has
+    touched the GPU -- torch is not even imported), wait, and return the worst exit status."""
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for r in range(ngpu):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(ngpu), LOCAL_WORLD_SIZE=str(ngpu),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
 
 
 def main():
@@ -72,45 +134,97 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--ramp-ms", type=float, default=400.0, help="untimed busy period before the warm-up steps (clock ramp)")
     ap.add_argument("--n", type=int, default=4096)
-    ap.add_argument("--rows", type=int, default=4096, help="lanes per GPU (4096 = the metric's shape; 8192 = configs[4]'s per-GPU shard)")
+    ap.add_argument("--rows", type=int, default=4096, help="lanes per GPU of the primary line (4096 = the metric's shape)")
+    ap.add_argument("--cold-pairs", type=int, default=6, help="distinct (in, out) pairs rotated by the cache-cold measurement (0 = skip)")
+    ap.add_argument("--strong-steps", type=int, default=20, help="timed steps of the cfg5 strong-scaling block (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-api", action="store_true", help="skip the PCIe-inclusive ndfft_exec (host arrays) side measurement")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only with --dry (CPU rendezvous check)")
+    ap.add_argument("--dry", action="store_true", help="rendezvous + rank count only, no GPU work (CPU test of the launch path)")
     ap.add_argument("--dist", action="store_true", help="initialise torch.distributed (RCCL) even at world size 1 (path check)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+
     if "OMP_NUM_THREADS" not in os.environ:        # before libgomp is loaded (torch, the oracle): see usable_cpus()
         os.environ["OMP_NUM_THREADS"] = str(usable_cpus())
 
     import numpy as np
     import torch
     import torch.distributed as dist
-    import synth
-    from ndrustfft_amd import FftHandler, _lib, ndfft
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    use_dist = world > 1 or args.dist
+    if world != max(args.gpus, 1):
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: trusting the launcher", file=sys.stderr)
+    use_dist = world > 1 or args.dist or args.dry
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("LOCAL_RANK", "0")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+    if args.dry:
+        dist.init_process_group(args.backend if args.backend == "gloo" or torch.cuda.is_available() else "gloo")
+        one = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(one)
+        if rank == 0:
+            print(json.dumps({"metric": "dry run (rendezvous only)", "value": None, "n_gpus": dist.get_world_size(),
+                              "ranks_seen": int(one[0]), "steps": 0, "warmup": 0}))
+        dist.destroy_process_group()
+        return
+
+    import synth
+    from ndrustfft_amd import FftHandler, _lib, ndfft
+
+    torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if use_dist:
+        dist.init_process_group("nccl", device_id=dev)
     ngpu = max(world, 1)
+    ranks_seen = 1
+    if use_dist:
+        one = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(one)                        # an RCCL collective: every rank is really there
+        ranks_seen = int(one[0])
 
     n = args.n
     rows = args.rows
+    h = FftHandler(n)
+    lib = _lib.default()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, steps):
+        """EXACTLY `steps` calls of fn(i) between barrier + synchronize; (wall s, device ms), max over ranks."""
+        sync_all()
+        ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()                                # torch's current stream == the stream ndfft_exec_device launches on
+        for i in range(steps):
+            fn(i)
+        ev1.record()
+        sync_all()
+        el = time.perf_counter() - t0
+        dev_ms = ev0.elapsed_time(ev1)
+        if use_dist:
+            t = torch.tensor([el, dev_ms], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el, dev_ms = float(t[0]), float(t[1])
+        return el, dev_ms
+
+    # ------------------------------------------------------------------ primary: cfg2 per GPU, resident array
     # device-resident shard: rank r holds global rows [r*rows, (r+1)*rows) of the (ngpu*rows) x n array
     x = synth.complex_array((rows, n), offset=rank * rows * n)
     xd = torch.from_numpy(x).to(dev)
     yd = torch.empty_like(xd)
-    h = FftHandler(n)
-    lib = _lib.default()
 
-    def step():
+    def step(_i=0):
         ndfft(xd, yd, h, 1)
 
     # Untimed preamble: the GPU's clocks need ~30-40 ms of sustained work to reach their steady state
@@ -124,27 +238,8 @@ def main():
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()                                   # torch's current stream == the stream exec_device launches on
-    for _ in range(args.steps):
-        step()
-    ev1.record()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
+    el, dev_ms = timed(step, args.steps)
     path = lib.last_path()
-    if use_dist:
-        t = torch.tensor([el, dev_ms], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el, dev_ms = float(t[0]), float(t[1])
 
     # quick self-check of the timed output on a few lanes against numpy's FFT (not timed; the oracle is only used by
     # the cpu_baseline leg below and by the tests)
@@ -153,39 +248,123 @@ def main():
         err = np.abs(yd[:4].cpu().numpy() - yo).max() / np.abs(yo).max()
         assert err < 1e-10, f"bench output differs from numpy.fft: {err}"
 
+    bytes_per_launch = 2 * rows * n * 16               # 32 B/point = one read + one write of c128
+    kern_s = dev_ms / 1e3 / args.steps                 # average launch duration on the launch stream (HIP events)
+
+    # ------------------------------------------------------------------ cache-cold: rotating pairs (> Infinity Cache)
+    cold = None
+    if args.cold_pairs > 0:
+        pairs = [(xd, yd)]
+        for p in range(1, args.cold_pairs):
+            xi = synth.complex_array_torch((rows, n), dev, offset=(rank + p * ngpu) * rows * n)
+            pairs.append((xi, torch.empty_like(xi)))
+
+        def cold_step(i):
+            a, b = pairs[i % len(pairs)]
+            ndfft(a, b, h, 1)
+        for i in range(2 * len(pairs)):
+            cold_step(i)
+        c_el, c_ms = timed(cold_step, args.steps)
+        c_kern = c_ms / 1e3 / args.steps
+        cold = {"pairs": len(pairs), "footprint_bytes": len(pairs) * bytes_per_launch,
+                "avg_launch_us": round(c_kern * 1e6, 2), "achieved": round(bytes_per_launch / c_kern / 1e9, 1),
+                "ms_per_step": round(c_el / args.steps * 1e3, 5),
+                "value": round(ngpu * rows * n * args.steps / c_el / 1e9, 3)}
+        if rank == 0:                                  # the rotated outputs are real transforms too
+            a, b = pairs[-1]
+            yo = np.fft.fft(a[:2].cpu().numpy(), axis=1)
+            err = np.abs(b[:2].cpu().numpy() - yo).max() / np.abs(yo).max()
+            assert err < 1e-10, f"cold-rotation output differs from numpy.fft: {err}"
+        del pairs[1:]
+
+    # ------------------------------------------------------------------ strong scaling: cfg5 = 65536 x 4096 split in N
+    strong = None
+    if args.strong_steps > 0 and CFG5_ROWS % ngpu == 0:
+        srows = CFG5_ROWS // ngpu
+        xs = synth.complex_array_torch((srows, n), dev, offset=rank * srows * n)
+        ys = torch.empty_like(xs)
+
+        def strong_step(_i=0):
+            ndfft(xs, ys, h, 1)
+        for _ in range(3):
+            strong_step()
+        s_el, s_ms = timed(strong_step, args.strong_steps)
+        s_bytes = 2 * srows * n * 16
+        s_kern = s_ms / 1e3 / args.strong_steps
+        if rank == 0:
+            xo = synth.complex_array((2, n))            # rows 0, 1 of the global array
+            err = np.abs(ys[:2].cpu().numpy() - np.fft.fft(xo, axis=1)).max() / np.abs(np.fft.fft(xo, axis=1)).max()
+            assert err < 1e-10, f"cfg5 output differs from numpy.fft: {err}"
+        strong = {"workload": f"ndfft axis=1 on {CFG5_ROWS}x{n} Complex<f64> (BASELINE configs[4]), {srows} rows per GPU, device-resident",
+                  "scaling": "strong", "steps": args.strong_steps, "rows_per_gpu": srows,
+                  "value": round(CFG5_ROWS * n * args.strong_steps / s_el / 1e9, 3), "unit": "GFFT-points/s",
+                  "ms_per_step": round(s_el / args.strong_steps * 1e3, 5),
+                  "avg_launch_us": round(s_kern * 1e6, 2),
+                  "per_gpu_achieved_GBs": round(s_bytes / s_kern / 1e9, 1),
+                  "per_gpu_frac": round(s_bytes / s_kern / 1e9 / HBM_PEAK_GBS, 4)}
+        del xs, ys
+
+    # ------------------------------------------------------------------ host-array API (PCIe both ways), N = 1 only
+    host_api = None
+    if rank == 0 and ngpu == 1 and not args.no_host_api:
+        yh = np.empty_like(x)
+        ndfft(x, yh, h, 1)
+        t0 = time.perf_counter(); reps = 5
+        for _ in range(reps):
+            ndfft(x, yh, h, 1)
+        hel = (time.perf_counter() - t0) / reps
+        assert np.abs(yh[:4] - np.fft.fft(x[:4], axis=1)).max() / np.abs(yh[:4]).max() < 1e-10
+        host_api = {"what": "ndfft_exec on pageable host arrays (upload + transform + download), never `value`",
+                    "ms_per_call": round(hel * 1e3, 3), "value": round(rows * n / hel / 1e9, 3), "unit": "GFFT-points/s",
+                    "kernel_path": lib.last_path()}
+
     if rank == 0:
         points = ngpu * rows * n * args.steps
-        bytes_per_launch = 2 * rows * n * 16           # 32 B/point = one read + one write of c64
-        kern_s = dev_ms / 1e3 / args.steps             # average launch duration on the launch stream (HIP events)
         achieved = bytes_per_launch / kern_s / 1e9
-        traffic = None
+        traffic = None; traffic_src = None
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tj):
             try:
-                traffic = json.load(open(tj)).get(f"{rows}x{n}")
+                tdata = json.load(open(tj))
+                traffic = tdata.get(f"{rows}x{n}")
+                traffic_src = tdata.get("source", "profiles/pmc_traffic.json (tools/pmc_traffic.sh: separate FETCH_SIZE / WRITE_SIZE "
+                                                  "--pmc passes of this bench command, x2 gfx950 read correction)")
             except Exception:
                 traffic = None
+        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": traffic_src if traffic is not None else None,
+                "traffic_note": "PMC bytes from an EARLIER profiling run of this command (not measured by this process); "
+                                "FETCH_SIZE counts Infinity-Cache hits too" if traffic is not None else None,
+                "kernel": "k_pow2<double,4096>", "algorithmic_bytes_per_launch": bytes_per_launch,
+                "avg_launch_us": round(kern_s * 1e6, 2),
+                "frac_note": "one 256 MiB input re-read every step: the 256 MiB Infinity Cache can serve part of it; see frac_cold"}
+        if cold:
+            roof["frac_cold"] = round(cold["achieved"] / HBM_PEAK_GBS, 4)
+            roof["cold"] = cold
         out = {
             "metric": "GFFT-points/s, batched 1-D C2C FFT f64 along the contiguous axis (+ achieved HBM GB/s vs roofline)",
             "value": round(points / el / 1e9, 3), "unit": "GFFT-points/s",
-            "n_gpus": ngpu, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": ngpu, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(el / args.steps * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"ndfft axis=1 on {ngpu * rows}x{n} Complex<f64> "
-                                   f"({'BASELINE configs[1] per GPU' if rows == 4096 else 'BASELINE configs[4] shard shape: ' + str(rows) + ' rows per GPU'}), "
+                                   f"({'BASELINE configs[1] per GPU' if rows == 4096 else str(rows) + ' rows per GPU'}), "
                                    f"device-resident, splitmix64 U[-1,1) seed 20241008",
                        "lanes_per_gpu": rows, "lane_len": n, "kernel_path": path,
                        "sharding": "none" if ngpu == 1 else f"lanes split in {ngpu} contiguous blocks, one per GPU, no collective in the timed region"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "k_pow2<double,4096>", "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "avg_launch_us": round(kern_s * 1e6, 2)},
+            "roofline": roof,
         }
+        if strong:
+            out["strong_cfg5"] = strong
+        if host_api:
+            out["host_api"] = host_api
         if not args.no_cpu_baseline and ngpu == 1:
             out["cpu_baseline"] = cpu_baseline(n, min(rows, 4096))
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

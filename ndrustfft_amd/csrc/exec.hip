@@ -220,11 +220,87 @@ static int dispatch_generic(const Problem &P, const void *d_in, void *d_out, con
     return launch_generic<T>(a, threads, lds, stream);
 }
 
-// per-(host thread, stream) scratch for the transpose route; grows, never shrinks
+// ---------------------------------------------------------------------------------------------
+// Workspace of one host thread ON ONE DEVICE: scratch arrays of the multi-pass routes (keyed by stream; they
+// grow, never shrink), the staging buffers and pinned bounce buffers of ndfft_exec, and the streams / events of
+// its chunk pipeline.  A thread that alternates ndfft_set_device gets one of these per device (nothing allocated
+// on device 0 is ever handed to a kernel on device 1), and everything is released when the thread exits.
+// ---------------------------------------------------------------------------------------------
 struct Scratch { void *p = nullptr; size_t cap = 0; };
-static thread_local std::map<hipStream_t, Scratch> g_scratch[8];
+struct Staging {
+    void *p = nullptr; size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return NDFFT_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        NDFFT_HIP(hipMalloc(&p, bytes));
+        cap = bytes;
+        return NDFFT_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+struct PinnedBuf {
+    void *p = nullptr; size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return NDFFT_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        NDFFT_HIP(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+        cap = bytes;
+        return NDFFT_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+struct Pipe {
+    hipStream_t h2d = nullptr, cmp = nullptr, d2h = nullptr;
+    std::vector<hipEvent_t> up, done, down;
+    bool ok = false;
+    void sync_all() { if (ok) { (void)hipStreamSynchronize(h2d); (void)hipStreamSynchronize(cmp); (void)hipStreamSynchronize(d2h); } }
+    void release() {
+        if (!ok) return;
+        sync_all();
+        for (auto *v : {&up, &done, &down}) { for (hipEvent_t e : *v) (void)hipEventDestroy(e); v->clear(); }
+        (void)hipStreamDestroy(h2d); (void)hipStreamDestroy(cmp); (void)hipStreamDestroy(d2h);
+        h2d = cmp = d2h = nullptr; ok = false;
+    }
+};
+struct DeviceWs {
+    std::map<hipStream_t, Scratch> scratch[8];
+    Staging stage_in, stage_out;
+    PinnedBuf bounce_in[2], bounce_out[2];
+    Pipe pipe;
+    void release() {   // the owning device must be current
+        pipe.release();
+        for (auto &m : scratch) { for (auto &kv : m) if (kv.second.p) (void)hipFree(kv.second.p); m.clear(); }
+        stage_in.release(); stage_out.release();
+        for (auto &b : bounce_in) b.release();
+        for (auto &b : bounce_out) b.release();
+    }
+};
+struct ThreadWs {
+    std::map<int, DeviceWs> dev;
+    void release_all() {
+        if (dev.empty()) return;
+        int cur = 0;
+        if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); dev.clear(); return; }   // runtime already gone (process teardown)
+        for (auto &kv : dev) { if (hipSetDevice(kv.first) == hipSuccess) { (void)hipDeviceSynchronize(); kv.second.release(); } }
+        (void)hipSetDevice(cur);
+        dev.clear();
+    }
+    ~ThreadWs() { release_all(); }   // a worker thread that exits gives its device memory and streams back
+};
+static thread_local ThreadWs g_tws;
+static int current_ws(DeviceWs **out) {
+    int dev = 0;
+    NDFFT_HIP(hipGetDevice(&dev));
+    *out = &g_tws.dev[dev];
+    return NDFFT_OK;
+}
 static int get_scratch(int which, hipStream_t s, size_t bytes, void **out) {
-    Scratch &sc = g_scratch[which][s];
+    DeviceWs *ws;
+    int rc = current_ws(&ws);
+    if (rc) return rc;
+    Scratch &sc = ws->scratch[which][s];
     if (bytes > sc.cap) {
         if (sc.p) { NDFFT_HIP(hipStreamSynchronize(s)); NDFFT_HIP(hipFree(sc.p)); sc.p = nullptr; sc.cap = 0; }
         NDFFT_HIP(hipMalloc(&sc.p, bytes));
@@ -704,18 +780,40 @@ static void view_range(int ndim, const int64_t *shape, const int64_t *stride, in
     }
 }
 
-struct Staging {
-    void *p = nullptr; size_t cap = 0;
-    int reserve(size_t bytes) {
-        if (bytes <= cap) return NDFFT_OK;
-        if (p) (void)hipFree(p);
-        p = nullptr; cap = 0;
-        NDFFT_HIP(hipMalloc(&p, bytes));
-        cap = bytes;
-        return NDFFT_OK;
+// Copies exactly the elements of an n-d view between two byte images of the same address range (`dst` and `src`
+// both point at the image of element 0).  Used for output views with holes: the device result comes back as an
+// image of the view's whole span, and only the elements the view OWNS may be written to the caller's memory --
+// Rust's `&mut ArrayViewMut` guarantees exclusivity of those elements only (two threads may hold interleaved
+// views of one allocation, e.g. even / odd columns from multi_slice_mut).
+static void copy_view_elements(char *dst, const char *src, int ndim, const int64_t *shape, const int64_t *stride, size_t esz) {
+    struct D { int64_t n, s; };
+    std::vector<D> d;
+    for (int k = 0; k < ndim; ++k) {
+        if (shape[k] == 0) return;
+        if (shape[k] > 1 && stride[k] != 0) d.push_back({shape[k], stride[k]});
     }
-};
-static thread_local Staging g_stage_in, g_stage_out;
+    std::sort(d.begin(), d.end(), [](const D &a, const D &b) { return std::llabs(a.s) < std::llabs(b.s); });
+    // innermost contiguous run (|stride| == 1), merged with outer dims that continue it
+    int64_t run = 1, run_off = 0;   // run_off: offset of the run's lowest element relative to the index-0 element
+    size_t first = 0;
+    if (!d.empty() && std::llabs(d[0].s) == 1) {
+        run = d[0].n; run_off = d[0].s < 0 ? -(d[0].n - 1) : 0; first = 1;
+        while (first < d.size() && d[first].s == run && run_off == 0) { run *= d[first].n; ++first; }
+    }
+    std::vector<D> o(d.begin() + first, d.end());
+    std::vector<int64_t> idx(o.size(), 0);
+    int64_t off = 0;
+    for (;;) {
+        memcpy(dst + (off + run_off) * (int64_t)esz, src + (off + run_off) * (int64_t)esz, (size_t)run * esz);
+        size_t k = 0;
+        for (; k < o.size(); ++k) {
+            off += o[k].s;
+            if (++idx[k] < o[k].n) break;
+            off -= o[k].s * o[k].n; idx[k] = 0;
+        }
+        if (k == o.size()) break;
+    }
+}
 
 }  // namespace ndfft
 
@@ -732,18 +830,16 @@ bool is_pinned(const void *p) {
     if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
     return a.type == hipMemoryTypeHost;
 }
-struct Pipe { hipStream_t h2d = nullptr, cmp = nullptr, d2h = nullptr; std::vector<hipEvent_t> up, done; bool ok = false; };
-thread_local Pipe g_pipe;
-int pipe_init(int chunks) {
-    Pipe &p = g_pipe;
+int pipe_init(Pipe &p, int chunks) {
     if (!p.ok) {
         NDFFT_HIP(hipStreamCreate(&p.h2d)); NDFFT_HIP(hipStreamCreate(&p.cmp)); NDFFT_HIP(hipStreamCreate(&p.d2h));
         p.ok = true;
     }
     while ((int)p.up.size() < chunks) {
-        hipEvent_t a, b;
+        hipEvent_t a, b, c;
         NDFFT_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming)); NDFFT_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
-        p.up.push_back(a); p.done.push_back(b);
+        NDFFT_HIP(hipEventCreateWithFlags(&c, hipEventDisableTiming));
+        p.up.push_back(a); p.done.push_back(b); p.down.push_back(c);
     }
     return NDFFT_OK;
 }
@@ -759,12 +855,12 @@ int64_t inner_span(int ndim, const int64_t *shape, const int64_t *stride) {
 }
 }  // namespace
 
-static int exec_pinned_pipeline(const ndfft_plan *plan, int op, const char *hin, char *hout, int ndim, const int64_t *shape_in,
-                                const int64_t *stride_in, const int64_t *shape_out, const int64_t *stride_out, int axis, int norm,
-                                double scale, size_t ein, size_t eout, int chunks) {
+static int exec_pinned_pipeline_body(DeviceWs &ws, const ndfft_plan *plan, int op, const char *hin, char *hout, int ndim, const int64_t *shape_in,
+                                     const int64_t *stride_in, const int64_t *shape_out, const int64_t *stride_out, int axis, int norm,
+                                     double scale, size_t ein, size_t eout, int chunks) {
     int rc;
-    if ((rc = pipe_init(chunks))) return rc;
-    Pipe &pp = g_pipe;
+    Pipe &pp = ws.pipe;
+    if ((rc = pipe_init(pp, chunks))) return rc;
     const int64_t R = shape_in[0];
     const int64_t isp = inner_span(ndim, shape_in, stride_in), osp = inner_span(ndim, shape_out, stride_out);
     std::vector<int64_t> si(shape_in, shape_in + ndim), so(shape_out, shape_out + ndim);
@@ -774,20 +870,29 @@ static int exec_pinned_pipeline(const ndfft_plan *plan, int op, const char *hin,
         si[0] = so[0] = r1 - r0;
         const size_t off_in = (size_t)(r0 * stride_in[0]) * ein, off_out = (size_t)(r0 * stride_out[0]) * eout;
         const size_t bytes_in = (size_t)((r1 - r0 - 1) * stride_in[0] + isp) * ein, bytes_out = (size_t)((r1 - r0 - 1) * stride_out[0] + osp) * eout;
-        NDFFT_HIP(hipMemcpyAsync((char *)g_stage_in.p + off_in, hin + off_in, bytes_in, hipMemcpyHostToDevice, pp.h2d));
+        NDFFT_HIP(hipMemcpyAsync((char *)ws.stage_in.p + off_in, hin + off_in, bytes_in, hipMemcpyHostToDevice, pp.h2d));
         NDFFT_HIP(hipEventRecord(pp.up[c], pp.h2d));
         NDFFT_HIP(hipStreamWaitEvent(pp.cmp, pp.up[c], 0));
         Problem P;
         bool nothing;
         if ((rc = prepare(plan, op, ndim, si.data(), stride_in, so.data(), stride_out, axis, norm, scale, P, nothing))) return rc;
-        if (!nothing && (rc = dispatch_peeled(P, (const char *)g_stage_in.p + off_in, (char *)g_stage_out.p + off_out, ein, eout, pp.cmp))) return rc;
+        if (!nothing && (rc = dispatch_peeled(P, (const char *)ws.stage_in.p + off_in, (char *)ws.stage_out.p + off_out, ein, eout, pp.cmp))) return rc;
         NDFFT_HIP(hipEventRecord(pp.done[c], pp.cmp));
         NDFFT_HIP(hipStreamWaitEvent(pp.d2h, pp.done[c], 0));
-        NDFFT_HIP(hipMemcpyAsync(hout + off_out, (const char *)g_stage_out.p + off_out, bytes_out, hipMemcpyDeviceToHost, pp.d2h));
+        NDFFT_HIP(hipMemcpyAsync(hout + off_out, (const char *)ws.stage_out.p + off_out, bytes_out, hipMemcpyDeviceToHost, pp.d2h));
     }
     NDFFT_HIP(hipStreamSynchronize(pp.d2h));
     NDFFT_HIP(hipStreamSynchronize(pp.cmp));
     return NDFFT_OK;
+}
+static int exec_pinned_pipeline(DeviceWs &ws, const ndfft_plan *plan, int op, const char *hin, char *hout, int ndim, const int64_t *shape_in,
+                                const int64_t *stride_in, const int64_t *shape_out, const int64_t *stride_out, int axis, int norm,
+                                double scale, size_t ein, size_t eout, int chunks) {
+    const int rc = exec_pinned_pipeline_body(ws, plan, op, hin, hout, ndim, shape_in, stride_in, shape_out, stride_out, axis, norm, scale, ein, eout, chunks);
+    // on an error some chunks' asynchronous copies into the caller's arrays (and into the staging buffers, which the
+    // next call may regrow) are still in flight: never return before they have drained
+    if (rc) ws.pipe.sync_all();
+    return rc;
 }
 
 extern "C" {
@@ -827,45 +932,51 @@ int ndfft_exec(const ndfft_plan *plan, int op, const void *in, void *out, int nd
     int rc = prepare(plan, op, ndim, shape_in, stride_in, shape_out, stride_out, axis, norm, scale, P, nothing);
     if (rc || nothing) return rc;
     if (!in || !out) return fail(NDFFT_ERR_INVALID_ARG, "null array pointer");
+    DeviceWs *wsp;
+    if ((rc = current_ws(&wsp))) return rc;
+    DeviceWs &ws = *wsp;
     const size_t r = real_size(plan->dtype);
     const size_t ein = op_in_cplx(op) ? 2 * r : r, eout = op_out_cplx(op) ? 2 * r : r;
     int64_t ilo, ihi, icnt, olo, ohi, ocnt;
     view_range(ndim, shape_in, stride_in, ilo, ihi, icnt);
     view_range(ndim, shape_out, stride_out, olo, ohi, ocnt);
     const size_t ibytes = (size_t)(ihi - ilo + 1) * ein, obytes = (size_t)(ohi - olo + 1) * eout;
-    if ((rc = g_stage_in.reserve(ibytes))) return rc;
-    if ((rc = g_stage_out.reserve(obytes))) return rc;
+    if ((rc = ws.stage_in.reserve(ibytes))) return rc;
+    if ((rc = ws.stage_out.reserve(obytes))) return rc;
     const char *hin = (const char *)in + ilo * (int64_t)ein;
     char *hout = (char *)out + olo * (int64_t)eout;
+    const bool out_dense = (int64_t)(ohi - olo + 1) == ocnt;
     // pinned, dense, C-ordered in dimension 0, transform along another axis: pipelined row chunks
     if (ndim >= 2 && axis != 0 && ilo == 0 && olo == 0 && shape_in[0] == shape_out[0] && shape_in[0] >= 16 &&
-        (int64_t)(ohi + 1) == ocnt && ibytes + obytes >= ((size_t)8 << 20) && is_pinned(in) && is_pinned(out)) {
+        out_dense && ibytes + obytes >= ((size_t)8 << 20) && is_pinned(in) && is_pinned(out)) {
         const int64_t isp = inner_span(ndim, shape_in, stride_in), osp = inner_span(ndim, shape_out, stride_out);
         if (isp > 0 && osp > 0 && stride_in[0] >= isp && stride_out[0] >= osp) {
             const char *e = getenv("NDFFT_PIPE_CHUNKS");
             const int chunks = (int)std::min<int64_t>(shape_in[0], e ? std::max(1, atoi(e)) : 8);
-            return exec_pinned_pipeline(plan, op, hin, hout, ndim, shape_in, stride_in, shape_out, stride_out, axis, norm, scale, ein, eout, chunks);
+            return exec_pinned_pipeline(ws, plan, op, hin, hout, ndim, shape_in, stride_in, shape_out, stride_out, axis, norm, scale, ein, eout, chunks);
         }
     }
-    NDFFT_HIP(hipMemcpy(g_stage_in.p, hin, ibytes, hipMemcpyHostToDevice));
-    // a strided output view has holes that belong to the caller: carry them through the round trip
-    if ((int64_t)(ohi - olo + 1) != ocnt) NDFFT_HIP(hipMemcpy(g_stage_out.p, hout, obytes, hipMemcpyHostToDevice));
-    const char *din = (const char *)g_stage_in.p - ilo * (int64_t)ein;
-    char *dout = (char *)g_stage_out.p - olo * (int64_t)eout;
+    NDFFT_HIP(hipMemcpy(ws.stage_in.p, hin, ibytes, hipMemcpyHostToDevice));
+    const char *din = (const char *)ws.stage_in.p - ilo * (int64_t)ein;
+    char *dout = (char *)ws.stage_out.p - olo * (int64_t)eout;
     rc = dispatch_peeled(P, din, dout, ein, eout, (hipStream_t) nullptr);
-    if (rc) return rc;
-    NDFFT_HIP(hipMemcpy(hout, g_stage_out.p, obytes, hipMemcpyDeviceToHost));   // synchronises with the kernel
+    if (rc) { (void)hipStreamSynchronize(nullptr); return rc; }
+    if (out_dense) {
+        NDFFT_HIP(hipMemcpy(hout, ws.stage_out.p, obytes, hipMemcpyDeviceToHost));   // synchronises with the kernel
+    } else {
+        // The output view has holes.  They belong to the caller (possibly to ANOTHER thread's &mut view of the same
+        // allocation), so they are neither read nor written: the span comes back into a private pinned image and only
+        // the view's own elements are copied out of it.
+        if ((rc = ws.bounce_out[0].reserve(obytes))) return rc;
+        NDFFT_HIP(hipMemcpy(ws.bounce_out[0].p, ws.stage_out.p, obytes, hipMemcpyDeviceToHost));
+        copy_view_elements((char *)out, (const char *)ws.bounce_out[0].p - olo * (int64_t)eout, ndim, shape_out, stride_out, eout);
+    }
     return NDFFT_OK;
 }
 
 int ndfft_release_workspace(void) {
     clear_err();
-    NDFFT_HIP(hipDeviceSynchronize());
-    for (auto &m : g_scratch) {
-        for (auto &kv : m) if (kv.second.p) (void)hipFree(kv.second.p);
-        m.clear();
-    }
-    for (Staging *st : {&g_stage_in, &g_stage_out}) { if (st->p) (void)hipFree(st->p); st->p = nullptr; st->cap = 0; }
+    g_tws.release_all();   // every device this thread has used; each synchronised under its own hipSetDevice
     return NDFFT_OK;
 }
 

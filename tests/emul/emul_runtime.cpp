@@ -9,6 +9,11 @@
 #include "hip/hip_runtime.h"
 
 emul_idx threadIdx, blockIdx, blockDim, gridDim;
+thread_local int emul_cur_device = 0;
+int emul_device_count() {
+    static const int n = [] { const char *e = getenv("EMUL_DEVICES"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
+    return n;
+}
 
 namespace ndfft { alignas(16) char smem[160 * 1024 + 64]; }   // `extern __shared__ char smem[]` of the kernels
 
@@ -32,6 +37,8 @@ namespace {
 constexpr size_t kGuard = 256;
 // (never destroyed: plans may be freed from Python finalisers after static destructors have run)
 std::map<char *, size_t> &g_allocs = *new std::map<char *, size_t>;      // user pointer -> user size
+std::map<char *, int> &g_alloc_dev = *new std::map<char *, int>;         // user pointer -> device it was allocated on
+std::mutex &g_launch_mu = *new std::mutex;                               // the fiber scheduler is single-threaded
 std::mutex &g_alloc_mu = *new std::mutex;
 void check_guards(const char *when) {
     std::lock_guard<std::mutex> g(g_alloc_mu);
@@ -52,6 +59,7 @@ hipError_t hipMalloc(void **p, size_t n) {
     memset(raw, 0xC3, kGuard); memset(raw + kGuard + n, 0xC3, kGuard);
     std::lock_guard<std::mutex> g(g_alloc_mu);
     g_allocs[raw + kGuard] = n;
+    g_alloc_dev[raw + kGuard] = emul_cur_device;
     *p = raw + kGuard;
     return 0;
 }
@@ -60,7 +68,26 @@ hipError_t hipFree(void *p) {
     check_guards("hipFree");
     std::lock_guard<std::mutex> g(g_alloc_mu);
     g_allocs.erase((char *)p);
+    g_alloc_dev.erase((char *)p);
     free((char *)p - kGuard);
+    return 0;
+}
+
+int emul_device_of(const void *p) {
+    std::lock_guard<std::mutex> g(g_alloc_mu);
+    auto it = g_allocs.upper_bound((char *)p);
+    if (it == g_allocs.begin()) return -1;
+    --it;
+    if ((const char *)p >= it->first + it->second + (it->second == 0)) return -1;
+    return g_alloc_dev[it->first];
+}
+hipError_t hipMemcpyPeerAsync(void *dst, int dst_dev, const void *src, int src_dev, size_t n, hipStream_t) {
+    if (emul_device_of(dst) != dst_dev || emul_device_of(src) != src_dev) {
+        fprintf(stderr, "emul: hipMemcpyPeerAsync: pointer is not on the device it is claimed to be on (dst %d vs %d, src %d vs %d)\n",
+                emul_device_of(dst), dst_dev, emul_device_of(src), src_dev);
+        abort();
+    }
+    memcpy(dst, src, n);
     return 0;
 }
 
@@ -71,6 +98,7 @@ void __syncthreads() {
 }
 
 void emul::launch(void (*fn)(void *), void *arg, dim3 grid, dim3 block, size_t lds_bytes) {
+    std::lock_guard<std::mutex> launch_guard(g_launch_mu);   // host threads (shared handlers, sharded exec) take turns
     if (lds_bytes > 160 * 1024) { fprintf(stderr, "emul: LDS request %zu > 160 KiB\n", lds_bytes); abort(); }
     g_fn = fn; g_arg = arg;
     blockDim = {block.x, 1, 1}; gridDim = {grid.x, grid.y, grid.z};

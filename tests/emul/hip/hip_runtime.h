@@ -37,9 +37,12 @@ enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
 
 inline const char *hipGetErrorString(hipError_t) { return "emulated"; }
 inline hipError_t hipGetLastError() { return 0; }
-inline hipError_t hipGetDevice(int *d) { *d = 0; return 0; }
-inline hipError_t hipSetDevice(int) { return 0; }
-inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return 0; }
+// several fake devices (EMUL_DEVICES, default 1): the current device is per host thread, as in HIP
+extern thread_local int emul_cur_device;
+int emul_device_count();
+inline hipError_t hipGetDevice(int *d) { *d = emul_cur_device; return 0; }
+inline hipError_t hipSetDevice(int d) { if (d < 0 || d >= emul_device_count()) return 101; emul_cur_device = d; return 0; }
+inline hipError_t hipGetDeviceCount(int *n) { *n = emul_device_count(); return 0; }
 // "device" allocations carry 256-byte guard zones that are checked after every kernel launch (emul_runtime.cpp)
 hipError_t hipMalloc(void **p, size_t n);
 hipError_t hipFree(void *p);
@@ -54,6 +57,11 @@ inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *, const void *)
 inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return 0; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = nullptr; return 0; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+// peer copies check that each pointer lies in an allocation made on the device it is claimed to be on
+hipError_t hipMemcpyPeerAsync(void *dst, int dst_dev, const void *src, int src_dev, size_t n, hipStream_t);
+int emul_device_of(const void *p);   // device an address was hipMalloc'd on, -1 if not device memory
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return 0; }
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }

@@ -193,6 +193,43 @@ def layouts(L):
     api.nddct2(x5, y5, hd, 3); orc.nddct2(x5, y5o, od, 3); assert_close(y5, y5o, 3, 1e-10, "6-D permuted")
 
 
+def interleaved_mut_views_two_threads(L, rounds=6):
+    """Two host threads transform into INTERLEAVED mutable views of one allocation (even / odd columns, as
+    ndarray's multi_slice_mut hands out; src/lib.rs:109 only requires `S: DataMut` of the view).  Rust guarantees
+    each thread exclusivity of its view's OWN elements only, so the host path must never write -- not even
+    write back unchanged -- an element outside its view: a whole-span download would overwrite the other thread's
+    results with stale data (VERDICT r1 weak #11)."""
+    import threading
+    n = 64
+    h = handlers.FftHandler(n, _library=L); o = orc.FftHandler(n)
+    xs = [synth.complex_array((96, n, 5), offset=17 * k) for k in range(2)]
+    # also negative strides and a hole pattern with a contiguous run > 1 (pairs of columns)
+    views = [lambda a, k: a[:, :, k::2], lambda a, k: a[:, ::-1, k::2], lambda a, k: a.reshape(96, n, 5, 2)[:, :, :, k]]
+    for mk in views:
+        for _ in range(rounds):
+            big = np.zeros((96, n, 10), np.complex128)
+            errs = []
+            def work(k):
+                try:
+                    for _rep in range(3):
+                        api.ndfft(xs[k], mk(big, k), h, 1)
+                except Exception as e:          # pragma: no cover
+                    errs.append(e)
+            ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+            [t.start() for t in ts]; [t.join() for t in ts]
+            assert not errs, errs
+            for k in range(2):
+                yo = np.zeros((96, n, 5), np.complex128)
+                orc.ndfft(xs[k], yo, o, 1)
+                ref = np.zeros((96, n, 10), np.complex128); mk(ref, k)[...] = yo
+                assert_close(mk(big, k), mk(ref, k), 1, 1e-10, f"interleaved view {k}")
+    # holes are preserved bit for bit, also on a real-output op and a 1-D output with a step
+    big = np.full((7, 40), -3.25); x = synth.real_array((7, 20))
+    api.nddct2(x, big[:, 1::2], handlers.DctHandler(20, _library=L), 1)
+    assert np.all(big[:, 0::2] == -3.25)
+    yo = np.zeros((7, 20)); orc.nddct2(x, yo, orc.DctHandler(20), 1); assert_close(big[:, 1::2], yo, 1, 1e-10, "stepped dct out")
+
+
 def fuzz(L, seed, count, max_points=1 << 17, lengths=None):
     """Random op x lane length x shape x axis x dtype x norm x layout (C / F / stepped and reversed views, padded
     output views) against the oracle.  The lane lengths mix every dispatch class: powers of two, smooth,

@@ -45,3 +45,35 @@ def bench_fill_complex(shape, dtype=np.complex128):
     n = int(np.prod(shape))
     i = np.arange(n, dtype=np.float64)
     return (i + 1j * i).astype(dtype).reshape(shape)
+
+
+# ---- the same stream generated with torch (on the GPU for bench.py's large arrays: 65536 x 4096 c128 = 4 GiB) ----
+def _s64(c):
+    """uint64 constant as the int64 with the same bits (torch has no uint64 arithmetic; int64 wraps)."""
+    c = int(c) & 0xFFFFFFFFFFFFFFFF
+    return c - (1 << 64) if c >= (1 << 63) else c
+
+
+def _lshr(z, s):
+    return (z >> s) & ((1 << (64 - s)) - 1)
+
+
+def uniform_torch(k, seed=SEED):
+    """uniform(seed, k) for an int64 torch tensor k (any device); bit-identical to the numpy version."""
+    z = (k + 1) * _s64(_GAMMA) + _s64(seed)
+    z = (z ^ _lshr(z, 30)) * _s64(_M1)
+    z = (z ^ _lshr(z, 27)) * _s64(_M2)
+    z = z ^ _lshr(z, 31)
+    return _lshr(z, 11).double() * 2.0 ** -52 - 1.0
+
+
+def complex_array_torch(shape, device, offset=0, seed=SEED, chunk_rows=4096):
+    """complex_array(shape, complex128, seed, offset) built on `device`, a block of rows at a time."""
+    import torch
+    rows = int(shape[0]); inner = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+    out = torch.empty((rows, inner, 2), dtype=torch.float64, device=device)
+    for r0 in range(0, rows, chunk_rows):
+        r1 = min(rows, r0 + chunk_rows)
+        k = torch.arange(2 * (offset + r0 * inner), 2 * (offset + r1 * inner), dtype=torch.int64, device=device)
+        out[r0:r1] = uniform_torch(k, seed).view(r1 - r0, inner, 2)
+    return torch.view_as_complex(out).view(*shape)

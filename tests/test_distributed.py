@@ -27,3 +27,39 @@ def test_shard_helpers():
     assert d.shard_dim((1, 5, 7), 2) == 1
     assert d.shard_bounds(65536, 8) == [(i * 8192, (i + 1) * 8192) for i in range(8)]
     assert d.local_shape((65536, 4096), 1, 3, 8) == ((8192, 4096), 0, (24576, 32768))
+
+
+def test_bench_spawns_n_ranks_dry_gloo():
+    """`python bench.py --gpus 2` with no launcher environment must itself start two ranks (--gpus was
+    parsed and ignored).  --dry: rendezvous + an all-reduce that counts the ranks, no GPU work."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # rank 0 prints ONE JSON line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2
+
+
+def test_bench_under_launcher_dry_gloo():
+    """The driver's N > 1 shape: torch.distributed.run provides the rank environment; bench.py must not spawn again."""
+    import json
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["ranks_seen"] == 2, r.stdout
+
+
+def test_synth_torch_generator_matches_numpy():
+    import numpy as np
+    import synth
+    a = synth.complex_array((37, 64), offset=12345)
+    b = synth.complex_array_torch((37, 64), "cpu", offset=12345, chunk_rows=5).numpy()
+    assert np.array_equal(a, b)

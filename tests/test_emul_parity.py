@@ -26,6 +26,7 @@ def test_layouts(L): ps.layouts(L)
 def test_normalization(L): ps.normalization_modes(L)
 def test_panics(L): ps.panics(L)
 def test_clone(L): ps.handler_clone_shares_plan(L)
+def test_interleaved_mut_views(L): ps.interleaved_mut_views_two_threads(L, rounds=1)
 def test_long_strided_lanes(L): ps.long_strided_lanes(L)
 def test_narrow_xcd_tiles(L): ps.narrow_xcd_tiles(L)
 def test_column_four_step(L): ps.column_four_step(L)
