@@ -125,6 +125,31 @@ int ndfft_exec_device(const ndfft_plan *plan, int op, const void *d_in, void *d_
                       const int64_t *shape_out, const int64_t *stride_out,
                       int axis, int norm, double scale, void *stream);
 
+/* ---- the same call spread over several GPUs of one node, from ONE host process ---------------------------
+ * The `_par` twins of the reference hand the independent lanes to rayon's worker threads (create_transform_par!,
+ * lib.rs:169-238; lanes never interact, lib.rs:187-194).  Here the workers are GPUs: the array is cut into
+ * n_devices contiguous blocks along its outermost non-transform dimension and device_ids[g] transforms block g
+ * with the ordinary single-device path -- no collective, no exchange.  Same argument checks and panic texts as
+ * ndfft_exec.  device_ids may name a device more than once (its blocks then run one after the other).
+ *
+ * ndfft_exec_sharded        : host arrays; every device moves its block over its OWN PCIe link, concurrently.
+ *                             Synchronous like ndfft_exec.
+ * ndfft_exec_sharded_device : arrays resident on ONE device (the one that owns d_out): blocks for the other devices are
+ *                             scattered and gathered host-less with hipMemcpyPeerAsync over xGMI.  `stream` is the stream
+ *                             the input was produced on; it is synchronised first, and the call returns when the
+ *                             whole output is complete.  (One xGMI link carries ~153 GB/s against ~6 TB/s of HBM: for a
+ *                             single transform the two transfers dwarf the kernel -- DESIGN.md section 7 -- so this entry
+ *                             point is for arrays that must end up back on one device; arrays that STAY sharded are
+ *                             driven with ndfft_set_device + ndfft_exec_device from one host thread per device.) */
+int ndfft_exec_sharded(const ndfft_plan *plan, int op, const void *in, void *out, int ndim,
+                       const int64_t *shape_in, const int64_t *stride_in,
+                       const int64_t *shape_out, const int64_t *stride_out,
+                       int axis, int norm, double scale, int n_devices, const int *device_ids);
+int ndfft_exec_sharded_device(const ndfft_plan *plan, int op, const void *d_in, void *d_out, int ndim,
+                              const int64_t *shape_in, const int64_t *stride_in,
+                              const int64_t *shape_out, const int64_t *stride_out,
+                              int axis, int norm, double scale, int n_devices, const int *device_ids, void *stream);
+
 /* Name of the kernel path the last successful exec on this thread dispatched to
  * ("pow2_reg", "generic_row", "generic_col", "generic_strided", "transpose+row", ...). */
 const char *ndfft_last_path(void);
@@ -144,7 +169,7 @@ int ndfft_dev_sync(void *stream);                                     /* hipStre
 int ndfft_host_alloc(void **h_ptr, size_t bytes);
 int ndfft_host_free(void *h_ptr);
 
-/* Frees the CALLING THREAD's device workspace: the scratch arrays of the multi-pass paths (transpose route,
+/* Frees the CALLING THREAD's device workspace on EVERY device it has used: the scratch arrays of the multi-pass paths (transpose route,
  * four-step, column four-step, global Bluestein) and the staging buffers of ndfft_exec.  They are otherwise
  * kept per thread and per stream for reuse (HIP-graph capture needs them stable).  Synchronises the device.
  * No reference counterpart: rustfft allocates its scratch inside every process() call (src/lib.rs:317). */

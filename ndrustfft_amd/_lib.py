@@ -21,7 +21,7 @@ SYMBOLS = [
     "ndfft_abi_version", "ndfft_last_error", "ndfft_device_count", "ndfft_set_device",
     "ndfft_plan_create", "ndfft_plan_retain", "ndfft_plan_destroy", "ndfft_plan_n", "ndfft_plan_kind",
     "ndfft_plan_dtype", "ndfft_plan_lane_len_in", "ndfft_plan_lane_len_out",
-    "ndfft_exec", "ndfft_exec_device", "ndfft_last_path",
+    "ndfft_exec", "ndfft_exec_device", "ndfft_exec_sharded", "ndfft_exec_sharded_device", "ndfft_last_path",
     "ndfft_dev_alloc", "ndfft_dev_free", "ndfft_dev_upload", "ndfft_dev_download", "ndfft_dev_sync",
     "ndfft_release_workspace", "ndfft_host_alloc", "ndfft_host_free",
 ]
@@ -62,6 +62,9 @@ class Library:
             f.restype = sz; f.argtypes = [vp, i32]
         L.ndfft_exec.argtypes = [vp, i32, vp, vp, i32, i64p, i64p, i64p, i64p, i32, i32, dbl]
         L.ndfft_exec_device.argtypes = [vp, i32, vp, vp, i32, i64p, i64p, i64p, i64p, i32, i32, dbl, vp]
+        ip = ctypes.POINTER(ctypes.c_int)
+        L.ndfft_exec_sharded.argtypes = [vp, i32, vp, vp, i32, i64p, i64p, i64p, i64p, i32, i32, dbl, i32, ip]
+        L.ndfft_exec_sharded_device.argtypes = [vp, i32, vp, vp, i32, i64p, i64p, i64p, i64p, i32, i32, dbl, i32, ip, vp]
         L.ndfft_dev_alloc.argtypes = [ctypes.POINTER(vp), sz]
         L.ndfft_dev_free.argtypes = [vp]
         L.ndfft_dev_upload.argtypes = [vp, vp, sz]

@@ -31,6 +31,24 @@ _SPEC = {
 }
 
 
+_PAR_DEVICES = None
+
+
+def set_par_devices(device_ids):
+    """Which GPUs the `_par` functions spread one call over (None / one id = the current device only).
+
+    The reference's `_par` twins hand the independent lanes to rayon's worker threads (create_transform_par!,
+    lib.rs:169-238); here the workers are GPUs: the array is cut in contiguous blocks along its outermost
+    non-transform dimension, one per device, no collective (ndfft_exec_sharded / ndfft_exec_sharded_device)."""
+    global _PAR_DEVICES
+    ids = None if device_ids is None else [int(d) for d in device_ids]
+    _PAR_DEVICES = ids if ids and len(ids) >= 1 else None
+
+
+def par_devices():
+    return None if _PAR_DEVICES is None else list(_PAR_DEVICES)
+
+
 def _i64(v):
     return (ctypes.c_int64 * max(len(v), 1))(*[int(x) for x in v])
 
@@ -58,7 +76,7 @@ def _apply_custom_host(op, inp, handler, axis):
     return work
 
 
-def _transform(op, inp, out, handler, axis):
+def _transform(op, inp, out, handler, axis, par=False):
     htype, in_c, out_c = _SPEC[op]
     if not isinstance(handler, htype):
         raise TypeError(f"handler must be a {htype.__name__}")
@@ -93,19 +111,40 @@ def _transform(op, inp, out, handler, axis):
                 inp = _apply_custom_host(op, inp, handler, axis)
 
     if dev:
+        if inp.device != out.device:
+            raise ValueError(f"input is on {inp.device} but output is on {out.device}: both arrays must live on the same GPU")
+        # torch's lazy conj / neg bits are not in the bytes data_ptr() points at: materialise them for the input,
+        # refuse them on the output (writing through such a view would store the wrong sign)
+        inp = inp.resolve_conj().resolve_neg()
+        if out.is_conj() or out.is_neg():
+            raise ValueError("output tensor has a lazy conj/neg bit set: pass a plain tensor (out.resolve_conj())")
         shape_in, shape_out = list(inp.shape), list(out.shape)
         sin, sout = list(inp.stride()), list(out.stride())
-        stream = ctypes.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)
-        st = L.c.ndfft_exec_device(handler._plan, op, ctypes.c_void_p(inp.data_ptr()), ctypes.c_void_p(out.data_ptr()),
-                                   inp.ndim, _i64(shape_in), _i64(sin), _i64(shape_out), _i64(sout), int(axis), mode,
-                                   scale, stream)
+        # the C side picks twiddle tables, JIT modules and workspaces by the CURRENT device: make it the tensors' one
+        with torch.cuda.device(out.device):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)
+            if par and _PAR_DEVICES and len(_PAR_DEVICES) > 1:
+                ids = (ctypes.c_int * len(_PAR_DEVICES))(*_PAR_DEVICES)
+                st = L.c.ndfft_exec_sharded_device(handler._plan, op, ctypes.c_void_p(inp.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                                   inp.ndim, _i64(shape_in), _i64(sin), _i64(shape_out), _i64(sout), int(axis), mode,
+                                                   scale, len(_PAR_DEVICES), ids, stream)
+            else:
+                st = L.c.ndfft_exec_device(handler._plan, op, ctypes.c_void_p(inp.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                       inp.ndim, _i64(shape_in), _i64(sin), _i64(shape_out), _i64(sout), int(axis), mode,
+                                       scale, stream)
     else:
         if not out.flags.writeable:
             raise ValueError("output must be writeable (&mut)")
         sin = [s // inp.itemsize for s in inp.strides]
         sout = [s // out.itemsize for s in out.strides]
-        st = L.c.ndfft_exec(handler._plan, op, ctypes.c_void_p(inp.ctypes.data), ctypes.c_void_p(out.ctypes.data), inp.ndim,
-                            _i64(inp.shape), _i64(sin), _i64(out.shape), _i64(sout), int(axis), mode, scale)
+        if par and _PAR_DEVICES and len(_PAR_DEVICES) > 1:
+            ids = (ctypes.c_int * len(_PAR_DEVICES))(*_PAR_DEVICES)
+            st = L.c.ndfft_exec_sharded(handler._plan, op, ctypes.c_void_p(inp.ctypes.data), ctypes.c_void_p(out.ctypes.data), inp.ndim,
+                                        _i64(inp.shape), _i64(sin), _i64(out.shape), _i64(sout), int(axis), mode, scale,
+                                        len(_PAR_DEVICES), ids)
+        else:
+            st = L.c.ndfft_exec(handler._plan, op, ctypes.c_void_p(inp.ctypes.data), ctypes.c_void_p(out.ctypes.data), inp.ndim,
+                                _i64(inp.shape), _i64(sin), _i64(out.shape), _i64(sout), int(axis), mode, scale)
     L.check(st)
     if post_custom:
         host = out.cpu().numpy() if dev else out
@@ -128,10 +167,16 @@ def nddct3(input, output, handler, axis): _transform(_lib.OP_DCT3, input, output
 def nddct4(input, output, handler, axis): _transform(_lib.OP_DCT4, input, output, handler, axis)
 
 
-# #[cfg(feature = "parallel")] twins (lib.rs:374-421, 589-611, 777-844)
-ndfft_par, ndifft_par = ndfft, ndifft
-ndfft_r2c_par, ndifft_r2c_par = ndfft_r2c, ndifft_r2c
-nddct1_par, nddct2_par, nddct3_par, nddct4_par = nddct1, nddct2, nddct3, nddct4
+# #[cfg(feature = "parallel")] twins (lib.rs:374-421, 589-611, 777-844).  On one GPU every lane is processed in
+# parallel anyway, so they are the same batched call; with set_par_devices([...]) they spread the call over several GPUs.
+def ndfft_par(input, output, handler, axis): _transform(_lib.OP_C2C_FWD, input, output, handler, axis, par=True)
+def ndifft_par(input, output, handler, axis): _transform(_lib.OP_C2C_INV, input, output, handler, axis, par=True)
+def ndfft_r2c_par(input, output, handler, axis): _transform(_lib.OP_R2C, input, output, handler, axis, par=True)
+def ndifft_r2c_par(input, output, handler, axis): _transform(_lib.OP_C2R, input, output, handler, axis, par=True)
+def nddct1_par(input, output, handler, axis): _transform(_lib.OP_DCT1, input, output, handler, axis, par=True)
+def nddct2_par(input, output, handler, axis): _transform(_lib.OP_DCT2, input, output, handler, axis, par=True)
+def nddct3_par(input, output, handler, axis): _transform(_lib.OP_DCT3, input, output, handler, axis, par=True)
+def nddct4_par(input, output, handler, axis): _transform(_lib.OP_DCT4, input, output, handler, axis, par=True)
 
 
 def pinned_empty(shape, dtype, _library=None):

@@ -145,6 +145,9 @@ const char *last_path();
 const std::string &last_err();
 void clear_err();
 int get_dev_tables(const ndfft_plan *plan, const DevTables **out);
+// exec.hip: the argument checks of one nd* call (the reference's panics) without running it -- for shard.hip
+int validate_call(const ndfft_plan *plan, int op, int ndim, const int64_t *shape_in, const int64_t *stride_in, const int64_t *shape_out,
+                  const int64_t *stride_out, int axis, int norm, double scale, bool *nothing);
 
 // kernels_generic.hip
 template <typename T> int launch_generic(const GenArgs<T> &a, int threads, size_t lds_bytes, hipStream_t s);

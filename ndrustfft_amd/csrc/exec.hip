@@ -109,6 +109,12 @@ static int prepare(const ndfft_plan *plan, int op, int ndim, const int64_t *shap
     return NDFFT_OK;
 }
 
+int validate_call(const ndfft_plan *plan, int op, int ndim, const int64_t *shape_in, const int64_t *stride_in, const int64_t *shape_out,
+                  const int64_t *stride_out, int axis, int norm, double scale, bool *nothing) {
+    Problem P;
+    return prepare(plan, op, ndim, shape_in, stride_in, shape_out, stride_out, axis, norm, scale, P, *nothing);
+}
+
 // ---------------------------------------------------------------------------------------------
 // dispatch of one canonicalised problem with <= kMaxBatchDims batch dims
 // ---------------------------------------------------------------------------------------------

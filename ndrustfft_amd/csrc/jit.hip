@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 
@@ -58,8 +59,12 @@ Rtc &rtc() {
 }
 
 struct Entry { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; bool failed = false; };
+// key -> entry; `ready == false` marks a compile in flight on some thread: a second thread that wants the SAME kernel
+// waits on g_cv, threads that want other kernels (or cached ones) are never held up by a ~0.5 s hiprtc compile
+struct Slot { Entry e; bool ready = false; };
 std::mutex g_mu;
-std::map<std::string, Entry> g_cache;
+std::condition_variable g_cv;
+std::map<std::string, Slot> g_cache;
 
 bool jit_disabled() {
     static const bool off = [] { const char *e = getenv("NDFFT_JIT"); return e && e[0] == '0'; }();
@@ -218,25 +223,20 @@ void write_file_atomic(const std::string &path, const std::string &data) {
     if (!ok || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());
 }
 
-Entry get_or_compile(const std::string &key, const std::string &src, const std::string &what) {
+static Entry compile_entry(const std::string &src, const std::string &what) {
     Rtc &r = rtc();
-    std::lock_guard<std::mutex> g(g_mu);
-    auto it = g_cache.find(key);
-    if (it != g_cache.end()) return it->second;
     Entry ne;
     {   // a code object compiled by an earlier process?
         const char *hs0[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h, jit_src_realops_h, jit_src_pow2_real_h, jit_src_blue_kernel_h};
         const std::string path = cache_path(src, hs0, 6);
         std::string code;
         if (!path.empty() && read_file(path, code) && hipModuleLoadData(&ne.mod, code.data()) == hipSuccess &&
-            hipModuleGetFunction(&ne.fn, ne.mod, "k_jit") == hipSuccess) {
-            g_cache.emplace(key, ne);
+            hipModuleGetFunction(&ne.fn, ne.mod, "k_jit") == hipSuccess)
             return ne;
-        }
         (void)hipGetLastError();
         ne = Entry();
         if (const char *e = getenv("NDFFT_JIT_NOCOMPILE")) {      // test switch: cached code objects only
-            if (e[0] == '1') { ne.failed = true; g_cache.emplace(key, ne); return ne; }
+            if (e[0] == '1') { ne.failed = true; return ne; }
         }
     }
     const char *hn[] = {"device_common.h", "butterflies.h", "pow2_kernel.h", "realops.h", "pow2_real.h", "blue_kernel.h"};
@@ -257,7 +257,26 @@ Entry get_or_compile(const std::string &key, const std::string &src, const std::
     if (ok) ok = hipModuleLoadData(&ne.mod, code.data()) == hipSuccess && hipModuleGetFunction(&ne.fn, ne.mod, "k_jit") == hipSuccess;
     if (ok) { const std::string path = cache_path(src, hs, 6); if (!path.empty()) write_file_atomic(path, code); }
     if (!ok) { (void)hipGetLastError(); ne.failed = true; }
-    g_cache.emplace(key, ne);
+    return ne;
+}
+
+Entry get_or_compile(const std::string &key, const std::string &src, const std::string &what) {
+    {
+        std::unique_lock<std::mutex> g(g_mu);
+        auto it = g_cache.find(key);
+        if (it != g_cache.end()) {
+            g_cv.wait(g, [&] { return g_cache[key].ready; });   // someone else is compiling this very kernel
+            return g_cache[key].e;
+        }
+        g_cache.emplace(key, Slot());                            // ours to compile; the lock is NOT held meanwhile
+    }
+    const Entry ne = compile_entry(src, what);
+    {
+        std::lock_guard<std::mutex> g(g_mu);
+        Slot &sl = g_cache[key];
+        sl.e = ne; sl.ready = true;
+    }
+    g_cv.notify_all();
     return ne;
 }
 std::string radix_list(const JitCfg &cfg) {

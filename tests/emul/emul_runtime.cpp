@@ -81,6 +81,13 @@ int emul_device_of(const void *p) {
     if ((const char *)p >= it->first + it->second + (it->second == 0)) return -1;
     return g_alloc_dev[it->first];
 }
+void emul_check_current(const void *devptr, const char *what) {
+    const int d = emul_device_of(devptr);
+    if (d >= 0 && d != emul_cur_device) {
+        fprintf(stderr, "emul: %s: device memory of device %d used while device %d is current\n", what, d, emul_cur_device);
+        abort();
+    }
+}
 hipError_t hipMemcpyPeerAsync(void *dst, int dst_dev, const void *src, int src_dev, size_t n, hipStream_t) {
     if (emul_device_of(dst) != dst_dev || emul_device_of(src) != src_dev) {
         fprintf(stderr, "emul: hipMemcpyPeerAsync: pointer is not on the device it is claimed to be on (dst %d vs %d, src %d vs %d)\n",

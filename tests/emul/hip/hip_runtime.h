@@ -46,14 +46,27 @@ inline hipError_t hipGetDeviceCount(int *n) { *n = emul_device_count(); return 0
 // "device" allocations carry 256-byte guard zones that are checked after every kernel launch (emul_runtime.cpp)
 hipError_t hipMalloc(void **p, size_t n);
 hipError_t hipFree(void *p);
-inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return 0; }
+// host <-> device copies must name memory of the CURRENT device: the library keeps one workspace per device, and a
+// staging buffer of device 0 showing up while device 1 is current is exactly the bug class this catches
+void emul_check_current(const void *devptr, const char *what);
+inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind k) {
+    if (k == hipMemcpyHostToDevice) emul_check_current(d, "hipMemcpy H2D");
+    if (k == hipMemcpyDeviceToHost) emul_check_current(s, "hipMemcpy D2H");
+    memcpy(d, s, n); return 0;
+}
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline hipError_t hipDeviceSynchronize() { return 0; }
 // pinned-host pipeline of ndfft_exec: never taken in the emulation (no pointer is ever "pinned"), stubs only
 typedef void *hipEvent_t;
 enum { hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipMemoryTypeHost = 1 };
-struct hipPointerAttribute_t { int type; };
-inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *, const void *) { return 1; }
+struct hipPointerAttribute_t { int type; int device; };
+int emul_device_of(const void *p);   // device an address was hipMalloc'd on, -1 if not device memory
+inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *p) {
+    const int d = emul_device_of(p);
+    if (d < 0) return 1;                       // plain host memory: no pointer is ever "pinned" in the emulation
+    a->type = 2; a->device = d;
+    return 0;
+}
 inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return 0; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = nullptr; return 0; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
@@ -63,7 +76,7 @@ inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 hipError_t hipMemcpyPeerAsync(void *dst, int dst_dev, const void *src, int src_dev, size_t n, hipStream_t);
 int emul_device_of(const void *p);   // device an address was hipMalloc'd on, -1 if not device memory
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
-inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return 0; }
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t) { return hipMemcpy(d, s, n, k); }
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
 inline hipError_t hipHostFree(void *p) { free(p); return 0; }
 inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return 0; }

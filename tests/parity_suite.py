@@ -230,6 +230,62 @@ def interleaved_mut_views_two_threads(L, rounds=6):
     yo = np.zeros((7, 20)); orc.nddct2(x, yo, orc.DctHandler(20), 1); assert_close(big[:, 1::2], yo, 1, 1e-10, "stepped dct out")
 
 
+def sharded_exec(L, device_ids, torch_device=None):
+    """ndfft_exec_sharded (host arrays) and ndfft_exec_sharded_device (arrays resident on one device) over `device_ids`:
+    every op, the split dimension in every position, uneven blocks, fewer lanes than devices, a single lane, views with
+    negative strides and holes -- bit-identical to the single-device call, and the same panics."""
+    import ctypes
+    api.set_par_devices(device_ids)
+    try:
+        cases = [("ndfft", (6, 16), 1), ("ndfft", (5, 16), 1), ("ndifft", (12, 7, 3), 0), ("ndfft_r2c", (9, 10), 1),
+                 ("ndifft_r2c", (4, 3, 10), 2), ("nddct1", (3, 9, 5), 1), ("nddct2", (4, 3, 8), 2), ("nddct3", (7, 8), 1),
+                 ("nddct4", (8, 7), 0), ("ndfft", (1, 16), 1), ("ndfft", (16,), 0), ("ndfft", (3, 64, 40), 1)]
+        for name, shape, axis in cases:
+            for rdt in (np.float64, np.float32):
+                sin, sout = shapes_for(name, shape, axis)
+                x = make_input(name, sin, rdt)
+                odt = cdt_of(rdt) if OPS[name][4] else np.dtype(rdt)
+                h, o = handlers_for(name, shape[axis], rdt, L)
+                y1 = np.zeros(sout, odt); y2 = np.zeros(sout, odt); yo = np.zeros(sout, odt)
+                OPS[name][0](x, y1, h, axis)                               # single device
+                getattr(api, name + "_par")(x, y2, h, axis)                # sharded
+                assert L.last_path().startswith("sharded:"), L.last_path()
+                assert np.array_equal(y1, y2), (name, shape, axis)
+                OPS[name][1](x, yo, o, axis)
+                assert_close(y2, yo, axis, TOL[np.dtype(rdt)], f"sharded {name} {shape}")
+        # views: reversed input, output with holes; holes must survive
+        x = synth.complex_array((9, 16, 6)); h = handlers.FftHandler(16, _library=L); o = orc.FftHandler(16)
+        big = np.full((9, 16, 12), 2.5 + 0j); ref = big.copy()
+        api.ndfft_par(x[::-1, :, :], big[:, :, ::2], h, 1); orc.ndfft(x[::-1, :, :], ref[:, :, ::2], o, 1)
+        assert_close(big, ref, 1, 1e-10, "sharded strided views"); assert np.all(big[:, :, 1::2] == 2.5)
+        # F-layout: the outermost dimension in memory is the LAST index
+        xf = np.asfortranarray(synth.complex_array((16, 10))); yf = np.zeros((16, 10), np.complex128, order="F"); yo = np.zeros((16, 10), np.complex128)
+        api.ndfft_par(xf, yf, h, 0); orc.ndfft(np.ascontiguousarray(xf), yo, o, 0); assert_close(yf, yo, 0, 1e-10, "sharded F layout")
+        # the reference's panics come out before any device starts
+        import pytest
+        with pytest.raises(_lib.Panic, match="Size mismatch in fft, got 15 expected 16"):
+            api.ndfft_par(np.zeros((4, 15), np.complex128), np.zeros((4, 15), np.complex128), h, 1)
+        # bad device id
+        ids = (ctypes.c_int * 2)(0, 99)
+        st = L.c.ndfft_exec_sharded(h._plan, 0, ctypes.c_void_p(x.ctypes.data), ctypes.c_void_p(x.ctypes.data), 3, api._i64((9, 16, 6)), api._i64((96, 6, 1)),
+                                    api._i64((9, 16, 6)), api._i64((96, 6, 1)), 1, 1, 0.0, 2, ids)
+        assert st == _lib.ERR_INVALID_ARG and b"out of range" in L.c.ndfft_last_error()
+        if torch_device is not None:
+            import torch
+            for name, shape, axis in (("ndfft", (37, 256), 1), ("ndfft_r2c", (64, 5, 3), 0), ("nddct2", (10, 33, 128), 2)):
+                sin, sout = shapes_for(name, shape, axis)
+                x = make_input(name, sin, np.float64)
+                h, o = handlers_for(name, shape[axis], np.float64, L)
+                odt = np.complex128 if OPS[name][4] else np.float64
+                yo = np.zeros(sout, odt); OPS[name][1](x, yo, o, axis)
+                xd = torch.from_numpy(x).to(torch_device); yd = torch.zeros(sout, dtype=torch.from_numpy(yo).dtype, device=torch_device)
+                getattr(api, name + "_par")(xd, yd, h, axis)
+                assert L.last_path().startswith("sharded:")
+                assert_close(yd.cpu().numpy(), yo, axis, 1e-10, f"sharded device-resident {name} {shape}")
+    finally:
+        api.set_par_devices(None)
+
+
 def fuzz(L, seed, count, max_points=1 << 17, lengths=None):
     """Random op x lane length x shape x axis x dtype x norm x layout (C / F / stepped and reversed views, padded
     output views) against the oracle.  The lane lengths mix every dispatch class: powers of two, smooth,

@@ -14,6 +14,9 @@ from ndrustfft_amd import _lib
 EMUL_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emul")
 
 
+os.environ.setdefault("EMUL_DEVICES", "3")     # three fake devices: the multi-device paths run on the CPU container too
+
+
 @pytest.fixture(scope="module")
 def L():
     subprocess.check_call(["make", "-C", EMUL_DIR, "-s", "-j4"])
@@ -26,6 +29,10 @@ def test_layouts(L): ps.layouts(L)
 def test_normalization(L): ps.normalization_modes(L)
 def test_panics(L): ps.panics(L)
 def test_clone(L): ps.handler_clone_shares_plan(L)
+def test_sharded_exec_three_fake_devices(L):
+    assert L.c.ndfft_device_count() == 3
+    ps.sharded_exec(L, [0, 1, 2])
+    ps.sharded_exec(L, [2, 0])
 def test_interleaved_mut_views(L): ps.interleaved_mut_views_two_threads(L, rounds=1)
 def test_long_strided_lanes(L): ps.long_strided_lanes(L)
 def test_narrow_xcd_tiles(L): ps.narrow_xcd_tiles(L)
@@ -68,3 +75,62 @@ def test_pow2_real_sizes(L):
 def test_pow2_col_sizes(L):
     ps.pow2_col_sizes(L, sizes=(64, 256), dtypes=(np.float64,))
     ps.pow2_col_sizes(L, sizes=(128, 1024), dtypes=(np.float32,))
+
+
+def test_alternating_devices_on_one_thread(L):
+    """one host thread alternates ndfft_set_device between calls.  Workspaces (staging, scratch) are kept
+    per device: the emulation aborts if a buffer allocated on one device is used while another is current."""
+    import ctypes
+    import synth
+    from ndrustfft_amd import api, handlers
+    from oracle import oracle_ctypes as orc
+    x = synth.real_array((4096, 24), np.float32); yo = np.zeros((2049, 24), np.complex64)
+    orc.ndfft_r2c(x, yo, orc.R2cFftHandler(4096, np.float32), 0)
+    h = handlers.R2cFftHandler(4096, np.float32, _library=L)          # axis 0, long lanes: scratch + staging in play
+    try:
+        for rep in range(2):
+            for dev in (0, 1, 2, 1, 0):
+                assert L.c.ndfft_set_device(dev) == 0
+                y = np.zeros((2049, 24), np.complex64)
+                api.ndfft_r2c(x, y, h, 0)
+                assert np.abs(y - yo).max() <= 1e-4 * np.abs(yo).max()
+                # device-resident call on the null stream of that device
+                nb_in, nb_out = x.nbytes, y.nbytes
+                din, dout = ctypes.c_void_p(), ctypes.c_void_p()
+                L.check(L.c.ndfft_dev_alloc(ctypes.byref(din), nb_in)); L.check(L.c.ndfft_dev_alloc(ctypes.byref(dout), nb_out))
+                L.check(L.c.ndfft_dev_upload(din, ctypes.c_void_p(x.ctypes.data), nb_in))
+                L.check(L.c.ndfft_exec_device(h._plan, _lib.OP_R2C, din, dout, 2, api._i64(x.shape), api._i64((24, 1)), api._i64(y.shape),
+                                              api._i64((24, 1)), 0, _lib.NORM_DEFAULT, 0.0, None))
+                y2 = np.zeros_like(y)
+                L.check(L.c.ndfft_dev_sync(None)); L.check(L.c.ndfft_dev_download(ctypes.c_void_p(y2.ctypes.data), dout, nb_out))
+                assert np.array_equal(y2, y)
+                L.check(L.c.ndfft_dev_free(din)); L.check(L.c.ndfft_dev_free(dout))
+        assert L.c.ndfft_release_workspace() == 0
+    finally:
+        L.c.ndfft_set_device(0)
+
+
+def test_sharded_device_resident_fake_devices(L):
+    """ndfft_exec_sharded_device with the array resident on fake device 1 and blocks on devices 0, 1, 2: the emulation's
+    hipMemcpyPeerAsync checks that every pointer is on the device it is claimed to be on."""
+    import ctypes
+    import synth
+    from ndrustfft_amd import api, handlers
+    from oracle import oracle_ctypes as orc
+    x = synth.complex_array((7, 64, 3)); yo = np.zeros_like(x)
+    orc.ndfft(x, yo, orc.FftHandler(64), 1)
+    h = handlers.FftHandler(64, _library=L)
+    try:
+        assert L.c.ndfft_set_device(1) == 0
+        din, dout = ctypes.c_void_p(), ctypes.c_void_p()
+        L.check(L.c.ndfft_dev_alloc(ctypes.byref(din), x.nbytes)); L.check(L.c.ndfft_dev_alloc(ctypes.byref(dout), x.nbytes))
+        L.check(L.c.ndfft_dev_upload(din, ctypes.c_void_p(x.ctypes.data), x.nbytes))
+        ids = (ctypes.c_int * 3)(0, 1, 2)
+        L.check(L.c.ndfft_exec_sharded_device(h._plan, _lib.OP_C2C_FWD, din, dout, 3, api._i64(x.shape), api._i64((192, 3, 1)), api._i64(x.shape),
+                                              api._i64((192, 3, 1)), 1, _lib.NORM_DEFAULT, 0.0, 3, ids, None))
+        y = np.zeros_like(x)
+        L.check(L.c.ndfft_dev_download(ctypes.c_void_p(y.ctypes.data), dout, x.nbytes))
+        assert np.abs(y - yo).max() <= 1e-10 * np.abs(yo).max()
+        L.check(L.c.ndfft_dev_free(din)); L.check(L.c.ndfft_dev_free(dout))
+    finally:
+        L.c.ndfft_set_device(0)

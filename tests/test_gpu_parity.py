@@ -30,6 +30,9 @@ def test_layouts(L): ps.layouts(L)
 def test_normalization(L): ps.normalization_modes(L)
 def test_panics(L): ps.panics(L)
 def test_clone(L): ps.handler_clone_shares_plan(L)
+def test_sharded_exec_same_device_twice(L):
+    n = L.c.ndfft_device_count()
+    ps.sharded_exec(L, list(range(n)) if n > 1 else [0, 0, 0], torch_device="cuda:0")
 def test_interleaved_mut_views_two_threads(L): ps.interleaved_mut_views_two_threads(L)
 def test_shared_handler_across_threads(L): ps.shared_handler_across_threads(L)
 def test_long_strided_lanes(L): ps.long_strided_lanes(L)

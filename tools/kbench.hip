@@ -187,6 +187,25 @@ int main(int argc, char **argv) {
         V(b, double, 4096, "half 256x16 16.16.16 nt1", 256, true, 1, 1, 16, 16, 16);
         V(b, double, 4096, "half 256x16 16.16.16 nt3", 256, true, 3, 1, 16, 16, 16);
         b.run(1e-12);
+    } else if (what == "f64_cold") {
+        // cache-cold: 32768 lanes = 2 GiB in + 2 GiB out per launch, far beyond the 256 MiB Infinity Cache
+        const int64_t lanes = argc > 3 ? atoll(argv[3]) : 32768;
+        Bench<double> b{4096, lanes, rounds}; b.init();
+#define VC(name, TPL, LPB, FL, MINW, NT, ...) b.template add<Pow2Kernel<double, 4096, TPL, LPB, true, RadixList<__VA_ARGS__>, FL, MINW, NT, 1>, RadixList<__VA_ARGS__>>(name)
+        VC("512x8 8.8.8.8 TWP nt1 (product)", 512, 1, 16, 1, 1, 8, 8, 8, 8);
+        VC("512x8 8.8.8.8 TWP nt3", 512, 1, 16, 1, 3, 8, 8, 8, 8);
+        VC("512x8 8.8.8.8 TWP nt0", 512, 1, 16, 1, 0, 8, 8, 8, 8);
+        VC("512x8 8.8.8.8 TWP nt2", 512, 1, 16, 1, 2, 8, 8, 8, 8);
+        VC("512x8 8.8.8.8 plain-tw nt1", 512, 1, 0, 1, 1, 8, 8, 8, 8);
+        VC("2 lanes/WG 1024thr TWP nt1", 512, 2, 16, 1, 1, 8, 8, 8, 8);
+        VC("2 lanes/WG 1024thr TWP nt3", 512, 2, 16, 1, 3, 8, 8, 8, 8);
+        VC("256x16 16.16.16 nt1", 256, 1, 0, 1, 1, 16, 16, 16);
+        VC("256x16 16.16.16 nt3", 256, 1, 0, 1, 3, 16, 16, 16);
+        VC("256x16 4 lanes/WG nt1", 256, 4, 0, 1, 1, 16, 16, 16);
+        VC("1024x4 4.4.4.4.4.4 nt1", 1024, 1, 0, 1, 1, 4, 4, 4, 4, 4, 4);
+        VC("ABLATE load+store only", 512, 1, 7, 1, 1, 8, 8, 8, 8);
+        VC("ABLATE no LDS exchange", 512, 1, 2, 1, 1, 8, 8, 8, 8);
+        b.run(1e-12);
     } else if (what == "f64_full") {
         { Bench<double> b{4096, 4096, rounds}; b.init();
           V(b, double, 4096, "4096 half 512x8 8.8.8.8 (product)", 512, true, 1, 1, 8, 8, 8, 8);
