@@ -160,6 +160,8 @@ bool pow2_supported(int dtype, int n);
 // layout of the per-pass transposed twiddle table for length n (host builder in plan.cpp)
 void pow2_build_twiddles(int dtype, int n, HostTable &out);
 int launch_pow2(int dtype, int n, const Pow2Args &a, hipStream_t s);
+int xcd_chunk_for(size_t block_bytes, int64_t nblk);   // lane blocks per XCD chunk of the workgroup -> lane map (0: identity)
+bool stream_loads_for(size_t in_bytes);                // input larger than the Infinity Cache: streaming (nt) loads
 
 // kernels_pow2_real.hip : register-resident real-op kernels (R2C/C2R/DCT) for power-of-two inner FFT length F
 bool pow2_real_supported(int F);

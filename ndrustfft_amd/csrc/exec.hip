@@ -597,7 +597,8 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
         a.inverse = P.op == NDFFT_OP_C2C_INV;
         a.scale = P.scale;
         a.twp = dt->cfg[CFG_MAIN].twp;
-        const int rcj = launch_jit_c2c(plan->dtype, plan->cfg[CFG_MAIN].jitcfg, 1, a, stream);
+        const int nt = stream_loads_for((size_t)P.nlanes * plan->n * 2 * real_size(plan->dtype)) ? 3 : 1;
+        const int rcj = launch_jit_c2c(plan->dtype, plan->cfg[CFG_MAIN].jitcfg, nt, a, stream);
         if (rcj == NDFFT_OK) { set_last_path("jit_reg"); return NDFFT_OK; }
         if (rcj != NDFFT_ERR_UNSUPPORTED) return rcj;   // a real HIP error; UNSUPPORTED = no hiprtc / compile failed -> LDS kernel
     }

@@ -314,6 +314,7 @@ int launch_jit_c2c(int dtype, const JitCfg &cfg, int nt, const Pow2Args &a, hipS
     if (nblk <= 0) return NDFFT_OK;
     if (nblk > 0x7fffffffLL) return NDFFT_ERR_UNSUPPORTED;
     Pow2Args arg = a;
+    arg.xcd_chunk = xcd_chunk_for((size_t)cfg.lpb * cfg.n * 2 * esz, nblk);
     void *params[] = {(void *)&arg};
     NDFFT_HIP(hipModuleLaunchKernel(e.fn, (unsigned)nblk, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, s, params, nullptr));
     return NDFFT_OK;

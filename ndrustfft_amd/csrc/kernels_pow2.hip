@@ -20,6 +20,9 @@
 //  * Streaming cache policy: non-temporal stores (and loads, for inputs larger than the Infinity
 //    Cache) -- see launch_pow2.
 //  * No MFMA: ~1.9 flop/byte, the kernel is HBM-bound by design.
+#include <algorithm>
+#include <cstdlib>
+
 #include "pow2_kernel.h"
 
 namespace ndfft {
@@ -89,18 +92,49 @@ void pow2_build_twiddles(int dtype, int n, HostTable &out) {
     }
 }
 
-template <typename T, int N, int NT, int VEC, int FL = 0> static int launch_one(const Pow2Args &a, hipStream_t s) {
+// Lane blocks per XCD chunk of the workgroup -> lane map (device_common.h: xcd_block): every XCD streams contiguous
+// runs of ~512 KiB instead of every eighth lane block.  Measured with tools/kbench f64_map on 4096-point c128 lanes
+// (profiles/r02c_*): cache-cold 2 GiB arrays 5.56 -> 6.09 TB/s (6.24 with streaming loads), Infinity-Cache-warm
+// 4096 x 4096 6.58 -> 6.85 TB/s; runs of 128 KiB .. 8 MiB are within 2 % of each other, one eighth of the array per
+// XCD is worse when cold.  NDFFT_XCD_CHUNK_KB overrides the run length (0 = identity map).
+int xcd_chunk_for(size_t block_bytes, int64_t nblk) {
+    static const long kb = [] { const char *e = getenv("NDFFT_XCD_CHUNK_KB"); return e ? atol(e) : 512L; }();
+    if (kb <= 0 || block_bytes == 0) return 0;
+    if (block_bytes >= ((size_t)256 << 10)) return 0;   // one workgroup already streams >= 256 KiB (n = 16384): the map only cost there (0.54 -> 0.50)
+    int64_t c = (int64_t)((size_t)kb * 1024 / block_bytes);
+    if (c < 1) c = 1;
+    if (nblk < 16 * c) return 0;              // fewer than two whole groups: nothing to gain
+    return (int)std::min<int64_t>(c, 1 << 20);
+}
+// Inputs larger than the 256 MiB Infinity Cache cannot be resident in it: they are loaded with the streaming (nt)
+// policy (cache-cold 2 GiB arrays: +3 % alone, +8..12 % together with the XCD map).  Smaller inputs keep the default
+// policy: if their producer left them in the Infinity Cache plain loads are up to 15 % faster (4096 x 4096 c128:
+// 0.86 vs 0.74 of the roofline), if not they cost 6 % (0.70 vs 0.74) -- the asymmetric bet.  NDFFT_STREAM_LOADS=0/1 forces it.
+bool stream_loads_for(size_t in_bytes) {
+    static const int force = [] { const char *e = getenv("NDFFT_STREAM_LOADS"); return e ? atoi(e) : -1; }();
+    if (force >= 0) return force != 0;
+    return in_bytes > ((size_t)256 << 20);
+}
+
+template <typename T, int N, int NT, int VEC, int FL = 0> static int launch_inst(const Pow2Args &a0, hipStream_t s) {
     constexpr int TPL = Pow2Cfg<T, N>::TPL, LPB = lpb_for(TPL);
     // FLAGS bit 4 from n = 4096: late passes whose twiddle table exceeds 32 KiB load W^k, W^2k, W^4k (, W^8k) and build
     // the other powers (2-4 % on the instruction-bound long kernels; two extra roundings on those twiddles)
     using K = Pow2Kernel<T, N, TPL, LPB, Pow2Half<T, N>::value, typename Pow2Cfg<T, N>::RL, FL | (N >= 4096 ? 16 : 0), 1, NT, VEC>;
     NDFFT_ENSURE_LDS_ATTR((k_pow2<K>));
-    const int64_t nblk = (a.nlanes + LPB - 1) / LPB;
+    const int64_t nblk = (a0.nlanes + LPB - 1) / LPB;
     if (nblk <= 0) return NDFFT_OK;
     if (nblk > 0x7fffffffLL) return fail(NDFFT_ERR_UNSUPPORTED, "too many lanes for one launch");
+    Pow2Args a = a0;
+    a.xcd_chunk = xcd_chunk_for((size_t)LPB * N * sizeof(cpx<T>), nblk);
     hipLaunchKernelGGL(k_pow2<K>, dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, a);
     NDFFT_HIP(hipGetLastError());
     return NDFFT_OK;
+}
+template <typename T, int N, int NT, int VEC, int FL = 0> static int launch_one(const Pow2Args &a, hipStream_t s) {
+    static_assert(NT == 1, "callers name the store policy; the load policy is chosen here");
+    if (stream_loads_for((size_t)a.nlanes * N * sizeof(cpx<T>))) return launch_inst<T, N, 3, VEC, FL>(a, s);
+    return launch_inst<T, N, 1, VEC, FL>(a, s);
 }
 
 // f32: 16-byte (two-element) accesses where the configuration allows them (an even number of butterflies per

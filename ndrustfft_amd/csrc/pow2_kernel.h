@@ -186,7 +186,7 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
     static __device__ __forceinline__ void run(const Pow2Args &a) {
         extern __shared__ __attribute__((aligned(16))) char smem[];
         const int t = threadIdx.x % TPL, ll = threadIdx.x / TPL;
-        const int64_t lane = (int64_t)blockIdx.x * LPB + ll;
+        const int64_t lane = (int64_t)xcd_block(blockIdx.x, gridDim.x, a.xcd_chunk) * LPB + ll;
         const bool live = lane < a.nlanes;
         const cpx<T> *in = (const cpx<T> *)a.in + (live ? lane : 0) * a.pitch_in;
         cpx<T> *out = (cpx<T> *)a.out + (live ? lane : 0) * a.pitch_out;

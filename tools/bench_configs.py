@@ -41,8 +41,20 @@ def timeit(fn, steps, warmup=5, ramp_ms=None):
     return e0.elapsed_time(e1) * 1e-3 / steps
 
 
+PAIRS = 1   # --pairs K: rotate K distinct (in, out) pairs so that every launch finds its input in HBM, not in the Infinity Cache
+
+
 def run(name, fn, x, y, h, axis, points, steps):
-    t = timeit(lambda: fn(x, y, h, axis), steps)
+    if PAIRS > 1:
+        xs = [x] + [x.clone() for _ in range(PAIRS - 1)]; ys = [y] + [torch.empty_like(y) for _ in range(PAIRS - 1)]
+        cnt = [0]
+        def go():
+            k = cnt[0] % PAIRS; cnt[0] += 1
+            fn(xs[k], ys[k], h, axis)
+        t = timeit(go, steps)
+        name = name + f" [cold: {PAIRS} rotating pairs]"
+    else:
+        t = timeit(lambda: fn(x, y, h, axis), steps)
     nbytes = x.numel() * x.element_size() + y.numel() * y.element_size()
     gbs = nbytes / t / 1e9
     print(json.dumps({"workload": name, "us": round(t * 1e6, 2), "GFFT-points/s": round(points / t / 1e9, 2),
@@ -51,10 +63,10 @@ def run(name, fn, x, y, h, axis, points, steps):
 
 
 def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=50); ap.add_argument("--only", default=""); ap.add_argument("--ramp-ms", type=float, default=150.0)
+    ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=50); ap.add_argument("--only", default=""); ap.add_argument("--ramp-ms", type=float, default=150.0); ap.add_argument("--pairs", type=int, default=1)
     a = ap.parse_args()
-    global RAMP_MS
-    RAMP_MS = a.ramp_ms
+    global RAMP_MS, PAIRS
+    RAMP_MS = a.ramp_ms; PAIRS = a.pairs
     dev = torch.device("cuda:0")
     want = lambda k: (not a.only) or a.only in k
     if want("cfg2"):

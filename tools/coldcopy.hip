@@ -31,24 +31,30 @@ template <int POL> __device__ __forceinline__ v4f ldg(const v4f *p) {
     return v;
 }
 template <int POL> __device__ __forceinline__ void stg(v4f *p, v4f v) {
-    if constexpr (POL == 0) asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(v) : "memory");
-    if constexpr (POL == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(v) : "memory");
-    if constexpr (POL == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
-    if constexpr (POL == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
-    if constexpr (POL == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" : : "v"(p), "v"(v) : "memory");
-    if constexpr (POL == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0" : : "v"(p), "v"(v) : "memory");
-    if constexpr (POL == 6) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(p), "v"(v) : "memory");
-    if constexpr (POL == 7) asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" : : "v"(p), "v"(v) : "memory");
+    if constexpr (POL == 0) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+    if constexpr (POL == 1) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+    if constexpr (POL == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+    if constexpr (POL == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+    if constexpr (POL == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+    if constexpr (POL == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+    if constexpr (POL == 6) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+    if constexpr (POL == 7) asm volatile("global_store_dwordx4 %0, %1, off sc0 nt\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 
 // One workgroup of T threads per 64 KiB lane: thread t loads elements t + r T, r = 0..E-1 (E = 4096 / T), all loads
 // first, then all stores -- the register kernel's first and last pass.  MAP 1: XCD x (= blockIdx % 8) owns a
 // contiguous eighth of the lanes instead of every eighth lane.
+// MAP: 0 identity; C > 0: workgroups are dealt round-robin over the 8 XCDs, so XCD x = blockIdx % 8 gets, out of every
+// group of 8 C consecutive lanes, the C CONTIGUOUS lanes [x C, (x+1) C) instead of every eighth one; 1 = one eighth of all
 template <int T, int LD, int ST, int MAP> __global__ __launch_bounds__(T) void k_lane(const v4f *in, v4f *out, unsigned nlanes) {
     extern __shared__ char occupancy_pad[];
     constexpr int E = 4096 / T;
     unsigned lane = blockIdx.x;
     if constexpr (MAP == 1) lane = (blockIdx.x & 7) * (nlanes >> 3) + (blockIdx.x >> 3);
+    if constexpr (MAP > 1) {
+        const unsigned g = blockIdx.x / (8 * MAP), r = blockIdx.x % (8 * MAP);
+        lane = g * (8 * MAP) + (r & 7) * MAP + (r >> 3);
+    }
     const v4f *s = in + (size_t)lane * 4096 + threadIdx.x;
     v4f *d = out + (size_t)lane * 4096 + threadIdx.x;
     v4f v[E];
@@ -112,8 +118,11 @@ int main(int argc, char **argv) {
     LANE(512, 0, 1, 0, 0) LANE(512, 0, 1, 0, 17) LANE(512, 0, 1, 0, 68) LANE(512, 0, 1, 0, 136)
     // workgroup shape
     LANE(256, 0, 1, 0, 17) LANE(256, 0, 1, 0, 34) LANE(1024, 0, 1, 0, 68) LANE(1024, 0, 1, 0, 34) LANE(1024, 1, 1, 0, 68)
-    // XCD-contiguous lane map
-    LANE(512, 0, 1, 1, 34) LANE(512, 1, 1, 1, 34) LANE(512, 0, 0, 1, 34) LANE(1024, 0, 1, 1, 68)
+    // XCD-contiguous lane maps: one eighth per XCD (1), or chunks of C lanes per XCD
+    LANE(512, 0, 1, 1, 34) LANE(512, 1, 1, 1, 34) LANE(512, 0, 0, 1, 34) LANE(512, 1, 0, 1, 34) LANE(1024, 0, 1, 1, 68) LANE(1024, 1, 1, 1, 68)
+    LANE(512, 1, 1, 2, 34) LANE(512, 1, 1, 4, 34) LANE(512, 1, 1, 8, 34) LANE(512, 1, 1, 16, 34) LANE(512, 1, 1, 32, 34) LANE(512, 1, 1, 64, 34) LANE(512, 1, 1, 128, 34) LANE(512, 1, 1, 512, 34)
+    LANE(512, 0, 1, 4, 34) LANE(512, 0, 1, 16, 34) LANE(512, 0, 1, 32, 34) LANE(512, 0, 1, 64, 34) LANE(512, 0, 1, 128, 34) LANE(512, 0, 1, 512, 34)
+    LANE(512, 0, 0, 32, 34) LANE(512, 1, 0, 32, 34)
 #define RD(T, LD, LDSKB) vs.push_back({"read  T" #T " ld" #LD " lds" #LDSKB "K", [=]() { hipLaunchKernelGGL((k_lane_read<T, LD>), dim3(nlanes), dim3(T), LDSKB * 1024, 0, a, b, nlanes); }, cb / 2, false});
 #define WR(T, ST, LDSKB) vs.push_back({"write T" #T " st" #ST " lds" #LDSKB "K", [=]() { hipLaunchKernelGGL((k_lane_write<T, ST>), dim3(nlanes), dim3(T), LDSKB * 1024, 0, a, b, nlanes); }, cb / 2, false});
     RD(512, 0, 34) RD(512, 1, 34) RD(512, 2, 34) RD(512, 4, 34)
@@ -127,6 +136,7 @@ int main(int argc, char **argv) {
     CK(hipFuncSetAttribute((const void *)k_lane<1024, 0, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CK(hipFuncSetAttribute((const void *)k_lane<1024, 1, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CK(hipFuncSetAttribute((const void *)k_lane<1024, 0, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void *)k_lane<1024, 1, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 
     std::vector<std::vector<float>> t(vs.size());
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));

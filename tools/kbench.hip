@@ -50,29 +50,36 @@ template <typename T> static void *upload_tw(const HostTable &t) {
     return d;
 }
 
-template <typename K, typename T, typename RL> static Variant fft_variant(const char *name, const void *in, void *out, int64_t lanes, int n, size_t extra_lds = 0) {
+template <typename K, typename T, typename RL> static Variant fft_variant(const char *name, const void *in, void *out, int64_t lanes, int n, size_t extra_lds = 0, int xcd_chunk = 0, int rot = 1) {
     HostTable t; build_tw<RL>(t);
     void *tw = upload_tw<T>(t);
     CK(hipFuncSetAttribute((const void *)k_pow2<K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    Pow2Args a; a.in = in; a.out = out; a.nlanes = lanes; a.pitch_in = n; a.pitch_out = n; a.inverse = 0; a.scale = 1.0; a.twp = tw;
+    Pow2Args a; a.in = in; a.out = out; a.nlanes = lanes; a.pitch_in = n; a.pitch_out = n; a.inverse = 0; a.scale = 1.0; a.twp = tw; a.xcd_chunk = xcd_chunk;
     const size_t lds = K::LDS_BYTES + extra_lds;
     const int per_blk = K::THREADS / (n / K::E);
     const unsigned nblk = (unsigned)((lanes + per_blk - 1) / per_blk);
     Variant v;
     v.name = name;
-    v.launch = [=]() { hipLaunchKernelGGL(k_pow2<K>, dim3(nblk), dim3(K::THREADS), lds, 0, a); };
+    static size_t counter = 0;   // rot > 1: successive launches walk over `rot` distinct (in, out) pairs (cache-cold at any size)
+    const size_t pair_bytes = (size_t)lanes * n * 2 * sizeof(T);
+    v.launch = [=]() {
+        Pow2Args b = a;
+        const size_t k = rot > 1 ? (counter++ % (size_t)rot) : 0;
+        b.in = (const char *)a.in + k * pair_bytes; b.out = (char *)a.out + k * pair_bytes;
+        hipLaunchKernelGGL(k_pow2<K>, dim3(nblk), dim3(K::THREADS), lds, 0, b);
+    };
     v.bytes = 2.0 * lanes * n * 2 * sizeof(T);
     v.check = true;
     return v;
 }
 
 template <typename T> struct Bench {
-    int n; int64_t lanes; int rounds;
+    int n; int64_t lanes; int rounds; int rot = 1;
     cpx<T> *din, *dout, *dref;
     std::vector<Variant> vs;
     void init() {
-        const size_t elems = (size_t)lanes * n;
-        CK(hipMalloc(&din, elems * sizeof(cpx<T>))); CK(hipMalloc(&dout, elems * sizeof(cpx<T>))); CK(hipMalloc(&dref, elems * sizeof(cpx<T>)));
+        const size_t elems = (size_t)lanes * n * rot;
+        CK(hipMalloc(&din, elems * sizeof(cpx<T>))); CK(hipMalloc(&dout, elems * sizeof(cpx<T>))); CK(hipMalloc(&dref, (size_t)lanes * n * sizeof(cpx<T>)));
         std::vector<cpx<T>> h(elems);
         unsigned long long s = 88172645463325252ull;
         for (size_t i = 0; i < elems; ++i) {
@@ -81,7 +88,7 @@ template <typename T> struct Bench {
         }
         CK(hipMemcpy(din, h.data(), elems * sizeof(cpx<T>), hipMemcpyHostToDevice));
     }
-    template <typename K, typename RL> void add(const char *name) { vs.push_back(fft_variant<K, T, RL>(name, din, dout, lanes, n)); }
+    template <typename K, typename RL> void add(const char *name, int xcd_chunk = 0) { vs.push_back(fft_variant<K, T, RL>(name, din, dout, lanes, n, 0, xcd_chunk, rot)); }
     void run(double tol) {
         const size_t elems = (size_t)lanes * n;
         vs[0].launch(); CK(hipDeviceSynchronize());
@@ -205,6 +212,22 @@ int main(int argc, char **argv) {
         VC("1024x4 4.4.4.4.4.4 nt1", 1024, 1, 0, 1, 1, 4, 4, 4, 4, 4, 4);
         VC("ABLATE load+store only", 512, 1, 7, 1, 1, 8, 8, 8, 8);
         VC("ABLATE no LDS exchange", 512, 1, 2, 1, 1, 8, 8, 8, 8);
+        b.run(1e-12);
+    } else if (what == "f64_map") {
+        // XCD-aware lane-block maps (device_common.h: xcd_block) x lanes per workgroup x load policy; lanes = 4096 is the
+        // Infinity-Cache-warm bench shape, 32768 the cache-cold one
+        const int64_t lanes = argc > 3 ? atoll(argv[3]) : 32768;
+        Bench<double> b{4096, lanes, rounds}; b.rot = argc > 4 ? atoi(argv[4]) : 1; b.init();
+        using RL8 = RadixList<8, 8, 8, 8>;
+        const int eighth1 = (int)(lanes / 8), eighth2 = (int)(lanes / 16);
+        static char names[64][64]; int ni = 0;
+        for (int chunk : {0, 2, 8, 32, 128, 512, -1}) {
+            const int c1 = chunk < 0 ? eighth1 : chunk, c2 = chunk < 0 ? eighth2 : chunk / 2;
+            snprintf(names[ni], 64, "1 lane/WG nt1 chunk %d", c1);  b.template add<Pow2Kernel<double, 4096, 512, 1, true, RL8, 16, 1, 1, 1>, RL8>(names[ni++], c1);
+            snprintf(names[ni], 64, "1 lane/WG nt3 chunk %d", c1);  b.template add<Pow2Kernel<double, 4096, 512, 1, true, RL8, 16, 1, 3, 1>, RL8>(names[ni++], c1);
+            snprintf(names[ni], 64, "2 lanes/WG nt1 chunk %d", c2); b.template add<Pow2Kernel<double, 4096, 512, 2, true, RL8, 16, 1, 1, 1>, RL8>(names[ni++], c2);
+            snprintf(names[ni], 64, "2 lanes/WG nt3 chunk %d", c2); b.template add<Pow2Kernel<double, 4096, 512, 2, true, RL8, 16, 1, 3, 1>, RL8>(names[ni++], c2);
+        }
         b.run(1e-12);
     } else if (what == "f64_full") {
         { Bench<double> b{4096, 4096, rounds}; b.init();
