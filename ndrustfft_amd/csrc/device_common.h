@@ -63,6 +63,16 @@ struct Pow2Args {
     int32_t xcd_chunk = 0;
 };
 
+// arguments of the LDS-free wavefront kernel for short dense C2C lanes (wave_kernel.h)
+struct WaveArgs {
+    const void *in; void *out;
+    int64_t total;            // complex elements = lanes * n (lanes are dense: pitch == n)
+    int32_t inverse;
+    double scale;
+    const void *tw;           // tw[k] = e^{-2 pi i k / n}, k < n
+    int32_t xcd_chunk;        // XCD-aware workgroup -> chunk map (xcd_block below), 0 = identity
+};
+
 // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8; MI355X_MICROARCH.md).  With the identity map every
 // XCD touches every eighth lane of the array: 8 interleaved streams per 512 KiB of addresses, and every XCD's L2 /
 // TLB sees every page.  xcd_block() hands XCD x, out of each group of 8 C consecutive lane blocks, the C CONTIGUOUS

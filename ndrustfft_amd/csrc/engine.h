@@ -75,6 +75,7 @@ struct FftConfig {                 // one complex-FFT-of-length-F recipe + op ta
     HostTable twp;                 // per-pass transposed twiddles
     HostTable twp_col;             // C2C slot only: twiddles in the radix order of the column kernel (pow2_real.h)
     HostTable twp_narrow;          // twiddles in the radix order of the narrow (XCD-aware) column kernel
+    HostTable wave_tw;             // C2C slot, n = 2..64 power of two: W_n^k, k < n, for the wavefront kernel (wave_kernel.h)
     // long lanes (one lane does not fit LDS): four-step F = F1 * F2 on top of the row kernels
     bool big = false; int F1 = 0, F2 = 0, logB = 0;
     bool bigblue = false;          // big && no usable split (huge prime factor): Bluestein over global memory, sub1 = C2C plan of length M
@@ -96,6 +97,7 @@ struct DevConfig {                 // device copies (typed by dtype) of one FftC
     void *tw = nullptr, *twM = nullptr, *chirp = nullptr, *bhat = nullptr, *aux1 = nullptr, *aux2 = nullptr, *twp = nullptr;
     void *twlo = nullptr, *twhi = nullptr, *twp_col = nullptr, *twp_narrow = nullptr;
     void *cs_twlo = nullptr, *cs_twhi = nullptr;
+    void *wave_tw = nullptr;
 };
 
 enum ConfigSlot { CFG_MAIN = 0, CFG_DCT1 = 1, CFG_DCT4 = 2, CFG_COUNT = 3 };
@@ -162,6 +164,10 @@ void pow2_build_twiddles(int dtype, int n, HostTable &out);
 int launch_pow2(int dtype, int n, const Pow2Args &a, hipStream_t s);
 int xcd_chunk_for(size_t block_bytes, int64_t nblk);   // lane blocks per XCD chunk of the workgroup -> lane map (0: identity)
 bool stream_loads_for(size_t in_bytes);                // input larger than the Infinity Cache: streaming (nt) loads
+
+// kernels_wave.hip : LDS-free wavefront kernel (cross-lane shuffles) for dense C2C lanes of n = 2..64
+bool wave_supported(int n);
+int launch_wave(int dtype, int n, const WaveArgs &a, hipStream_t s);
 
 // kernels_pow2_real.hip : register-resident real-op kernels (R2C/C2R/DCT) for power-of-two inner FFT length F
 bool pow2_real_supported(int F);

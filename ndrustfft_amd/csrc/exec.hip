@@ -27,6 +27,7 @@ struct Problem {
     int64_t nlanes;
     double scale;
     int keep_out = 0;            // column kernels: cache-allocating stores (the output is re-read right away, col_split)
+    int stream_in = 0;           // column kernels: streaming loads (the input must not evict a cache-resident intermediate)
 };
 
 static size_t real_size(int dtype) { return dtype == NDFFT_F32 ? 4 : 8; }
@@ -336,6 +337,12 @@ static bool narrow_enabled() {
     return on;
 }
 
+// developer / test switch: NDFFT_WAVE=0 keeps short dense C2C lanes on the older kernels (read per call)
+static bool wave_enabled() {
+    const char *e = getenv("NDFFT_WAVE");
+    return !(e && e[0] == '0');
+}
+
 // developer switch: NDFFT_BLUE=0 keeps Bluestein lengths on the LDS kernel
 static bool blue_enabled() {
     const char *e = getenv("NDFFT_BLUE");
@@ -401,7 +408,8 @@ static int col_split(const Problem &P, const void *d_in, void *d_out, const FftC
         Q.plan = c.cs_sub1; Q.nlanes = O * F2 * Cc; Q.scale = 1.0;
         if (!c2r) {
             // A: column transform of length F1 over a = row / F2; lanes (b, i)
-            Q.op = P.op; Q.xlen = F1; Q.ylen = K1; Q.xs = (int64_t)F2 * I; Q.ys = (int64_t)F2 * Cc; Q.keep_out = chunked;
+            Q.op = P.op; Q.xlen = F1; Q.ylen = K1; Q.xs = (int64_t)F2 * I; Q.ys = (int64_t)F2 * Cc;
+            { const char *e1 = getenv("NDFFT_CS_KEEP"); Q.keep_out = e1 ? atoi(e1) : chunked; const char *e2 = getenv("NDFFT_CS_NT_IN"); Q.stream_in = e2 ? atoi(e2) : 0; }
             if (chunked) { Q.b.push_back({(int64_t)F2, I, Cc}); Q.b.push_back({Cc, 1, 1}); }
             else {
                 if (O > 1) Q.b.push_back({O, sin_o, (int64_t)K1 * F2 * I});
@@ -574,6 +582,17 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
     int rc = get_dev_tables(P.plan, &dt);
     if (rc) return rc;
     const ndfft_plan *plan = P.plan;
+    // short dense power-of-two C2C lanes (n = 2..64): the LDS-free wavefront kernel -- coalesced 16-byte accesses and
+    // cross-lane shuffles (wave_kernel.h).  NDFFT_WAVE=0 keeps the older paths (parity tests cover both).
+    if (plan->kind == NDFFT_KIND_C2C && dt->cfg[CFG_MAIN].wave_tw && P.xs == 1 && P.ys == 1 && P.b.size() <= 1 &&
+        (P.b.empty() || (P.b[0].sin == (int64_t)plan->n && P.b[0].sout == (int64_t)plan->n)) &&
+        (uintptr_t)d_in % 16 == 0 && (uintptr_t)d_out % 16 == 0 && wave_enabled()) {
+        WaveArgs a;
+        a.in = d_in; a.out = d_out; a.total = P.nlanes * (int64_t)plan->n;
+        a.inverse = P.op == NDFFT_OP_C2C_INV; a.scale = P.scale; a.tw = dt->cfg[CFG_MAIN].wave_tw; a.xcd_chunk = 0;
+        set_last_path("wave_reg");
+        return launch_wave(plan->dtype, (int)plan->n, a, stream);
+    }
     // tuned path: contiguous power-of-two C2C lanes at a uniform pitch
     if (plan->kind == NDFFT_KIND_C2C && plan->cfg[CFG_MAIN].pow2 && P.xs == 1 && P.ys == 1 && P.b.size() <= 1) {
         Pow2Args a;
@@ -674,7 +693,7 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
                 a.elem_in = P.xs; a.elem_out = P.ys;
                 const size_t es_in = (op_in_cplx(P.op) ? 2 : 1) * real_size(plan->dtype);
                 a.vec_in = !col && ((uintptr_t)d_in % 16 == 0) && ((size_t)a.pitch_in * es_in) % 16 == 0;
-                a.xcd_remap = 0; a.keep_out = P.keep_out;
+                a.xcd_remap = 0; a.keep_out = P.keep_out; a.stream_in = P.stream_in;
                 const size_t es_out = (op_out_cplx(P.op) ? 2 : 1) * real_size(plan->dtype);
                 a.vec_out = !col && ((uintptr_t)d_out % 16 == 0) && ((size_t)a.pitch_out * es_out) % 16 == 0;
             };

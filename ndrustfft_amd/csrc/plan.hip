@@ -194,6 +194,7 @@ static void build_plan_tables(ndfft_plan *p) {
         build_fft(m, n, p->dtype);
         if (pow2_supported(p->dtype, n)) { m.pow2 = true; pow2_build_twiddles(p->dtype, n, m.twp); }
         if (pow2_real_supported(n)) pow2_real_build_twiddles(n, m.twp_col);
+        if (wave_supported(n)) for (int k = 0; k < n; ++k) unit(m.wave_tw, k, n);   // W_n^k
         if (!m.pow2 && !m.blue && jit_choose(p->dtype, n, m.jitcfg, true)) { m.jit = true; jit_build_twiddles(m.jitcfg, m.twp); }
         p->has_cfg[CFG_MAIN] = true;
     } else if (p->kind == NDFFT_KIND_R2C) {
@@ -329,6 +330,7 @@ int get_dev_tables(const ndfft_plan *cplan, const DevTables **out) {
         if ((rc = upload_any(plan->dtype, c.cs_twhi, &d.cs_twhi))) return rc;
         if ((rc = upload_any(plan->dtype, c.twp_col, &d.twp_col))) return rc;
         if ((rc = upload_any(plan->dtype, c.twp_narrow, &d.twp_narrow))) return rc;
+        if ((rc = upload_any(plan->dtype, c.wave_tw, &d.wave_tw))) return rc;
     }
     auto ins = plan->dev.emplace(dev, t);
     *out = &ins.first->second;
@@ -393,7 +395,7 @@ int ndfft_plan_destroy(ndfft_plan *plan) {
         (void)hipSetDevice(kv.first);
         for (int i = 0; i < CFG_COUNT; ++i) {
             DevConfig &d = kv.second.cfg[i];
-            void *ptrs[] = {d.tw, d.twM, d.chirp, d.bhat, d.aux1, d.aux2, d.twp, d.twlo, d.twhi, d.twp_col, d.twp_narrow, d.cs_twlo, d.cs_twhi};
+            void *ptrs[] = {d.tw, d.twM, d.chirp, d.bhat, d.aux1, d.aux2, d.twp, d.twlo, d.twhi, d.twp_col, d.twp_narrow, d.cs_twlo, d.cs_twhi, d.wave_tw};
             for (void *q : ptrs) if (q) (void)hipFree(q);
         }
     }

@@ -43,6 +43,8 @@ template <typename T> struct RealArgs {
     const cpx<T> *chirp, *bhat;          // Bluestein kernels (blue_kernel.h): e^{-i pi j^2/F}, FFT_M(conj chirp)/M
     int32_t keep_out;                    // COL kernels: 1 = plain (cache-allocating) stores instead of non-temporal ones: the
                                          // output is an intermediate that the next launch re-reads from the Infinity Cache
+    int32_t stream_in = 0;               // COL kernels: 1 = streaming (nt) loads of the input: it is read once and must not
+                                         // push the intermediate of a two-stage route out of the Infinity Cache
 };
 
 struct ZiNone { static __device__ __forceinline__ int map(int p) { return p; } };
@@ -176,10 +178,12 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                         });
                 } else if constexpr (IN_CPLX) {
                     const cpx<T> *in = (const cpx<T> *)a.in + base;
-                    stage_loop<STEP>(j0, a.n_in, [&](int j) { return in[(int64_t)j * a.elem_in]; }, [&](int j, cpx<T> v) { ((cpx<T> *)dst)[j] = v; });
+                    if (a.stream_in) stage_loop<STEP>(j0, a.n_in, [&](int j) { return gload<T, true>(in + (int64_t)j * a.elem_in); }, [&](int j, cpx<T> v) { ((cpx<T> *)dst)[j] = v; });
+                    else stage_loop<STEP>(j0, a.n_in, [&](int j) { return in[(int64_t)j * a.elem_in]; }, [&](int j, cpx<T> v) { ((cpx<T> *)dst)[j] = v; });
                 } else {
                     const T *in = (const T *)a.in + base;
-                    stage_loop<STEP>(j0, a.n_in, [&](int j) { return in[(int64_t)j * a.elem_in]; }, [&](int j, T v) { ((T *)dst)[j] = v; });
+                    if (a.stream_in) stage_loop<STEP>(j0, a.n_in, [&](int j) { return __builtin_nontemporal_load(in + (int64_t)j * a.elem_in); }, [&](int j, T v) { ((T *)dst)[j] = v; });
+                    else stage_loop<STEP>(j0, a.n_in, [&](int j) { return in[(int64_t)j * a.elem_in]; }, [&](int j, T v) { ((T *)dst)[j] = v; });
                 }
             }
         } else if constexpr (!DIRECT_IN) {

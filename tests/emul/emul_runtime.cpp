@@ -104,6 +104,19 @@ void __syncthreads() {
     swapcontext(&g_f[g_cur].ctx, &g_main);
 }
 
+// wave_kernel.h's bit swap between thread bit `tb` and a register pair (lo, hi), emulated with two block barriers:
+// threads with the bit clear end with (own lo, partner's lo), threads with it set with (partner's hi, own hi)
+namespace ndfft { void emul_wave_swap(unsigned &lo, unsigned &hi, int tb); }
+void ndfft::emul_wave_swap(unsigned &lo, unsigned &hi, int tb) {
+    static unsigned slo[1024], shi[1024];
+    const unsigned t = threadIdx.x;
+    slo[t] = lo; shi[t] = hi;
+    __syncthreads();
+    const unsigned p = t ^ (1u << tb);
+    if ((t >> tb) & 1u) lo = shi[p]; else hi = slo[p];
+    __syncthreads();
+}
+
 void emul::launch(void (*fn)(void *), void *arg, dim3 grid, dim3 block, size_t lds_bytes) {
     std::lock_guard<std::mutex> launch_guard(g_launch_mu);   // host threads (shared handlers, sharded exec) take turns
     if (lds_bytes > 160 * 1024) { fprintf(stderr, "emul: LDS request %zu > 160 KiB\n", lds_bytes); abort(); }

@@ -13,6 +13,9 @@
 #include <cstring>
 #include <algorithm>
 
+// wave_kernel.h's cross-lane bit swap, emulated with block barriers (emul_runtime.cpp)
+namespace ndfft { void emul_wave_swap(unsigned &lo, unsigned &hi, int tb); }
+#define NDFFT_WAVE_SWAP_OVERRIDE(lo, hi, tb) ::ndfft::emul_wave_swap(lo, hi, tb)
 #define __host__
 #define __device__
 #define __global__
@@ -82,6 +85,12 @@ inline hipError_t hipHostFree(void *p) { free(p); return 0; }
 inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return 0; }
 
 void __syncthreads();
+// bit-pattern casts used by the wavefront kernel
+inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+inline int __double2loint(double d) { unsigned long long u; memcpy(&u, &d, 8); return (int)(unsigned)(u & 0xffffffffu); }
+inline int __double2hiint(double d) { unsigned long long u; memcpy(&u, &d, 8); return (int)(unsigned)(u >> 32); }
+inline double __hiloint2double(int hi, int lo) { unsigned long long u = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo; double d; memcpy(&d, &u, 8); return d; }
 
 namespace emul {
 // runs fn(arg) as grid x block fibers, with lds_bytes of "LDS" per block

@@ -230,6 +230,34 @@ def interleaved_mut_views_two_threads(L, rounds=6):
     yo = np.zeros((7, 20)); orc.nddct2(x, yo, orc.DctHandler(20), 1); assert_close(big[:, 1::2], yo, 1, 1e-10, "stepped dct out")
 
 
+def wave_short_lanes(L):
+    """Dense C2C lanes of n = 2..64 (powers of two) run on the LDS-free wavefront kernel (wave_kernel.h: coalesced
+    16-byte accesses + DPP / v_permlane swaps); every size, both dtypes, both directions and norms, chunk tails (a
+    wavefront owns 512 elements: row counts that leave partial chunks), 3-D arrays; and the older kernels stay covered
+    with NDFFT_WAVE=0."""
+    for rdt in (np.float64, np.float32):
+        for n in (2, 4, 8, 16, 32, 64):
+            for rows in (1, 5, 512 // n, 512 // n + 1, 777):
+                for name in ("ndfft", "ndifft"):
+                    for norm in ("Default", "None"):
+                        assert run_case(L, name, (rows, n), 1, rdt, norm=norm, offset=rows * n) == "wave_reg", (n, rows)
+        assert run_case(L, "ndfft", (6, 10, 32), 2, rdt) == "wave_reg"          # rows() flattens the leading dims
+        assert run_case(L, "ndfft", (10, 32, 6), 1, rdt) != "wave_reg"          # strided lanes keep the column kernels
+    # a view whose rows are padded (pitch != n) is not dense: older path
+    x = synth.complex_array((9, 80))[:, :64]; y = np.zeros((9, 64), np.complex128); yo = np.zeros_like(y)
+    api.ndfft(x, y, handlers.FftHandler(64, _library=L), 1); orc.ndfft(np.ascontiguousarray(x), yo, orc.FftHandler(64), 1)
+    assert_close(y, yo, 1, 1e-10, "padded rows n=64")
+    old = os.environ.get("NDFFT_WAVE")
+    os.environ["NDFFT_WAVE"] = "0"
+    try:
+        for rdt in (np.float64, np.float32):
+            assert run_case(L, "ndfft", (37, 64), 1, rdt) == "pow2_reg"
+            assert run_case(L, "ndifft", (37, 16), 1, rdt) == "generic_row"
+    finally:
+        if old is None: del os.environ["NDFFT_WAVE"]
+        else: os.environ["NDFFT_WAVE"] = old
+
+
 def sharded_exec(L, device_ids, torch_device=None):
     """ndfft_exec_sharded (host arrays) and ndfft_exec_sharded_device (arrays resident on one device) over `device_ids`:
     every op, the split dimension in every position, uneven blocks, fewer lanes than devices, a single lane, views with

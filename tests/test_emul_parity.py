@@ -29,6 +29,7 @@ def test_layouts(L): ps.layouts(L)
 def test_normalization(L): ps.normalization_modes(L)
 def test_panics(L): ps.panics(L)
 def test_clone(L): ps.handler_clone_shares_plan(L)
+def test_wave_short_lanes(L): ps.wave_short_lanes(L)
 def test_sharded_exec_three_fake_devices(L):
     assert L.c.ndfft_device_count() == 3
     ps.sharded_exec(L, [0, 1, 2])

@@ -30,6 +30,7 @@ def test_layouts(L): ps.layouts(L)
 def test_normalization(L): ps.normalization_modes(L)
 def test_panics(L): ps.panics(L)
 def test_clone(L): ps.handler_clone_shares_plan(L)
+def test_wave_short_lanes(L): ps.wave_short_lanes(L)
 def test_sharded_exec_same_device_twice(L):
     n = L.c.ndfft_device_count()
     ps.sharded_exec(L, list(range(n)) if n > 1 else [0, 0, 0], torch_device="cuda:0")
@@ -71,7 +72,7 @@ def test_sizes_f32(L, n): ps.size_sweep(L, n, np.float32)
 def test_pow2_tuned(L, n, rdt):
     for name in ("ndfft", "ndifft"):
         for norm in ("Default", "None"):
-            assert ps.run_case(L, name, (37, n), 1, rdt, norm=norm, offset=n) == "pow2_reg"
+            assert ps.run_case(L, name, (37, n), 1, rdt, norm=norm, offset=n) == ("wave_reg" if n == 64 else "pow2_reg")
 
 
 # ---- BASELINE.json configs at full size: EVERY lane against the oracle ---------------------------

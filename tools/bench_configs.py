@@ -151,6 +151,13 @@ def main():
         for n in (129, 265, 513, 1025):
             x = torch.from_numpy(np.arange(n * n, dtype=np.float64).reshape(n, n)).to(dev); y = torch.empty_like(x)
             run(f"refbench dct2d n={n} axis=0 f64", nddct1, x, y, DctHandler(n), 0, n * n, a.steps)
+    if want("smallsweep"):
+        # short dense lanes: the wavefront kernel (wave_kernel.h); NDFFT_WAVE=0 shows the kernels it replaces
+        for rdt, cdt in ((np.float64, np.complex128), (np.float32, np.complex64)):
+            for n in (2, 4, 8, 16, 32, 64):
+                rows = (1 << 24) // n
+                x = torch.from_numpy(synth.complex_array((rows, n), cdt)).to(dev); y = torch.empty_like(x)
+                run(f"small ndfft axis=1 {rows}x{n} {np.dtype(cdt).name}", ndfft, x, y, FftHandler(n, rdt), 1, x.numel(), a.steps)
     if want("pow2sweep"):
         for rdt, cdt in ((np.float64, np.complex128), (np.float32, np.complex64)):
             for n in (64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384):
