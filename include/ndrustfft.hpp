@@ -198,6 +198,19 @@ template <typename T> class DctHandler {   // lib.rs:640-751
 // ---- the transform body: one FFI call per nd* call --------------------------------------------------------
 namespace detail {
 
+// GPUs the _par functions spread one call over (create_transform_par!, lib.rs:169-238: the independent lanes go to
+// rayon's workers; here the workers are GPUs).  Empty or one id: the current device only.
+inline std::vector<int> &par_devices_ref() { static std::vector<int> ids; return ids; }
+
+// one C-ABI call: serial names -> ndfft_exec, _par names -> ndfft_exec_sharded when several devices are selected
+inline int exec_host(bool par, ndfft_plan *plan, int op, const void *in, void *out, int ndim, const std::int64_t *shape_in,
+                     const std::int64_t *stride_in, const std::int64_t *shape_out, const std::int64_t *stride_out, int axis, int mode) {
+    const std::vector<int> &ids = par_devices_ref();
+    if (par && ids.size() > 1)
+        return ndfft_exec_sharded(plan, op, in, out, ndim, shape_in, stride_in, shape_out, stride_out, axis, mode, 0.0, (int)ids.size(), ids.data());
+    return ndfft_exec(plan, op, in, out, ndim, shape_in, stride_in, shape_out, stride_out, axis, mode, 0.0);
+}
+
 // apply a Custom normalisation to every lane along `axis` of a contiguous C-order copy
 template <typename A> void for_each_lane(A *data, const std::vector<std::int64_t> &shape, std::size_t axis,
                                          void (*fn)(A *, std::size_t)) {
@@ -237,7 +250,7 @@ template <typename A> std::vector<std::int64_t> c_strides(const std::vector<std:
 // input lane (C2R, DCT: lib.rs:511-515, 692-696) or AFTER on the output lane (C2C inverse: 326-330)
 template <typename In, typename Out, typename NormT>
 void transform(int op, const ArrayView<const In> &input, ArrayView<Out> &output, ndfft_plan *plan,
-               const Normalization<NormT> &norm, bool norm_applies, bool norm_is_pre, std::size_t axis) {
+               const Normalization<NormT> &norm, bool norm_applies, bool norm_is_pre, std::size_t axis, bool par = false) {
     if (input.ndim() != output.ndim()) throw Error(NDFFT_ERR_INVALID_ARG, "input and output must have the same dimensionality D");
     const int ndim = (int)input.ndim();
     int mode = NDFFT_NORM_DEFAULT;
@@ -251,14 +264,14 @@ void transform(int op, const ArrayView<const In> &input, ArrayView<Out> &output,
                 std::vector<In> tmp = gather_c_order<In>(input);
                 for_each_lane<In>(tmp.data(), input.shape, axis, norm.fn);
                 auto cs = c_strides<In>(input.shape);
-                check(ndfft_exec(plan, op, tmp.data(), output.ptr, ndim, input.shape.data(), cs.data(), output.shape.data(),
-                                 output.strides.data(), (int)axis, mode, 0.0));
+                check(exec_host(par, plan, op, tmp.data(), output.ptr, ndim, input.shape.data(), cs.data(), output.shape.data(),
+                                output.strides.data(), (int)axis, mode));
                 return;
             }
         }
     }
-    check(ndfft_exec(plan, op, input.ptr, output.ptr, ndim, input.shape.data(), input.strides.data(), output.shape.data(),
-                     output.strides.data(), (int)axis, mode, 0.0));
+    check(exec_host(par, plan, op, input.ptr, output.ptr, ndim, input.shape.data(), input.strides.data(), output.shape.data(),
+                    output.strides.data(), (int)axis, mode));
     if (custom && !norm_is_pre) {
         if constexpr (std::is_same<Out, NormT>::value) {
             std::vector<Out> tmp = gather_c_order<Out>(ArrayView<const Out>{output.ptr, output.shape, output.strides});
@@ -324,12 +337,18 @@ template <typename A> class DeviceArray {
 namespace detail {
 template <typename In, typename Out, typename NormT>
 void transform_device(int op, const DeviceArray<In> &input, DeviceArray<Out> &output, ndfft_plan *plan,
-                      const Normalization<NormT> &norm, bool norm_applies, std::size_t axis) {
+                      const Normalization<NormT> &norm, bool norm_applies, std::size_t axis, bool par = false) {
     if (input.shape().size() != output.shape().size()) throw Error(NDFFT_ERR_INVALID_ARG, "input and output must have the same dimensionality D");
     if (norm.kind == Normalization<NormT>::Custom && norm_applies)
         throw Error(NDFFT_ERR_INVALID_ARG, "Normalization::Custom is a host function: not available on device-resident arrays");
     const int mode = norm.kind == Normalization<NormT>::Default ? NDFFT_NORM_DEFAULT : NDFFT_NORM_NONE;
     if (axis > 0x7fffffffu) throw Panic(NDFFT_ERR_AXIS, "index out of bounds");
+    const std::vector<int> &ids = par_devices_ref();
+    if (par && ids.size() > 1) {   // scatter / transform / gather over xGMI, host-less
+        check(ndfft_exec_sharded_device(plan, op, input.ptr(), output.ptr(), (int)input.shape().size(), input.shape().data(), input.strides().data(),
+                                        output.shape().data(), output.strides().data(), (int)axis, mode, 0.0, (int)ids.size(), ids.data(), nullptr));
+        return;
+    }
     check(ndfft_exec_device(plan, op, input.ptr(), output.ptr(), (int)input.shape().size(), input.shape().data(), input.strides().data(),
                             output.shape().data(), output.strides().data(), (int)axis, mode, 0.0, nullptr));
 }
@@ -346,11 +365,12 @@ void transform_device(int op, const DeviceArray<In> &input, DeviceArray<Out> &ou
     }                                                                                                        \
     template <typename T>                                                                                    \
     void NAME##_par(const ArrayView<const IN> &input, ArrayView<OUT> output, const HANDLER<T> &handler, std::size_t axis) { \
-        NAME<T>(input, output, handler, axis); /* every lane is already processed in parallel on the GPU */  \
+        /* one GPU processes every lane in parallel anyway; set_par_devices() spreads the call over several */ \
+        detail::transform<IN, OUT, NORMT>(OP, input, output, handler.plan(), handler.norm(), APPLIES, PRE, axis, true); \
     }                                                                                                        \
     template <typename T>                                                                                    \
     void NAME##_par(const Array<IN> &input, Array<OUT> &output, const HANDLER<T> &handler, std::size_t axis) { \
-        NAME<T>(input.view(), output.view(), handler, axis);                                                 \
+        NAME##_par<T>(input.view(), output.view(), handler, axis);                                           \
     }                                                                                                        \
     template <typename T>                                                                                    \
     void NAME(const DeviceArray<IN> &input, DeviceArray<OUT> &output, const HANDLER<T> &handler, std::size_t axis) { \
@@ -358,7 +378,7 @@ void transform_device(int op, const DeviceArray<In> &input, DeviceArray<Out> &ou
     }                                                                                                        \
     template <typename T>                                                                                    \
     void NAME##_par(const DeviceArray<IN> &input, DeviceArray<OUT> &output, const HANDLER<T> &handler, std::size_t axis) { \
-        NAME<T>(input, output, handler, axis);                                                               \
+        detail::transform_device<IN, OUT, NORMT>(OP, input, output, handler.plan(), handler.norm(), APPLIES, axis, true); \
     }
 
 NDRUSTFFT_DEFINE(ndfft, Complex<T>, Complex<T>, FftHandler, NDFFT_OP_C2C_FWD, Complex<T>, false, false)       // lib.rs:350-372
@@ -370,6 +390,9 @@ NDRUSTFFT_DEFINE(nddct2, T, T, DctHandler, NDFFT_OP_DCT2, T, true, true)        
 NDRUSTFFT_DEFINE(nddct3, T, T, DctHandler, NDFFT_OP_DCT3, T, true, true)                                      // lib.rs:808-815
 NDRUSTFFT_DEFINE(nddct4, T, T, DctHandler, NDFFT_OP_DCT4, T, true, true)                                      // lib.rs:827-834
 #undef NDRUSTFFT_DEFINE
+
+/// Selects the GPUs the `_par` functions spread one call over (ids as ndfft_set_device numbers them).
+inline void set_par_devices(std::vector<int> ids) { detail::par_devices_ref() = std::move(ids); }
 
 /// Frees the calling thread's device scratch and staging buffers (the engine keeps them for reuse).
 inline void release_workspace() { detail::check(ndfft_release_workspace()); }

@@ -43,6 +43,19 @@ extern "C" {
         shape_in: *const i64, stride_in: *const i64, shape_out: *const i64, stride_out: *const i64,
         axis: c_int, norm: c_int, scale: c_double,
     ) -> c_int;
+    /// the same call spread over several GPUs from one process (contiguous lane blocks, no collective)
+    pub fn ndfft_exec_sharded(
+        plan: *const ndfft_plan, op: c_int, input: *const c_void, output: *mut c_void, ndim: c_int,
+        shape_in: *const i64, stride_in: *const i64, shape_out: *const i64, stride_out: *const i64,
+        axis: c_int, norm: c_int, scale: c_double, n_devices: c_int, device_ids: *const c_int,
+    ) -> c_int;
+    pub fn ndfft_exec_sharded_device(
+        plan: *const ndfft_plan, op: c_int, d_input: *const c_void, d_output: *mut c_void, ndim: c_int,
+        shape_in: *const i64, stride_in: *const i64, shape_out: *const i64, stride_out: *const i64,
+        axis: c_int, norm: c_int, scale: c_double, n_devices: c_int, device_ids: *const c_int, stream: *mut c_void,
+    ) -> c_int;
+    pub fn ndfft_set_device(device: c_int) -> c_int;
+    pub fn ndfft_device_count() -> c_int;
     /// frees the calling thread's device scratch / staging buffers (kept for reuse otherwise)
     pub fn ndfft_release_workspace() -> c_int;
     // device-resident arrays (no reference counterpart)

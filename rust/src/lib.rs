@@ -2,12 +2,14 @@
 //!
 //! Same public surface as ndrustfft 0.5.0 -- `ndfft`, `ndifft`, `ndfft_r2c`, `ndifft_r2c`,
 //! `nddct1..4`, their `_par` twins, `FftHandler`, `R2cFftHandler`, `DctHandler`, `Normalization`,
-//! and the re-exports `Complex`, `Zero` -- but every call is ONE FFI call into `libndfft_mi355x`,
+//! and the re-exports `Complex`, `Zero`, `FftNum` -- but every call is ONE FFI call into `libndfft_mi355x`,
 //! whose other side is hand-written HIP for gfx950.  Arrays may have any layout ndarray allows
 //! (strides are passed through, signed, in elements).
 //!
 //! Differences a caller can observe:
-//! * `T` is `f32` or `f64` (the reference's `FftNum` bound admits nothing else in practice).
+//! * `T: FftNum + FloatConst` exactly as in the reference (src/lib.rs:111); `FftNum` is implemented for `f32` and
+//!   `f64`, the two types rustfft implements it for, so code that is generic over the reference's bounds compiles.
+//! * The `_par` twins spread one call over the GPUs named by [`set_par_devices`] (one GPU: same as the serial name).
 //! * `Normalization::Custom(f)` runs `f` on the host, on a lane-major copy, at the point the
 //!   reference applies it (after the inverse C2C transform; before the C2R and DCT transforms).
 //! * Errors of the device runtime panic with the HIP error string.
@@ -15,20 +17,42 @@ pub use num_complex::Complex;
 pub use num_traits::Zero;
 
 use ndarray::{ArrayBase, Axis, Data, DataMut, Dimension};
+use num_traits::FloatConst;
 use std::ffi::CStr;
 use std::os::raw::{c_int, c_void};
+use std::sync::RwLock;
 
 pub mod ffi;
 
-/// Element types the device engine computes in.
-pub trait GpuFloat: Copy + Zero + 'static {
+mod sealed {
+    pub trait Sealed {}
+    impl Sealed for f32 {}
+    impl Sealed for f64 {}
+}
+
+/// The reference re-exports `rustfft::FftNum` (src/lib.rs:85) and bounds every function by `T: FftNum + FloatConst`
+/// (src/lib.rs:111).  This is the same-named trait with the same supertraits rustfft 6.1 gives it, implemented for
+/// the two element types rustfft implements it for; downstream code written `fn f<T: FftNum + FloatConst>` compiles
+/// against this crate unchanged.  (Sealed: the device engine computes in f32 and f64.)
+pub trait FftNum:
+    Copy + num_traits::FromPrimitive + num_traits::Signed + Sync + Send + std::fmt::Debug + 'static + sealed::Sealed
+{
+    #[doc(hidden)]
     const DTYPE: c_int;
 }
-impl GpuFloat for f32 {
+impl FftNum for f32 {
     const DTYPE: c_int = ffi::NDFFT_F32;
 }
-impl GpuFloat for f64 {
+impl FftNum for f64 {
     const DTYPE: c_int = ffi::NDFFT_F64;
+}
+
+/// GPUs the `_par` functions spread one call over (`create_transform_par!`, src/lib.rs:169-238, hands the independent
+/// lanes to rayon's workers; here the workers are GPUs).  Empty / one id: the current device only.
+static PAR_DEVICES: RwLock<Vec<c_int>> = RwLock::new(Vec::new());
+/// Selects the GPUs used by `ndfft_par` & co. (device ids as `rocm-smi` numbers them).
+pub fn set_par_devices(ids: &[i32]) {
+    *PAR_DEVICES.write().unwrap() = ids.iter().map(|&d| d as c_int).collect();
 }
 
 /// How the inverse / real / cosine transforms are scaled.
@@ -81,7 +105,7 @@ macro_rules! handler {
             plan: Plan,
             norm: Normalization<$norm_elem>,
         }
-        impl<T: GpuFloat> $name<T> {
+        impl<T: FftNum + FloatConst> $name<T> {
             /// Plans the transform of length `n` on the current device.
             #[must_use]
             pub fn new(n: usize) -> Self {
@@ -121,75 +145,114 @@ fn apply_custom<A: Clone, S: DataMut<Elem = A>, D: Dimension>(arr: &mut ArrayBas
     }
 }
 
-#[derive(PartialEq)]
-enum NormPoint { Ignored, After, Before }
+/// bad axis: the reference indexes `output.shape()[axis]` first (src/lib.rs:116) and panics with this text
+fn check_axis(ndim: usize, axis: usize) {
+    if axis >= ndim {
+        panic!("index out of bounds: the len is {} but the index is {}", ndim, axis);
+    }
+}
+
+/// one FFI call: serial -> ndfft_exec, parallel -> ndfft_exec_sharded over PAR_DEVICES (when more than one is set)
+#[allow(clippy::too_many_arguments)]
+fn exec(plan: &Plan, op: c_int, in_ptr: *const c_void, out_ptr: *mut c_void, shape_in: &[i64], stride_in: &[i64],
+        shape_out: &[i64], stride_out: &[i64], axis: usize, mode: c_int, par: bool) {
+    let devs = if par { PAR_DEVICES.read().unwrap().clone() } else { Vec::new() };
+    check(unsafe {
+        if devs.len() > 1 {
+            ffi::ndfft_exec_sharded(plan.0, op, in_ptr, out_ptr, shape_in.len() as c_int, shape_in.as_ptr(), stride_in.as_ptr(),
+                                    shape_out.as_ptr(), stride_out.as_ptr(), axis as c_int, mode, 0.0, devs.len() as c_int, devs.as_ptr())
+        } else {
+            ffi::ndfft_exec(plan.0, op, in_ptr, out_ptr, shape_in.len() as c_int, shape_in.as_ptr(), stride_in.as_ptr(),
+                            shape_out.as_ptr(), stride_out.as_ptr(), axis as c_int, mode, 0.0)
+        }
+    });
+}
+
+// The three application points of `Normalization`: forward C2C and R2C ignore it (src/lib.rs:313-318,
+// 497-503); the inverse C2C applies it AFTER, on the output lane (321-331); C2R and the DCTs apply it BEFORE, on a copy
+// of the input lane (506-523, 688-734).  `Custom(f)` is a host function: it runs here, on the host, at that point.
+macro_rules! transform_body {
+    (ignored, $input:ident, $output:ident, $handler:ident, $axis:ident, $op:expr, $par:expr) => {{
+        check_axis($output.ndim(), $axis);
+        let (shape_in, stride_in) = strides_i64($input);
+        let (shape_out, stride_out) = strides_i64($output);
+        let mode = match $handler.norm { Normalization::Default => ffi::NDFFT_NORM_DEFAULT, _ => ffi::NDFFT_NORM_NONE };
+        exec(&$handler.plan, $op, $input.as_ptr() as *const c_void, $output.as_mut_ptr() as *mut c_void, &shape_in, &stride_in,
+             &shape_out, &stride_out, $axis, mode, $par);
+    }};
+    (after, $input:ident, $output:ident, $handler:ident, $axis:ident, $op:expr, $par:expr) => {{
+        check_axis($output.ndim(), $axis);
+        let (shape_in, stride_in) = strides_i64($input);
+        let (shape_out, stride_out) = strides_i64($output);
+        let mode = match $handler.norm { Normalization::Default => ffi::NDFFT_NORM_DEFAULT, _ => ffi::NDFFT_NORM_NONE };
+        exec(&$handler.plan, $op, $input.as_ptr() as *const c_void, $output.as_mut_ptr() as *mut c_void, &shape_in, &stride_in,
+             &shape_out, &stride_out, $axis, mode, $par);
+        if let Normalization::Custom(f) = $handler.norm {
+            apply_custom($output, $axis, f);
+        }
+    }};
+    (before, $input:ident, $output:ident, $handler:ident, $axis:ident, $op:expr, $par:expr) => {{
+        check_axis($output.ndim(), $axis);
+        let (shape_out, stride_out) = strides_i64($output);
+        if let Normalization::Custom(f) = $handler.norm {
+            // acts on the input: run on an owned copy so that `input` stays untouched (it is a shared borrow)
+            let mut staged = $input.to_owned();
+            apply_custom(&mut staged, $axis, f);
+            let (shape_in, stride_in) = strides_i64(&staged);
+            exec(&$handler.plan, $op, staged.as_ptr() as *const c_void, $output.as_mut_ptr() as *mut c_void, &shape_in, &stride_in,
+                 &shape_out, &stride_out, $axis, ffi::NDFFT_NORM_NONE, $par);
+        } else {
+            let (shape_in, stride_in) = strides_i64($input);
+            let mode = match $handler.norm { Normalization::Default => ffi::NDFFT_NORM_DEFAULT, _ => ffi::NDFFT_NORM_NONE };
+            exec(&$handler.plan, $op, $input.as_ptr() as *const c_void, $output.as_mut_ptr() as *mut c_void, &shape_in, &stride_in,
+                 &shape_out, &stride_out, $axis, mode, $par);
+        }
+    }};
+}
 
 macro_rules! transform {
-    ($(#[$m:meta])* $name:ident, $par:ident, $a:ty, $b:ty, $h:ident, $op:expr, $point:expr) => {
+    ($(#[$m:meta])* $name:ident, $par:ident, $a:ty, $b:ty, $h:ident, $op:expr, $point:ident) => {
         $(#[$m])*
         pub fn $name<R, S, T, D>(input: &ArrayBase<R, D>, output: &mut ArrayBase<S, D>, handler: &$h<T>, axis: usize)
         where
-            T: GpuFloat,
+            T: FftNum + FloatConst,
             R: Data<Elem = $a>,
             S: Data<Elem = $b> + DataMut,
             D: Dimension,
         {
-            let (shape_in, stride_in) = strides_i64(input);
-            let (shape_out, stride_out) = strides_i64(output);
-            let mut mode = match handler.norm { Normalization::None => ffi::NDFFT_NORM_NONE, _ => ffi::NDFFT_NORM_DEFAULT };
-            let custom = match &handler.norm { Normalization::Custom(f) if $point != NormPoint::Ignored => Some(*f), _ => None };
-            if let Normalization::Custom(_) = handler.norm { mode = ffi::NDFFT_NORM_NONE; }
-            // Before-points act on the input: run on an owned copy so `input` stays untouched.
-            let staged;
-            let (in_ptr, shape_in, stride_in) = if let (Some(f), true) = (custom, $point == NormPoint::Before) {
-                let mut c = input.to_owned();
-                #[allow(clippy::unnecessary_cast)]
-                apply_custom(&mut c, axis.min(c.ndim().saturating_sub(1)), unsafe { std::mem::transmute::<_, fn(&mut [$a])>(f) });
-                let (s, st) = strides_i64(&c);
-                staged = c;
-                (staged.as_ptr() as *const c_void, s, st)
-            } else {
-                (input.as_ptr() as *const c_void, shape_in, stride_in)
-            };
-            check(unsafe {
-                ffi::ndfft_exec(handler.plan.0, $op, in_ptr, output.as_mut_ptr() as *mut c_void, input.ndim() as c_int,
-                                shape_in.as_ptr(), stride_in.as_ptr(), shape_out.as_ptr(), stride_out.as_ptr(),
-                                axis as c_int, mode, 0.0)
-            });
-            if let (Some(f), true) = (custom, $point == NormPoint::After) {
-                apply_custom(output, axis, unsafe { std::mem::transmute::<_, fn(&mut [$b])>(f) });
-            }
+            transform_body!($point, input, output, handler, axis, $op, false)
         }
-        /// Parallel twin: on the GPU every lane is already processed in parallel.
+        /// Parallel twin: one GPU processes every lane in parallel anyway; with [`set_par_devices`] the call is spread
+        /// over several GPUs (contiguous blocks of the outermost non-transform dimension, no collective).
         #[cfg(feature = "parallel")]
         pub fn $par<R, S, T, D>(input: &ArrayBase<R, D>, output: &mut ArrayBase<S, D>, handler: &$h<T>, axis: usize)
         where
-            T: GpuFloat,
+            T: FftNum + FloatConst,
             R: Data<Elem = $a>,
             S: Data<Elem = $b> + DataMut,
             D: Dimension,
         {
-            $name(input, output, handler, axis)
+            transform_body!($point, input, output, handler, axis, $op, true)
         }
     };
 }
 
 transform!(/// Complex-to-complex forward FFT along `axis`.
-    ndfft, ndfft_par, Complex<T>, Complex<T>, FftHandler, ffi::NDFFT_OP_C2C_FWD, NormPoint::Ignored);
+    ndfft, ndfft_par, Complex<T>, Complex<T>, FftHandler, ffi::NDFFT_OP_C2C_FWD, ignored);
 transform!(/// Complex-to-complex inverse FFT along `axis`.
-    ndifft, ndifft_par, Complex<T>, Complex<T>, FftHandler, ffi::NDFFT_OP_C2C_INV, NormPoint::After);
+    ndifft, ndifft_par, Complex<T>, Complex<T>, FftHandler, ffi::NDFFT_OP_C2C_INV, after);
 transform!(/// Real-to-complex FFT along `axis`.
-    ndfft_r2c, ndfft_r2c_par, T, Complex<T>, R2cFftHandler, ffi::NDFFT_OP_R2C, NormPoint::Ignored);
+    ndfft_r2c, ndfft_r2c_par, T, Complex<T>, R2cFftHandler, ffi::NDFFT_OP_R2C, ignored);
 transform!(/// Complex-to-real inverse FFT along `axis`.
-    ndifft_r2c, ndifft_r2c_par, Complex<T>, T, R2cFftHandler, ffi::NDFFT_OP_C2R, NormPoint::Before);
+    ndifft_r2c, ndifft_r2c_par, Complex<T>, T, R2cFftHandler, ffi::NDFFT_OP_C2R, before);
 transform!(/// DCT-I along `axis`.
-    nddct1, nddct1_par, T, T, DctHandler, ffi::NDFFT_OP_DCT1, NormPoint::Before);
+    nddct1, nddct1_par, T, T, DctHandler, ffi::NDFFT_OP_DCT1, before);
 transform!(/// DCT-II along `axis`.
-    nddct2, nddct2_par, T, T, DctHandler, ffi::NDFFT_OP_DCT2, NormPoint::Before);
+    nddct2, nddct2_par, T, T, DctHandler, ffi::NDFFT_OP_DCT2, before);
 transform!(/// DCT-III along `axis`.
-    nddct3, nddct3_par, T, T, DctHandler, ffi::NDFFT_OP_DCT3, NormPoint::Before);
+    nddct3, nddct3_par, T, T, DctHandler, ffi::NDFFT_OP_DCT3, before);
 transform!(/// DCT-IV along `axis`.
-    nddct4, nddct4_par, T, T, DctHandler, ffi::NDFFT_OP_DCT4, NormPoint::Before);
+    nddct4, nddct4_par, T, T, DctHandler, ffi::NDFFT_OP_DCT4, before);
 
 /// Device-resident arrays: keep the `work` array of a multi-axis transform (examples/fft2.rs:23-27 in the
 /// reference) in HBM between the axis passes instead of crossing PCIe twice per call.
@@ -243,7 +306,7 @@ pub mod device {
     macro_rules! device_transform {
         ($name:ident, $a:ty, $b:ty, $h:ident, $op:expr) => {
             /// Device-resident twin of the host function of the same name (asynchronous on the null stream).
-            pub fn $name<T: GpuFloat>(input: &DeviceArray<$a>, output: &mut DeviceArray<$b>, handler: &$h<T>, axis: usize) {
+            pub fn $name<T: FftNum + FloatConst>(input: &DeviceArray<$a>, output: &mut DeviceArray<$b>, handler: &$h<T>, axis: usize) {
                 let mode = match handler.norm {
                     Normalization::None => ffi::NDFFT_NORM_NONE,
                     Normalization::Default => ffi::NDFFT_NORM_DEFAULT,

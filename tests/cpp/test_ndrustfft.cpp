@@ -156,6 +156,31 @@ static void device_resident_fft2() {   // examples/fft2.rs with the work array k
     ndfft_r2c(dx, w1, hr, 1); ndfft(w1, w2, hc, 0); ndifft(w2, w3, hc, 0); ndifft_r2c(w3, dy, hr, 1);
     approx_eq(dy.to_host().to_logical(), d, 1e-10);
 }
+static void par_over_devices() {   // `_par` = create_transform_par! (lib.rs:169-238): lanes handed to the workers -- here GPUs
+    const int ndev = ndfft_device_count();
+    std::vector<int> ids;
+    if (ndev > 1) for (int d = 0; d < ndev; ++d) ids.push_back(d); else ids = {0, 0, 0};   // one GPU: three blocks on it
+    set_par_devices(ids);
+    const int rows = 37, n = 96;
+    std::vector<C> in; for (int i = 0; i < rows * n; ++i) in.emplace_back(std::sin(0.11 * i), std::cos(0.07 * i));
+    auto x = Array<C>::from({rows, n}, in); auto y1 = Array<C>::zeros({rows, n}); auto y2 = Array<C>::zeros({rows, n});
+    FftHandler<double> h(n);
+    ndfft(x, y1, h, 1);
+    ndfft_par(x, y2, h, 1);
+    EXPECT(std::string(ndfft_last_path()).rfind("sharded:", 0) == 0);
+    auto a = y1.to_logical(), b = y2.to_logical();
+    for (size_t i = 0; i < a.size(); ++i) EXPECT(a[i] == b[i]);
+    // device-resident array: scatter / transform / gather without the host
+    auto dx = DeviceArray<C>::from_host(x); DeviceArray<C> dy({rows, n});
+    ndfft_par(dx, dy, h, 1);
+    auto c = dy.to_host().to_logical();
+    for (size_t i = 0; i < a.size(); ++i) EXPECT(a[i] == c[i]);
+    // the reference's panic text comes out before any device starts
+    auto bad = Array<C>::zeros({rows, n + 1});
+    try { ndfft_par(bad, bad, h, 1); EXPECT(!"no panic"); }
+    catch (const Panic &p) { EXPECT(std::string(p.what()) == "Size mismatch in fft, got 97 expected 96"); }
+    set_par_devices({});
+}
 static void panics() {                                                                                              // lib.rs:340-347, 116, 120-121
     auto x = Array<C>::zeros({3, 5}); auto y = Array<C>::zeros({3, 5});
     try { ndfft(x, y, FftHandler<double>(6), 1); EXPECT(!"no panic"); }
@@ -195,7 +220,7 @@ int main(int argc, char **argv) {
         {"test_dct4", test_dct<4, false>}, {"test_dct4_par", test_dct<4, true>},
         {"example_fft2", example_fft2}, {"example_rfft2", example_rfft2}, {"example_fft_norm", example_fft_norm},
         {"readme_r2c_6x4", readme_r2c_6x4}, {"panics", panics}, {"f32_and_clone", f32_and_clone},
-        {"device_resident_fft2", device_resident_fft2},
+        {"device_resident_fft2", device_resident_fft2}, {"par_over_devices", par_over_devices},
     };
     int bad = 0;
     for (const T &t : tests) {
