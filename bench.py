@@ -139,10 +139,25 @@ def main():
     ap.add_argument("--strong-steps", type=int, default=20, help="timed steps of the cfg5 strong-scaling block (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-api", action="store_true", help="skip the PCIe-inclusive ndfft_exec (host arrays) side measurement")
+    ap.add_argument("--no-xgmi", action="store_true", help="N > 1: skip the scatter / gather / all-to-all measurements over xGMI")
+    ap.add_argument("--profile-phase", default="", choices=["", "primary", "cold", "strong"],
+                    help="profiling aid (tools/prof_bench.sh): run ONLY this timed region at full length so that rocprofv3's per-kernel "
+                         "averages belong to it (the others shrink to one step / are skipped); the printed line is then not a bench result")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only with --dry (CPU rendezvous check)")
     ap.add_argument("--dry", action="store_true", help="rendezvous + rank count only, no GPU work (CPU test of the launch path)")
     ap.add_argument("--dist", action="store_true", help="initialise torch.distributed (RCCL) even at world size 1 (path check)")
     args = ap.parse_args()
+    primary_steps = args.steps
+    if args.profile_phase:
+        args.no_cpu_baseline = args.no_host_api = args.no_xgmi = True
+        if args.profile_phase != "primary":
+            primary_steps = 1; args.warmup = 1; args.ramp_ms = 0.0
+        if args.profile_phase != "cold":
+            args.cold_pairs = 0
+        if args.profile_phase != "strong":
+            args.strong_steps = 0
+        elif args.strong_steps < args.steps:
+            args.strong_steps = args.steps
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
@@ -238,7 +253,7 @@ def main():
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
-    el, dev_ms = timed(step, args.steps)
+    el, dev_ms = timed(step, primary_steps)
     path = lib.last_path()
 
     # quick self-check of the timed output on a few lanes against numpy's FFT (not timed; the oracle is only used by
@@ -249,7 +264,7 @@ def main():
         assert err < 1e-10, f"bench output differs from numpy.fft: {err}"
 
     bytes_per_launch = 2 * rows * n * 16               # 32 B/point = one read + one write of c128
-    kern_s = dev_ms / 1e3 / args.steps                 # average launch duration on the launch stream (HIP events)
+    kern_s = dev_ms / 1e3 / primary_steps              # average launch duration on the launch stream (HIP events)
 
     # ------------------------------------------------------------------ cache-cold: rotating pairs (> Infinity Cache)
     cold = None
@@ -304,6 +319,61 @@ def main():
                   "per_gpu_frac": round(s_bytes / s_kern / 1e9 / HBM_PEAK_GBS, 4)}
         del xs, ys
 
+    # ------------------------------------------------------------------ N > 1: the data movement of SURVEY 8e / 8f rank 3 over xGMI
+    # (never part of `value`: lanes that are born sharded need none of it).  Root scatter and gather of batch slices
+    # (point-to-point groups, one slice per link) and the all-to-all re-shard between the two axis passes of a sharded
+    # fft2; GB/s per link against the ~153 GB/s an xGMI link carries, and a correctness check of each.
+    xgmi = None
+    if use_dist and ngpu > 1 and not args.no_xgmi:
+        try:
+            from ndrustfft_amd import distributed as nd_dist
+            xgmi = {}
+            prow = 2048                                                  # rows per rank: 2048 x 4096 c128 = 128 MiB per link
+            gshape = (prow * ngpu, n)
+            full = synth.complex_array_torch(gshape, dev) if rank == 0 else None
+
+            def best(fn, reps=3):
+                ts = []
+                for _ in range(reps):
+                    sync_all(); t0 = time.perf_counter(); r = fn(); sync_all(); ts.append(time.perf_counter() - t0)
+                t = torch.tensor([min(ts)], device=dev, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                return float(t[0]), r
+            link_bytes = prow * n * 16
+            t_sc, shard = best(lambda: nd_dist.scatter_lanes(full, gshape, torch.complex128, 1, 0, dev))
+            yl = torch.empty_like(shard); ndfft(shard, yl, h, 1)
+            t_ga, gathered = best(lambda: nd_dist.gather_lanes(yl, gshape, 0, 0))
+            ok = True
+            if rank == 0:
+                ref = np.fft.fft(synth.complex_array((2, n), offset=(gshape[0] - 2) * n), axis=1)     # the last rank's last two lanes
+                ok = bool(np.abs(gathered[-2:].cpu().numpy() - ref).max() / np.abs(ref).max() < 1e-10)
+            xgmi["scatter"] = {"bytes_per_link": link_bytes, "links": ngpu - 1, "ms": round(t_sc * 1e3, 3), "GBs_per_link": round(link_bytes / t_sc / 1e9, 1)}
+            xgmi["gather"] = {"bytes_per_link": link_bytes, "links": ngpu - 1, "ms": round(t_ga * 1e3, 3), "GBs_per_link": round(link_bytes / t_ga / 1e9, 1),
+                              "scatter_transform_gather_matches_numpy": ok}
+            del full, gathered
+            # all-to-all: re-shard an (N 1024) x 4096... square-ish c128 array from row slabs to column slabs
+            side = 1024 * ngpu
+            slab = synth.complex_array_torch((side // ngpu, side), dev, offset=rank * (side // ngpu) * side)
+            t_a2a, cols = best(lambda: nd_dist.reshard(slab, (side, side), 0, 1))
+            pair_bytes = (side // ngpu) * (side // ngpu) * 16
+            back = nd_dist.reshard(cols, (side, side), 1, 0)
+            xgmi["all_to_all_reshard"] = {"array": f"{side}x{side} c128", "bytes_per_pair": pair_bytes, "ms": round(t_a2a * 1e3, 3),
+                                          "GBs_per_link": round(pair_bytes / t_a2a / 1e9, 1), "round_trip_exact": bool(torch.equal(back, slab))}
+            # sharded fft2 (axis 1, all-to-all, axis 0) against numpy on a 1024 x 1024 array
+            m = 1024
+            a_full = synth.complex_array((m, m))
+            lo, hi = nd_dist.shard_bounds(m, ngpu)[rank]
+            hm = FftHandler(m)
+            yl2, gsh, dsh = nd_dist.transform_axes_sharded([(ndfft, hm, 1, m, torch.complex128), (ndfft, hm, 0, m, torch.complex128)],
+                                                           torch.from_numpy(a_full[lo:hi]).to(dev), (m, m), 0)
+            ref2 = np.fft.fft2(a_full)
+            clo, chi = nd_dist.shard_bounds(m, ngpu)[rank]
+            err2 = np.abs(yl2.cpu().numpy() - ref2[:, clo:chi]).max() / np.abs(ref2).max()
+            e = torch.tensor([err2], device=dev, dtype=torch.float64); dist.all_reduce(e, op=dist.ReduceOp.MAX)
+            xgmi["sharded_fft2_1024_rel_err"] = float(e[0])
+            xgmi["peak_GBs_per_link"] = 153.0
+        except Exception as ex:                                           # never lose the bench line to this side measurement
+            xgmi = {"error": repr(ex)[:300]}
+
     # ------------------------------------------------------------------ host-array API (PCIe both ways), N = 1 only
     host_api = None
     if rank == 0 and ngpu == 1 and not args.no_host_api:
@@ -319,7 +389,7 @@ def main():
                     "kernel_path": lib.last_path()}
 
     if rank == 0:
-        points = ngpu * rows * n * args.steps
+        points = ngpu * rows * n * primary_steps
         achieved = bytes_per_launch / kern_s / 1e9
         traffic = None; traffic_src = None
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -345,8 +415,8 @@ def main():
         out = {
             "metric": "GFFT-points/s, batched 1-D C2C FFT f64 along the contiguous axis (+ achieved HBM GB/s vs roofline)",
             "value": round(points / el / 1e9, 3), "unit": "GFFT-points/s",
-            "n_gpus": ngpu, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(el / args.steps * 1e3, 5),
+            "n_gpus": ngpu, "ranks_seen": ranks_seen, "steps": primary_steps, "warmup": args.warmup,
+            "ms_per_step": round(el / primary_steps * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"ndfft axis=1 on {ngpu * rows}x{n} Complex<f64> "
@@ -356,8 +426,12 @@ def main():
                        "sharding": "none" if ngpu == 1 else f"lanes split in {ngpu} contiguous blocks, one per GPU, no collective in the timed region"},
             "roofline": roof,
         }
+        if args.profile_phase:
+            out["profile_phase"] = args.profile_phase + " (profiling run: not a bench result)"
         if strong:
             out["strong_cfg5"] = strong
+        if xgmi:
+            out["xgmi"] = xgmi
         if host_api:
             out["host_api"] = host_api
         if not args.no_cpu_baseline and ngpu == 1:
