@@ -411,7 +411,11 @@ def main():
                 "frac_note": "one 256 MiB input re-read every step: the 256 MiB Infinity Cache can serve part of it; see frac_cold"}
         if cold:
             roof["frac_cold"] = round(cold["achieved"] / HBM_PEAK_GBS, 4)
+            if traffic is not None and rows == 4096 and n == 4096:
+                cold["traffic"] = tdata.get("4096x4096_cold_rotating"); cold["traffic_source"] = traffic_src
             roof["cold"] = cold
+        if strong and traffic is not None and ngpu == 1 and n == 4096:
+            strong["traffic"] = tdata.get("65536x4096"); strong["traffic_source"] = traffic_src
         out = {
             "metric": "GFFT-points/s, batched 1-D C2C FFT f64 along the contiguous axis (+ achieved HBM GB/s vs roofline)",
             "value": round(points / el / 1e9, 3), "unit": "GFFT-points/s",

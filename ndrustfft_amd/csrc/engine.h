@@ -185,6 +185,10 @@ int colsplit_inner_len();
 int colsplit_tile_lanes();
 template <typename T> int launch_colsplit(int cs, bool inverse, const RealArgs<T> &a, hipStream_t s);
 
+// kernels_fourstep.hip : the two passes of the row four-step on the column kernels (no transpose launch)
+bool fourstep_supported(int F);
+template <typename T> int launch_fourstep(int pass, int F, bool inverse, const RealArgs<T> &a, hipStream_t s);
+
 // big.hip : four-step pieces for lanes that do not fit LDS
 template <typename T>
 int launch_big_twiddle(cpx<T> *data, int64_t lanes, int F1, int F2, const cpx<T> *twlo, const cpx<T> *twhi, int logB, int conj,

@@ -343,6 +343,12 @@ static bool wave_enabled() {
     return !(e && e[0] == '0');
 }
 
+// developer / test switch: NDFFT_FOURSTEP2=0 keeps long power-of-two lanes on the three-pass form (read per call)
+static bool fourstep2_enabled() {
+    const char *e = getenv("NDFFT_FOURSTEP2");
+    return !(e && e[0] == '0');
+}
+
 // developer switch: NDFFT_BLUE=0 keeps Bluestein lengths on the LDS kernel
 static bool blue_enabled() {
     const char *e = getenv("NDFFT_BLUE");
@@ -468,6 +474,30 @@ static int big_fft(const FftConfig &c, const DevConfig &d, const cpx<T> *zin, in
     void *s1, *s2;
     int rc;
     if ((rc = get_scratch(2, stream, (size_t)(L * F) * esz, &s1))) return rc;
+    // Two-pass form, no transpose launch, when both factors have a column kernel (powers of two, 64..1024):
+    //   (1) length-F1 FFTs over the strided n1 axis, column load, stored TRANSPOSED as s1[n2][k1] (row store)
+    //   (2) length-F2 FFTs over n2 of s1 (stride F1, adjacent k1 contiguous), twiddle W_F^(n2 k1) on load, stored at
+    //       k1 + F1 k2 = natural order.   256 x 65536 c128: 317 us (three passes) -> see DESIGN.md section 3.5
+    if (fourstep_supported(F1) && fourstep_supported(F2) && !c.sub1->cfg[CFG_MAIN].twp_col.re.empty() &&
+        !c.sub2->cfg[CFG_MAIN].twp_col.re.empty() && fourstep2_enabled()) {
+        const DevTables *dt1, *dt2;
+        if ((rc = get_dev_tables(c.sub1, &dt1)) || (rc = get_dev_tables(c.sub2, &dt2))) return rc;
+        RealArgs<T> a;
+        a.pitch_in = 0; a.vec_in = 0; a.vec_out = 0; a.xcd_remap = 0; a.keep_out = 0; a.stream_in = 0;
+        a.aux1 = nullptr; a.aux2 = nullptr; a.chirp = nullptr; a.bhat = nullptr;
+        a.cs_twlo = (const cpx<T> *)d.twlo; a.cs_twhi = (const cpx<T> *)d.twhi; a.cs_logB = c.logB;
+        a.cs_k1n = 1; a.cs_f1 = F1; a.cs_n = (int)F; a.cs_outer_in = 0; a.cs_outer_out = 0; a.cs_pitch = 0;
+        // pass 1: lanes (l, n2)
+        a.in = zin; a.out = s1; a.nlanes = L * F2; a.n = F1; a.F = F1; a.n_in = F1; a.n_out = F1; a.scale = (T)1;
+        a.inner = F2; a.outer_in = pitch_in; a.outer_out = 0; a.elem_in = F2; a.elem_out = 0; a.pitch_out = F1;
+        a.twp = (const cpx<T> *)dt1->cfg[CFG_MAIN].twp_col;
+        if ((rc = launch_fourstep<T>(1, F1, inverse, a, stream))) return rc;
+        // pass 2: lanes (l, k1)
+        a.in = s1; a.out = zout; a.nlanes = L * F1; a.n = F2; a.F = F2; a.n_in = F2; a.n_out = F2; a.scale = scale;
+        a.inner = F1; a.outer_in = F; a.outer_out = pitch_out; a.elem_in = F1; a.elem_out = F1; a.pitch_out = 0;
+        a.twp = (const cpx<T> *)dt2->cfg[CFG_MAIN].twp_col;
+        return launch_fourstep<T>(2, F2, inverse, a, stream);
+    }
     if ((rc = get_scratch(3, stream, (size_t)(L * F) * esz, &s2))) return rc;
     // Fused three-pass form when both halves run on the register kernels:
     //   (1) length-F1 FFTs IN PLACE of the layout, on the strided n1 axis, by the column-tile kernels

@@ -1,0 +1,61 @@
+// kernels_fourstep.hip -- the two passes of the ROW four-step for lanes longer than one workgroup (exec.hip: big_fft),
+// both on the register-resident column kernels of pow2_real.h, no transpose launch:
+//   pass 1  x[n1 F2 + n2]: FFTs of length F1 over n1 (stride F2, adjacent n2 contiguous: column LOAD), stored
+//           TRANSPOSED as s[n2][k1] (every lane one contiguous run: ROW store)                      -- ROWOUT kernels
+//   pass 2  s[n2][k1]: FFTs of length F2 over n2 (stride F1, adjacent k1 contiguous), twiddle W_F^(n2 k1) on load,
+//           stored at k1 + F1 k2 = natural order (column store)                                     -- CS = 4 kernels
+// Replaces transpose -> row FFT -> twiddle -> transpose -> row FFT -> transpose (six passes) and the three-pass form.
+#include "pow2_real.h"
+
+namespace ndfft {
+
+// the E = 8 configurations of kernels_pow2_real.hip (per-pass twiddles: the C2C plans' twp_col tables)
+template <int F> struct FsCfg;
+#define NDFFT_FS(F_, TPL_, ...) template <> struct FsCfg<F_> { static constexpr int TPL = TPL_; using RL = RadixList<__VA_ARGS__>; };
+NDFFT_FS(64, 8, 8, 8)
+NDFFT_FS(128, 16, 8, 4, 4)
+NDFFT_FS(256, 32, 8, 8, 4)
+NDFFT_FS(512, 64, 8, 8, 8)
+NDFFT_FS(1024, 128, 8, 8, 4, 4)
+
+template <typename T, int F> struct FsGeom {
+    static constexpr int TPL = FsCfg<F>::TPL;
+    // adjacent lanes per tile: 128-byte rows (8 complex f64 / 16 complex f32), at least 256 threads.  Narrower than the
+    // 32-lane tiles of the general column kernels on purpose: F = 256 f64 then takes 35 KiB of LDS instead of 140 KiB,
+    // four workgroups per CU instead of one (256 x 65536 c128: 251 -> see DESIGN.md section 3.5)
+    static constexpr int MINL = sizeof(T) == 8 ? 8 : 16;
+    static constexpr int LPB = TPL * MINL < 256 ? 256 / TPL : (TPL * MINL > 1024 ? 1024 / TPL : MINL);
+    static_assert(TPL * LPB <= 1024, "workgroup too large");
+};
+
+template <typename T, int F, int OP, int CS, bool ROWOUT> static int launch_fs(const RealArgs<T> &a, hipStream_t s) {
+    constexpr int LPB = FsGeom<T, F>::LPB;
+    using K = RealPow2Kernel<T, F, FsCfg<F>::TPL, LPB, typename FsCfg<F>::RL, OP, true, false, CS, ROWOUT>;
+    static_assert(K::LDS_BYTES <= 160 * 1024, "tile does not fit LDS");
+    NDFFT_ENSURE_LDS_ATTR((k_pow2_real<K, T>));
+    const int64_t nblk = (a.nlanes + LPB - 1) / LPB;
+    if (nblk <= 0) return NDFFT_OK;
+    if (nblk > 0x7fffffffLL) return fail(NDFFT_ERR_UNSUPPORTED, "too many lanes for one launch");
+    hipLaunchKernelGGL((k_pow2_real<K, T>), dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, a);
+    NDFFT_HIP(hipGetLastError());
+    return NDFFT_OK;
+}
+
+bool fourstep_supported(int F) { return F == 64 || F == 128 || F == 256 || F == 512 || F == 1024; }
+
+// pass = 1: column load / row store; pass = 2: twiddle by the inner index on load, column store
+template <typename T> int launch_fourstep(int pass, int F, bool inverse, const RealArgs<T> &a, hipStream_t s) {
+#define NDFFT_FS_CASE(F_)                                                                                              \
+    case F_:                                                                                                           \
+        if (pass == 1) return inverse ? launch_fs<T, F_, G_C2C_INV, 0, true>(a, s) : launch_fs<T, F_, G_C2C_FWD, 0, true>(a, s); \
+        return inverse ? launch_fs<T, F_, G_C2C_INV, 4, false>(a, s) : launch_fs<T, F_, G_C2C_FWD, 4, false>(a, s);
+    switch (F) {
+        NDFFT_FS_CASE(64) NDFFT_FS_CASE(128) NDFFT_FS_CASE(256) NDFFT_FS_CASE(512) NDFFT_FS_CASE(1024)
+        default: return fail(NDFFT_ERR_UNSUPPORTED, "row four-step: unsupported factor");
+    }
+#undef NDFFT_FS_CASE
+}
+template int launch_fourstep<float>(int, int, bool, const RealArgs<float> &, hipStream_t);
+template int launch_fourstep<double>(int, int, bool, const RealArgs<double> &, hipStream_t);
+
+}  // namespace ndfft

@@ -73,8 +73,13 @@ struct ZiPhi { static __device__ __forceinline__ int map(int p) { return p + (p 
 //           N - (k1 + F1 k2) = (F1 - k1) + F1 (F - 1 - k2)
 //   CS = 3  first stage of C2R (OP = C2C_INV): the Hermitian gather of CS = 2 on load (imaginary parts of
 //           DC and Nyquist dropped, src/lib.rs:514-518), conj twiddle on store into the scratch array
-template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = false, bool XCD = false, int CS = 0> struct RealPow2Kernel {
+//   CS = 4  second pass of the ROW four-step (exec.hip: big_fft): lanes (L, k1) with k1 the INNER (contiguous) index;
+//           twiddle W_N^(j k1) on load, ordinary column store (row k2, adjacent k1 contiguous = natural order k1 + F1 k2)
+// ROWOUT (COL, C2C): column load, ROW store -- the tile is read with lanes fastest and every lane is written as one
+// contiguous run (pitch_out): the transposing first pass of the row four-step.
+template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = false, bool XCD = false, int CS = 0, bool ROWOUT = false> struct RealPow2Kernel {
     static_assert(CS == 0 || (COL && !XCD && (OP == G_C2C_FWD || OP == G_C2C_INV)), "CS kernels are column C2C kernels");
+    static_assert(!ROWOUT || (COL && !XCD && CS == 0 && (OP == G_C2C_FWD || OP == G_C2C_INV)), "ROWOUT is a column-load C2C kernel");
     // strided staging loop with U independent global loads in flight per thread before the first LDS store
     // (a plain `for (j) dst[j] = in[j * stride]` leaves one or two loads outstanding: latency-bound)
     template <int STEP, typename LD, typename ST> static __device__ __forceinline__ void stage_loop(int j0, int n, LD ld, ST st) {
@@ -157,9 +162,9 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                 const int64_t base = (L / a.inner) * a.outer_in + (L % a.inner);
                 char *dst = smem + (size_t)cl * LANE_LDS * 2 * sizeof(T);
                 constexpr int STEP = THREADS / LPB;
-                if constexpr (CS == 1 || CS == 2) {
+                if constexpr (CS == 1 || CS == 2 || CS == 4) {
                     const cpx<T> *in = (const cpx<T> *)a.in + base;
-                    const int k1 = (int)((L / a.inner) % a.cs_k1n);
+                    const int k1 = CS == 4 ? (int)(L % a.inner) : (int)((L / a.inner) % a.cs_k1n);
                     struct VW { cpx<T> v, w; };
                     stage_loop<STEP>(j0, a.n_in,
                         [&](int j) { VW r; r.v = in[(int64_t)j * a.elem_in]; r.w = cs_tw(a, j * k1); return r; },
@@ -273,7 +278,7 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
         }
         __syncthreads();
         // ---- POST gather + store ----
-        if constexpr (COL) {
+        if constexpr (COL && !ROWOUT) {
             const int cl = threadIdx.x % LPB, j0 = threadIdx.x / LPB;
             const int64_t L = lane0 + cl;
             if (L >= a.nlanes) return;

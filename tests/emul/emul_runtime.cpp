@@ -119,6 +119,7 @@ void ndfft::emul_wave_swap(unsigned &lo, unsigned &hi, int tb) {
 
 void emul::launch(void (*fn)(void *), void *arg, dim3 grid, dim3 block, size_t lds_bytes) {
     std::lock_guard<std::mutex> launch_guard(g_launch_mu);   // host threads (shared handlers, sharded exec) take turns
+    if (block.x > 1024 || block.x == 0) { fprintf(stderr, "emul: invalid workgroup size %u (a gfx950 workgroup has at most 1024 threads)\n", block.x); abort(); }
     if (lds_bytes > 160 * 1024) { fprintf(stderr, "emul: LDS request %zu > 160 KiB\n", lds_bytes); abort(); }
     g_fn = fn; g_arg = arg;
     blockDim = {block.x, 1, 1}; gridDim = {grid.x, grid.y, grid.z};

@@ -475,10 +475,24 @@ def long_lanes_four_step(L, full=True):
              ("ndfft", (20000, 3), 0, np.float64, "transpose+four_step"), ("ndfft_r2c", (2, 9999), 1, np.float64, "four_step"),
              ("nddct2", (2, 9999), 1, np.float32, "four_step")]
     if full:
-        cases += [("ndfft", (2, 1 << 20), 1, np.float64, "four_step"), ("ndifft", (1, 1 << 22), 1, np.float32, "four_step"),
+        cases += [("ndfft", (2, 1 << 20), 1, np.float64, "four_step"), ("ndfft", (2, 1 << 20), 1, np.float32, "four_step"), ("ndifft", (3, 1 << 19), 1, np.float32, "four_step"), ("ndifft", (1, 1 << 22), 1, np.float32, "four_step"),
                   ("nddct2", (3, 1 << 18), 1, np.float64, "four_step"), ("ndfft_r2c", (2, 3 * (1 << 17)), 1, np.float32, "four_step")]
     for name, shape, axis, rdt, want in cases:
         assert run_case(L, name, shape, axis, rdt) == want, (name, shape)
+    # the power-of-two lengths above took the two-pass form (column load / row store, then twiddled column pass); the
+    # three-pass form they replace stays covered, and both directions / norms of the new one on an odd lane count
+    for name in ("ndfft", "ndifft"):
+        for norm in ("Default", "None"):
+            assert run_case(L, name, (3, 32768), 1, np.float64, norm=norm) == "four_step"
+            assert run_case(L, name, (5, 65536), 1, np.float32, norm=norm) == "four_step"
+    old = os.environ.get("NDFFT_FOURSTEP2")
+    os.environ["NDFFT_FOURSTEP2"] = "0"
+    try:
+        assert run_case(L, "ndfft", (2, 32768), 1, np.float64) == "four_step"
+        assert run_case(L, "ndifft", (2, 65536), 1, np.float32) == "four_step"
+    finally:
+        if old is None: del os.environ["NDFFT_FOURSTEP2"]
+        else: os.environ["NDFFT_FOURSTEP2"] = old
     # long lanes in an arbitrary strided layout (stepped + reversed input view, padded output view): pack -> rows -> unpack
     n = 1 << 15
     big = synth.complex_array((3, 2 * n)); x = big[::-1, ::2]
