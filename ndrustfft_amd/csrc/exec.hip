@@ -4,6 +4,11 @@
 // iterator strategies collapse into "every lane along `axis`, arbitrary signed strides"), kernel
 // choice, and -- for host arrays -- staging through HBM.
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -274,7 +279,7 @@ struct Pipe {
 struct DeviceWs {
     std::map<hipStream_t, Scratch> scratch[8];
     Staging stage_in, stage_out;
-    PinnedBuf bounce_in[2], bounce_out[2];
+    PinnedBuf bounce_in[3], bounce_out[3];
     Pipe pipe;
     void release() {   // the owning device must be current
         pipe.release();
@@ -951,6 +956,126 @@ static int exec_pinned_pipeline(DeviceWs &ws, const ndfft_plan *plan, int op, co
     return rc;
 }
 
+// ---- pageable host arrays: the same chunk pipeline through pinned bounce buffers --------------------------------
+// hipMemcpy from / to pageable memory is staged by the runtime on one thread, and the two PCIe directions never overlap
+// (tools/h2d_bench.hip: 9.7 ms for 2 x 256 MiB).  Here the staging is ours: a small pool of host threads copies row
+// chunks between the caller's arrays and three pinned slots per direction while the DMA engines move the previous
+// chunks, so upload, transform and download overlap for ANY host array (ndarray allocates pageable memory).
+namespace {
+struct CopyGroup { std::atomic<int> left{0}; std::mutex m; std::condition_variable cv; };
+class CopyPool {
+  public:
+    static CopyPool &get() { static CopyPool *p = new CopyPool; return *p; }   // never destroyed: detached workers
+    int threads() const { return nthreads_; }
+    // copies `bytes` in `pieces` slices on the pool; returns immediately
+    void copy_async(CopyGroup &g, char *dst, const char *src, size_t bytes, int pieces) {
+        pieces = (int)std::max<size_t>(1, std::min<size_t>((size_t)pieces, bytes / (256 << 10) + 1));
+        g.left.store(pieces);
+        const size_t per = (bytes / pieces + 63) & ~(size_t)63;
+        std::lock_guard<std::mutex> lk(mu_);
+        for (int i = 0; i < pieces; ++i) {
+            const size_t o = std::min(bytes, (size_t)i * per), e = i + 1 == pieces ? bytes : std::min(bytes, (size_t)(i + 1) * per);
+            q_.push_back({dst + o, src + o, e - o, &g});
+        }
+        cv_.notify_all();
+    }
+    static void wait(CopyGroup &g) {
+        std::unique_lock<std::mutex> lk(g.m);
+        g.cv.wait(lk, [&] { return g.left.load() == 0; });
+    }
+  private:
+    struct Piece { char *d; const char *s; size_t n; CopyGroup *g; };
+    CopyPool() {
+        // threads: three quarters of the CPUs this process may use (affinity / hardware count capped by the cgroup quota:
+        // the MI355X boxes show 256 CPUs and grant 16), between 2 and 12.  Measured on 4096 x 4096 c128 (2 x 256 MiB,
+        // plain path 9.8 ms): 4 threads 9.5-10.6 ms, 8 threads 8.8 ms, 12 threads 7.9-8.4 ms -- the host copies, not PCIe, bound it
+        const char *e = getenv("NDFFT_COPY_THREADS");
+        long hw = (long)std::thread::hardware_concurrency();
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32] = {0}; long per = 0;
+            if (fscanf(f, "%31s %ld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) hw = std::min(hw, std::max(1L, (atol(q) + per - 1) / per));
+            fclose(f);
+        }
+        nthreads_ = e ? atoi(e) : (int)std::max(2L, std::min(12L, hw * 3 / 4));
+        if (nthreads_ < 1) nthreads_ = 1;
+        for (int i = 0; i < nthreads_; ++i) std::thread([this] { loop(); }).detach();
+    }
+    void loop() {
+        for (;;) {
+            Piece p;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [this] { return !q_.empty(); });
+                p = q_.front(); q_.pop_front();
+            }
+            memcpy(p.d, p.s, p.n);
+            if (p.g->left.fetch_sub(1) == 1) { std::lock_guard<std::mutex> lk(p.g->m); p.g->cv.notify_all(); }
+        }
+    }
+    int nthreads_ = 1;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<Piece> q_;
+};
+}  // namespace
+
+static int exec_bounce_pipeline_body(DeviceWs &ws, const ndfft_plan *plan, int op, const char *hin, char *hout, int ndim, const int64_t *shape_in,
+                                     const int64_t *stride_in, const int64_t *shape_out, const int64_t *stride_out, int axis, int norm,
+                                     double scale, size_t ein, size_t eout, int chunks) {
+    int rc;
+    Pipe &pp = ws.pipe;
+    if ((rc = pipe_init(pp, chunks))) return rc;
+    CopyPool &pool = CopyPool::get();
+    const int64_t R = shape_in[0];
+    const int64_t isp = inner_span(ndim, shape_in, stride_in), osp = inner_span(ndim, shape_out, stride_out);
+    auto r0_of = [&](int c) { return R * c / chunks; };
+    auto off_in = [&](int c) { return (size_t)(r0_of(c) * stride_in[0]) * ein; };
+    auto off_out = [&](int c) { return (size_t)(r0_of(c) * stride_out[0]) * eout; };
+    auto bytes_in = [&](int c) { const int64_t n = r0_of(c + 1) - r0_of(c); return n <= 0 ? (size_t)0 : (size_t)((n - 1) * stride_in[0] + isp) * ein; };
+    auto bytes_out = [&](int c) { const int64_t n = r0_of(c + 1) - r0_of(c); return n <= 0 ? (size_t)0 : (size_t)((n - 1) * stride_out[0] + osp) * eout; };
+    size_t max_in = 0, max_out = 0;
+    for (int c = 0; c < chunks; ++c) { max_in = std::max(max_in, bytes_in(c)); max_out = std::max(max_out, bytes_out(c)); }
+    for (int k = 0; k < 3; ++k) { if ((rc = ws.bounce_in[k].reserve(max_in)) || (rc = ws.bounce_out[k].reserve(max_out))) return rc; }
+    std::vector<int64_t> si(shape_in, shape_in + ndim), so(shape_out, shape_out + ndim);
+    const int half = std::max(1, pool.threads() / 2);
+    CopyGroup gu, gd;
+    for (int it = 0; it < chunks + 2; ++it) {
+        const int cu = it, cd = it - 2;
+        const bool up = cu < chunks && bytes_in(cu) > 0, dn = cd >= 0 && bytes_out(cd) > 0;
+        if (up) {
+            if (cu >= 3) NDFFT_HIP(hipEventSynchronize(pp.up[cu - 3]));        // the slot's previous upload has left it
+            pool.copy_async(gu, (char *)ws.bounce_in[cu % 3].p, hin + off_in(cu), bytes_in(cu), half);
+        }
+        if (dn) {
+            NDFFT_HIP(hipEventSynchronize(pp.down[cd]));                          // chunk cd has arrived in its slot
+            pool.copy_async(gd, hout + off_out(cd), (const char *)ws.bounce_out[cd % 3].p, bytes_out(cd), half);
+        }
+        if (up) CopyPool::wait(gu);
+        if (dn) CopyPool::wait(gd);
+        if (!up) continue;
+        NDFFT_HIP(hipMemcpyAsync((char *)ws.stage_in.p + off_in(cu), ws.bounce_in[cu % 3].p, bytes_in(cu), hipMemcpyHostToDevice, pp.h2d));
+        NDFFT_HIP(hipEventRecord(pp.up[cu], pp.h2d));
+        NDFFT_HIP(hipStreamWaitEvent(pp.cmp, pp.up[cu], 0));
+        si[0] = so[0] = r0_of(cu + 1) - r0_of(cu);
+        Problem P;
+        bool nothing;
+        if ((rc = prepare(plan, op, ndim, si.data(), stride_in, so.data(), stride_out, axis, norm, scale, P, nothing))) return rc;
+        if (!nothing && (rc = dispatch_peeled(P, (const char *)ws.stage_in.p + off_in(cu), (char *)ws.stage_out.p + off_out(cu), ein, eout, pp.cmp))) return rc;
+        NDFFT_HIP(hipEventRecord(pp.done[cu], pp.cmp));
+        NDFFT_HIP(hipStreamWaitEvent(pp.d2h, pp.done[cu], 0));
+        NDFFT_HIP(hipMemcpyAsync(ws.bounce_out[cu % 3].p, (const char *)ws.stage_out.p + off_out(cu), bytes_out(cu), hipMemcpyDeviceToHost, pp.d2h));
+        NDFFT_HIP(hipEventRecord(pp.down[cu], pp.d2h));
+    }
+    return NDFFT_OK;
+}
+static int exec_bounce_pipeline(DeviceWs &ws, const ndfft_plan *plan, int op, const char *hin, char *hout, int ndim, const int64_t *shape_in,
+                                const int64_t *stride_in, const int64_t *shape_out, const int64_t *stride_out, int axis, int norm,
+                                double scale, size_t ein, size_t eout, int chunks) {
+    const int rc = exec_bounce_pipeline_body(ws, plan, op, hin, hout, ndim, shape_in, stride_in, shape_out, stride_out, axis, norm, scale, ein, eout, chunks);
+    if (rc) ws.pipe.sync_all();   // (pool copies are always waited for inside the body; only device work can be in flight)
+    return rc;
+}
+
 extern "C" {
 
 int ndfft_exec_device(const ndfft_plan *plan, int op, const void *d_in, void *d_out, int ndim,
@@ -1002,14 +1127,24 @@ int ndfft_exec(const ndfft_plan *plan, int op, const void *in, void *out, int nd
     const char *hin = (const char *)in + ilo * (int64_t)ein;
     char *hout = (char *)out + olo * (int64_t)eout;
     const bool out_dense = (int64_t)(ohi - olo + 1) == ocnt;
-    // pinned, dense, C-ordered in dimension 0, transform along another axis: pipelined row chunks
+    // dense, C-ordered in dimension 0, transform along another axis: pipelined row chunks -- straight DMA for pinned arrays
+    // (ndfft_host_alloc), through pinned bounce buffers filled by the copy pool for pageable ones.  NDFFT_HOST_PIPE=0: plain path.
     if (ndim >= 2 && axis != 0 && ilo == 0 && olo == 0 && shape_in[0] == shape_out[0] && shape_in[0] >= 16 &&
-        out_dense && ibytes + obytes >= ((size_t)8 << 20) && is_pinned(in) && is_pinned(out)) {
+        out_dense && ibytes + obytes >= ((size_t)8 << 20)) {
         const int64_t isp = inner_span(ndim, shape_in, stride_in), osp = inner_span(ndim, shape_out, stride_out);
         if (isp > 0 && osp > 0 && stride_in[0] >= isp && stride_out[0] >= osp) {
             const char *e = getenv("NDFFT_PIPE_CHUNKS");
-            const int chunks = (int)std::min<int64_t>(shape_in[0], e ? std::max(1, atoi(e)) : 8);
-            return exec_pinned_pipeline(ws, plan, op, hin, hout, ndim, shape_in, stride_in, shape_out, stride_out, axis, norm, scale, ein, eout, chunks);
+            if (is_pinned(in) && is_pinned(out)) {
+                const int chunks = (int)std::min<int64_t>(shape_in[0], e ? std::max(1, atoi(e)) : 8);
+                return exec_pinned_pipeline(ws, plan, op, hin, hout, ndim, shape_in, stride_in, shape_out, stride_out, axis, norm, scale, ein, eout, chunks);
+            }
+            const char *hp = getenv("NDFFT_HOST_PIPE");
+            if (!(hp && hp[0] == '0')) {
+                // chunks of ~32 MiB per direction (at least 4, at most 64)
+                const int64_t want = std::max<int64_t>(4, std::min<int64_t>(64, (int64_t)(std::max(ibytes, obytes) >> 25)));
+                const int chunks = (int)std::min<int64_t>(shape_in[0], e ? std::max(1, atoi(e)) : want);
+                return exec_bounce_pipeline(ws, plan, op, hin, hout, ndim, shape_in, stride_in, shape_out, stride_out, axis, norm, scale, ein, eout, chunks);
+            }
         }
     }
     NDFFT_HIP(hipMemcpy(ws.stage_in.p, hin, ibytes, hipMemcpyHostToDevice));

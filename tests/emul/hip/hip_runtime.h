@@ -74,6 +74,7 @@ inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return 0; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = nullptr; return 0; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 // peer copies check that each pointer lies in an allocation made on the device it is claimed to be on
 hipError_t hipMemcpyPeerAsync(void *dst, int dst_dev, const void *src, int src_dev, size_t n, hipStream_t);

@@ -230,6 +230,35 @@ def interleaved_mut_views_two_threads(L, rounds=6):
     yo = np.zeros((7, 20)); orc.nddct2(x, yo, orc.DctHandler(20), 1); assert_close(big[:, 1::2], yo, 1, 1e-10, "stepped dct out")
 
 
+def host_pipeline_pageable(L, shapes=None):
+    """ndfft_exec on ordinary (pageable) host arrays of >= 8 MiB whose dimension 0 is a batch dimension runs as a
+    chunk pipeline through pinned bounce buffers (host copy pool || H2D || kernel || D2H); same results as the
+    plain path (NDFFT_HOST_PIPE=0), uneven last chunk, padded rows, every op family."""
+    shapes = shapes or (("ndfft", (1000, 1024), 1, np.float64), ("ndfft_r2c", (301, 8, 2048), 2, np.float32),
+                        ("nddct2", (130, 96, 128), 1, np.float64), ("ndifft_r2c", (515, 2049), 1, np.float64))
+    for name, shape, axis, rdt in shapes:
+        sin, sout = shapes_for(name, shape, axis)
+        x = make_input(name, sin, rdt)
+        odt = cdt_of(rdt) if OPS[name][4] else np.dtype(rdt)
+        h, o = handlers_for(name, shape[axis], rdt, L)
+        y1 = np.zeros(sout, odt); y2 = np.zeros(sout, odt); yo = np.zeros(sout, odt)
+        OPS[name][0](x, y1, h, axis)
+        os.environ["NDFFT_HOST_PIPE"] = "0"
+        try:
+            OPS[name][0](x, y2, h, axis)
+        finally:
+            del os.environ["NDFFT_HOST_PIPE"]
+        assert np.abs(y1 - y2).max() <= 50 * np.finfo(rdt).eps * np.abs(y2).max(), (name, shape)
+        OPS[name][1](x, yo, o, axis)
+        assert_close(y1, yo, axis, TOL[np.dtype(rdt)], f"host pipeline {name} {shape}")
+    # rows with padding between them (stride[0] > row length) on both sides
+    xb = synth.complex_array((600, 1100)); x = xb[:, :1024]
+    yb = np.full((600, 1030), 9.0 + 0j); y = yb[:, :1024]
+    h = handlers.FftHandler(1024, _library=L); api.ndfft(x, y, h, 1)
+    yo = np.zeros((600, 1024), np.complex128); orc.ndfft(np.ascontiguousarray(x), yo, orc.FftHandler(1024), 1)
+    assert_close(y, yo, 1, 1e-10, "host path, padded rows"); assert np.all(yb[:, 1024:] == 9.0)
+
+
 def wave_short_lanes(L):
     """Dense C2C lanes of n = 2..64 (powers of two) run on the LDS-free wavefront kernel (wave_kernel.h: coalesced
     16-byte accesses + DPP / v_permlane swaps); every size, both dtypes, both directions and norms, chunk tails (a
