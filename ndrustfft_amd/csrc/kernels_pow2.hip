@@ -106,14 +106,15 @@ int xcd_chunk_for(size_t block_bytes, int64_t nblk) {
     if (nblk < 16 * c) return 0;              // fewer than two whole groups: nothing to gain
     return (int)std::min<int64_t>(c, 1 << 20);
 }
-// Inputs larger than the 256 MiB Infinity Cache cannot be resident in it: they are loaded with the streaming (nt)
+// Inputs well beyond the 256 MiB Infinity Cache (> 384 MiB) cannot be resident in it: they are loaded with the streaming (nt)
 // policy (cache-cold 2 GiB arrays: +3 % alone, +8..12 % together with the XCD map).  Smaller inputs keep the default
 // policy: if their producer left them in the Infinity Cache plain loads are up to 15 % faster (4096 x 4096 c128:
-// 0.86 vs 0.74 of the roofline), if not they cost 6 % (0.70 vs 0.74) -- the asymmetric bet.  NDFFT_STREAM_LOADS=0/1 forces it.
+// 0.86 vs 0.74 of the roofline), if not they cost 6 % (0.70 vs 0.74) -- the asymmetric bet; a 268 MB input that the bench loop
+// re-reads (cfg3-B) still ran 88 us with plain loads vs 99 us streaming, hence the margin above 256 MiB.  NDFFT_STREAM_LOADS=0/1 forces it.
 bool stream_loads_for(size_t in_bytes) {
     static const int force = [] { const char *e = getenv("NDFFT_STREAM_LOADS"); return e ? atoi(e) : -1; }();
     if (force >= 0) return force != 0;
-    return in_bytes > ((size_t)256 << 20);
+    return in_bytes > ((size_t)384 << 20);
 }
 
 template <typename T, int N, int NT, int VEC, int FL = 0> static int launch_inst(const Pow2Args &a0, hipStream_t s) {
