@@ -728,7 +728,7 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
                 a.elem_in = P.xs; a.elem_out = P.ys;
                 const size_t es_in = (op_in_cplx(P.op) ? 2 : 1) * real_size(plan->dtype);
                 a.vec_in = !col && ((uintptr_t)d_in % 16 == 0) && ((size_t)a.pitch_in * es_in) % 16 == 0;
-                a.xcd_remap = 0; a.keep_out = P.keep_out; a.stream_in = P.stream_in;
+                a.xcd_remap = 0; a.keep_out = P.keep_out; a.stream_in = P.stream_in; a.xcd_chunk = -1;
                 const size_t es_out = (op_out_cplx(P.op) ? 2 : 1) * real_size(plan->dtype);
                 a.vec_out = !col && ((uintptr_t)d_out % 16 == 0) && ((size_t)a.pitch_out * es_out) % 16 == 0;
             };

@@ -1,5 +1,8 @@
 // kernels_pow2_real.hip -- instantiations + launcher of the register-resident real-op kernels
 // (see pow2_real.h).  F = inner complex FFT length.
+#include <algorithm>
+#include <cstdlib>
+
 #include "pow2_real.h"
 
 namespace ndfft {
@@ -57,7 +60,19 @@ template <typename K, typename T> static int launch_k(const RealArgs<T> &a, int 
     const int64_t nblk = (a.nlanes + lpb - 1) / lpb;
     if (nblk <= 0) return NDFFT_OK;
     if (nblk > 0x7fffffffLL) return fail(NDFFT_ERR_UNSUPPORTED, "too many lanes for one launch");
-    hipLaunchKernelGGL((k_pow2_real<K, T>), dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, a);
+    RealArgs<T> b = a;
+    if (b.xcd_chunk < 0) {   // -1: the caller leaves the choice to the launcher
+        if (a.inner > 1) {
+            // column tiles: consecutive tiles are adjacent pieces of the SAME rows; 4 per XCD run (1 KiB of every row) measured
+            // +3 % on cfg4' warm, +1 % cold, 16 / 64 nothing (profiles/r02n_xcd_map_real_kernels.txt); row kernels: neutral at n = 512
+            static const int col = [] { const char *e = getenv("NDFFT_XCD_CHUNK_COL"); return e ? atoi(e) : 4; }();
+            b.xcd_chunk = nblk >= 16 * (int64_t)std::max(col, 1) ? col : 0;
+        } else {
+            const size_t esz = sizeof(T) * (K::IN_CPLX ? 2 : 1);
+            b.xcd_chunk = xcd_chunk_for((size_t)lpb * (size_t)a.n_in * esz, nblk);
+        }
+    }
+    hipLaunchKernelGGL((k_pow2_real<K, T>), dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, b);
     NDFFT_HIP(hipGetLastError());
     return NDFFT_OK;
 }

@@ -43,6 +43,7 @@ template <typename T> struct RealArgs {
     const cpx<T> *chirp, *bhat;          // Bluestein kernels (blue_kernel.h): e^{-i pi j^2/F}, FFT_M(conj chirp)/M
     int32_t keep_out;                    // COL kernels: 1 = plain (cache-allocating) stores instead of non-temporal ones: the
                                          // output is an intermediate that the next launch re-reads from the Infinity Cache
+    int32_t xcd_chunk = 0;               // non-XCD kernels: XCD-aware workgroup -> tile map (device_common.h: xcd_block), 0 = identity
     int32_t stream_in = 0;               // COL kernels: 1 = streaming (nt) loads of the input: it is read once and must not
                                          // push the intermediate of a two-stage route out of the Infinity Cache
 };
@@ -142,6 +143,7 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
         extern __shared__ __attribute__((aligned(16))) char smem[];
         const int t = threadIdx.x % TPL, ll = threadIdx.x / TPL;
         int64_t tile = blockIdx.x;
+        if constexpr (!XCD) tile = xcd_block(blockIdx.x, gridDim.x, a.xcd_chunk);
         if constexpr (XCD) {
             const int64_t nb64 = (int64_t)gridDim.x & ~(int64_t)63;
             if (a.xcd_remap && tile < nb64) {   // b = 8 q + x  ->  tile = 8 (8 (q / 8) + x) + q % 8
