@@ -73,6 +73,18 @@ struct WaveArgs {
     int32_t xcd_chunk;        // XCD-aware workgroup -> chunk map (xcd_block below), 0 = identity
 };
 
+// arguments of the thread-per-lane kernel for very short C2C lanes (tiny_kernel.h)
+struct TinyArgs {
+    const void *in; void *out;
+    int64_t nlanes;
+    int64_t inner;                     // lane L = (o, i) = (L / inner, L % inner)
+    int64_t outer_in, outer_out;       // stride of o (elements)
+    int64_t lane_in, lane_out;         // stride of i
+    int64_t elem_in, elem_out;         // stride of the element index j
+    int32_t inverse;
+    double scale;
+};
+
 // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8; MI355X_MICROARCH.md).  With the identity map every
 // XCD touches every eighth lane of the array: 8 interleaved streams per 512 KiB of addresses, and every XCD's L2 /
 // TLB sees every page.  xcd_block() hands XCD x, out of each group of 8 C consecutive lane blocks, the C CONTIGUOUS

@@ -169,6 +169,10 @@ bool stream_loads_for(size_t in_bytes);                // input larger than the 
 bool wave_supported(int n);
 int launch_wave(int dtype, int n, const WaveArgs &a, hipStream_t s);
 
+// kernels_tiny.hip : one thread per lane, C2C n = 2..13, 16 (tiny_kernel.h)
+bool tiny_supported(int n);
+int launch_tiny(int dtype, int n, bool stage, const TinyArgs &a, hipStream_t s);
+
 // kernels_pow2_real.hip : register-resident real-op kernels (R2C/C2R/DCT) for power-of-two inner FFT length F
 bool pow2_real_supported(int F);
 void pow2_real_build_twiddles(int F, HostTable &out);

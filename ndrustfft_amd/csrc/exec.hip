@@ -354,6 +354,12 @@ static bool fourstep2_enabled() {
     return !(e && e[0] == '0');
 }
 
+// developer / test switch: NDFFT_TINY=0 keeps very short lanes on the LDS kernel (read per call)
+static bool tiny_enabled() {
+    const char *e = getenv("NDFFT_TINY");
+    return !(e && e[0] == '0');
+}
+
 // developer switch: NDFFT_BLUE=0 keeps Bluestein lengths on the LDS kernel
 static bool blue_enabled() {
     const char *e = getenv("NDFFT_BLUE");
@@ -627,6 +633,25 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
         a.inverse = P.op == NDFFT_OP_C2C_INV; a.scale = P.scale; a.tw = dt->cfg[CFG_MAIN].wave_tw; a.xcd_chunk = 0;
         set_last_path("wave_reg");
         return launch_wave(plan->dtype, (int)plan->n, a, stream);
+    }
+    // very short C2C lanes (n = 2..13, 16) that the wavefront kernel did not take: one thread per lane (tiny_kernel.h).
+    // Column layouts (adjacent lanes contiguous) are coalesced as they are; dense rows are staged through LDS.
+    if (plan->kind == NDFFT_KIND_C2C && tiny_supported((int)plan->n) && P.b.size() <= 2 && tiny_enabled()) {
+        const int n = (int)plan->n;
+        const bool rows = P.xs == 1 && P.ys == 1 && P.b.size() <= 1;
+        const bool dense = rows && (P.b.empty() || (P.b[0].sin == n && P.b[0].sout == n));
+        const bool cols = !P.b.empty() && P.b.back().sin == 1 && P.b.back().sout == 1;
+        {
+            TinyArgs a;
+            a.in = d_in; a.out = d_out; a.nlanes = P.nlanes; a.inverse = P.op == NDFFT_OP_C2C_INV; a.scale = P.scale;
+            a.elem_in = P.xs; a.elem_out = P.ys;
+            a.inner = P.b.empty() ? 1 : P.b.back().shape;
+            a.lane_in = P.b.empty() ? 0 : P.b.back().sin; a.lane_out = P.b.empty() ? 0 : P.b.back().sout;
+            a.outer_in = P.b.size() == 2 ? P.b[0].sin : 0; a.outer_out = P.b.size() == 2 ? P.b[0].sout : 0;
+            const bool stage = dense;   // 256 lanes x (n | 1) elements of LDS: at most 68 KiB (n = 16, f64)
+            set_last_path(stage ? "tiny_row" : cols ? "tiny_col" : "tiny_strided");
+            return launch_tiny(plan->dtype, n, stage, a, stream);
+        }
     }
     // tuned path: contiguous power-of-two C2C lanes at a uniform pitch
     if (plan->kind == NDFFT_KIND_C2C && plan->cfg[CFG_MAIN].pow2 && P.xs == 1 && P.ys == 1 && P.b.size() <= 1) {

@@ -259,6 +259,28 @@ def host_pipeline_pageable(L, shapes=None):
     assert_close(y, yo, 1, 1e-10, "host path, padded rows"); assert np.all(yb[:, 1024:] == 9.0)
 
 
+def tiny_lanes(L):
+    """C2C lanes of 2..13 and 16 points on the thread-per-lane kernel: dense rows (LDS-staged), strided axes with adjacent
+    lanes contiguous (middle / first axis of C-layout arrays), F-layout and stepped views (direct), both directions and
+    norms, workgroup tails -- including n = 6, the length of the reference's own unit tests (src/lib.rs:903-1406)."""
+    seen = set()
+    for rdt in (np.float64, np.float32):
+        for n in (2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 16):
+            for name in ("ndfft", "ndifft"):
+                seen.add(run_case(L, name, (300, n, 70), 1, rdt, offset=n))            # middle axis: tiny_col (n < 12) / jit_col
+                seen.add(run_case(L, name, (n, 1000), 0, rdt, norm="None", offset=n))  # first axis
+                if n & (n - 1):                                                        # (dense power-of-two rows: wave kernel)
+                    seen.add(run_case(L, name, (777, n), 1, rdt, offset=3 * n))        # dense rows: tiny_row (n < 12)
+                seen.add(run_case(L, name, (40, n), 1, rdt, layout="F"))               # F layout: lanes strided, neighbours n apart
+            x = synth.complex_array((50, 2 * n + 3), cdt_of(rdt))[:, 1:2 * n + 1:2]    # stepped lanes, padded rows
+            y = np.zeros((50, n), cdt_of(rdt)); yo = np.zeros_like(y)
+            h, o = handlers_for("ndfft", n, rdt, L)
+            api.ndfft(x, y, h, 1); orc.ndfft(np.ascontiguousarray(x), yo, o, 1)
+            seen.add(L.last_path())
+            assert_close(y, yo, 1, TOL[np.dtype(rdt)], f"tiny stepped n={n}")
+    assert {"tiny_col", "tiny_row", "tiny_strided"} <= seen, seen
+
+
 def wave_short_lanes(L):
     """Dense C2C lanes of n = 2..64 (powers of two) run on the LDS-free wavefront kernel (wave_kernel.h: coalesced
     16-byte accesses + DPP / v_permlane swaps); every size, both dtypes, both directions and norms, chunk tails (a
@@ -281,7 +303,12 @@ def wave_short_lanes(L):
     try:
         for rdt in (np.float64, np.float32):
             assert run_case(L, "ndfft", (37, 64), 1, rdt) == "pow2_reg"
-            assert run_case(L, "ndifft", (37, 16), 1, rdt) == "generic_row"
+            assert run_case(L, "ndifft", (37, 16), 1, rdt) == "tiny_row"
+            os.environ["NDFFT_TINY"] = "0"
+            try:
+                assert run_case(L, "ndifft", (37, 16), 1, rdt) == "generic_row"
+            finally:
+                del os.environ["NDFFT_TINY"]
     finally:
         if old is None: del os.environ["NDFFT_WAVE"]
         else: os.environ["NDFFT_WAVE"] = old

@@ -163,6 +163,20 @@ def main():
                 rows = (1 << 24) // n
                 x = torch.from_numpy(synth.complex_array((rows, n), cdt)).to(dev); y = torch.empty_like(x)
                 run(f"small ndfft axis=1 {rows}x{n} {np.dtype(cdt).name}", ndfft, x, y, FftHandler(n, rdt), 1, x.numel(), a.steps)
+    if want("smallcol"):
+        # short lanes along a STRIDED axis (middle axis of a 3-D array, adjacent lanes contiguous)
+        for rdt, cdt in ((np.float64, np.complex128), (np.float32, np.complex64)):
+            for n in (2, 3, 4, 6, 8, 11, 12, 13, 16, 32, 64):
+                outer = (1 << 24) // (n * 4096)
+                x = torch.from_numpy(synth.complex_array((outer, n, 4096), cdt)).to(dev); y = torch.empty_like(x)
+                run(f"smallcol ndfft axis=1 {outer}x{n}x4096 {np.dtype(cdt).name}", ndfft, x, y, FftHandler(n, rdt), 1, x.numel(), a.steps)
+    if want("tinyrow"):
+        # very short NON-power-of-two dense lanes (and n = 16 padded): the thread-per-lane kernel, LDS-staged
+        for rdt, cdt in ((np.float64, np.complex128), (np.float32, np.complex64)):
+            for n in (3, 5, 6, 7, 9, 10, 11, 12, 13):
+                rows = (1 << 24) // n
+                x = torch.from_numpy(synth.complex_array((rows, n), cdt)).to(dev); y = torch.empty_like(x)
+                run(f"tinyrow ndfft axis=1 {rows}x{n} {np.dtype(cdt).name}", ndfft, x, y, FftHandler(n, rdt), 1, x.numel(), a.steps)
     if want("pow2sweep"):
         for rdt, cdt in ((np.float64, np.complex128), (np.float32, np.complex64)):
             for n in (64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384):
