@@ -83,6 +83,7 @@ struct TinyArgs {
     int64_t elem_in, elem_out;         // stride of the element index j
     int32_t inverse;
     double scale;
+    const void *mat = nullptr;         // tinymat_kernel.h: the transform as a dense real matrix, NO x NI, row-major
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8; MI355X_MICROARCH.md).  With the identity map every

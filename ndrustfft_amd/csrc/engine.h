@@ -75,6 +75,8 @@ struct FftConfig {                 // one complex-FFT-of-length-F recipe + op ta
     HostTable twp;                 // per-pass transposed twiddles
     HostTable twp_col;             // C2C slot only: twiddles in the radix order of the column kernel (pow2_real.h)
     HostTable twp_narrow;          // twiddles in the radix order of the narrow (XCD-aware) column kernel
+    HostTable tinymat[4];          // MAIN slot, n = 2..16: the real-data transforms as dense real matrices (tinymat_kernel.h);
+                                   // R2C plans: [0] R2C, [1] C2R; DCT plans: [0..3] DCT-I..IV; stored two reals per (re, im) entry
     HostTable wave_tw;             // C2C slot, n = 2..64 power of two: W_n^k, k < n, for the wavefront kernel (wave_kernel.h)
     // long lanes (one lane does not fit LDS): four-step F = F1 * F2 on top of the row kernels
     bool big = false; int F1 = 0, F2 = 0, logB = 0;
@@ -98,6 +100,7 @@ struct DevConfig {                 // device copies (typed by dtype) of one FftC
     void *twlo = nullptr, *twhi = nullptr, *twp_col = nullptr, *twp_narrow = nullptr;
     void *cs_twlo = nullptr, *cs_twhi = nullptr;
     void *wave_tw = nullptr;
+    void *tinymat[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 enum ConfigSlot { CFG_MAIN = 0, CFG_DCT1 = 1, CFG_DCT4 = 2, CFG_COUNT = 3 };
@@ -172,6 +175,11 @@ int launch_wave(int dtype, int n, const WaveArgs &a, hipStream_t s);
 // kernels_tiny.hip : one thread per lane, C2C n = 2..13, 16 (tiny_kernel.h)
 bool tiny_supported(int n);
 int launch_tiny(int dtype, int n, bool stage, const TinyArgs &a, hipStream_t s);
+
+// kernels_tinymat_f32/f64.hip : one thread per lane, R2C / C2R / DCT-I..IV of n = 2..16 as a dense matrix (tinymat_kernel.h)
+// shape: 0 = R2C, 1 = C2R, 2 = DCT
+int launch_tinymat_f32(int n, int shape, bool stage, const TinyArgs &a, hipStream_t s);
+int launch_tinymat_f64(int n, int shape, bool stage, const TinyArgs &a, hipStream_t s);
 
 // kernels_pow2_real.hip : register-resident real-op kernels (R2C/C2R/DCT) for power-of-two inner FFT length F
 bool pow2_real_supported(int F);

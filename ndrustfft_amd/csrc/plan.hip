@@ -241,10 +241,56 @@ static void build_plan_tables(ndfft_plan *p) {
     }
 }
 
+// The real-data transforms of a very short lane as dense real matrices (tinymat_kernel.h), NO x NI row-major, in long double.
+// Unnormalised, exactly the lane methods' definitions; the scalar of the normalisation is applied by the kernel.
+static void push_real_matrix(HostTable &t, const std::vector<long double> &m) {
+    for (size_t i = 0; i < m.size(); i += 2) { t.re.push_back(m[i]); t.im.push_back(i + 1 < m.size() ? m[i + 1] : 0.0L); }
+}
+static void build_tiny_mats(ndfft_plan *p) {
+    const int n = (int)p->n;
+    if (n < 2 || n > 16 || p->kind == NDFFT_KIND_C2C) return;
+    FftConfig &c = p->cfg[CFG_MAIN];
+    auto cs = [&](unsigned long long num, unsigned long long den, bool sine) {   // cos / sin of 2 pi num / den, argument reduced in integers
+        num %= den;
+        const long double ang = 2.0L * kPiL * (long double)num / (long double)den;
+        return sine ? sinl(ang) : cosl(ang);
+    };
+    if (p->kind == NDFFT_KIND_R2C) {
+        const int m = n / 2 + 1;
+        std::vector<long double> f((size_t)2 * m * n), b((size_t)n * 2 * m, 0.0L);
+        for (int k = 0; k < m; ++k)
+            for (int j = 0; j < n; ++j) {
+                const long double co = cs((unsigned long long)j * k, n, false), si = cs((unsigned long long)j * k, n, true);
+                f[(size_t)(2 * k) * n + j] = co;                       // X[k] = sum x[j] e^{-2 pi i jk/n}   (lib.rs:497-503)
+                f[(size_t)(2 * k + 1) * n + j] = -si;
+                // x[j] = sum over the Hermitian-extended spectrum; imaginary parts of DC and Nyquist are dropped (lib.rs:516-521)
+                const bool edge = k == 0 || (n % 2 == 0 && k == n / 2);
+                const long double w = edge ? 1.0L : 2.0L;
+                b[(size_t)j * 2 * m + 2 * k] = w * co;
+                b[(size_t)j * 2 * m + 2 * k + 1] = edge ? 0.0L : -w * si;
+            }
+        push_real_matrix(c.tinymat[0], f); push_real_matrix(c.tinymat[1], b);
+        return;
+    }
+    std::vector<long double> d1((size_t)n * n), d2((size_t)n * n), d3((size_t)n * n), d4((size_t)n * n);
+    for (int k = 0; k < n; ++k)
+        for (int j = 0; j < n; ++j) {
+            // DCT-I: y[k] = x[0]/2 + (-1)^k x[n-1]/2 + sum_{0<j<n-1} x[j] cos(pi jk/(n-1))            (lib.rs:688-698)
+            if (j == 0) d1[(size_t)k * n + j] = 0.5L;
+            else if (j == n - 1) d1[(size_t)k * n + j] = (k % 2 ? -0.5L : 0.5L);
+            else d1[(size_t)k * n + j] = cs((unsigned long long)j * k, 2ull * (n - 1), false);
+            d2[(size_t)k * n + j] = cs((unsigned long long)k * (2 * j + 1), 4ull * n, false);            // cos(pi k(2j+1)/(2n))
+            d3[(size_t)k * n + j] = j == 0 ? 0.5L : cs((unsigned long long)j * (2 * k + 1), 4ull * n, false);
+            d4[(size_t)k * n + j] = cs((unsigned long long)(2 * j + 1) * (2 * k + 1), 8ull * n, false);  // cos(pi(2j+1)(2k+1)/(4n))
+        }
+    push_real_matrix(c.tinymat[0], d1); push_real_matrix(c.tinymat[1], d2); push_real_matrix(c.tinymat[2], d3); push_real_matrix(c.tinymat[3], d4);
+}
+
 static ndfft_plan *make_plan(int kind, int dtype, size_t n) {
     ndfft_plan *p = new ndfft_plan();
     p->kind = kind; p->dtype = dtype; p->n = n; p->refcount = 1;
     build_plan_tables(p);
+    build_tiny_mats(p);
     add_narrow_tables(p);
     add_colsplit(p);
     return p;
@@ -331,6 +377,7 @@ int get_dev_tables(const ndfft_plan *cplan, const DevTables **out) {
         if ((rc = upload_any(plan->dtype, c.twp_col, &d.twp_col))) return rc;
         if ((rc = upload_any(plan->dtype, c.twp_narrow, &d.twp_narrow))) return rc;
         if ((rc = upload_any(plan->dtype, c.wave_tw, &d.wave_tw))) return rc;
+        for (int q = 0; q < 4; ++q) if ((rc = upload_any(plan->dtype, c.tinymat[q], &d.tinymat[q]))) return rc;
     }
     auto ins = plan->dev.emplace(dev, t);
     *out = &ins.first->second;
@@ -395,7 +442,7 @@ int ndfft_plan_destroy(ndfft_plan *plan) {
         (void)hipSetDevice(kv.first);
         for (int i = 0; i < CFG_COUNT; ++i) {
             DevConfig &d = kv.second.cfg[i];
-            void *ptrs[] = {d.tw, d.twM, d.chirp, d.bhat, d.aux1, d.aux2, d.twp, d.twlo, d.twhi, d.twp_col, d.twp_narrow, d.cs_twlo, d.cs_twhi, d.wave_tw};
+            void *ptrs[] = {d.tw, d.twM, d.chirp, d.bhat, d.aux1, d.aux2, d.twp, d.twlo, d.twhi, d.twp_col, d.twp_narrow, d.cs_twlo, d.cs_twhi, d.wave_tw, d.tinymat[0], d.tinymat[1], d.tinymat[2], d.tinymat[3]};
             for (void *q : ptrs) if (q) (void)hipFree(q);
         }
     }

@@ -172,7 +172,10 @@ def layouts(L):
             seen.add(run_case(L, name, (3, 4, 9), 2, rdt))               # strategy (i), 3-D (rows() flattens)
             seen.add(run_case(L, name, (6, 9), 1, rdt, layout="F"))      # strategy (iii)
             seen.add(run_case(L, name, (6, 9), 0, rdt, layout="F"))      # strategy (iii), contiguous lanes
-    assert {"generic_row", "generic_col"} <= seen, seen
+            seen.add(run_case(L, name, (5, 20), 1, rdt))                 # beyond the thread-per-lane kernels (n <= 16): LDS kernel
+            seen.add(run_case(L, name, (20, 5), 0, rdt))
+            seen.add(run_case(L, name, (4, 21, 3), 1, rdt, layout="F"))
+    assert {"generic_row", "generic_col", "tiny_row", "tiny_col", "tinymat_row", "tinymat_col"} <= seen, seen
     # negative strides, stepped views, broadcast (stride 0) input, non-dense output view
     x = synth.complex_array((4, 8, 6))
     h = handlers.FftHandler(8, _library=L); o = orc.FftHandler(8)
@@ -279,6 +282,35 @@ def tiny_lanes(L):
             seen.add(L.last_path())
             assert_close(y, yo, 1, TOL[np.dtype(rdt)], f"tiny stepped n={n}")
     assert {"tiny_col", "tiny_row", "tiny_strided"} <= seen, seen
+
+
+def tinymat_lanes(L):
+    """R2C / C2R / DCT-I..IV on lanes of 2..16 points (thread-per-lane, the transform as a dense matrix): every op and n,
+    both dtypes, None / Default norms, dense rows, strided axes, F layout, stepped views, workgroup tails."""
+    seen = set()
+    for rdt in (np.float64, np.float32):
+        for n in range(2, 17):
+            for name in ("ndfft_r2c", "ndifft_r2c", "nddct1", "nddct2", "nddct3", "nddct4"):
+                for norm in ("Default", "None"):
+                    seen.add(run_case(L, name, (300, n), 1, rdt, norm=norm, offset=n))
+                seen.add(run_case(L, name, (9, n, 70), 1, rdt, offset=2 * n))
+                seen.add(run_case(L, name, (n, 300), 0, rdt, norm="None"))
+                seen.add(run_case(L, name, (33, n), 1, rdt, layout="F"))
+        # stepped input lanes, padded output rows
+        x = synth.real_array((40, 2 * 12 + 1), rdt)[:, ::2][:, :12]; yb = np.full((40, 16), 3.0, rdt); y = yb[:, 2:14]; yo = np.zeros((40, 12), rdt)
+        h, o = handlers_for("nddct2", 12, rdt, L)
+        api.nddct2(x, y, h, 1); orc.nddct2(np.ascontiguousarray(x), yo, o, 1)
+        seen.add(L.last_path())
+        assert_close(y, yo, 1, TOL[np.dtype(rdt)], "tinymat stepped"); assert np.all(yb[:, :2] == 3.0) and np.all(yb[:, 14:] == 3.0)
+    assert {"tinymat_row", "tinymat_col", "tinymat_strided"} <= seen, seen
+    # the DC / Nyquist imaginary parts of a C2R input are ignored (lib.rs:516-521), n even and odd
+    for n in (6, 7):
+        m = n // 2 + 1
+        z = synth.complex_array((5, m)); z2 = z.copy(); z2[:, 0] = z2[:, 0].real + 7j
+        if n % 2 == 0: z2[:, -1] = z2[:, -1].real - 3j
+        a = np.zeros((5, n)); b = np.zeros((5, n)); h = handlers.R2cFftHandler(n, _library=L)
+        api.ndifft_r2c(z, a, h, 1); api.ndifft_r2c(z2, b, h, 1)
+        assert np.array_equal(a, b)
 
 
 def wave_short_lanes(L):

@@ -177,6 +177,17 @@ def main():
                 rows = (1 << 24) // n
                 x = torch.from_numpy(synth.complex_array((rows, n), cdt)).to(dev); y = torch.empty_like(x)
                 run(f"tinyrow ndfft axis=1 {rows}x{n} {np.dtype(cdt).name}", ndfft, x, y, FftHandler(n, rdt), 1, x.numel(), a.steps)
+    if want("tinyreal"):
+        # real-data transforms on very short lanes: thread-per-lane, the transform as a dense matrix (tinymat_kernel.h)
+        for n in (4, 6, 8, 9, 12, 16):
+            rows = (1 << 25) // n
+            x = torch.from_numpy(synth.real_array((rows, n))).to(dev); y = torch.empty_like(x)
+            run(f"tinyreal nddct2 axis=1 {rows}x{n} f64", nddct2, x, y, DctHandler(n), 1, x.numel(), a.steps)
+            xc = torch.from_numpy(synth.real_array((rows // 4096, n, 4096))).to(dev); yc = torch.empty_like(xc)
+            run(f"tinyreal nddct2 axis=1 {rows // 4096}x{n}x4096 f64", nddct2, xc, yc, DctHandler(n), 1, xc.numel(), a.steps)
+            xf = torch.from_numpy(synth.real_array((rows, n), np.float32)).to(dev); w = torch.empty((rows, n // 2 + 1), dtype=torch.complex64, device=dev)
+            run(f"tinyreal ndfft_r2c axis=1 {rows}x{n} f32", ndfft_r2c, xf, w, R2cFftHandler(n, np.float32), 1, xf.numel(), a.steps)
+            run(f"tinyreal ndifft_r2c axis=1 -> {rows}x{n} f32", ndifft_r2c, w, xf, R2cFftHandler(n, np.float32), 1, xf.numel(), a.steps)
     if want("pow2sweep"):
         for rdt, cdt in ((np.float64, np.complex128), (np.float32, np.complex64)):
             for n in (64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384):
