@@ -700,6 +700,7 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
         const int rcj = launch_jit_c2c(plan->dtype, plan->cfg[CFG_MAIN].jitcfg, nt, a, stream);
         if (rcj == NDFFT_OK) { set_last_path("jit_reg"); return NDFFT_OK; }
         if (rcj != NDFFT_ERR_UNSUPPORTED) return rcj;   // a real HIP error; UNSUPPORTED = no hiprtc / compile failed -> LDS kernel
+        if (getenv("NDFFT_JIT_VERBOSE")) fprintf(stderr, "ndfft: jit_reg declined n = %zu\n", plan->n);
     }
     // tuned paths on the register-resident real-op engine (pow2_real.h), power-of-two inner FFT:
     //   row: R2C / C2R / DCT on contiguous lanes;  col: the same ops AND C2C on a strided axis whose
@@ -1179,15 +1180,19 @@ int ndfft_exec(const ndfft_plan *plan, int op, const void *in, void *out, int nd
         const int64_t isp = inner_span(ndim, shape_in, stride_in), osp = inner_span(ndim, shape_out, stride_out);
         if (isp > 0 && osp > 0 && stride_in[0] >= isp && stride_out[0] >= osp) {
             const char *e = getenv("NDFFT_PIPE_CHUNKS");
+            // a chunk must stay a real problem: kernel choice depends on the size of a call (hiprtc specialisation from 2^16-2^17
+            // points), so never cut below 2^18 points per chunk
+            const int64_t max_chunks = std::max<int64_t>(1, (P.nlanes * std::max(P.xlen, P.ylen)) >> 18);
             if (is_pinned(in) && is_pinned(out)) {
-                const int chunks = (int)std::min<int64_t>(shape_in[0], e ? std::max(1, atoi(e)) : 8);
+                const int chunks = (int)std::min<int64_t>(std::min<int64_t>(shape_in[0], max_chunks), e ? std::max(1, atoi(e)) : 8);
                 return exec_pinned_pipeline(ws, plan, op, hin, hout, ndim, shape_in, stride_in, shape_out, stride_out, axis, norm, scale, ein, eout, chunks);
             }
             const char *hp = getenv("NDFFT_HOST_PIPE");
-            if (!(hp && hp[0] == '0')) {
+            const bool force = hp && hp[0] == '1';            // tests: pipeline small calls too
+            if (force || (!(hp && hp[0] == '0') && max_chunks >= 4 && ibytes + obytes >= ((size_t)32 << 20))) {   // small calls: the plain path
                 // chunks of ~32 MiB per direction (at least 4, at most 64)
                 const int64_t want = std::max<int64_t>(4, std::min<int64_t>(64, (int64_t)(std::max(ibytes, obytes) >> 25)));
-                const int chunks = (int)std::min<int64_t>(shape_in[0], e ? std::max(1, atoi(e)) : want);
+                const int chunks = (int)std::min<int64_t>(std::min<int64_t>(shape_in[0], force ? 64 : max_chunks), e ? std::max(1, atoi(e)) : want);
                 return exec_bounce_pipeline(ws, plan, op, hin, hout, ndim, shape_in, stride_in, shape_out, stride_out, axis, norm, scale, ein, eout, chunks);
             }
         }

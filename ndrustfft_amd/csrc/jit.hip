@@ -254,7 +254,14 @@ static Entry compile_entry(const std::string &src, const std::string &what) {
     std::string code;
     if (ok) { size_t cs = 0; ok = r.code_size(prog, &cs) == 0 && cs > 0; if (ok) { code.resize(cs); ok = r.code(prog, &code[0]) == 0; } }
     if (prog) r.destroy(&prog);
-    if (ok) ok = hipModuleLoadData(&ne.mod, code.data()) == hipSuccess && hipModuleGetFunction(&ne.fn, ne.mod, "k_jit") == hipSuccess;
+    if (ok) {
+        const hipError_t e1 = hipModuleLoadData(&ne.mod, code.data());
+        const hipError_t e2 = e1 == hipSuccess ? hipModuleGetFunction(&ne.fn, ne.mod, "k_jit") : e1;
+        ok = e2 == hipSuccess;
+        if (!ok && getenv("NDFFT_JIT_VERBOSE")) fprintf(stderr, "ndfft jit: loading %s failed: %s\n", what.c_str(), hipGetErrorString(e2));
+    } else if (getenv("NDFFT_JIT_VERBOSE")) {
+        fprintf(stderr, "ndfft jit: no code object for %s (hiprtc %s)\n", what.c_str(), r.ok ? "present" : "missing");
+    }
     if (ok) { const std::string path = cache_path(src, hs, 6); if (!path.empty()) write_file_atomic(path, code); }
     if (!ok) { (void)hipGetLastError(); ne.failed = true; }
     return ne;
@@ -306,10 +313,10 @@ int launch_jit_c2c(int dtype, const JitCfg &cfg, int nt, const Pow2Args &a, hipS
     const std::string src = "#include \"pow2_kernel.h\"\nusing namespace ndfft;\nextern \"C\" __global__ __launch_bounds__(" +
                             std::to_string(threads) + ") void k_jit(const Pow2Args a) { " + inst + "::run(a); }\n";
     const Entry e = get_or_compile("dev" + std::to_string(dev) + ":" + inst, src, inst);
-    if (e.failed) return NDFFT_ERR_UNSUPPORTED;
+    if (e.failed) { if (getenv("NDFFT_JIT_VERBOSE")) fprintf(stderr, "ndfft jit: %s unavailable\n", inst.c_str()); return NDFFT_ERR_UNSUPPORTED; }
     const size_t esz = dtype == NDFFT_F32 ? 4 : 8;
     const size_t lds = (size_t)cfg.lpb * (size_t)(cfg.n + (cfg.n >> 4) + 1) * esz * (half ? 1 : 2);   // Pow2Kernel::LDS_BYTES
-    if (lds > jit_lds_limit()) return NDFFT_ERR_UNSUPPORTED;
+    if (lds > jit_lds_limit()) { if (getenv("NDFFT_JIT_VERBOSE")) fprintf(stderr, "ndfft jit: %s needs %zu B of LDS\n", inst.c_str(), lds); return NDFFT_ERR_UNSUPPORTED; }
     const int64_t nblk = (a.nlanes + cfg.lpb - 1) / cfg.lpb;
     if (nblk <= 0) return NDFFT_OK;
     if (nblk > 0x7fffffffLL) return NDFFT_ERR_UNSUPPORTED;

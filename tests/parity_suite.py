@@ -245,7 +245,11 @@ def host_pipeline_pageable(L, shapes=None):
         odt = cdt_of(rdt) if OPS[name][4] else np.dtype(rdt)
         h, o = handlers_for(name, shape[axis], rdt, L)
         y1 = np.zeros(sout, odt); y2 = np.zeros(sout, odt); yo = np.zeros(sout, odt)
-        OPS[name][0](x, y1, h, axis)
+        os.environ["NDFFT_HOST_PIPE"] = "1"                      # force the pipeline whatever the size
+        try:
+            OPS[name][0](x, y1, h, axis)
+        finally:
+            del os.environ["NDFFT_HOST_PIPE"]
         os.environ["NDFFT_HOST_PIPE"] = "0"
         try:
             OPS[name][0](x, y2, h, axis)
@@ -257,7 +261,12 @@ def host_pipeline_pageable(L, shapes=None):
     # rows with padding between them (stride[0] > row length) on both sides
     xb = synth.complex_array((600, 1100)); x = xb[:, :1024]
     yb = np.full((600, 1030), 9.0 + 0j); y = yb[:, :1024]
-    h = handlers.FftHandler(1024, _library=L); api.ndfft(x, y, h, 1)
+    h = handlers.FftHandler(1024, _library=L)
+    os.environ["NDFFT_HOST_PIPE"] = "1"
+    try:
+        api.ndfft(x, y, h, 1)
+    finally:
+        del os.environ["NDFFT_HOST_PIPE"]
     yo = np.zeros((600, 1024), np.complex128); orc.ndfft(np.ascontiguousarray(x), yo, orc.FftHandler(1024), 1)
     assert_close(y, yo, 1, 1e-10, "host path, padded rows"); assert np.all(yb[:, 1024:] == 9.0)
 
