@@ -127,6 +127,61 @@ def spawn_ranks(ngpu):
     return rc
 
 
+def xgmi_block(dist, torch, dev, rank, ngpu, n, ndfft, FftHandler, sync_all, prow=2048, side_per_rank=1024, m=1024):
+    """N > 1: the data movement of SURVEY 8e / 8f rank 3 over xGMI (never part of `value`: lanes that are born sharded need
+    none of it).  Root scatter and gather of batch slices (point-to-point groups, one slice per link) and the all-to-all
+    re-shard between the two axis passes of a sharded fft2; GB/s per link against the ~153 GB/s an xGMI link carries, and a
+    correctness check of each.  Every rank makes the same sequence of collective calls (tests/test_distributed.py runs this
+    function at world size 2 on gloo with the oracle as the executor)."""
+    import numpy as np
+    import synth
+    from ndrustfft_amd import distributed as nd_dist
+    out = {}
+    gshape = (prow * ngpu, n)                                             # prow rows per rank: 2048 x 4096 c128 = 128 MiB per link
+    full = synth.complex_array_torch(gshape, dev) if rank == 0 else None
+
+    def best(fn, reps=3):
+        ts = []; r = None
+        for _ in range(reps):
+            sync_all(); t0 = time.perf_counter(); r = fn(); sync_all(); ts.append(time.perf_counter() - t0)
+        t = torch.tensor([min(ts)], device=dev, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0]), r
+    link_bytes = prow * n * 16
+    h = FftHandler(n)
+    t_sc, shard = best(lambda: nd_dist.scatter_lanes(full, gshape, torch.complex128, 1, 0, dev))
+    yl = torch.empty_like(shard); ndfft(shard, yl, h, 1)
+    t_ga, gathered = best(lambda: nd_dist.gather_lanes(yl, gshape, 0, 0))
+    ok = True
+    if rank == 0:
+        ref = np.fft.fft(synth.complex_array((2, n), offset=(gshape[0] - 2) * n), axis=1)     # the last rank's last two lanes
+        ok = bool(np.abs(gathered[-2:].cpu().numpy() - ref).max() / np.abs(ref).max() < 1e-10)
+    out["scatter"] = {"bytes_per_link": link_bytes, "links": ngpu - 1, "ms": round(t_sc * 1e3, 3), "GBs_per_link": round(link_bytes / t_sc / 1e9, 1)}
+    out["gather"] = {"bytes_per_link": link_bytes, "links": ngpu - 1, "ms": round(t_ga * 1e3, 3), "GBs_per_link": round(link_bytes / t_ga / 1e9, 1),
+                     "scatter_transform_gather_matches_numpy": ok}
+    del full, gathered
+    # all-to-all: re-shard an (N side) x (N side) c128 array from row slabs to column slabs
+    side = side_per_rank * ngpu
+    slab = synth.complex_array_torch((side // ngpu, side), dev, offset=rank * (side // ngpu) * side)
+    t_a2a, cols = best(lambda: nd_dist.reshard(slab, (side, side), 0, 1))
+    pair_bytes = (side // ngpu) * (side // ngpu) * 16
+    back = nd_dist.reshard(cols, (side, side), 1, 0)
+    out["all_to_all_reshard"] = {"array": f"{side}x{side} c128", "bytes_per_pair": pair_bytes, "ms": round(t_a2a * 1e3, 3),
+                                 "GBs_per_link": round(pair_bytes / t_a2a / 1e9, 1), "round_trip_exact": bool(torch.equal(back, slab))}
+    # sharded fft2 (axis 1, all-to-all, axis 0) against numpy on an m x m array
+    a_full = synth.complex_array((m, m))
+    lo, hi = nd_dist.shard_bounds(m, ngpu)[rank]
+    hm = FftHandler(m)
+    yl2, gsh, dsh = nd_dist.transform_axes_sharded([(ndfft, hm, 1, m, torch.complex128), (ndfft, hm, 0, m, torch.complex128)],
+                                                   torch.from_numpy(a_full[lo:hi]).to(dev), (m, m), 0)
+    ref2 = np.fft.fft2(a_full)
+    clo, chi = nd_dist.shard_bounds(m, ngpu)[rank]
+    err2 = np.abs(yl2.cpu().numpy() - ref2[:, clo:chi]).max() / np.abs(ref2).max()
+    e = torch.tensor([err2], device=dev, dtype=torch.float64); dist.all_reduce(e, op=dist.ReduceOp.MAX)
+    out["sharded_fft2_rel_err"] = float(e[0])
+    out["peak_GBs_per_link"] = 153.0
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -326,51 +381,7 @@ def main():
     xgmi = None
     if use_dist and ngpu > 1 and not args.no_xgmi:
         try:
-            from ndrustfft_amd import distributed as nd_dist
-            xgmi = {}
-            prow = 2048                                                  # rows per rank: 2048 x 4096 c128 = 128 MiB per link
-            gshape = (prow * ngpu, n)
-            full = synth.complex_array_torch(gshape, dev) if rank == 0 else None
-
-            def best(fn, reps=3):
-                ts = []
-                for _ in range(reps):
-                    sync_all(); t0 = time.perf_counter(); r = fn(); sync_all(); ts.append(time.perf_counter() - t0)
-                t = torch.tensor([min(ts)], device=dev, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                return float(t[0]), r
-            link_bytes = prow * n * 16
-            t_sc, shard = best(lambda: nd_dist.scatter_lanes(full, gshape, torch.complex128, 1, 0, dev))
-            yl = torch.empty_like(shard); ndfft(shard, yl, h, 1)
-            t_ga, gathered = best(lambda: nd_dist.gather_lanes(yl, gshape, 0, 0))
-            ok = True
-            if rank == 0:
-                ref = np.fft.fft(synth.complex_array((2, n), offset=(gshape[0] - 2) * n), axis=1)     # the last rank's last two lanes
-                ok = bool(np.abs(gathered[-2:].cpu().numpy() - ref).max() / np.abs(ref).max() < 1e-10)
-            xgmi["scatter"] = {"bytes_per_link": link_bytes, "links": ngpu - 1, "ms": round(t_sc * 1e3, 3), "GBs_per_link": round(link_bytes / t_sc / 1e9, 1)}
-            xgmi["gather"] = {"bytes_per_link": link_bytes, "links": ngpu - 1, "ms": round(t_ga * 1e3, 3), "GBs_per_link": round(link_bytes / t_ga / 1e9, 1),
-                              "scatter_transform_gather_matches_numpy": ok}
-            del full, gathered
-            # all-to-all: re-shard an (N 1024) x 4096... square-ish c128 array from row slabs to column slabs
-            side = 1024 * ngpu
-            slab = synth.complex_array_torch((side // ngpu, side), dev, offset=rank * (side // ngpu) * side)
-            t_a2a, cols = best(lambda: nd_dist.reshard(slab, (side, side), 0, 1))
-            pair_bytes = (side // ngpu) * (side // ngpu) * 16
-            back = nd_dist.reshard(cols, (side, side), 1, 0)
-            xgmi["all_to_all_reshard"] = {"array": f"{side}x{side} c128", "bytes_per_pair": pair_bytes, "ms": round(t_a2a * 1e3, 3),
-                                          "GBs_per_link": round(pair_bytes / t_a2a / 1e9, 1), "round_trip_exact": bool(torch.equal(back, slab))}
-            # sharded fft2 (axis 1, all-to-all, axis 0) against numpy on a 1024 x 1024 array
-            m = 1024
-            a_full = synth.complex_array((m, m))
-            lo, hi = nd_dist.shard_bounds(m, ngpu)[rank]
-            hm = FftHandler(m)
-            yl2, gsh, dsh = nd_dist.transform_axes_sharded([(ndfft, hm, 1, m, torch.complex128), (ndfft, hm, 0, m, torch.complex128)],
-                                                           torch.from_numpy(a_full[lo:hi]).to(dev), (m, m), 0)
-            ref2 = np.fft.fft2(a_full)
-            clo, chi = nd_dist.shard_bounds(m, ngpu)[rank]
-            err2 = np.abs(yl2.cpu().numpy() - ref2[:, clo:chi]).max() / np.abs(ref2).max()
-            e = torch.tensor([err2], device=dev, dtype=torch.float64); dist.all_reduce(e, op=dist.ReduceOp.MAX)
-            xgmi["sharded_fft2_1024_rel_err"] = float(e[0])
-            xgmi["peak_GBs_per_link"] = 153.0
+            xgmi = xgmi_block(dist, torch, dev, rank, ngpu, n, ndfft, FftHandler, sync_all)
         except Exception as ex:                                           # never lose the bench line to this side measurement
             xgmi = {"error": repr(ex)[:300]}
 

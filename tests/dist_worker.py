@@ -106,6 +106,19 @@ def main():
         for w in (1, 2, 3, 8):
             b = nd_dist.shard_bounds(ext, w)
             assert b[0][0] == 0 and b[-1][1] == ext and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+    # bench.py's N > 1 side measurement (scatter / gather / all-to-all / sharded fft2): the same function, world size 2 on gloo,
+    # the oracle as the executor -- every rank must make the same sequence of collective calls, and the checks must hold
+    import bench
+    def sync_all():
+        dist.barrier()
+    class H:                                               # FftHandler stand-in: bench passes it to ndfft only
+        def __init__(self, n): self.h = orc.FftHandler(n)
+    def ndfft_o(x, y, handler, axis):
+        wrap(orc.ndfft)(x, y, handler.h, axis)
+    xg = bench.xgmi_block(dist, torch, torch.device("cpu"), rank, world, 64, ndfft_o, H, sync_all, prow=8, side_per_rank=16, m=32)
+    if rank == 0:
+        print("xgmi block:", xg)
+    ok &= xg["gather"]["scatter_transform_gather_matches_numpy"] and xg["all_to_all_reshard"]["round_trip_exact"] and xg["sharded_fft2_rel_err"] < 1e-12
     if rank == 0:
         print("DIST_OK" if ok else "DIST_FAIL")
     dist.destroy_process_group()
