@@ -33,6 +33,7 @@ struct Problem {
     double scale;
     int keep_out = 0;            // column kernels: cache-allocating stores (the output is re-read right away, col_split)
     int stream_in = 0;           // column kernels: streaming loads (the input must not evict a cache-resident intermediate)
+    int no_xcd_map = 0;          // column kernels: identity workgroup -> tile map (the stages of col_split: the map cost 7-20 us there)
 };
 
 static size_t real_size(int dtype) { return dtype == NDFFT_F32 ? 4 : 8; }
@@ -422,7 +423,7 @@ static int col_split(const Problem &P, const void *d_in, void *d_out, const FftC
         a.cs_twlo = (const cpx<T> *)d.cs_twlo; a.cs_twhi = (const cpx<T> *)d.cs_twhi; a.cs_logB = c.cs_logB;
         a.cs_k1n = K1; a.cs_f1 = F1; a.cs_n = (int)P.plan->n; a.cs_outer_in = sin_o; a.cs_outer_out = sout_o; a.cs_pitch = I;
         Problem Q;
-        Q.plan = c.cs_sub1; Q.nlanes = O * F2 * Cc; Q.scale = 1.0;
+        Q.plan = c.cs_sub1; Q.nlanes = O * F2 * Cc; Q.scale = 1.0; Q.no_xcd_map = 1;
         if (!c2r) {
             // A: column transform of length F1 over a = row / F2; lanes (b, i)
             Q.op = P.op; Q.xlen = F1; Q.ylen = K1; Q.xs = (int64_t)F2 * I; Q.ys = (int64_t)F2 * Cc;
@@ -774,7 +775,7 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
                 a.elem_in = P.xs; a.elem_out = P.ys;
                 const size_t es_in = (op_in_cplx(P.op) ? 2 : 1) * real_size(plan->dtype);
                 a.vec_in = !col && ((uintptr_t)d_in % 16 == 0) && ((size_t)a.pitch_in * es_in) % 16 == 0;
-                a.xcd_remap = 0; a.keep_out = P.keep_out; a.stream_in = P.stream_in; a.xcd_chunk = -1;
+                a.xcd_remap = 0; a.keep_out = P.keep_out; a.stream_in = P.stream_in; a.xcd_chunk = P.no_xcd_map ? 0 : -1;
                 const size_t es_out = (op_out_cplx(P.op) ? 2 : 1) * real_size(plan->dtype);
                 a.vec_out = !col && ((uintptr_t)d_out % 16 == 0) && ((size_t)a.pitch_out * es_out) % 16 == 0;
             };

@@ -82,9 +82,13 @@ template <typename K, typename T> static int launch_k(const RealArgs<T> &a, int 
 #endif
 // threads of a COL workgroup: aim at 32 adjacent lanes per tile row, at most 1024 threads
 static constexpr int col_threads(int tpl, int lanes) { return tpl * lanes > 1024 ? 1024 : (tpl * lanes < 256 ? 256 : tpl * lanes); }
-template <typename T, int F> struct ColGeom {
+// Rows of a column tile should be 256 bytes wide: tools/tilecopy.hip (profiles/r02t_tilecopy.txt) copies 128-row tiles whose
+// rows are 2 MiB apart -- the column four-step's first stage on cfg3-A -- at 0.56-0.62 of 8 TB/s with 128-byte rows, 0.71-0.74
+// with 256-byte rows, 0.68-0.71 with 512.  f32 REAL data (4 bytes per lane) therefore takes 64 lanes per tile where the
+// tile still fits (REAL = the op reads or writes real lanes); everything else keeps 32 lanes (256 B for c64 / f64, 512 B for c128).
+template <typename T, int F, bool REAL = false> struct ColGeom {
     static constexpr int TPL = RealCfg<F>::TPL;
-    static constexpr int WANT = sizeof(T) == 4 ? NDFFT_COL_LANES_F32 : 32;   // f32 rows of a real tile are 4 B per lane
+    static constexpr int WANT = (sizeof(T) == 4 && REAL) ? 2 * NDFFT_COL_LANES_F32 : (sizeof(T) == 4 ? NDFFT_COL_LANES_F32 : 32);
     static constexpr int LPB = col_threads(TPL, WANT) / TPL;
     static constexpr size_t LDS = (size_t)LPB * (((F + (F >> 4) + 2) | 1)) * 2 * sizeof(T);
     static constexpr bool OK = LPB >= 8 && LDS <= 160 * 1024;
@@ -168,8 +172,9 @@ template <typename T, int F, int OP> static int launch_real_one(const RealArgs<T
             return launch_k<RealPow2Kernel<T, F, TPL, LPB, typename RealCfg<F>::RL, OP, false>, T>(a, LPB, s);
         }
     }
-    if constexpr (ColGeom<T, F>::OK) {
-        constexpr int LPB = ColGeom<T, F>::LPB;
+    constexpr bool REAL = !(OP == G_C2C_FWD || OP == G_C2C_INV);   // the op reads or writes real lanes (cfg3-A 210 -> 202 us, cfg3-A' 259 -> 235 us)
+    if constexpr (ColGeom<T, F, REAL>::OK) {
+        constexpr int LPB = ColGeom<T, F, REAL>::LPB;
         return launch_k<RealPow2Kernel<T, F, TPL, LPB, typename RealCfg<F>::RL, OP, true>, T>(a, LPB, s);
     } else {
         return fail(NDFFT_ERR_UNSUPPORTED, "pow2 real kernel: no column tile for this F");

@@ -88,6 +88,11 @@ def main():
         x = torch.from_numpy(synth.real_array((n, n), np.float32)).to(dev)
         w = torch.empty((m, n), dtype=torch.complex64, device=dev)
         run("cfg3A ndfft_r2c axis=0 8192x8192 f32", ndfft_r2c, x, w, R2cFftHandler(n, np.float32), 0, n * n, a.steps)
+    if a.only == "cfg3Ap_only":
+        n = 8192; m = n // 2 + 1
+        w = torch.from_numpy(synth.complex_array((m, n), np.complex64)).to(dev)
+        x = torch.empty((n, n), dtype=torch.float32, device=dev)
+        run("cfg3A' ndifft_r2c axis=0 -> 8192x8192 f32", ndifft_r2c, w, x, R2cFftHandler(n, np.float32), 0, n * n, a.steps)
     if want("cfg4"):
         x = torch.from_numpy(synth.real_array((256, 256, 512))).to(dev); y = torch.empty_like(x)
         h = DctHandler(512)
