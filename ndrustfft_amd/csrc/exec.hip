@@ -1089,14 +1089,11 @@ static int exec_bounce_pipeline_body(DeviceWs &ws, const ndfft_plan *plan, int o
     for (int it = 0; it < chunks + 2; ++it) {
         const int cu = it, cd = it - 2;
         const bool up = cu < chunks && bytes_in(cu) > 0, dn = cd >= 0 && bytes_out(cd) > 0;
-        if (up) {
-            if (cu >= 3) NDFFT_HIP(hipEventSynchronize(pp.up[cu - 3]));        // the slot's previous upload has left it
-            pool.copy_async(gu, (char *)ws.bounce_in[cu % 3].p, hin + off_in(cu), bytes_in(cu), half);
-        }
-        if (dn) {
-            NDFFT_HIP(hipEventSynchronize(pp.down[cd]));                          // chunk cd has arrived in its slot
-            pool.copy_async(gd, hout + off_out(cd), (const char *)ws.bounce_out[cd % 3].p, bytes_out(cd), half);
-        }
+        // (both waits BEFORE any pool copy is submitted: an error return must never leave the pool working on gu / gd)
+        if (up && cu >= 3) NDFFT_HIP(hipEventSynchronize(pp.up[cu - 3]));      // the slot's previous upload has left it
+        if (dn) NDFFT_HIP(hipEventSynchronize(pp.down[cd]));                    // chunk cd has arrived in its slot
+        if (up) pool.copy_async(gu, (char *)ws.bounce_in[cu % 3].p, hin + off_in(cu), bytes_in(cu), half);
+        if (dn) pool.copy_async(gd, hout + off_out(cd), (const char *)ws.bounce_out[cd % 3].p, bytes_out(cd), half);
         if (up) CopyPool::wait(gu);
         if (dn) CopyPool::wait(gd);
         if (!up) continue;

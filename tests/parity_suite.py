@@ -386,6 +386,23 @@ def sharded_exec(L, device_ids, torch_device=None):
         # F-layout: the outermost dimension in memory is the LAST index
         xf = np.asfortranarray(synth.complex_array((16, 10))); yf = np.zeros((16, 10), np.complex128, order="F"); yo = np.zeros((16, 10), np.complex128)
         api.ndfft_par(xf, yf, h, 0); orc.ndfft(np.ascontiguousarray(xf), yo, o, 0); assert_close(yf, yo, 0, 1e-10, "sharded F layout")
+        # several host threads issue sharded calls at once: their blocks interleave on the per-device workers
+        import threading
+        xs = [synth.complex_array((64, 128), offset=1000 * k) for k in range(4)]
+        ys = [np.zeros((64, 128), np.complex128) for _ in range(4)]
+        h128 = handlers.FftHandler(128, _library=L); errs = []
+        def work(k):
+            try:
+                for _ in range(5):
+                    api.ndfft_par(xs[k], ys[k], h128, 1)
+            except Exception as e:          # pragma: no cover
+                errs.append(e)
+        ts = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+        [t.start() for t in ts]; [t.join() for t in ts]
+        assert not errs, errs
+        for k in range(4):
+            yo = np.zeros((64, 128), np.complex128); orc.ndfft(xs[k], yo, orc.FftHandler(128), 1)
+            assert_close(ys[k], yo, 1, 1e-10, f"concurrent sharded calls, thread {k}")
         # the reference's panics come out before any device starts
         import pytest
         with pytest.raises(_lib.Panic, match="Size mismatch in fft, got 15 expected 16"):
