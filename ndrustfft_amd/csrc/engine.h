@@ -219,6 +219,10 @@ bool jit_choose(int dtype, int n, JitCfg &cfg, bool allow_partial = false);
 void jit_build_twiddles(const JitCfg &cfg, HostTable &out);
 int launch_jit_c2c(int dtype, const JitCfg &cfg, int nt, const Pow2Args &a, hipStream_t s);
 int jit_col_lanes(int dtype, const JitCfg &cfg);
+// thread-per-lane two-factor kernels (reg_kernel.h), specialised with hiprtc
+bool regfft_factor(int n, int *n1, int *n2);
+int regfft_max_n(int dtype);
+int launch_jit_regfft(int dtype, int n1, int n2, bool stage, const TinyArgs &a, hipStream_t s);
 template <typename T> int launch_jit_real(int gen_op, const JitCfg &cfg, bool col, const RealArgs<T> &a, hipStream_t s);
 
 // transpose.hip : batched LDS-padded 2-D transpose, elem size 4/8/16 bytes

@@ -626,7 +626,7 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
     const ndfft_plan *plan = P.plan;
     // short dense power-of-two C2C lanes (n = 2..64): the LDS-free wavefront kernel -- coalesced 16-byte accesses and
     // cross-lane shuffles (wave_kernel.h).  NDFFT_WAVE=0 keeps the older paths (parity tests cover both).
-    if (plan->kind == NDFFT_KIND_C2C && dt->cfg[CFG_MAIN].wave_tw && P.xs == 1 && P.ys == 1 && P.b.size() <= 1 &&
+    if (plan->kind == NDFFT_KIND_C2C && wave_supported((int)plan->n) && dt->cfg[CFG_MAIN].wave_tw && P.xs == 1 && P.ys == 1 && P.b.size() <= 1 &&
         (P.b.empty() || (P.b[0].sin == (int64_t)plan->n && P.b[0].sout == (int64_t)plan->n)) &&
         (uintptr_t)d_in % 16 == 0 && (uintptr_t)d_out % 16 == 0 && wave_enabled()) {
         WaveArgs a;
@@ -652,6 +652,30 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
             const bool stage = dense;   // 256 lanes x (n | 1) elements of LDS: at most 68 KiB (n = 16, f64)
             set_last_path(stage ? "tiny_row" : cols ? "tiny_col" : "tiny_strided");
             return launch_tiny(plan->dtype, n, stage, a, stream);
+        }
+    }
+    // C2C lanes of 14 .. 64 (f64) / 96 (f32) points that factor into two butterflies: one thread per lane, two passes in
+    // registers (reg_kernel.h), specialised with hiprtc; only worth a compile when there is real work
+    if (plan->kind == NDFFT_KIND_C2C && plan->n >= 14 && (int)plan->n <= regfft_max_n(plan->dtype) && dt->cfg[CFG_MAIN].wave_tw &&
+        P.b.size() <= 2 && P.nlanes * (int64_t)plan->n >= (1 << 16) && tiny_enabled() && !tiny_supported((int)plan->n)) {
+        int n1, n2;
+        if (regfft_factor((int)plan->n, &n1, &n2)) {
+            const int n = (int)plan->n;
+            const bool rows = P.xs == 1 && P.ys == 1 && P.b.size() <= 1;
+            const bool dense = rows && (P.b.empty() || (P.b[0].sin == n && P.b[0].sout == n));
+            const bool cols = !P.b.empty() && P.b.back().sin == 1 && P.b.back().sout == 1;
+            if ((dense && n <= 63) || (cols && !dense)) {          // rows beyond 63 points: the general register kernel is faster
+                TinyArgs a;
+                a.in = d_in; a.out = d_out; a.nlanes = P.nlanes; a.inverse = P.op == NDFFT_OP_C2C_INV; a.scale = P.scale;
+                a.mat = dt->cfg[CFG_MAIN].wave_tw;
+                a.elem_in = P.xs; a.elem_out = P.ys;
+                a.inner = P.b.empty() ? 1 : P.b.back().shape;
+                a.lane_in = P.b.empty() ? 0 : P.b.back().sin; a.lane_out = P.b.empty() ? 0 : P.b.back().sout;
+                a.outer_in = P.b.size() == 2 ? P.b[0].sin : 0; a.outer_out = P.b.size() == 2 ? P.b[0].sout : 0;
+                const int rcj = launch_jit_regfft(plan->dtype, n1, n2, dense, a, stream);
+                if (rcj == NDFFT_OK) { set_last_path(dense ? "reg_row" : "reg_col"); return NDFFT_OK; }
+                if (rcj != NDFFT_ERR_UNSUPPORTED) return rcj;
+            }
         }
     }
     // the real-data transforms on very short lanes (n = 2..16): one thread per lane, the transform as a dense matrix

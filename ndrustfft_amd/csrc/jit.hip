@@ -227,8 +227,8 @@ static Entry compile_entry(const std::string &src, const std::string &what) {
     Rtc &r = rtc();
     Entry ne;
     {   // a code object compiled by an earlier process?
-        const char *hs0[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h, jit_src_realops_h, jit_src_pow2_real_h, jit_src_blue_kernel_h};
-        const std::string path = cache_path(src, hs0, 6);
+        const char *hs0[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h, jit_src_realops_h, jit_src_pow2_real_h, jit_src_blue_kernel_h, jit_src_reg_kernel_h};
+        const std::string path = cache_path(src, hs0, 7);
         std::string code;
         if (!path.empty() && read_file(path, code) && hipModuleLoadData(&ne.mod, code.data()) == hipSuccess &&
             hipModuleGetFunction(&ne.fn, ne.mod, "k_jit") == hipSuccess)
@@ -239,10 +239,10 @@ static Entry compile_entry(const std::string &src, const std::string &what) {
             if (e[0] == '1') { ne.failed = true; return ne; }
         }
     }
-    const char *hn[] = {"device_common.h", "butterflies.h", "pow2_kernel.h", "realops.h", "pow2_real.h", "blue_kernel.h"};
-    const char *hs[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h, jit_src_realops_h, jit_src_pow2_real_h, jit_src_blue_kernel_h};
+    const char *hn[] = {"device_common.h", "butterflies.h", "pow2_kernel.h", "realops.h", "pow2_real.h", "blue_kernel.h", "reg_kernel.h"};
+    const char *hs[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h, jit_src_realops_h, jit_src_pow2_real_h, jit_src_blue_kernel_h, jit_src_reg_kernel_h};
     rtcProgram prog = nullptr;
-    bool ok = r.ok && r.create(&prog, src.c_str(), "k_jit.hip", 6, hs, hn) == 0;
+    bool ok = r.ok && r.create(&prog, src.c_str(), "k_jit.hip", 7, hs, hn) == 0;
     if (ok) {
         ok = r.compile(prog, 4, (const char **)kJitOpts) == 0;
         if (!ok && getenv("NDFFT_JIT_VERBOSE")) {
@@ -262,7 +262,7 @@ static Entry compile_entry(const std::string &src, const std::string &what) {
     } else if (getenv("NDFFT_JIT_VERBOSE")) {
         fprintf(stderr, "ndfft jit: no code object for %s (hiprtc %s)\n", what.c_str(), r.ok ? "present" : "missing");
     }
-    if (ok) { const std::string path = cache_path(src, hs, 6); if (!path.empty()) write_file_atomic(path, code); }
+    if (ok) { const std::string path = cache_path(src, hs, 7); if (!path.empty()) write_file_atomic(path, code); }
     if (!ok) { (void)hipGetLastError(); ne.failed = true; }
     return ne;
 }
@@ -324,6 +324,52 @@ int launch_jit_c2c(int dtype, const JitCfg &cfg, int nt, const Pow2Args &a, hipS
     arg.xcd_chunk = xcd_chunk_for((size_t)cfg.lpb * cfg.n * 2 * esz, nblk);
     void *params[] = {(void *)&arg};
     NDFFT_HIP(hipModuleLaunchKernel(e.fn, (unsigned)nblk, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, s, params, nullptr));
+    return NDFFT_OK;
+}
+
+// ---- thread-per-lane two-factor kernels (reg_kernel.h) ---------------------------------------------------------------
+// n = n1 * n2 with both factors in {2..13, 16}; the most balanced pair (fewest multiply-adds).  false: no such pair.
+bool regfft_factor(int n, int *n1, int *n2) {
+    auto ok = [](int r) { return (r >= 2 && r <= 13) || r == 16 || r == 17 || r == 19 || r == 23 || r == 29 || r == 31; };
+    if (n > 16 && ok(n)) { *n1 = n; *n2 = 1; return true; }      // a prime with its own butterfly
+    int best = 0;
+    for (int a = 2; a * a <= n; ++a)
+        if (n % a == 0 && ok(a) && ok(n / a)) best = a;
+    if (!best) return false;
+    *n1 = n / best; *n2 = best;          // n1 >= n2
+    return true;
+}
+// largest n whose lane fits the registers of one thread with room for the butterflies (2 / 4 VGPRs per complex element)
+int regfft_max_n(int dtype) {
+    // measured (profiles/r03c_reg_kernel_sweep.txt): dense rows win up to n = 63 in both precisions (0.80 -> 0.50 of 8 TB/s; the
+    // general register kernel takes over from n = 72: 0.65-0.86); strided axes up to 63 (f64: 0.73-0.86, n = 64 has its tile
+    // kernel) and 96 (f32: 0.70-0.85 against 0.49-0.75)
+    static const int f32 = [] { const char *e = getenv("NDFFT_REG_MAX_F32"); return e ? atoi(e) : 96; }();
+    static const int f64 = [] { const char *e = getenv("NDFFT_REG_MAX_F64"); return e ? atoi(e) : 63; }();
+    return dtype == NDFFT_F32 ? f32 : f64;
+}
+int launch_jit_regfft(int dtype, int n1, int n2, bool stage, const TinyArgs &a, hipStream_t s) {
+    if (!rtc().ok) return NDFFT_ERR_UNSUPPORTED;
+    const int n = n1 * n2;
+    const size_t esz = dtype == NDFFT_F32 ? 8 : 16;
+    int lanes = 256;
+    if (stage) while (lanes > 64 && (size_t)lanes * (size_t)(n | 1) * esz > (size_t)64 * 1024) lanes >>= 1;
+    if (stage && (size_t)lanes * (size_t)(n | 1) * esz > jit_lds_limit()) return NDFFT_ERR_UNSUPPORTED;
+    int dev = 0;
+    NDFFT_HIP(hipGetDevice(&dev));
+    const char *tn = dtype == NDFFT_F32 ? "float" : "double";
+    const std::string inst = std::string("RegFft2<") + tn + ", " + std::to_string(n1) + ", " + std::to_string(n2) + ", " + std::to_string(lanes) + ", " + (stage ? "true" : "false") + ">";
+    const std::string src = std::string("#include \"reg_kernel.h\"\nusing namespace ndfft;\nextern \"C\" __global__ __launch_bounds__(") +
+                            std::to_string(lanes) + ") void k_jit(const TinyArgs a) { " + inst + "::run(a); }\n";
+    const Entry e = get_or_compile("dev" + std::to_string(dev) + ":" + inst, src, inst);
+    if (e.failed) return NDFFT_ERR_UNSUPPORTED;
+    const int64_t nblk = (a.nlanes + lanes - 1) / lanes;
+    if (nblk <= 0) return NDFFT_OK;
+    if (nblk > 0x7fffffffLL) return NDFFT_ERR_UNSUPPORTED;
+    const size_t lds = stage ? (size_t)lanes * (size_t)(n | 1) * esz : 0;
+    TinyArgs arg = a;
+    void *params[] = {(void *)&arg};
+    NDFFT_HIP(hipModuleLaunchKernel(e.fn, (unsigned)nblk, 1, 1, (unsigned)lanes, 1, 1, (unsigned)lds, s, params, nullptr));
     return NDFFT_OK;
 }
 

@@ -194,7 +194,7 @@ static void build_plan_tables(ndfft_plan *p) {
         build_fft(m, n, p->dtype);
         if (pow2_supported(p->dtype, n)) { m.pow2 = true; pow2_build_twiddles(p->dtype, n, m.twp); }
         if (pow2_real_supported(n)) pow2_real_build_twiddles(n, m.twp_col);
-        if (wave_supported(n)) for (int k = 0; k < n; ++k) unit(m.wave_tw, k, n);   // W_n^k
+        if (wave_supported(n) || n <= 128) for (int k = 0; k < n; ++k) unit(m.wave_tw, k, n);   // W_n^k: wavefront and thread-per-lane kernels
         if (!m.pow2 && !m.blue && jit_choose(p->dtype, n, m.jitcfg, true)) { m.jit = true; jit_build_twiddles(m.jitcfg, m.twp); }
         p->has_cfg[CFG_MAIN] = true;
     } else if (p->kind == NDFFT_KIND_R2C) {

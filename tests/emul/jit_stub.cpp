@@ -4,6 +4,7 @@
 // hiprtc for any M; see ndrustfft_amd/csrc/jit.hip: launch_jit_blue).
 #include "engine.h"
 #include "blue_kernel.h"
+#include "reg_kernel.h"
 namespace ndfft {
 // two PARTIAL-round configurations of the C2C row kernel (pow2_kernel.h: slots / full) instantiated ahead of
 // time, so that the predicated passes are exercised on the CPU: 264 = 11.8.3 on 12 threads, 210 = 7.6.5 on 14
@@ -90,4 +91,34 @@ template <typename T> int launch_jit_blue(int gop, const JitCfg &cfg, bool col, 
 }
 template int launch_jit_blue<float>(int, const JitCfg &, bool, const RealArgs<float> &, hipStream_t);
 template int launch_jit_blue<double>(int, const JitCfg &, bool, const RealArgs<double> &, hipStream_t);
+
+// thread-per-lane kernels (reg_kernel.h): 18 = 6 x 3, 30 = 6 x 5, 40 = 8 x 5 and the prime 23 instantiated ahead of time for the CPU tests
+bool regfft_factor(int n, int *n1, int *n2) {
+    if (n == 18) { *n1 = 6; *n2 = 3; return true; }
+    if (n == 30) { *n1 = 6; *n2 = 5; return true; }
+    if (n == 40) { *n1 = 8; *n2 = 5; return true; }
+    if (n == 23) { *n1 = 23; *n2 = 1; return true; }
+    return false;
+}
+int regfft_max_n(int) { return 64; }
+template <typename K> __global__ void k_reg_emul(const TinyArgs a) { K::run(a); }
+template <typename T, int N1, int N2, int LANES, bool STAGE> static int reg_one(const TinyArgs &a, hipStream_t s) {
+    using K = RegFft2<T, N1, N2, LANES, STAGE>;
+    hipLaunchKernelGGL((k_reg_emul<K>), dim3((unsigned)((a.nlanes + LANES - 1) / LANES)), dim3(K::THREADS), K::LDS_BYTES, s, a);
+    return NDFFT_OK;
+}
+template <typename T, int N1, int N2> static int reg_n(bool stage, const TinyArgs &a, hipStream_t s) {
+    if (!stage) return reg_one<T, N1, N2, 256, false>(a, s);
+    int lanes = 256;
+    while (lanes > 64 && (size_t)lanes * ((N1 * N2) | 1) * sizeof(cpx<T>) > (size_t)64 * 1024) lanes >>= 1;
+    return lanes == 256 ? reg_one<T, N1, N2, 256, true>(a, s) : lanes == 128 ? reg_one<T, N1, N2, 128, true>(a, s) : reg_one<T, N1, N2, 64, true>(a, s);
+}
+int launch_jit_regfft(int dtype, int n1, int n2, bool stage, const TinyArgs &a, hipStream_t s) {
+    if (a.nlanes <= 0) return NDFFT_OK;
+    if (n1 == 6 && n2 == 3) return dtype == NDFFT_F32 ? reg_n<float, 6, 3>(stage, a, s) : reg_n<double, 6, 3>(stage, a, s);
+    if (n1 == 6 && n2 == 5) return dtype == NDFFT_F32 ? reg_n<float, 6, 5>(stage, a, s) : reg_n<double, 6, 5>(stage, a, s);
+    if (n1 == 8 && n2 == 5) return dtype == NDFFT_F32 ? reg_n<float, 8, 5>(stage, a, s) : reg_n<double, 8, 5>(stage, a, s);
+    if (n1 == 23 && n2 == 1) return dtype == NDFFT_F32 ? reg_n<float, 23, 1>(stage, a, s) : reg_n<double, 23, 1>(stage, a, s);
+    return NDFFT_ERR_UNSUPPORTED;
+}
 }

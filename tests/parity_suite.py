@@ -293,6 +293,20 @@ def tiny_lanes(L):
     assert {"tiny_col", "tiny_row", "tiny_strided"} <= seen, seen
 
 
+def reg_lanes(L, sizes=(14, 15, 17, 18, 19, 20, 21, 23, 24, 28, 29, 30, 31, 34, 36, 38, 40, 45, 46, 48, 49, 51, 56, 57, 58, 60, 62, 63), sizes_f32=(70, 72, 80, 90, 96), want=True):
+    """C2C lanes of 14..64 (f64) / 96 (f32) points that factor into two butterflies: one thread per lane, two passes in
+    registers (reg_kernel.h, hiprtc-specialised): dense rows (LDS-staged chunks, workgroup tails), strided axes, both
+    directions and norms.  `want`: the path must be taken (False where only some sizes are built, as in the CPU emulation)."""
+    for rdt in (np.float64, np.float32):
+        for n in tuple(sizes) + (tuple(sizes_f32) if rdt == np.float32 else ()):
+            rows = (1 << 16) // n + 37
+            for name, norm in (("ndfft", "Default"), ("ndifft", "Default"), ("ndifft", "None")):
+                p1 = run_case(L, name, (rows, n), 1, rdt, norm=norm, offset=n)
+                p2 = run_case(L, name, (5, n, rows // 4), 1, rdt, norm=norm, offset=2 * n)
+                if want:
+                    assert p2 == "reg_col" and (p1 == "reg_row" or n > 63), (n, rdt, p1, p2)
+
+
 def tinymat_lanes(L):
     """R2C / C2R / DCT-I..IV on lanes of 2..16 points (thread-per-lane, the transform as a dense matrix): every op and n,
     both dtypes, None / Default norms, dense rows, strided axes, F layout, stepped views, workgroup tails."""

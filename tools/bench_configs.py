@@ -193,6 +193,25 @@ def main():
             xf = torch.from_numpy(synth.real_array((rows, n), np.float32)).to(dev); w = torch.empty((rows, n // 2 + 1), dtype=torch.complex64, device=dev)
             run(f"tinyreal ndfft_r2c axis=1 {rows}x{n} f32", ndfft_r2c, xf, w, R2cFftHandler(n, np.float32), 1, xf.numel(), a.steps)
             run(f"tinyreal ndifft_r2c axis=1 -> {rows}x{n} f32", ndifft_r2c, w, xf, R2cFftHandler(n, np.float32), 1, xf.numel(), a.steps)
+    if want("midc2c"):
+        # C2C lanes of 14..100 points: thread-per-lane two-factor kernels (reg_kernel.h) vs the general register kernel
+        for rdt, cdt in ((np.float64, np.complex128), (np.float32, np.complex64)):
+            for n in (14, 17, 18, 20, 23, 24, 30, 31, 34, 36, 40, 46, 48, 56, 60, 62, 63, 64, 72, 80, 96, 100):
+                rows = (1 << 24) // n
+                x = torch.from_numpy(synth.complex_array((rows, n), cdt)).to(dev); y = torch.empty_like(x)
+                run(f"midc2c ndfft axis=1 {rows}x{n} {np.dtype(cdt).name}", ndfft, x, y, FftHandler(n, rdt), 1, x.numel(), a.steps)
+                xc = torch.from_numpy(synth.complex_array((rows // 2048, n, 2048), cdt)).to(dev); yc = torch.empty_like(xc)
+                run(f"midc2c ndfft axis=1 {rows // 2048}x{n}x2048 {np.dtype(cdt).name}", ndfft, xc, yc, FftHandler(n, rdt), 1, xc.numel(), a.steps)
+    if want("midreal"):
+        # real-data transforms on medium-short lanes (beyond the thread-per-lane kernels, below the pow2 real kernels)
+        for n in (18, 20, 24, 30, 32, 48, 64, 96, 100, 128):
+            rows = (1 << 25) // n
+            x = torch.from_numpy(synth.real_array((rows, n))).to(dev); y = torch.empty_like(x)
+            run(f"midreal nddct2 axis=1 {rows}x{n} f64", nddct2, x, y, DctHandler(n), 1, x.numel(), a.steps)
+            xf = torch.from_numpy(synth.real_array((rows, n), np.float32)).to(dev); w = torch.empty((rows, n // 2 + 1), dtype=torch.complex64, device=dev)
+            run(f"midreal ndfft_r2c axis=1 {rows}x{n} f32", ndfft_r2c, xf, w, R2cFftHandler(n, np.float32), 1, xf.numel(), a.steps)
+            xc = torch.from_numpy(synth.complex_array((rows // 2, n))).to(dev); yc = torch.empty_like(xc)
+            run(f"midreal ndfft axis=1 {rows // 2}x{n} c128", ndfft, xc, yc, FftHandler(n), 1, xc.numel(), a.steps)
     if want("pow2sweep"):
         for rdt, cdt in ((np.float64, np.complex128), (np.float32, np.complex64)):
             for n in (64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384):
