@@ -86,6 +86,12 @@ struct TinyArgs {
     const void *mat = nullptr;         // tinymat_kernel.h: the transform as a dense real matrix, NO x NI, row-major
 };
 
+// arguments of the thread-per-lane real-op register kernel (reg_kernel.h: RegReal)
+struct RegRealArgs {
+    TinyArgs t;                      // layout, scale (t.mat = W_F^k table of the inner FFT)
+    const void *aux1, *aux2;         // op tables of the plan slot (plan.hip)
+};
+
 // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8; MI355X_MICROARCH.md).  With the identity map every
 // XCD touches every eighth lane of the array: 8 interleaved streams per 512 KiB of addresses, and every XCD's L2 /
 // TLB sees every page.  xcd_block() hands XCD x, out of each group of 8 C consecutive lane blocks, the C CONTIGUOUS

@@ -223,6 +223,7 @@ int jit_col_lanes(int dtype, const JitCfg &cfg);
 bool regfft_factor(int n, int *n1, int *n2);
 int regfft_max_n(int dtype);
 int launch_jit_regfft(int dtype, int n1, int n2, bool stage, const TinyArgs &a, hipStream_t s);
+int launch_jit_regreal(int dtype, int gop, int n, int f1, int f2, bool stage, const RegRealArgs &a, hipStream_t s);
 template <typename T> int launch_jit_real(int gen_op, const JitCfg &cfg, bool col, const RealArgs<T> &a, hipStream_t s);
 
 // transpose.hip : batched LDS-padded 2-D transpose, elem size 4/8/16 bytes

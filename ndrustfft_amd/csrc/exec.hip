@@ -355,6 +355,13 @@ static bool fourstep2_enabled() {
     return !(e && e[0] == '0');
 }
 
+// largest handler length the thread-per-lane real-op register kernels take (raw lane + Z + outputs in registers)
+static int regreal_max_n(int f64) {
+    static const int m32 = [] { const char *e = getenv("NDFFT_REGREAL_MAX_F32"); return e ? atoi(e) : 72; }();   // f32 n = 64: 0.66 vs 0.50; n = 96 / 100: 0.39 / 0.37 vs 0.41 / 0.49
+    static const int m64 = [] { const char *e = getenv("NDFFT_REGREAL_MAX_F64"); return e ? atoi(e) : 48; }();   // f64 n = 48: 0.66 vs 0.30
+    return f64 ? m64 : m32;
+}
+
 // developer / test switch: NDFFT_TINY=0 keeps very short lanes on the LDS kernel (read per call)
 static bool tiny_enabled() {
     const char *e = getenv("NDFFT_TINY");
@@ -696,6 +703,35 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
             set_last_path(dense ? "tinymat_row" : cols ? "tinymat_col" : "tinymat_strided");
             const int shape = plan->kind == NDFFT_KIND_R2C ? (P.op == NDFFT_OP_R2C ? 0 : 1) : 2;
             return plan->dtype == NDFFT_F32 ? launch_tinymat_f32(n, shape, dense, a, stream) : launch_tinymat_f64(n, shape, dense, a, stream);
+        }
+    }
+    // the real-data transforms on lanes of 17 .. 48 (f64) / 72 (f32) points whose inner FFT factors into butterflies:
+    // one thread per lane, everything in registers (reg_kernel.h: RegReal), specialised with hiprtc
+    if (plan->kind != NDFFT_KIND_C2C && plan->n >= 17 && (int)plan->n <= (plan->dtype == NDFFT_F32 ? regreal_max_n(0) : regreal_max_n(1)) &&
+        P.b.size() <= 2 && P.nlanes * (int64_t)plan->n >= (1 << 16) && tiny_enabled()) {
+        const int n = (int)plan->n;
+        int slot;
+        const int gop = gen_op_of(P.op, n, &slot);
+        const FftConfig &c = plan->cfg[slot];
+        const DevConfig &d = dt->cfg[slot];
+        int f1, f2;
+        if (!c.big && d.wave_tw && regfft_factor(c.F, &f1, &f2)) {   // (c.blue does not matter: primes 17..31 have their own butterfly here)
+            const bool rows = P.xs == 1 && P.ys == 1 && P.b.size() <= 1;
+            const bool dense = rows && (P.b.empty() || (P.b[0].sin == P.xlen && P.b[0].sout == P.ylen));
+            const bool cols = !P.b.empty() && P.b.back().sin == 1 && P.b.back().sout == 1;
+            if (dense || cols) {
+                RegRealArgs ra;
+                TinyArgs &a = ra.t;
+                a.in = d_in; a.out = d_out; a.nlanes = P.nlanes; a.inverse = 0; a.scale = P.scale; a.mat = d.wave_tw;
+                a.elem_in = P.xs; a.elem_out = P.ys;
+                a.inner = P.b.empty() ? 1 : P.b.back().shape;
+                a.lane_in = P.b.empty() ? 0 : P.b.back().sin; a.lane_out = P.b.empty() ? 0 : P.b.back().sout;
+                a.outer_in = P.b.size() == 2 ? P.b[0].sin : 0; a.outer_out = P.b.size() == 2 ? P.b[0].sout : 0;
+                ra.aux1 = d.aux1; ra.aux2 = d.aux2;
+                const int rcj = launch_jit_regreal(plan->dtype, gop, n, f1, f2, dense, ra, stream);
+                if (rcj == NDFFT_OK) { set_last_path(dense ? "regreal_row" : "regreal_col"); return NDFFT_OK; }
+                if (rcj != NDFFT_ERR_UNSUPPORTED) return rcj;
+            }
         }
     }
     // tuned path: contiguous power-of-two C2C lanes at a uniform pitch

@@ -331,7 +331,7 @@ int launch_jit_c2c(int dtype, const JitCfg &cfg, int nt, const Pow2Args &a, hipS
 // n = n1 * n2 with both factors in {2..13, 16}; the most balanced pair (fewest multiply-adds).  false: no such pair.
 bool regfft_factor(int n, int *n1, int *n2) {
     auto ok = [](int r) { return (r >= 2 && r <= 13) || r == 16 || r == 17 || r == 19 || r == 23 || r == 29 || r == 31; };
-    if (n > 16 && ok(n)) { *n1 = n; *n2 = 1; return true; }      // a prime with its own butterfly
+    if (ok(n)) { *n1 = n; *n2 = 1; return true; }                // a length with its own butterfly (primes 17..31; short inner FFTs of the real ops)
     int best = 0;
     for (int a = 2; a * a <= n; ++a)
         if (n % a == 0 && ok(a) && ok(n / a)) best = a;
@@ -368,6 +368,34 @@ int launch_jit_regfft(int dtype, int n1, int n2, bool stage, const TinyArgs &a, 
     if (nblk > 0x7fffffffLL) return NDFFT_ERR_UNSUPPORTED;
     const size_t lds = stage ? (size_t)lanes * (size_t)(n | 1) * esz : 0;
     TinyArgs arg = a;
+    void *params[] = {(void *)&arg};
+    NDFFT_HIP(hipModuleLaunchKernel(e.fn, (unsigned)nblk, 1, 1, (unsigned)lanes, 1, 1, (unsigned)lds, s, params, nullptr));
+    return NDFFT_OK;
+}
+
+// RegReal (reg_kernel.h): R2C / C2R / DCT-I..IV with the whole lane in one thread's registers, inner FFT F = f1 * f2
+int launch_jit_regreal(int dtype, int gop, int n, int f1, int f2, bool stage, const RegRealArgs &a, hipStream_t s) {
+    if (!rtc().ok) return NDFFT_ERR_UNSUPPORTED;
+    const size_t rsz = dtype == NDFFT_F32 ? 4 : 8;
+    const bool in_c = gop == G_C2R_EVEN || gop == G_C2R_ODD, out_c = gop == G_R2C_EVEN || gop == G_R2C_ODD;
+    const int m2 = 2 * (n / 2 + 1), ni = in_c ? m2 : n, no = out_c ? m2 : n, pmax = std::max(ni | 1, no | 1);
+    int lanes = 256;
+    if (stage) while (lanes > 64 && (size_t)lanes * (size_t)pmax * rsz > (size_t)64 * 1024) lanes >>= 1;
+    if (stage && (size_t)lanes * (size_t)pmax * rsz > jit_lds_limit()) return NDFFT_ERR_UNSUPPORTED;
+    int dev = 0;
+    NDFFT_HIP(hipGetDevice(&dev));
+    const char *tn = dtype == NDFFT_F32 ? "float" : "double";
+    const std::string inst = std::string("RegReal<") + tn + ", " + std::to_string(gop) + ", " + std::to_string(n) + ", " + std::to_string(f1) + ", " +
+                             std::to_string(f2) + ", " + std::to_string(lanes) + ", " + (stage ? "true" : "false") + ">";
+    const std::string src = std::string("#include \"reg_kernel.h\"\nusing namespace ndfft;\nextern \"C\" __global__ __launch_bounds__(") +
+                            std::to_string(lanes) + ") void k_jit(const RegRealArgs a) { " + inst + "::run(a); }\n";
+    const Entry e = get_or_compile("dev" + std::to_string(dev) + ":" + inst, src, inst);
+    if (e.failed) return NDFFT_ERR_UNSUPPORTED;
+    const int64_t nblk = (a.t.nlanes + lanes - 1) / lanes;
+    if (nblk <= 0) return NDFFT_OK;
+    if (nblk > 0x7fffffffLL) return NDFFT_ERR_UNSUPPORTED;
+    const size_t lds = stage ? (size_t)lanes * (size_t)pmax * rsz : 0;
+    RegRealArgs arg = a;
     void *params[] = {(void *)&arg};
     NDFFT_HIP(hipModuleLaunchKernel(e.fn, (unsigned)nblk, 1, 1, (unsigned)lanes, 1, 1, (unsigned)lds, s, params, nullptr));
     return NDFFT_OK;

@@ -290,6 +290,10 @@ static ndfft_plan *make_plan(int kind, int dtype, size_t n) {
     ndfft_plan *p = new ndfft_plan();
     p->kind = kind; p->dtype = dtype; p->n = n; p->refcount = 1;
     build_plan_tables(p);
+    // W_F^k of every short inner FFT (F <= 128): twiddles of the thread-per-lane register kernels (reg_kernel.h)
+    for (int i = 0; i < CFG_COUNT; ++i)
+        if (p->has_cfg[i] && p->cfg[i].F >= 2 && p->cfg[i].F <= 128 && p->cfg[i].wave_tw.re.empty())
+            for (int k = 0; k < p->cfg[i].F; ++k) unit(p->cfg[i].wave_tw, k, p->cfg[i].F);
     build_tiny_mats(p);
     add_narrow_tables(p);
     add_colsplit(p);

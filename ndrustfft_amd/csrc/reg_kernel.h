@@ -13,6 +13,7 @@
 // accesses), a strided axis with adjacent lanes contiguous is coalesced as it is, anything else uses direct accesses.
 #pragma once
 #include "pow2_kernel.h"
+#include "realops.h"
 
 namespace ndfft {
 
@@ -121,6 +122,114 @@ template <typename T, int N1, int N2, int LANES, bool STAGE> struct RegFft2 {
             cpx<T> *out = (cpx<T> *)a.out + (L / a.inner) * a.outer_out + (L % a.inner) * a.lane_out;
 #pragma unroll
             for (int s = 0; s < N; ++s) gstore<T, true>(out + (int64_t)out_index(s) * a.elem_out, v[s]);
+        }
+    }
+};
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The REAL-DATA transforms (R2C, C2R, DCT-I..IV; even and odd n) on lanes of 17 .. ~100 points, one thread per lane:
+// raw lane -> PRE fold (realops.h, the same formulas the LDS kernels use: Hermitian fold with the reference's pre-scale and
+// DC / Nyquist zeroing lib.rs:511-521, Makhoul permutation, DCT-IV pre-twiddle, ...) -> complex FFT of length F = F1 * F2 in
+// registers (RegFft2::fft) -> POST gather (real-FFT split, post-twiddles, un-permutation) -> output lane.  Every index is a
+// compile-time constant after unrolling, so the raw lane, Z and the outputs live in registers and the op tables (aux1,
+// aux2) are read through scalar loads.  Replaces fft_r2c_lane / ifft_r2c_lane (lib.rs:497-523) and dct1..4_lane (lib.rs:688-734).
+// OP is the kernel op (device_common.h: GenOp); N the handler length; F1 * F2 = F the inner complex FFT length.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T> struct RegOpArgs { int n, F; T scale; const cpx<T> *aux1, *aux2; };
+struct RegZi { static __device__ __forceinline__ int map(int p) { return p; } };
+
+template <typename T, int OP, int N, int F1, int F2, int LANES, bool STAGE> struct RegReal {
+    static constexpr int F = F1 * F2;
+    static constexpr bool IN_CPLX = OP == G_C2R_EVEN || OP == G_C2R_ODD;
+    static constexpr bool OUT_CPLX = OP == G_R2C_EVEN || OP == G_R2C_ODD;
+    static constexpr int M = N / 2 + 1;
+    static constexpr int NI = IN_CPLX ? 2 * M : N, NO = OUT_CPLX ? 2 * M : N;   // reals per input / output lane
+    static constexpr int THREADS = LANES;
+    static constexpr int PI_ = NI | 1, PO_ = NO | 1, PMAX = PI_ > PO_ ? PI_ : PO_;
+    static constexpr size_t LDS_BYTES = STAGE ? (size_t)LANES * PMAX * sizeof(T) : 0;
+    using FFT = RegFft2<T, F1, F2, LANES, false>;
+
+    static __device__ __forceinline__ void run(const RegRealArgs &ra) {
+        extern __shared__ __attribute__((aligned(16))) char smem[];
+        const TinyArgs &a = ra.t;
+        const int64_t L = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+        const bool live = L < a.nlanes;
+        T raw[NI + 2];                                      // (+2: the odd-n C2R fold may index one complex past the half spectrum)
+        raw[NI] = (T)0; raw[NI + 1] = (T)0;
+        if constexpr (STAGE) {
+            T *lds = (T *)smem;
+            const int64_t c0 = (int64_t)blockIdx.x * THREADS * NI, total = a.nlanes * NI;
+            const T *in = (const T *)a.in + c0;
+            const int last = (int)std_min64(total - c0, (int64_t)THREADS * NI) - 1;
+#pragma unroll
+            for (int k = 0; k < NI; ++k) { const int g = threadIdx.x + k * THREADS; raw[k] = in[g < last ? g : last]; }
+#pragma unroll
+            for (int k = 0; k < NI; ++k) { const int g = threadIdx.x + k * THREADS; lds[(g / NI) * PI_ + g % NI] = raw[k]; }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < NI; ++j) raw[j] = lds[threadIdx.x * PI_ + j];
+            __syncthreads();
+        } else {
+            const int64_t Ls = live ? L : 0;
+            const int64_t base = (Ls / a.inner) * a.outer_in + (Ls % a.inner) * a.lane_in;
+            if constexpr (IN_CPLX) {
+                const cpx<T> *in = (const cpx<T> *)a.in + base;
+#pragma unroll
+                for (int j = 0; j < M; ++j) { const cpx<T> c = in[(int64_t)j * a.elem_in]; raw[2 * j] = c.x; raw[2 * j + 1] = c.y; }
+            } else {
+                const T *in = (const T *)a.in + base;
+#pragma unroll
+                for (int j = 0; j < N; ++j) raw[j] = in[(int64_t)j * a.elem_in];
+            }
+        }
+        RegOpArgs<T> oa;
+        oa.n = N; oa.F = F; oa.scale = (T)a.scale; oa.aux1 = (const cpx<T> *)ra.aux1; oa.aux2 = (const cpx<T> *)ra.aux2;
+        // ---- PRE ----
+        cpx<T> z[F];
+#pragma unroll
+        for (int i = 0; i < F; ++i) {
+            if constexpr (OP == G_R2C_EVEN) z[i] = mk<T>(raw[2 * i], raw[2 * i + 1]);
+            else if constexpr (OP == G_R2C_ODD) z[i] = mk<T>(raw[i], (T)0);
+            else z[i] = pre_elem<T, OP, RegZi>(oa, (const void *)raw, i);
+        }
+        FFT::fft(z, (const cpx<T> *)a.mat);
+        cpx<T> nat[F + 1];                                 // natural order (a renaming); one spare slot for folds that peek at F
+#pragma unroll
+        for (int s = 0; s < F; ++s) nat[FFT::out_index(s)] = z[s];
+        nat[F] = nat[0];
+        // ---- POST ----
+        T y[NO];
+        if constexpr (OUT_CPLX) {
+#pragma unroll
+            for (int q = 0; q < M; ++q) { const cpx<T> c = post_cplx<T, OP, RegZi>(oa, nat, q); y[2 * q] = c.x; y[2 * q + 1] = c.y; }
+        } else {
+#pragma unroll
+            for (int q = 0; q < N; ++q) y[q] = post_real<T, OP, RegZi>(oa, nat, q);
+        }
+        if constexpr (STAGE) {
+            T *lds = (T *)smem;
+#pragma unroll
+            for (int o = 0; o < NO; ++o) lds[threadIdx.x * PO_ + o] = y[o];
+            __syncthreads();
+            const int64_t c0 = (int64_t)blockIdx.x * THREADS * NO, total = a.nlanes * NO;
+            T *out = (T *)a.out + c0;
+#pragma unroll
+            for (int k = 0; k < NO; ++k) { const int g = threadIdx.x + k * THREADS; y[k] = lds[(g / NO) * PO_ + g % NO]; }
+#pragma unroll
+            for (int k = 0; k < NO; ++k) { const int g = threadIdx.x + k * THREADS; if (c0 + g < total) __builtin_nontemporal_store(y[k], out + g); }
+        } else {
+            if (!live) return;
+            const int64_t base = (L / a.inner) * a.outer_out + (L % a.inner) * a.lane_out;
+            if constexpr (OUT_CPLX) {
+                cpx<T> *out = (cpx<T> *)a.out + base;
+#pragma unroll
+                for (int o = 0; o < M; ++o) gstore<T, true>(out + (int64_t)o * a.elem_out, mk<T>(y[2 * o], y[2 * o + 1]));
+            } else {
+                T *out = (T *)a.out + base;
+#pragma unroll
+                for (int o = 0; o < N; ++o) __builtin_nontemporal_store(y[o], out + (int64_t)o * a.elem_out);
+            }
         }
     }
 };

@@ -98,6 +98,10 @@ bool regfft_factor(int n, int *n1, int *n2) {
     if (n == 30) { *n1 = 6; *n2 = 5; return true; }
     if (n == 40) { *n1 = 8; *n2 = 5; return true; }
     if (n == 23) { *n1 = 23; *n2 = 1; return true; }
+    if (n == 9 || n == 17) { *n1 = n; *n2 = 1; return true; }        // inner FFTs of the real-op kernels below
+    if (n == 21) { *n1 = 7; *n2 = 3; return true; }
+    if (n == 20) { *n1 = 5; *n2 = 4; return true; }
+    if (n == 42) { *n1 = 7; *n2 = 6; return true; }
     return false;
 }
 int regfft_max_n(int) { return 64; }
@@ -120,5 +124,30 @@ int launch_jit_regfft(int dtype, int n1, int n2, bool stage, const TinyArgs &a, 
     if (n1 == 8 && n2 == 5) return dtype == NDFFT_F32 ? reg_n<float, 8, 5>(stage, a, s) : reg_n<double, 8, 5>(stage, a, s);
     if (n1 == 23 && n2 == 1) return dtype == NDFFT_F32 ? reg_n<float, 23, 1>(stage, a, s) : reg_n<double, 23, 1>(stage, a, s);
     return NDFFT_ERR_UNSUPPORTED;
+}
+
+// RegReal (reg_kernel.h): handler lengths 18 (even ops, inner F = 9; DCT-I F = 17) and 21 (odd ops, F = 21; DCT-I F = 20;
+// DCT-IV F = 42) instantiated ahead of time so that every PRE / POST formula runs on the CPU in its register form
+template <typename K> __global__ void k_regreal_emul(const RegRealArgs a) { K::run(a); }
+template <typename T, int OP, int N, int F1, int F2> static int regreal_one(bool stage, const RegRealArgs &a, hipStream_t s) {
+    if (stage) {
+        using K = RegReal<T, OP, N, F1, F2, 64, true>;
+        hipLaunchKernelGGL((k_regreal_emul<K>), dim3((unsigned)((a.t.nlanes + 63) / 64)), dim3(64), K::LDS_BYTES, s, a);
+    } else {
+        using K = RegReal<T, OP, N, F1, F2, 256, false>;
+        hipLaunchKernelGGL((k_regreal_emul<K>), dim3((unsigned)((a.t.nlanes + 255) / 256)), dim3(256), 0, s, a);
+    }
+    return NDFFT_OK;
+}
+template <typename T> static int regreal_T(int gop, int n, int f1, int f2, bool stage, const RegRealArgs &a, hipStream_t s) {
+#define RR(OP_, N_, F1_, F2_) if (gop == OP_ && n == N_ && f1 == F1_ && f2 == F2_) return regreal_one<T, OP_, N_, F1_, F2_>(stage, a, s);
+    RR(G_R2C_EVEN, 18, 9, 1) RR(G_C2R_EVEN, 18, 9, 1) RR(G_DCT1, 18, 17, 1) RR(G_DCT2_EVEN, 18, 9, 1) RR(G_DCT3_EVEN, 18, 9, 1) RR(G_DCT4_EVEN, 18, 9, 1)
+    RR(G_R2C_ODD, 21, 7, 3) RR(G_C2R_ODD, 21, 7, 3) RR(G_DCT1, 21, 5, 4) RR(G_DCT2_ODD, 21, 7, 3) RR(G_DCT3_ODD, 21, 7, 3) RR(G_DCT4_ODD, 21, 7, 6)
+#undef RR
+    return NDFFT_ERR_UNSUPPORTED;
+}
+int launch_jit_regreal(int dtype, int gop, int n, int f1, int f2, bool stage, const RegRealArgs &a, hipStream_t s) {
+    if (a.t.nlanes <= 0) return NDFFT_OK;
+    return dtype == NDFFT_F32 ? regreal_T<float>(gop, n, f1, f2, stage, a, s) : regreal_T<double>(gop, n, f1, f2, stage, a, s);
 }
 }

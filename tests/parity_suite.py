@@ -307,6 +307,23 @@ def reg_lanes(L, sizes=(14, 15, 17, 18, 19, 20, 21, 23, 24, 28, 29, 30, 31, 34, 
                     assert p2 == "reg_col" and (p1 == "reg_row" or n > 63), (n, rdt, p1, p2)
 
 
+def regreal_lanes(L, sizes=(17, 18, 19, 20, 21, 22, 24, 25, 27, 30, 32, 33, 36, 40, 42, 45, 48), sizes_f32=(50, 56, 60, 64, 65, 72), want=True):
+    """R2C / C2R / DCT-I..IV on lanes of 17..48 (f64) / 72 (f32) points, even and odd: one thread per lane with the raw
+    lane, the inner FFT and the outputs in registers (reg_kernel.h: RegReal, hiprtc-specialised); dense rows, strided
+    axes, norms.  `want`: every factorable size must take the path (False: only what the build instantiates)."""
+    seen = set()
+    for rdt in (np.float64, np.float32):
+        for n in tuple(sizes) + (tuple(sizes_f32) if rdt == np.float32 else ()):
+            rows = (1 << 16) // n + 29
+            for name in ("ndfft_r2c", "ndifft_r2c", "nddct1", "nddct2", "nddct3", "nddct4"):
+                p1 = run_case(L, name, (rows, n), 1, rdt, offset=n)
+                p2 = run_case(L, name, (3, n, rows // 2), 1, rdt, norm="None", offset=3 * n)
+                seen.update((p1, p2))
+    if want:
+        assert {"regreal_row", "regreal_col"} <= seen, seen
+    return seen
+
+
 def tinymat_lanes(L):
     """R2C / C2R / DCT-I..IV on lanes of 2..16 points (thread-per-lane, the transform as a dense matrix): every op and n,
     both dtypes, None / Default norms, dense rows, strided axes, F layout, stepped views, workgroup tails."""

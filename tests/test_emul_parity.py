@@ -32,6 +32,9 @@ def test_clone(L): ps.handler_clone_shares_plan(L)
 def test_wave_short_lanes(L): ps.wave_short_lanes(L)
 def test_tiny_lanes(L): ps.tiny_lanes(L)
 def test_reg_lanes(L): ps.reg_lanes(L, sizes=(18, 23, 30, 40), sizes_f32=())
+def test_regreal_lanes(L):
+    seen = ps.regreal_lanes(L, sizes=(18, 21), sizes_f32=())
+    assert {"regreal_row", "regreal_col"} <= seen, seen
 def test_tinymat_lanes(L): ps.tinymat_lanes(L)
 def test_host_pipeline_pageable(L): ps.host_pipeline_pageable(L, shapes=(("ndfft", (520, 1024), 1, np.float64), ("nddct2", (70, 96, 128), 1, np.float64)))
 def test_sharded_exec_three_fake_devices(L):
