@@ -464,7 +464,8 @@ def fuzz(L, seed, count, max_points=1 << 17, lengths=None):
     output views) against the oracle.  The lane lengths mix every dispatch class: powers of two, smooth,
     partial-round smooth, prime / Bluestein, DCT-I n - 1 classes, tiny and long."""
     rng = np.random.default_rng(seed)
-    lengths = lengths or (1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 16, 17, 30, 31, 32, 33, 64, 65, 96, 97, 100, 127, 128, 129, 210, 243, 256,
+    lengths = lengths or (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 21, 23, 24, 29, 30, 31, 32, 33, 34, 36, 40, 45, 48, 56, 60,
+                          62, 63, 64, 65, 72, 96, 97, 100, 127, 128, 129, 210, 243, 256,
                           257, 264, 343, 500, 512, 513, 1000, 1009, 1024, 1025, 2048, 2187, 3000, 4096, 4097, 5000, 8192)
     names = list(OPS)
     paths = {}

@@ -48,6 +48,11 @@ def test_huge_prime_factors(L): ps.huge_prime_factors(L)
 def test_fuzz(L):
     paths = ps.fuzz(L, seed=7, count=400)
     assert len(paths) >= 8, paths
+def test_fuzz_short_lanes(L):
+    """the same fuzz restricted to lanes of <= 100 points with enough lanes to reach the plan-time specialisations: wavefront,
+    thread-per-lane (tiny / tinymat / reg / regreal) and their fallbacks, in every layout the fuzz generates"""
+    paths = ps.fuzz(L, seed=31, count=300, max_points=1 << 18, lengths=tuple(range(2, 65)) + (66, 70, 72, 80, 90, 96, 100))
+    assert {"tiny_col", "tinymat_col"} <= set(paths) and any(p.startswith("reg") for p in paths), paths
 def test_partial_round_configs(L): ps.partial_round_configs(L, sizes=(264, 210, 840, 1008, 630, 2520, 3003, 6006, 33, 66))
 def test_long_smooth_lanes(L): ps.long_smooth_lanes(L)
 def test_bluestein_register_kernel(L):
