@@ -685,29 +685,9 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
             }
         }
     }
-    // the real-data transforms on very short lanes (n = 2..16): one thread per lane, the transform as a dense matrix
-    if (plan->kind != NDFFT_KIND_C2C && plan->n >= 2 && plan->n <= 16 && P.b.size() <= 2 && tiny_enabled()) {
-        const int n = (int)plan->n;
-        const int q = plan->kind == NDFFT_KIND_R2C ? (P.op == NDFFT_OP_R2C ? 0 : 1) : P.op - NDFFT_OP_DCT1;
-        const void *mat = dt->cfg[CFG_MAIN].tinymat[q];
-        if (mat) {
-            const bool rows = P.xs == 1 && P.ys == 1 && P.b.size() <= 1;
-            const bool dense = rows && (P.b.empty() || (P.b[0].sin == P.xlen && P.b[0].sout == P.ylen));
-            const bool cols = !P.b.empty() && P.b.back().sin == 1 && P.b.back().sout == 1;
-            TinyArgs a;
-            a.in = d_in; a.out = d_out; a.nlanes = P.nlanes; a.inverse = 0; a.scale = P.scale; a.mat = mat;
-            a.elem_in = P.xs; a.elem_out = P.ys;
-            a.inner = P.b.empty() ? 1 : P.b.back().shape;
-            a.lane_in = P.b.empty() ? 0 : P.b.back().sin; a.lane_out = P.b.empty() ? 0 : P.b.back().sout;
-            a.outer_in = P.b.size() == 2 ? P.b[0].sin : 0; a.outer_out = P.b.size() == 2 ? P.b[0].sout : 0;
-            set_last_path(dense ? "tinymat_row" : cols ? "tinymat_col" : "tinymat_strided");
-            const int shape = plan->kind == NDFFT_KIND_R2C ? (P.op == NDFFT_OP_R2C ? 0 : 1) : 2;
-            return plan->dtype == NDFFT_F32 ? launch_tinymat_f32(n, shape, dense, a, stream) : launch_tinymat_f64(n, shape, dense, a, stream);
-        }
-    }
-    // the real-data transforms on lanes of 17 .. 48 (f64) / 72 (f32) points whose inner FFT factors into butterflies:
+    // the real-data transforms on lanes of 12 .. 48 (f64) / 72 (f32) points (from 12 up the butterflies beat the dense matrix of the tiny kernel: n = 16 0.49-0.59 -> see DESIGN 3.0c) whose inner FFT factors into butterflies:
     // one thread per lane, everything in registers (reg_kernel.h: RegReal), specialised with hiprtc
-    if (plan->kind != NDFFT_KIND_C2C && plan->n >= 17 && (int)plan->n <= (plan->dtype == NDFFT_F32 ? regreal_max_n(0) : regreal_max_n(1)) &&
+    if (plan->kind != NDFFT_KIND_C2C && plan->n >= 12 && (int)plan->n <= (plan->dtype == NDFFT_F32 ? regreal_max_n(0) : regreal_max_n(1)) &&
         P.b.size() <= 2 && P.nlanes * (int64_t)plan->n >= (1 << 16) && tiny_enabled()) {
         const int n = (int)plan->n;
         int slot;
@@ -732,6 +712,26 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
                 if (rcj == NDFFT_OK) { set_last_path(dense ? "regreal_row" : "regreal_col"); return NDFFT_OK; }
                 if (rcj != NDFFT_ERR_UNSUPPORTED) return rcj;
             }
+        }
+    }
+    // the real-data transforms on very short lanes (n = 2..16): one thread per lane, the transform as a dense matrix
+    if (plan->kind != NDFFT_KIND_C2C && plan->n >= 2 && plan->n <= 16 && P.b.size() <= 2 && tiny_enabled()) {
+        const int n = (int)plan->n;
+        const int q = plan->kind == NDFFT_KIND_R2C ? (P.op == NDFFT_OP_R2C ? 0 : 1) : P.op - NDFFT_OP_DCT1;
+        const void *mat = dt->cfg[CFG_MAIN].tinymat[q];
+        if (mat) {
+            const bool rows = P.xs == 1 && P.ys == 1 && P.b.size() <= 1;
+            const bool dense = rows && (P.b.empty() || (P.b[0].sin == P.xlen && P.b[0].sout == P.ylen));
+            const bool cols = !P.b.empty() && P.b.back().sin == 1 && P.b.back().sout == 1;
+            TinyArgs a;
+            a.in = d_in; a.out = d_out; a.nlanes = P.nlanes; a.inverse = 0; a.scale = P.scale; a.mat = mat;
+            a.elem_in = P.xs; a.elem_out = P.ys;
+            a.inner = P.b.empty() ? 1 : P.b.back().shape;
+            a.lane_in = P.b.empty() ? 0 : P.b.back().sin; a.lane_out = P.b.empty() ? 0 : P.b.back().sout;
+            a.outer_in = P.b.size() == 2 ? P.b[0].sin : 0; a.outer_out = P.b.size() == 2 ? P.b[0].sout : 0;
+            set_last_path(dense ? "tinymat_row" : cols ? "tinymat_col" : "tinymat_strided");
+            const int shape = plan->kind == NDFFT_KIND_R2C ? (P.op == NDFFT_OP_R2C ? 0 : 1) : 2;
+            return plan->dtype == NDFFT_F32 ? launch_tinymat_f32(n, shape, dense, a, stream) : launch_tinymat_f64(n, shape, dense, a, stream);
         }
     }
     // tuned path: contiguous power-of-two C2C lanes at a uniform pitch

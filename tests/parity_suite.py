@@ -307,7 +307,7 @@ def reg_lanes(L, sizes=(14, 15, 17, 18, 19, 20, 21, 23, 24, 28, 29, 30, 31, 34, 
                     assert p2 == "reg_col" and (p1 == "reg_row" or n > 63), (n, rdt, p1, p2)
 
 
-def regreal_lanes(L, sizes=(17, 18, 19, 20, 21, 22, 24, 25, 27, 30, 32, 33, 36, 40, 42, 45, 48), sizes_f32=(50, 56, 60, 64, 65, 72), want=True):
+def regreal_lanes(L, sizes=(12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 24, 25, 27, 30, 32, 33, 36, 40, 42, 45, 48), sizes_f32=(50, 56, 60, 64, 65, 72), want=True):
     """R2C / C2R / DCT-I..IV on lanes of 17..48 (f64) / 72 (f32) points, even and odd: one thread per lane with the raw
     lane, the inner FFT and the outputs in registers (reg_kernel.h: RegReal, hiprtc-specialised); dense rows, strided
     axes, norms.  `want`: every factorable size must take the path (False: only what the build instantiates)."""

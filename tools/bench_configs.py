@@ -212,6 +212,19 @@ def main():
             run(f"midreal ndfft_r2c axis=1 {rows}x{n} f32", ndfft_r2c, xf, w, R2cFftHandler(n, np.float32), 1, xf.numel(), a.steps)
             xc = torch.from_numpy(synth.complex_array((rows // 2, n))).to(dev); yc = torch.empty_like(xc)
             run(f"midreal ndfft axis=1 {rows // 2}x{n} c128", ndfft, xc, yc, FftHandler(n), 1, xc.numel(), a.steps)
+    if want("landscape"):
+        # the whole lane-length landscape on dense rows, 2^24 points per call: which kernel serves which n, and how well
+        sizes = (2, 3, 4, 6, 8, 12, 16, 17, 24, 31, 32, 48, 63, 64, 96, 100, 128, 256, 500, 512, 1000, 1024, 2048, 4096, 8192, 16384)
+        for n in sizes:
+            rows = (1 << 24) // n
+            x = torch.from_numpy(synth.complex_array((rows, n))).to(dev); y = torch.empty_like(x)
+            run(f"landscape ndfft c128 n={n}", ndfft, x, y, FftHandler(n), 1, x.numel(), a.steps)
+            x = torch.from_numpy(synth.complex_array((rows, n), np.complex64)).to(dev); y = torch.empty_like(x)
+            run(f"landscape ndfft c64 n={n}", ndfft, x, y, FftHandler(n, np.float32), 1, x.numel(), a.steps)
+            x = torch.from_numpy(synth.real_array((rows, n))).to(dev); y = torch.empty_like(x)
+            run(f"landscape nddct2 f64 n={n}", nddct2, x, y, DctHandler(n), 1, x.numel(), a.steps)
+            x = torch.from_numpy(synth.real_array((rows, n), np.float32)).to(dev); w = torch.empty((rows, n // 2 + 1), dtype=torch.complex64, device=dev)
+            run(f"landscape ndfft_r2c f32 n={n}", ndfft_r2c, x, w, R2cFftHandler(n, np.float32), 1, x.numel(), a.steps)
     if want("pow2sweep"):
         for rdt, cdt in ((np.float64, np.complex128), (np.float32, np.complex64)):
             for n in (64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384):
