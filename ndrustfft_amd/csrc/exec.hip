@@ -362,6 +362,12 @@ static int regreal_max_n(int f64) {
     return f64 ? m64 : m32;
 }
 
+// developer / test switch: NDFFT_CHUNK_OUT=0 keeps R2C rows on the per-lane stores
+static bool chunk_out_enabled() {
+    const char *e = getenv("NDFFT_CHUNK_OUT");
+    return !(e && e[0] == '0');
+}
+
 // developer / test switch: NDFFT_TINY=0 keeps very short lanes on the LDS kernel (read per call)
 static bool tiny_enabled() {
     const char *e = getenv("NDFFT_TINY");
@@ -838,6 +844,12 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
                 a.xcd_remap = 0; a.keep_out = P.keep_out; a.stream_in = P.stream_in; a.xcd_chunk = P.no_xcd_map ? 0 : -1;
                 const size_t es_out = (op_out_cplx(P.op) ? 2 : 1) * real_size(plan->dtype);
                 a.vec_out = !col && ((uintptr_t)d_out % 16 == 0) && ((size_t)a.pitch_out * es_out) % 16 == 0;
+                // R2C rows with dense output lanes: the workgroup stores its lanes as one contiguous chunk (pow2_real.h: chunk_out)
+                // Measured (profiles/r03j, 2^24 points f32): n = 96 / 100 48 -> 37 / 32 -> 30 us, powers of two 128..1024 +4 %; n = 500 / 1000 and
+                // n >= 2048 lose 2-8 % (fewer, longer lanes per workgroup: the per-lane stores are already long runs), so short lanes only.
+                const bool short_lane = c.F <= 64 || (c.F <= 512 && (c.F & (c.F - 1)) == 0);
+                a.chunk_out = !col && gop == G_R2C_EVEN && short_lane && ((uintptr_t)d_out % 16 == 0) && a.pitch_out == P.ylen && chunk_out_enabled();
+                if (a.chunk_out) a.xcd_chunk = 0;
             };
             int rc2;
             if (plan->dtype == NDFFT_F32) {

@@ -43,6 +43,8 @@ template <typename T> struct RealArgs {
     const cpx<T> *chirp, *bhat;          // Bluestein kernels (blue_kernel.h): e^{-i pi j^2/F}, FFT_M(conj chirp)/M
     int32_t keep_out;                    // COL kernels: 1 = plain (cache-allocating) stores instead of non-temporal ones: the
                                          // output is an intermediate that the next launch re-reads from the Infinity Cache
+    int32_t chunk_out = 0;               // row R2C: output lanes are dense (pitch == F + 1) and the array is 16-byte aligned: the workgroup's
+                                         // output lanes form ONE contiguous chunk, staged in LDS and stored with coalesced 16-byte accesses
     int32_t xcd_chunk = 0;               // non-XCD kernels: XCD-aware workgroup -> tile map (device_common.h: xcd_block), 0 = identity
     int32_t stream_in = 0;               // COL kernels: 1 = streaming (nt) loads of the input: it is read once and must not
                                          // push the intermediate of a two-stage route out of the Infinity Cache
@@ -379,6 +381,56 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                     const int nv = n / W;
                     for (int j = t; j < nv; j += TPL) __builtin_nontemporal_store(((const vec4f *)stage)[j], (vec4f *)out + j);
                     for (int j = W * nv + t; j < n; j += TPL) out[j] = stage[j];
+                    return;
+                }
+            }
+            if constexpr (OP == G_R2C_EVEN) {
+                // R2C rows: F + 1 complex per lane -- lanes start and end mid-line and the split produces two scattered streams
+                // (k ascending, F - k descending).  When the output lanes are dense the LPB lanes of this workgroup are one
+                // contiguous chunk: the outputs go registers -> LDS (own lane region, natural order) -> coalesced 16-byte
+                // stores over the whole chunk.  (8192 x 8192 f32 rows: 102 us -> see DESIGN.md section 3.2)
+                if (a.chunk_out) {
+                    constexpr int NSL = 4 * ((F / 2) / TPL + 1);
+                    cpx<T> o[NSL];
+                    int oq[NSL];
+#pragma unroll
+                    for (int i = 0; i < NSL / 4; ++i) {
+                        const int k = t + i * TPL;
+                        const PairOut<cpx<T>> r = post_pair<cpx<T>>(a, res, k <= F / 2 ? k : 0);
+#pragma unroll
+                        for (int z = 0; z < 4; ++z) { o[4 * i + z] = r.v[z]; oq[4 * i + z] = k <= F / 2 ? r.q[z] : -1; }
+                    }
+                    __syncthreads();                       // every read of Z is done: the lane region becomes the output lane
+                    cpx<T> *stage = (cpx<T> *)lds;
+#pragma unroll
+                    for (int i = 0; i < NSL; ++i) if (oq[i] >= 0) stage[oq[i]] = o[i];
+                    __syncthreads();
+                    constexpr int NOUT = F + 1;
+                    const int64_t e0 = (int64_t)blockIdx.x * LPB * NOUT;            // (identity tile map: chunk_out rows never use the XCD map)
+                    const int64_t etot = a.nlanes * NOUT;
+                    cpx<T> *outc = (cpx<T> *)a.out + e0;
+                    // complex elements per store: a 16-byte vector (2 x c64) when every workgroup's chunk starts 16-byte aligned
+                    // (LPB (F + 1) even), else one element (odd lane counts of the specialised partial-round configurations)
+                    constexpr int EPV = (sizeof(cpx<T>) == 8 && (LPB * NOUT) % 2 == 0) ? 2 : 1;
+                    constexpr int NV = (LPB * NOUT + EPV - 1) / EPV;
+                    for (int v = threadIdx.x; v < NV; v += THREADS) {
+                        const int g = v * EPV;
+                        if (e0 + g >= etot) break;
+                        const cpx<T> *l0 = (const cpx<T> *)(smem + (size_t)(g / NOUT) * LANE_LDS * 2 * sizeof(T));
+                        if constexpr (EPV == 1) {
+                            gstore<T, true>(outc + g, l0[g % NOUT]);
+                        } else {
+                            const cpx<T> c0 = l0[g % NOUT];
+                            if (e0 + g + 1 < etot && g + 1 < LPB * NOUT) {
+                                const cpx<T> *l1 = (const cpx<T> *)(smem + (size_t)((g + 1) / NOUT) * LANE_LDS * 2 * sizeof(T));
+                                const cpx<T> c1 = l1[(g + 1) % NOUT];
+                                vec4f w; w.x = c0.x; w.y = c0.y; w.z = c1.x; w.w = c1.y;
+                                __builtin_nontemporal_store(w, (vec4f *)(outc + g));
+                            } else {
+                                gstore<T, true>(outc + g, c0);
+                            }
+                        }
+                    }
                     return;
                 }
             }

@@ -762,11 +762,12 @@ def partial_round_configs(L, sizes=(264, 210)):
         rows = (1 << 17) // n + 7
         for rdt in (np.float64, np.float32):
             for name, norm in (("ndfft", "Default"), ("ndifft", "Default"), ("ndifft", "None")):
-                assert run_case(L, name, (rows, n), 1, rdt, norm=norm, offset=n) == "jit_reg", (name, n, rdt)
+                # (lanes short enough for the thread-per-lane register kernel go there first: reg_kernel.h)
+                assert run_case(L, name, (rows, n), 1, rdt, norm=norm, offset=n) in (("jit_reg", "reg_row") if n <= 96 else ("jit_reg",)), (name, n, rdt)
         # padded lane pitch
         big = synth.complex_array((rows, n + 3), np.complex128); x = big[:, :n]; y = np.zeros((rows, n + 5), np.complex128)[:, 2:n + 2]
         h = handlers.FftHandler(n, _library=L); api.ndfft(x, y, h, 1)
-        assert L.last_path() == "jit_reg"
+        assert L.last_path() in (("jit_reg", "reg_row") if n <= 96 else ("jit_reg",))
         assert_close(y, np.fft.fft(x, axis=1), 1, 1e-10, f"partial-round {n} padded")
     # the real-op / column kernel with the same configurations: inner FFT F = n (R2C / DCT of length 2F, DCT-I of F + 1)
     for F in sizes[:2]:
