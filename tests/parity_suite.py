@@ -740,17 +740,19 @@ def bluestein_register_kernel(L, sizes=((17, 64), (31, 64), (97, 256), (127, 256
             # C2C (n = F), odd-n real ops (inner FFT n = F; DCT-IV odd uses 2n, so it is not in this list)
             for name in ("ndfft", "ndifft", "ndfft_r2c", "ndifft_r2c", "nddct2", "nddct3"):
                 for norm in ("Default", "None"):
-                    assert run_case(L, name, (rows, F), 1, rdt, norm=norm, offset=F) == "blue_reg", (name, F, rdt)
+                    assert run_case(L, name, (rows, F), 1, rdt, norm=norm, offset=F) in (("blue_reg", "reg_row", "regreal_row") if F <= 96 else ("blue_reg",)), (name, F, rdt)
             # even-n real ops: inner FFT n/2 = F;  DCT-I: n - 1 = F
             for name in ("ndfft_r2c", "ndifft_r2c", "nddct2", "nddct3", "nddct4"):
-                assert run_case(L, name, (rows, 2 * F), 1, rdt, offset=F + 1) == "blue_reg", (name, 2 * F, rdt)
-            assert run_case(L, "nddct1", (rows, F + 1), 1, rdt, offset=F) == "blue_reg", ("nddct1", F + 1, rdt)
+                assert run_case(L, name, (rows, 2 * F), 1, rdt, offset=F + 1) in (("blue_reg", "regreal_row") if 2 * F <= 96 else ("blue_reg",)), (name, 2 * F, rdt)
+            assert run_case(L, "nddct1", (rows, F + 1), 1, rdt, offset=F) in (("blue_reg", "regreal_row") if F < 96 else ("blue_reg",)), ("nddct1", F + 1, rdt)
             if M > col_max_M:
                 continue
             # column tiles (strategy ii)
             for name, n in (("ndfft", F), ("ndifft_r2c", 2 * F), ("nddct1", F + 1), ("nddct2", F), ("ndfft_r2c", F)):
-                assert run_case(L, name, (n, rows + 3), 0, rdt, offset=n) == "blue_col", (name, n, rdt)
-                assert run_case(L, name, (3, n, rows // 2), 1, rdt, offset=n + 1) == "blue_col", (name, n, rdt)
+                # (short lanes with enough of them go to the thread-per-lane register kernels first: reg_kernel.h)
+                ok = ("blue_col", "reg_col", "regreal_col") if n <= 96 else ("blue_col",)
+                assert run_case(L, name, (n, rows + 3), 0, rdt, offset=n) in ok, (name, n, rdt)
+                assert run_case(L, name, (3, n, rows // 2), 1, rdt, offset=n + 1) in ok, (name, n, rdt)
     # few lanes: not worth a compile
     assert run_case(L, "ndfft", (3, 97), 1, np.float64) == "generic_row"
 
