@@ -61,6 +61,8 @@ template <typename T> struct GenArgs {
 // ------------------------------------------------------------------------------------------
 struct HostTable { std::vector<long double> re, im; };
 struct JitCfg { int n = 0, tpl = 0, e = 0, lpb = 1, vec = 1; bool partial = false; std::vector<int> radix; };   // partial: some pass has an incomplete last round
+// Rader / Good-Thomas recipe of rader_kernel.h: F = mc * p, p prime with p - 1 smooth; fft = register configuration of FFT_(p-1)
+struct RaderCfg { int p = 0, mc = 1; JitCfg fft; };
 }  // namespace ndfft
 struct ndfft_plan;
 namespace ndfft {   // built once in long double
@@ -91,6 +93,9 @@ struct FftConfig {                 // one complex-FFT-of-length-F recipe + op ta
     bool blue_reg_only = false;    // M exceeds the LDS kernel's reach: only the register kernel can run it
     bool bluereg = false;          // blue && M has a register-kernel configuration: blue_kernel.h, specialised with hiprtc
                                    // (jitcfg = configuration for M, twp = its per-pass twiddles)
+    // blue && F = mc * p with p - 1 smooth: rader_kernel.h instead of Bluestein (specialised with hiprtc); rader_bhat = FFT_(p-1)(W_p^(g^-q)) / (p - 1),
+    // rader_twp = per-pass twiddles of FFT_(p-1), rader_tab = g^i mod p (i < p - 1) followed by g^-i mod p
+    bool rader = false; RaderCfg radercfg; HostTable rader_bhat, rader_twp; std::vector<int32_t> rader_tab;
     bool jit = false; JitCfg jitcfg;   // C2C slot: smooth non-power-of-two n -> specialised register kernel (jit.hip); twiddles in twp
     bool unsupported = false;      // no single-kernel fit and no usable factorisation (large prime factor)
 };
@@ -101,6 +106,7 @@ struct DevConfig {                 // device copies (typed by dtype) of one FftC
     void *cs_twlo = nullptr, *cs_twhi = nullptr;
     void *wave_tw = nullptr;
     void *tinymat[4] = {nullptr, nullptr, nullptr, nullptr};
+    void *rader_bhat = nullptr, *rader_twp = nullptr, *rader_tab = nullptr;
 };
 
 enum ConfigSlot { CFG_MAIN = 0, CFG_DCT1 = 1, CFG_DCT4 = 2, CFG_COUNT = 3 };
@@ -192,6 +198,10 @@ template <typename T> int launch_pow2_real_narrow(int gen_op, const RealArgs<T> 
 // column four-step, twiddled stage (kernels_colsplit.hip): cs = 1 C2C, 2 = R2C second stage, 3 = C2R first stage
 bool pow2_real_config(int F, JitCfg &cfg);
 template <typename T> int launch_jit_blue(int gen_op, const JitCfg &cfgM, bool col, const RealArgs<T> &a, hipStream_t s);
+// rader_kernel.h (jit.hip): recipe for an inner FFT length F with one prime factor > 13 (false: none, Bluestein stays), lanes per column tile, launch
+bool rader_choose(int dtype, int F, RaderCfg &rc);
+int rader_col_lanes(int dtype, const RaderCfg &rc);
+template <typename T> int launch_jit_rader(int gen_op, const RaderCfg &rc, bool col, const RealArgs<T> &a, hipStream_t s);
 int launch_pack_lanes(const void *strided, void *dense, const LaneGeom &g, int64_t lanes, int64_t len, int64_t pitch, int esz, int unpack, hipStream_t s);   // big.hip
 int colsplit_inner_len();
 int colsplit_tile_lanes();

@@ -783,12 +783,13 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
         const bool use_jit = c.jit && !c.pow2 && P.nlanes * (int64_t)c.F >= (1 << 16);
         // Bluestein lengths on the register kernel (blue_kernel.h), every op incl. the odd-n variants and row C2C
         const bool use_blue = c.bluereg && ((P.nlanes * (int64_t)c.M >= (1 << 16) && blue_enabled()) || c.blue_reg_only);
+        const bool use_rader = use_blue && c.rader;     // Rader / Good-Thomas instead (rader_kernel.h); Bluestein stays the fallback
         const bool have_tw = use_jit || use_blue || (is_c2c ? !c.twp_col.re.empty() : c.pow2);
         const bool row = (!is_c2c || use_blue) && P.xs == 1 && P.ys == 1 && P.b.size() <= 1;
         bool col = false, narrow = false;
         if (!row && (!odd_variant || use_blue) && P.xlen > 1 && !P.b.empty() && P.b.size() <= 2 && P.b.back().sin == 1 && P.b.back().sout == 1) {
             if (have_tw && P.b.back().shape >= 8) {
-                const int lanes = (use_jit || use_blue) ? jit_col_lanes(plan->dtype, c.jitcfg)
+                const int lanes = (use_jit || use_blue) ? std::max(jit_col_lanes(plan->dtype, c.jitcfg), use_rader ? rader_col_lanes(plan->dtype, c.radercfg) : 0)
                                           : plan->dtype == NDFFT_F32 ? pow2_real_col_lanes<float>(c.F) : pow2_real_col_lanes<double>(c.F);
                 col = lanes > 0;
             }
@@ -856,12 +857,24 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
                 RealArgs<float> a; fill(a); a.scale = (float)P.scale;
                 a.aux1 = (const cpx<float> *)d.aux1; a.aux2 = (const cpx<float> *)d.aux2; a.twp = (const cpx<float> *)((is_c2c && !use_jit && !use_blue) ? d.twp_col : d.twp);
                 a.chirp = (const cpx<float> *)d.chirp; a.bhat = (const cpx<float> *)d.bhat;
+                if (use_rader) {
+                    RealArgs<float> r = a;
+                    r.twp = (const cpx<float> *)d.rader_twp; r.bhat = (const cpx<float> *)d.rader_bhat; r.rader_tab = (const int32_t *)d.rader_tab;
+                    const int rr = launch_jit_rader<float>(gop, c.radercfg, col, r, stream);
+                    if (rr != NDFFT_ERR_UNSUPPORTED) { set_last_path(col ? "rader_col" : "rader_reg"); return rr; }
+                }
                 rc2 = use_blue ? launch_jit_blue<float>(gop, c.jitcfg, col, a, stream)
                       : use_jit ? launch_jit_real<float>(gop, c.jitcfg, col, a, stream) : launch_pow2_real<float>(gop, a, col, stream);
             } else {
                 RealArgs<double> a; fill(a); a.scale = P.scale;
                 a.aux1 = (const double2 *)d.aux1; a.aux2 = (const double2 *)d.aux2; a.twp = (const double2 *)((is_c2c && !use_jit && !use_blue) ? d.twp_col : d.twp);
                 a.chirp = (const double2 *)d.chirp; a.bhat = (const double2 *)d.bhat;
+                if (use_rader) {
+                    RealArgs<double> r = a;
+                    r.twp = (const double2 *)d.rader_twp; r.bhat = (const double2 *)d.rader_bhat; r.rader_tab = (const int32_t *)d.rader_tab;
+                    const int rr = launch_jit_rader<double>(gop, c.radercfg, col, r, stream);
+                    if (rr != NDFFT_ERR_UNSUPPORTED) { set_last_path(col ? "rader_col" : "rader_reg"); return rr; }
+                }
                 rc2 = use_blue ? launch_jit_blue<double>(gop, c.jitcfg, col, a, stream)
                       : use_jit ? launch_jit_real<double>(gop, c.jitcfg, col, a, stream) : launch_pow2_real<double>(gop, a, col, stream);
             }

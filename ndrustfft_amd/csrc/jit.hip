@@ -78,8 +78,8 @@ bool jit_disabled() {
 // Cost ~ passes x (work incl. idle threads of partial rounds): minimise NP / utilisation; ties -> E nearest 16.
 static size_t jit_lds_limit();
 static int jit_full_min() { static const int v = [] { const char *e = getenv("NDFFT_JIT_FULL_MIN"); return e ? atoi(e) : 256; }(); return v; }
-static bool jit_choose_partial(int dtype, int n, JitCfg &cfg) {
-    const int emax = dtype == NDFFT_F32 ? 32 : 30;
+static bool jit_choose_partial(int dtype, int n, JitCfg &cfg, int emax_arg = 0) {
+    const int emax = emax_arg > 0 ? emax_arg : dtype == NDFFT_F32 ? 32 : 30;
     const int cand[] = {16, 13, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
     std::vector<int> cur, best;
     int best_tpl = 0, best_e = 0;
@@ -227,8 +227,8 @@ static Entry compile_entry(const std::string &src, const std::string &what) {
     Rtc &r = rtc();
     Entry ne;
     {   // a code object compiled by an earlier process?
-        const char *hs0[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h, jit_src_realops_h, jit_src_pow2_real_h, jit_src_blue_kernel_h, jit_src_reg_kernel_h};
-        const std::string path = cache_path(src, hs0, 7);
+        const char *hs0[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h, jit_src_realops_h, jit_src_pow2_real_h, jit_src_blue_kernel_h, jit_src_reg_kernel_h, jit_src_rader_kernel_h};
+        const std::string path = cache_path(src, hs0, 8);
         std::string code;
         if (!path.empty() && read_file(path, code) && hipModuleLoadData(&ne.mod, code.data()) == hipSuccess &&
             hipModuleGetFunction(&ne.fn, ne.mod, "k_jit") == hipSuccess)
@@ -239,10 +239,10 @@ static Entry compile_entry(const std::string &src, const std::string &what) {
             if (e[0] == '1') { ne.failed = true; return ne; }
         }
     }
-    const char *hn[] = {"device_common.h", "butterflies.h", "pow2_kernel.h", "realops.h", "pow2_real.h", "blue_kernel.h", "reg_kernel.h"};
-    const char *hs[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h, jit_src_realops_h, jit_src_pow2_real_h, jit_src_blue_kernel_h, jit_src_reg_kernel_h};
+    const char *hn[] = {"device_common.h", "butterflies.h", "pow2_kernel.h", "realops.h", "pow2_real.h", "blue_kernel.h", "reg_kernel.h", "rader_kernel.h"};
+    const char *hs[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h, jit_src_realops_h, jit_src_pow2_real_h, jit_src_blue_kernel_h, jit_src_reg_kernel_h, jit_src_rader_kernel_h};
     rtcProgram prog = nullptr;
-    bool ok = r.ok && r.create(&prog, src.c_str(), "k_jit.hip", 7, hs, hn) == 0;
+    bool ok = r.ok && r.create(&prog, src.c_str(), "k_jit.hip", 8, hs, hn) == 0;
     if (ok) {
         ok = r.compile(prog, 4, (const char **)kJitOpts) == 0;
         if (!ok && getenv("NDFFT_JIT_VERBOSE")) {
@@ -262,7 +262,7 @@ static Entry compile_entry(const std::string &src, const std::string &what) {
     } else if (getenv("NDFFT_JIT_VERBOSE")) {
         fprintf(stderr, "ndfft jit: no code object for %s (hiprtc %s)\n", what.c_str(), r.ok ? "present" : "missing");
     }
-    if (ok) { const std::string path = cache_path(src, hs, 7); if (!path.empty()) write_file_atomic(path, code); }
+    if (ok) { const std::string path = cache_path(src, hs, 8); if (!path.empty()) write_file_atomic(path, code); }
     if (!ok) { (void)hipGetLastError(); ne.failed = true; }
     return ne;
 }
@@ -468,6 +468,139 @@ template <typename T> int launch_jit_blue(int gop, const JitCfg &cfg, bool col, 
     NDFFT_HIP(hipModuleLaunchKernel(e.fn, (unsigned)nblk, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, s, params, nullptr));
     return NDFFT_OK;
 }
+// ---- Rader / Good-Thomas kernel (rader_kernel.h) ---------------------------------------------------------------------
+static bool rader_enabled() {   // developer / test switch: NDFFT_RADER=0 keeps every such length on Bluestein (read per call)
+    const char *e = getenv("NDFFT_RADER");
+    return !(e && e[0] == '0');
+}
+static size_t rader_lane_lds(const RaderCfg &rc, bool col) {   // complex elements per lane = RaderKernel::LANE_LDS
+    const size_t M = (size_t)rc.p - 1, F = (size_t)rc.p * rc.mc;
+    const size_t sub = M + (M >> 4) + 2, lane = std::max((size_t)rc.mc * sub, F + (F >> 4) + 3);
+    return col ? (lane | 1) : ((lane + 1) & ~(size_t)1);
+}
+// lanes per workgroup of the row kernel.  Measured (profiles/r04/r04d_rader_tune_lpb.txt): workgroups of ONE wave win wherever a lane needs
+// <= 64 threads (no real barriers: 127 c128 150 -> 121 us, 511 c128 125 -> 110 us), otherwise the fullest waves with the fewest of them.
+static int rader_row_lanes_for(int dtype, const RaderCfg &rc, double *util_out) {
+    const int forced = [] { const char *e = getenv("NDFFT_RADER_LPB"); return e ? atoi(e) : 0; }();
+    const int lt = rc.fft.tpl * rc.mc;
+    const size_t lane = rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8);
+    int best = 0; double best_score = -1.0, best_util = 0.0;
+    for (int l = 1; l <= std::max(1, 320 / lt); ++l) {
+        if (forced > 0 && l != forced) continue;
+        const int thr = l * lt, waves = (thr + 63) / 64;
+        if (thr > 1024 || (size_t)l * lane > jit_lds_limit()) break;
+        const double util = (double)thr / (64.0 * waves), score = util - 0.02 * (waves - 1);
+        if (score > best_score) { best_score = score; best = l; best_util = util; }
+    }
+    if (util_out) *util_out = best_util;
+    return best;
+}
+static int rader_row_lanes(int dtype, const RaderCfg &rc) { return rader_row_lanes_for(dtype, rc, nullptr); }
+
+// Configuration of FFT_(p-1): radix list (any multiset of 2..13, 16), threads per transform, partial rounds allowed.
+// cost = passes x (work incl. idle threads of partial rounds) / (fill of the workgroup's waves), 13 % / 5 % off for one- / two-wave
+// workgroups, plus a penalty for many elements per thread (f64: e = 21 costs 5-20 %, e = 24 twice the time) -- fitted to the sweeps
+// under profiles/r04/r04c_rader_tune.txt and r04d_rader_tune_lpb.txt (tools/probes/rader_tune.py).
+static bool rader_plan_fft(int dtype, int M, RaderCfg &rc) {
+    const int emax = dtype == NDFFT_F32 ? 32 : 21, esoft = dtype == NDFFT_F32 ? 21 : 18;
+    const double eslope = dtype == NDFFT_F32 ? 0.05 : 0.1;
+    const int cand[] = {16, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
+    std::vector<int> cur;
+    JitCfg best; double best_cost = 1e30;
+    auto eval = [&]() {
+        std::vector<int> tpls;
+        for (int r : cur) for (int sdiv = 1; sdiv <= 4; ++sdiv) tpls.push_back((M / r + sdiv - 1) / sdiv);
+        std::sort(tpls.begin(), tpls.end()); tpls.erase(std::unique(tpls.begin(), tpls.end()), tpls.end());
+        for (int tpl : tpls) {
+            if (tpl < 1 || tpl * rc.mc > 1024) continue;
+            int e = 0; double work = 0; bool partial = false;
+            for (int r : cur) { const int nb = M / r, sl = (nb + tpl - 1) / tpl; e = std::max(e, sl * r); work += (double)sl * tpl * r; if (nb % tpl) partial = true; }
+            if (e > emax) continue;
+            RaderCfg t = rc; t.fft.tpl = tpl;
+            double util = 0.0;
+            const int lpb = rader_row_lanes_for(dtype, t, &util);
+            if (lpb <= 0) continue;
+            const int waves = (lpb * tpl * rc.mc + 63) / 64;
+            const double cost = work / M / util * (waves == 1 ? 0.87 : waves == 2 ? 0.95 : 1.0) + (e > esoft ? eslope * (e - esoft) : 0.0) + 0.01 * e;
+            if (cost < best_cost) { best_cost = cost; best = JitCfg(); best.n = M; best.tpl = tpl; best.e = e; best.radix = cur; best.partial = partial; best.lpb = lpb; }
+        }
+    };
+    std::function<void(int, int)> rec = [&](int m, int maxr) {
+        if (m == 1) { eval(); return; }
+        if (cur.size() >= 6) return;
+        for (int c : cand) {
+            if (c > maxr || m % c) continue;
+            cur.push_back(c);
+            rec(m / c, c);
+            cur.pop_back();
+        }
+    };
+    rec(M, 16);
+    if (best.radix.empty()) return false;
+    rc.fft = best;
+    return true;
+}
+
+bool rader_choose(int dtype, int F, RaderCfg &rc) {
+    if (jit_disabled() || F < 17) return false;
+    int p = 1, m = F;
+    for (int f = 2; (int64_t)f * f <= m; ++f) while (m % f == 0) { p = f; m /= f; }
+    if (m > 1) p = m;                                   // largest prime factor
+    const int mc = F / p;
+    if (p <= 13 || mc > 16 || mc % p == 0) return false;
+    { int q = p - 1; for (int f : {2, 3, 5, 7, 11, 13}) while (q % f == 0) q /= f; if (q != 1) return false; }
+    rc.p = p; rc.mc = mc;
+    if (rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8) > jit_lds_limit()) return false;
+    if (const char *e = getenv("NDFFT_RADER_CFG")) {     // developer knob (tools/probes/rader_tune.py): "tpl:r0.r1.r2" for FFT_(p-1), read per plan
+        JitCfg &c = rc.fft;
+        c = JitCfg(); c.n = p - 1; c.tpl = atoi(e);
+        const char *q = strchr(e, ':');
+        int prod = 1;
+        while (q && *q) { const int r = atoi(q + 1); if (r < 2) break; c.radix.push_back(r); prod *= r; q = strchr(q + 1, '.'); }
+        if (c.tpl < 1 || prod != p - 1 || c.tpl * mc > 1024) return false;
+        for (int r : c.radix) { const int nb = c.n / r, sl = (nb + c.tpl - 1) / c.tpl; c.e = std::max(c.e, sl * r); if (nb % c.tpl) c.partial = true; }
+        return true;
+    }
+    return rader_plan_fft(dtype, p - 1, rc);
+}
+int rader_col_lanes(int dtype, const RaderCfg &rc) {
+    const int lt = rc.fft.tpl * rc.mc;
+    int thr = lt * 32;
+    thr = thr > 1024 ? 1024 : (thr < 256 ? 256 : thr);
+    const int lpb = thr / lt;
+    const size_t lane = rader_lane_lds(rc, true) * 2 * (dtype == NDFFT_F32 ? 4 : 8);
+    const int l = (int)std::min<size_t>((size_t)lpb, jit_lds_limit() / lane);
+    return l >= 8 ? l : 0;
+}
+template <typename T> int launch_jit_rader(int gop, const RaderCfg &rc, bool col, const RealArgs<T> &a, hipStream_t s) {
+    if (!rtc().ok || !rader_enabled()) return NDFFT_ERR_UNSUPPORTED;
+    const int dtype = sizeof(T) == 4 ? NDFFT_F32 : NDFFT_F64;
+    const int lt = rc.fft.tpl * rc.mc;
+    const int lpb = col ? rader_col_lanes(dtype, rc) : rader_row_lanes(dtype, rc);
+    if (lpb <= 0) return NDFFT_ERR_UNSUPPORTED;
+    int dev = 0;
+    NDFFT_HIP(hipGetDevice(&dev));
+    const char *tn = sizeof(T) == 4 ? "float" : "double";
+    const int threads = lt * lpb;
+    const std::string inst = std::string("RaderKernel<") + tn + ", " + std::to_string(rc.p) + ", " + std::to_string(rc.mc) + ", " + std::to_string(rc.fft.tpl) + ", " +
+                             std::to_string(lpb) + ", RadixList<" + radix_list(rc.fft) + ">, " + std::to_string(gop) + ", " + (col ? "true" : "false") + ">";
+    const std::string src = std::string("#include \"rader_kernel.h\"\nusing namespace ndfft;\nextern \"C\" __global__ __launch_bounds__(") +
+                            std::to_string(threads) + ") void k_jit(const RealArgs<" + tn + "> a) { " + inst + "::run(a); }\n";
+    const Entry e = get_or_compile("dev" + std::to_string(dev) + ":" + inst, src, inst);
+    if (e.failed) return NDFFT_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)lpb * rader_lane_lds(rc, col) * 2 * sizeof(T);
+    if (lds > jit_lds_limit()) return NDFFT_ERR_UNSUPPORTED;
+    const int64_t nblk = (a.nlanes + lpb - 1) / lpb;
+    if (nblk <= 0) return NDFFT_OK;
+    if (nblk > 0x7fffffffLL) return NDFFT_ERR_UNSUPPORTED;
+    RealArgs<T> arg = a;
+    void *params[] = {(void *)&arg};
+    NDFFT_HIP(hipModuleLaunchKernel(e.fn, (unsigned)nblk, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, s, params, nullptr));
+    return NDFFT_OK;
+}
+template int launch_jit_rader<float>(int, const RaderCfg &, bool, const RealArgs<float> &, hipStream_t);
+template int launch_jit_rader<double>(int, const RaderCfg &, bool, const RealArgs<double> &, hipStream_t);
+
 template int launch_jit_blue<float>(int, const JitCfg &, bool, const RealArgs<float> &, hipStream_t);
 template int launch_jit_blue<double>(int, const JitCfg &, bool, const RealArgs<double> &, hipStream_t);
 

@@ -129,6 +129,49 @@ static void build_bluestein_tables(FftConfig &c, int F, int M) {
     for (int k = 0; k < M; ++k) { c.bhat.re.push_back(br[k] / M); c.bhat.im.push_back(bi[k] / M); }
 }
 
+// ---- Rader / Good-Thomas tables (rader_kernel.h) ------------------------------------------------------------------------
+// forward DFT of any length in long double: recursive decimation in time over the smallest prime factor (plan time only)
+static void dft_ld(std::vector<long double> &re, std::vector<long double> &im) {
+    const size_t n = re.size();
+    if (n <= 1) return;
+    size_t r = n;
+    for (size_t f = 2; f * f <= n; ++f) if (n % f == 0) { r = f; break; }
+    const size_t m = n / r;
+    std::vector<std::vector<long double>> sr(r, std::vector<long double>(m)), si(r, std::vector<long double>(m));
+    for (size_t j = 0; j < r; ++j)
+        for (size_t i = 0; i < m; ++i) { sr[j][i] = re[i * r + j]; si[j][i] = im[i * r + j]; }
+    if (m > 1) for (size_t j = 0; j < r; ++j) dft_ld(sr[j], si[j]);
+    std::vector<long double> wr(n), wi(n);
+    for (size_t k = 0; k < n; ++k) { const long double ang = -2.0L * kPiL * (long double)k / (long double)n; wr[k] = cosl(ang); wi[k] = sinl(ang); }
+    for (size_t k = 0; k < n; ++k) {
+        long double ar = 0.0L, ai = 0.0L;
+        for (size_t j = 0; j < r; ++j) {
+            const size_t w = (j * k) % n;
+            const long double xr = sr[j][k % m], xi = si[j][k % m];
+            ar += xr * wr[w] - xi * wi[w]; ai += xr * wi[w] + xi * wr[w];
+        }
+        re[k] = ar; im[k] = ai;
+    }
+}
+static void build_rader_tables(FftConfig &c) {
+    const int p = c.radercfg.p, M = p - 1;
+    auto powmod = [&](unsigned long long b, unsigned long long e) { unsigned long long r = 1; b %= p; while (e) { if (e & 1) r = r * b % p; b = b * b % p; e >>= 1; } return r; };
+    std::vector<int> pf;
+    { int m = M; for (int f = 2; f * f <= m; ++f) if (m % f == 0) { pf.push_back(f); while (m % f == 0) m /= f; } if (m > 1) pf.push_back(m); }
+    int g = 2;
+    for (;; ++g) { bool ok = true; for (int f : pf) if (powmod(g, M / f) == 1) { ok = false; break; } if (ok) break; }   // smallest primitive root
+    c.rader_tab.assign(2 * (size_t)M, 0);
+    unsigned long long x = 1;
+    for (int i = 0; i < M; ++i) { c.rader_tab[i] = (int32_t)x; c.rader_tab[M + (M - i) % M] = (int32_t)x; x = x * g % p; }   // g^i; g^-j = g^(M - j)
+    std::vector<long double> br(M), bi(M);
+    for (int q = 0; q < M; ++q) { const long double ang = -2.0L * kPiL * (long double)c.rader_tab[M + q] / (long double)p; br[q] = cosl(ang); bi[q] = sinl(ang); }
+    dft_ld(br, bi);
+    c.rader_bhat = HostTable();
+    for (int k = 0; k < M; ++k) { c.rader_bhat.re.push_back(br[k] / M); c.rader_bhat.im.push_back(bi[k] / M); }
+    c.rader_twp = HostTable();
+    build_pass_twiddles(c.rader_twp, c.radercfg.fft.radix, M);
+}
+
 // fills F, radix / Bluestein, tw (and twM, chirp, bhat); or the four-step split for long lanes
 static void build_fft(FftConfig &c, int F, int dtype) {
     c.F = F;
@@ -327,6 +370,8 @@ static void add_narrow_tables(ndfft_plan *p) {
     for (int i = 0; i < CFG_COUNT; ++i) {
         FftConfig &c = p->cfg[i];
         if (p->has_cfg[i] && c.blue && pow2_real_config(c.M, c.jitcfg)) { c.bluereg = true; c.twp = HostTable(); pow2_real_build_twiddles(c.M, c.twp); }
+        // ... and, where F = (small cofactor) x (prime p with p - 1 smooth), Rader's convolution of length p - 1 instead (rader_kernel.h)
+        if (p->has_cfg[i] && c.bluereg && rader_choose(p->dtype, c.F, c.radercfg)) { c.rader = true; build_rader_tables(c); }
     }
     // specialised (hiprtc) register kernels for the real-data ops with a smooth non-power-of-two inner FFT
     if (p->kind != NDFFT_KIND_C2C)
@@ -382,6 +427,12 @@ int get_dev_tables(const ndfft_plan *cplan, const DevTables **out) {
         if ((rc = upload_any(plan->dtype, c.twp_narrow, &d.twp_narrow))) return rc;
         if ((rc = upload_any(plan->dtype, c.wave_tw, &d.wave_tw))) return rc;
         for (int q = 0; q < 4; ++q) if ((rc = upload_any(plan->dtype, c.tinymat[q], &d.tinymat[q]))) return rc;
+        if ((rc = upload_any(plan->dtype, c.rader_bhat, &d.rader_bhat))) return rc;
+        if ((rc = upload_any(plan->dtype, c.rader_twp, &d.rader_twp))) return rc;
+        if (!c.rader_tab.empty()) {
+            NDFFT_HIP(hipMalloc(&d.rader_tab, c.rader_tab.size() * sizeof(int32_t)));
+            NDFFT_HIP(hipMemcpy(d.rader_tab, c.rader_tab.data(), c.rader_tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
     }
     auto ins = plan->dev.emplace(dev, t);
     *out = &ins.first->second;
@@ -446,7 +497,7 @@ int ndfft_plan_destroy(ndfft_plan *plan) {
         (void)hipSetDevice(kv.first);
         for (int i = 0; i < CFG_COUNT; ++i) {
             DevConfig &d = kv.second.cfg[i];
-            void *ptrs[] = {d.tw, d.twM, d.chirp, d.bhat, d.aux1, d.aux2, d.twp, d.twlo, d.twhi, d.twp_col, d.twp_narrow, d.cs_twlo, d.cs_twhi, d.wave_tw, d.tinymat[0], d.tinymat[1], d.tinymat[2], d.tinymat[3]};
+            void *ptrs[] = {d.tw, d.twM, d.chirp, d.bhat, d.aux1, d.aux2, d.twp, d.twlo, d.twhi, d.twp_col, d.twp_narrow, d.cs_twlo, d.cs_twhi, d.wave_tw, d.tinymat[0], d.tinymat[1], d.tinymat[2], d.tinymat[3], d.rader_bhat, d.rader_twp, d.rader_tab};
             for (void *q : ptrs) if (q) (void)hipFree(q);
         }
     }

@@ -1,0 +1,227 @@
+// rader_kernel.h -- lengths with ONE large prime factor on the register-resident Stockham engine, without Bluestein's
+// zero padding: the inner complex FFT length is F = MC * P with P prime, P - 1 smooth, and a small cofactor MC (1..16,
+// coprime to P because P > 16).
+//
+//   Good-Thomas (no twiddles): x[(n1 P + n2 MC) mod F] -> X[(k1 C1 + k2 C2) mod F],  C1 = P (P^-1 mod MC), C2 = MC (MC^-1 mod P):
+//       X[k1, k2] = sum_n1 W_MC^(n1 k1) sum_n2 W_P^(n2 k2) x[n1, n2]
+//   Rader for each of the MC length-P transforms (g a primitive root of P, M = P - 1):
+//       a[q] = x[n1, g^q],  b[q] = W_P^(g^-q):   X[n1, g^-k] = x[n1, 0] + (a (*) b)[k]   (cyclic convolution of length M)
+//       X[n1, 0] = x[n1, 0] + A[0],  A = FFT_M(a);  (a (*) b) = conj FFT_M(conj(A * bhat)),  bhat = FFT_M(b) / M, and adding
+//       x[n1, 0] to bin 0 of the product adds it to every output of the convolution.
+//
+// Per lane: stage the raw lane -> LDS; PRE (realops.h) gathered through the index table straight into the first pass's
+// register pattern of MC independent FFT_M (MC * TPL threads per lane, the passes of pow2_kernel.h with any radix list);
+// * bhat, conj; one LDS exchange back into the first pass's pattern; the same passes; scatter to the Rader output order;
+// for MC > 1 one radix-MC butterfly across the MC sub-transforms; Z in LDS in natural order; POST gather (realops.h).
+// FFT work per lane: 2 MC (P - 1) ~ 2 F points against Bluestein's 2 M' with M' = 2^k >= 2F - 1 (2F .. 4F), in a workgroup
+// of 1/2 .. 1/4 of the LDS.  Specialised with hiprtc per (P, MC, op, dtype, layout) at first use (jit.hip: launch_jit_rader).
+// The lane semantics are the reference's (src/lib.rs:313-338, 497-531, 688-741) through realops.h, exactly as in blue_kernel.h.
+#pragma once
+#include "pow2_real.h"
+
+namespace ndfft {
+
+constexpr int rader_inv_mod(int a, int m) {   // a^-1 mod m for coprime a, m (0 when m == 1)
+    a %= m;
+    for (int x = 1; x < m; ++x) if ((a * x) % m == 1) return x;
+    return 0;
+}
+
+template <typename T, int P, int MC, int TPL, int LPB, typename RL, int OP, bool COL = false> struct RaderKernel {
+    static constexpr int M = P - 1, F = P * MC;
+    using FFT = Pow2Kernel<T, M, TPL, LPB * MC, false, RL, 0, 1, 0>;
+    static constexpr int E = FFT::E;
+    static constexpr int LTHREADS = TPL * MC;                       // threads of one lane
+    static constexpr int THREADS = LTHREADS * LPB;
+    static constexpr int SUB_LDS = M + (M >> 4) + 2;                // complex elements of one sub-transform's exchange region
+    static constexpr int LANE_MIN = (MC * SUB_LDS > F + (F >> 4) + 3) ? MC * SUB_LDS : F + (F >> 4) + 3;   // ... and the raw lane / Z
+    static constexpr int LANE_LDS = COL ? (LANE_MIN | 1) : ((LANE_MIN + 1) & ~1);
+    static constexpr size_t LDS_BYTES = (size_t)LPB * LANE_LDS * 2 * sizeof(T);
+    static constexpr bool IN_CPLX = OP == G_C2R_EVEN || OP == G_C2R_ODD || OP == G_C2C_FWD || OP == G_C2C_INV;
+    static constexpr bool OUT_CPLX = OP == G_R2C_EVEN || OP == G_R2C_ODD || OP == G_C2C_FWD || OP == G_C2C_INV;
+    static constexpr int PINV = rader_inv_mod(P, MC), MINV = rader_inv_mod(MC, P);   // P^-1 mod MC, MC^-1 mod P
+    static_assert(FFT::LANE_LDS <= SUB_LDS, "exchange region of one sub-transform");
+
+    template <int STEP, typename LD, typename ST> static __device__ __forceinline__ void stage_loop(int j0, int n, LD ld, ST st) {
+        constexpr int U = 8;
+        int j = j0;
+        for (; j + (U - 1) * STEP < n; j += U * STEP) {
+            decltype(ld(0)) tmp[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) tmp[u] = ld(j + u * STEP);
+#pragma unroll
+            for (int u = 0; u < U; ++u) st(j + u * STEP, tmp[u]);
+        }
+        for (; j < n; j += STEP) st(j, ld(j));
+    }
+
+    // inner-FFT input element i (natural order) from the raw lane
+    static __device__ __forceinline__ cpx<T> pre(const RealArgs<T> &a, const void *raw, int i) {
+        if constexpr (OP == G_C2C_FWD || OP == G_R2C_EVEN) return ((const cpx<T> *)raw)[i];   // R2C even: z[i] = (x[2i], x[2i+1])
+        else if constexpr (OP == G_C2C_INV) return cconj(((const cpx<T> *)raw)[i]);
+        else if constexpr (OP == G_R2C_ODD) return mk<T>(((const T *)raw)[i], (T)0);
+        else return pre_elem<T, OP, ZiNone>(a, raw, i);
+    }
+
+    static __device__ __forceinline__ void run(const RealArgs<T> &a) {
+        extern __shared__ __attribute__((aligned(16))) char smem[];
+        const int tl = threadIdx.x % LTHREADS, ll = threadIdx.x / LTHREADS;
+        const int t = tl % TPL, n1 = tl / TPL;
+        const int64_t lane0 = (int64_t)blockIdx.x * LPB;
+        const int64_t lane = lane0 + ll;
+        const bool live = lane < a.nlanes;
+        char *lds = smem + (size_t)ll * LANE_LDS * 2 * sizeof(T);       // the lane: raw data, then Z
+        char *sub = lds + (size_t)n1 * SUB_LDS * 2 * sizeof(T);        // this thread's sub-transform
+        // ---- stage the raw lane(s) ----
+        if constexpr (COL) {
+            const int cl = threadIdx.x % LPB, j0 = threadIdx.x / LPB;
+            const int64_t L = lane0 + cl;
+            if (L < a.nlanes) {
+                const int64_t base = (L / a.inner) * a.outer_in + (L % a.inner);
+                char *dst = smem + (size_t)cl * LANE_LDS * 2 * sizeof(T);
+                constexpr int STEP = THREADS / LPB;
+                if constexpr (IN_CPLX) {
+                    const cpx<T> *in = (const cpx<T> *)a.in + base;
+                    stage_loop<STEP>(j0, a.n_in, [&](int j) { return in[(int64_t)j * a.elem_in]; }, [&](int j, cpx<T> v) { ((cpx<T> *)dst)[j] = v; });
+                } else {
+                    const T *in = (const T *)a.in + base;
+                    stage_loop<STEP>(j0, a.n_in, [&](int j) { return in[(int64_t)j * a.elem_in]; }, [&](int j, T v) { ((T *)dst)[j] = v; });
+                }
+            }
+        } else {
+            const int64_t lsafe = live ? lane : 0;
+            if constexpr (IN_CPLX) {
+                const cpx<T> *in = (const cpx<T> *)a.in + lsafe * a.pitch_in;
+                cpx<T> *raw = (cpx<T> *)lds;
+                stage_loop<LTHREADS>(tl, a.n_in, [&](int j) { return in[j]; }, [&](int j, cpx<T> v) { raw[j] = v; });
+            } else {
+                const T *in = (const T *)a.in + lsafe * a.pitch_in;
+                T *raw = (T *)lds;
+                stage_loop<LTHREADS>(tl, a.n_in, [&](int j) { return in[j]; }, [&](int j, T v) { raw[j] = v; });
+            }
+        }
+        __syncthreads();
+        // ---- PRE, gathered in Rader order, in the first pass's register pattern ----
+        constexpr int R0 = RL::at(0), NB0 = FFT::nbfly(0), NBF0 = FFT::slots(0);
+        constexpr int RLAST = RL::at(RL::NP - 1), NBL = FFT::nbfly(RL::NP - 1), NBFL = FFT::slots(RL::NP - 1);
+        constexpr bool FULL0 = FFT::full(0), FULLL = FFT::full(RL::NP - 1);
+        const int32_t *gpow = a.rader_tab, *ginv = a.rader_tab + M;      // g^i mod P, g^-i mod P
+        const int row0 = (n1 * P) % F;                                    // (n1, n2 = 0)
+        const cpx<T> x0 = pre(a, (const void *)lds, row0);
+        cpx<T> v[E];
+#pragma unroll
+        for (int q = 0; q < NBF0; ++q)
+            if (FULL0 || t + q * TPL < NB0) {
+#pragma unroll
+                for (int r = 0; r < R0; ++r) {
+                    int i = row0 + MC * gpow[t + q * TPL + r * NB0];
+                    if (MC > 1 && i >= F) i -= F;
+                    v[q * R0 + r] = pre(a, (const void *)lds, i);
+                }
+            }
+        // (the first exchange inside passes() starts with a barrier, so the raw lane is dead by then)
+        FFT::template passes<0>(v, a.twp, sub, t);
+        // ---- * bhat (+ x0 in bin 0), conj; back into the first pass's pattern through LDS ----
+        cpx<T> X0 = x0;
+        {
+            cpx<T> *z = (cpx<T> *)sub;
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NBFL; ++q)
+                if (FULLL || t + q * TPL < NBL) {
+#pragma unroll
+                    for (int r = 0; r < RLAST; ++r) {
+                        const int o = t + q * TPL + r * NBL;
+                        cpx<T> c = cmul(v[q * RLAST + r], a.bhat[o]);
+                        if (q == 0 && r == 0) {
+                            if (t == 0) { X0 = cadd(x0, v[0]); c = cadd(c, x0); }
+                        }
+                        z[ZiPhi::map(o)] = cconj(c);
+                    }
+                }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NBF0; ++q)
+                if (FULL0 || t + q * TPL < NB0) {
+#pragma unroll
+                    for (int r = 0; r < R0; ++r) v[q * R0 + r] = z[ZiPhi::map(t + q * TPL + r * NB0)];
+                }
+        }
+        FFT::template passes<0>(v, a.twp, sub, t);
+        __syncthreads();
+        cpx<T> *zz = (cpx<T> *)lds;
+        if constexpr (MC == 1) {
+            // ---- Z[g^-k] = conj(.), Z[0] = x0 + A[0] ----
+#pragma unroll
+            for (int q = 0; q < NBFL; ++q)
+                if (FULLL || t + q * TPL < NBL) {
+#pragma unroll
+                    for (int r = 0; r < RLAST; ++r) zz[ZiPhi::map(ginv[t + q * TPL + r * NBL])] = cconj(v[q * RLAST + r]);
+                }
+            if (t == 0) zz[0] = X0;
+        } else {
+            // ---- Y[n1][k2] -> LDS as [k2][n1]; radix-MC butterflies across n1; Z[(k1 C1 + k2 C2) mod F] ----
+#pragma unroll
+            for (int q = 0; q < NBFL; ++q)
+                if (FULLL || t + q * TPL < NBL) {
+#pragma unroll
+                    for (int r = 0; r < RLAST; ++r) zz[ginv[t + q * TPL + r * NBL] * MC + n1] = cconj(v[q * RLAST + r]);
+                }
+            if (t == 0) zz[n1] = X0;
+            __syncthreads();
+            constexpr int NS = (P + LTHREADS - 1) / LTHREADS;
+            cpx<T> w[NS][MC];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int k2 = tl + s * LTHREADS;
+                if (k2 < P) {
+#pragma unroll
+                    for (int j = 0; j < MC; ++j) w[s][j] = zz[k2 * MC + j];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int k2 = tl + s * LTHREADS;
+                if (k2 < P) {
+                    Bfly<T, MC>::run(w[s]);
+                    const int kb = MC * ((k2 * MINV) % P);              // k2 C2 mod F
+#pragma unroll
+                    for (int k1 = 0; k1 < MC; ++k1) {
+                        int k = kb + P * ((k1 * PINV) % MC);            // + k1 C1 mod F
+                        if (k >= F) k -= F;
+                        zz[ZiPhi::map(k)] = w[s][k1];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- POST gather + store ----
+        if constexpr (COL) {
+            const int cl = threadIdx.x % LPB, j0 = threadIdx.x / LPB;
+            const int64_t L = lane0 + cl;
+            if (L >= a.nlanes) return;
+            const int64_t base = (L / a.inner) * a.outer_out + (L % a.inner);
+            const cpx<T> *res = (const cpx<T> *)(smem + (size_t)cl * LANE_LDS * 2 * sizeof(T));
+            if constexpr (OUT_CPLX) {
+                cpx<T> *out = (cpx<T> *)a.out + base;
+                for (int q = j0; q < a.n_out; q += THREADS / LPB) gstore<T, true>(out + (int64_t)q * a.elem_out, post_cplx<T, OP, ZiPhi>(a, res, q));
+            } else {
+                T *out = (T *)a.out + base;
+                for (int q = j0; q < a.n_out; q += THREADS / LPB) __builtin_nontemporal_store(post_real<T, OP, ZiPhi>(a, res, q), out + (int64_t)q * a.elem_out);
+            }
+        } else {
+            if (!live) return;
+            const cpx<T> *res = (const cpx<T> *)lds;
+            if constexpr (OUT_CPLX) {
+                cpx<T> *out = (cpx<T> *)a.out + lane * a.pitch_out;
+                for (int q = tl; q < a.n_out; q += LTHREADS) gstore<T, true>(out + q, post_cplx<T, OP, ZiPhi>(a, res, q));
+            } else {
+                T *out = (T *)a.out + lane * a.pitch_out;
+                for (int q = tl; q < a.n_out; q += LTHREADS) __builtin_nontemporal_store(post_real<T, OP, ZiPhi>(a, res, q), out + q);
+            }
+        }
+    }
+};
+
+}  // namespace ndfft

@@ -5,6 +5,7 @@
 #include "engine.h"
 #include "blue_kernel.h"
 #include "reg_kernel.h"
+#include "rader_kernel.h"
 namespace ndfft {
 // two PARTIAL-round configurations of the C2C row kernel (pow2_kernel.h: slots / full) instantiated ahead of
 // time, so that the predicated passes are exercised on the CPU: 264 = 11.8.3 on 12 threads, 210 = 7.6.5 on 14
@@ -91,6 +92,48 @@ template <typename T> int launch_jit_blue(int gop, const JitCfg &cfg, bool col, 
 }
 template int launch_jit_blue<float>(int, const JitCfg &, bool, const RealArgs<float> &, hipStream_t);
 template int launch_jit_blue<double>(int, const JitCfg &, bool, const RealArgs<double> &, hipStream_t);
+
+// Rader / Good-Thomas kernel (rader_kernel.h; the product specialises it with hiprtc, jit.hip: launch_jit_rader), ahead of time for
+// F = 31 and 97 (primes), 62 = 2 x 31 and 511 = 7 x 73 (cofactor butterflies); FFT_30 runs with a PARTIAL second pass (6.5 on 5 threads)
+bool rader_choose(int, int F, RaderCfg &rc) {
+    rc.fft.vec = 1; rc.fft.lpb = 1;
+    if (F == 31 || F == 62) { rc.p = 31; rc.mc = F / 31; rc.fft.n = 30; rc.fft.tpl = 5; rc.fft.e = 10; rc.fft.radix = {6, 5}; rc.fft.partial = true; return true; }
+    if (F == 97) { rc.p = 97; rc.mc = 1; rc.fft.n = 96; rc.fft.tpl = 8; rc.fft.e = 12; rc.fft.radix = {6, 4, 4}; return true; }
+    if (F == 511) { rc.p = 73; rc.mc = 7; rc.fft.n = 72; rc.fft.tpl = 6; rc.fft.e = 12; rc.fft.radix = {6, 4, 3}; return true; }
+    return false;
+}
+int rader_col_lanes(int, const RaderCfg &) { return 8; }
+template <typename T, int P, int MC, int TPL, typename RL, int OP> static int rader_one(bool col, const RealArgs<T> &a, hipStream_t s) {
+    if (col) {
+        using K = RaderKernel<T, P, MC, TPL, 8, RL, OP, true>;
+        hipLaunchKernelGGL((k_blue_emul<K, T>), dim3((unsigned)((a.nlanes + 7) / 8)), dim3(K::THREADS), K::LDS_BYTES, s, a);
+    } else {
+        constexpr int LPB = 256 / (TPL * MC);
+        using K = RaderKernel<T, P, MC, TPL, LPB, RL, OP, false>;
+        hipLaunchKernelGGL((k_blue_emul<K, T>), dim3((unsigned)((a.nlanes + LPB - 1) / LPB)), dim3(K::THREADS), K::LDS_BYTES, s, a);
+    }
+    return NDFFT_OK;
+}
+template <typename T, int P, int MC, int TPL, typename RL> static int rader_P(int gop, bool col, const RealArgs<T> &a, hipStream_t s) {
+    switch (gop) {
+#define B(OP_) case OP_: return rader_one<T, P, MC, TPL, RL, OP_>(col, a, s);
+        B(G_C2C_FWD) B(G_C2C_INV) B(G_R2C_EVEN) B(G_R2C_ODD) B(G_C2R_EVEN) B(G_C2R_ODD) B(G_DCT1)
+        B(G_DCT2_EVEN) B(G_DCT2_ODD) B(G_DCT3_EVEN) B(G_DCT3_ODD) B(G_DCT4_EVEN) B(G_DCT4_ODD)
+#undef B
+        default: return NDFFT_ERR_UNSUPPORTED;
+    }
+}
+template <typename T> int launch_jit_rader(int gop, const RaderCfg &rc, bool col, const RealArgs<T> &a, hipStream_t s) {
+    if (a.nlanes <= 0) return NDFFT_OK;
+    { const char *e = getenv("NDFFT_RADER"); if (e && e[0] == '0') return NDFFT_ERR_UNSUPPORTED; }
+    if (rc.p == 31 && rc.mc == 1) return rader_P<T, 31, 1, 5, RadixList<6, 5>>(gop, col, a, s);
+    if (rc.p == 31 && rc.mc == 2) return rader_P<T, 31, 2, 5, RadixList<6, 5>>(gop, col, a, s);
+    if (rc.p == 97 && rc.mc == 1) return rader_P<T, 97, 1, 8, RadixList<6, 4, 4>>(gop, col, a, s);
+    if (rc.p == 73 && rc.mc == 7) return rader_P<T, 73, 7, 6, RadixList<6, 4, 3>>(gop, col, a, s);
+    return NDFFT_ERR_UNSUPPORTED;
+}
+template int launch_jit_rader<float>(int, const RaderCfg &, bool, const RealArgs<float> &, hipStream_t);
+template int launch_jit_rader<double>(int, const RaderCfg &, bool, const RealArgs<double> &, hipStream_t);
 
 // thread-per-lane kernels (reg_kernel.h): 18 = 6 x 3, 30 = 6 x 5, 40 = 8 x 5 and the prime 23 instantiated ahead of time for the CPU tests
 bool regfft_factor(int n, int *n1, int *n2) {

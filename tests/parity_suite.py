@@ -733,7 +733,40 @@ def column_four_step(L):
 
 def bluestein_register_kernel(L, sizes=((17, 64), (31, 64), (97, 256), (127, 256)), col_max_M=256):
     """Lengths with a prime factor > 13 on the register-resident Bluestein kernel (blue_kernel.h): every op
-    family incl. the odd-n variants, rows and column tiles.  `sizes` = (F, M): inner FFT length F, M = 2^k >= 2F-1."""
+    family incl. the odd-n variants, rows and column tiles.  `sizes` = (F, M): inner FFT length F, M = 2^k >= 2F-1.
+    (NDFFT_RADER=0: lengths that have a Rader recipe would otherwise go to rader_kernel.h -- see rader_kernel below.)"""
+    os.environ["NDFFT_RADER"] = "0"
+    try:
+        _bluestein_register_kernel(L, sizes, col_max_M)
+    finally:
+        del os.environ["NDFFT_RADER"]
+
+
+def rader_kernel(L, sizes=(31, 62, 97, 511), col_max_F=128):
+    """Inner FFT lengths F = (cofactor <= 16) x (prime p, p - 1 smooth) on the Rader / Good-Thomas register kernel
+    (rader_kernel.h): every op family incl. the odd-n variants, both normalisations, rows and column tiles."""
+    for F in sizes:
+        rows = (1 << 17) // F + 5
+        for rdt in (np.float64, np.float32):
+            ok_row = ("rader_reg", "reg_row", "regreal_row") if F <= 96 else ("rader_reg",)
+            for name in ("ndfft", "ndifft", "ndfft_r2c", "ndifft_r2c", "nddct2", "nddct3"):       # n = F (odd-n variants when F is odd)
+                if F % 2 == 0 and name in ("ndfft_r2c", "ndifft_r2c", "nddct2", "nddct3"):
+                    continue        # even n: the inner FFT is n / 2, covered below
+                for norm in ("Default", "None"):
+                    assert run_case(L, name, (rows, F), 1, rdt, norm=norm, offset=F) in ok_row, (name, F, rdt)
+            ok2 = ("rader_reg", "regreal_row") if 2 * F <= 96 else ("rader_reg",)
+            for name in ("ndfft_r2c", "ndifft_r2c", "nddct2", "nddct3", "nddct4"):               # even n = 2F
+                assert run_case(L, name, (rows // 2, 2 * F), 1, rdt, offset=F + 1) in ok2, (name, 2 * F, rdt)
+            assert run_case(L, "nddct1", (rows, F + 1), 1, rdt, offset=F) in ok_row, ("nddct1", F + 1, rdt)
+            if F > col_max_F:
+                continue
+            ok_col = ("rader_col", "reg_col", "regreal_col") if F <= 96 else ("rader_col",)
+            for name, n in (("ndfft", F), ("ndifft", F), ("ndifft_r2c", 2 * F), ("nddct1", F + 1), ("nddct2", 2 * F), ("ndfft_r2c", 2 * F), ("nddct4", 2 * F)):
+                assert run_case(L, name, (n, rows + 3), 0, rdt, offset=n) in ok_col, (name, n, rdt)
+                assert run_case(L, name, (3, n, rows // 2), 1, rdt, offset=n + 1) in ok_col, (name, n, rdt)
+
+
+def _bluestein_register_kernel(L, sizes, col_max_M):
     for F, M in sizes:
         rows = (1 << 16) // M + 5
         for rdt in (np.float64, np.float32):

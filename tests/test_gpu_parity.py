@@ -55,6 +55,7 @@ def test_fuzz_short_lanes(L):
     assert {"tiny_col", "tinymat_col"} <= set(paths) and any(p.startswith("reg") for p in paths), paths
 def test_partial_round_configs(L): ps.partial_round_configs(L, sizes=(264, 210, 840, 1008, 630, 2520, 3003, 6006, 33, 66))
 def test_long_smooth_lanes(L): ps.long_smooth_lanes(L)
+def test_rader_kernel(L): ps.rader_kernel(L, sizes=(31, 62, 97, 127, 257, 406, 465, 511, 1009, 1168, 2017, 3027, 4001), col_max_F=1100)
 def test_bluestein_register_kernel(L):
     ps.bluestein_register_kernel(L, sizes=((17, 64), (31, 64), (97, 256), (127, 256), (511, 1024), (1009, 2048), (2039, 4096), (4093, 8192)), col_max_M=1024)
 def test_long_lanes_four_step(L): ps.long_lanes_four_step(L, full=True)

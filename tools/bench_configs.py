@@ -131,6 +131,33 @@ def main():
             run(f"long ndfft axis=1 {rows}x{n} {np.dtype(cdt).name}", ndfft, x, y, FftHandler(n, rdt), 1, x.numel(), max(a.steps // 3, 3))
         x = torch.from_numpy(synth.real_array((64, 1 << 18))).to(dev); y = torch.empty_like(x)
         run("long nddct2 axis=1 64x262144 f64", nddct2, x, y, DctHandler(1 << 18), 1, x.numel(), max(a.steps // 3, 3))
+    if a.only == "radersweep":
+        for n, cdt, rdt in ((1009, np.complex128, np.float64), (127, np.complex128, np.float64), (511, np.complex128, np.float64), (2017, np.complex128, np.float64),
+                            (4001, np.complex128, np.float64), (1009, np.complex64, np.float32)):
+            rows = (1 << 24) // n
+            x = torch.from_numpy(synth.complex_array((rows, n), cdt)).to(dev); y = torch.empty_like(x)
+            run(f"ndfft {n} {np.dtype(cdt).name}", ndfft, x, y, FftHandler(n, rdt), 1, x.numel(), a.steps)
+        x = torch.from_numpy(synth.real_array((256, 256, 512))).to(dev); y = torch.empty_like(x)
+        run("nddct1 axis=2 256x256x512 f64", nddct1, x, y, DctHandler(512), 2, x.numel(), a.steps)
+        return
+    if want("primes"):
+        # lengths with a prime factor > 13: Rader / Good-Thomas (rader_kernel.h) against Bluestein (NDFFT_RADER=0)
+        for rad in ("1", "0"):
+            os.environ["NDFFT_RADER"] = rad
+            tag = "rader" if rad == "1" else "bluestein"
+            for n, cdt, rdt in ((1009, np.complex128, np.float64), (97, np.complex128, np.float64), (127, np.complex128, np.float64), (257, np.complex128, np.float64),
+                                (511, np.complex128, np.float64), (2017, np.complex128, np.float64), (4001, np.complex128, np.float64), (3027, np.complex128, np.float64),
+                                (1009, np.complex64, np.float32), (511, np.complex64, np.float32), (4001, np.complex64, np.float32)):
+                rows = (1 << 24) // n
+                x = torch.from_numpy(synth.complex_array((rows, n), cdt)).to(dev); y = torch.empty_like(x)
+                run(f"primes[{tag}] ndfft axis=1 {rows}x{n} {np.dtype(cdt).name}", ndfft, x, y, FftHandler(n, rdt), 1, x.numel(), a.steps)
+            x = torch.from_numpy(synth.real_array((256, 256, 512))).to(dev); y = torch.empty_like(x)
+            run(f"primes[{tag}] nddct1 axis=2 256x256x512 f64", nddct1, x, y, DctHandler(512), 2, x.numel(), a.steps)
+            x = torch.from_numpy(synth.real_array((512, 256 * 256))).to(dev); y = torch.empty_like(x)
+            run(f"primes[{tag}] nddct1 axis=0 512x65536 f64", nddct1, x, y, DctHandler(512), 0, x.numel(), a.steps)
+            x = torch.from_numpy(synth.real_array((16384, 2018))).to(dev); y = torch.empty((16384, 1010), dtype=torch.complex128, device=dev)
+            run(f"primes[{tag}] ndfft_r2c axis=1 16384x2018 f64", ndfft_r2c, x, y, R2cFftHandler(2018), 1, x.numel(), a.steps)
+        del os.environ["NDFFT_RADER"]
     if want("generic"):
         for n in (1000, 264, 1331, 1009, 3000, 96):
             rows = (1 << 24) // n
