@@ -95,7 +95,7 @@ struct FftConfig {                 // one complex-FFT-of-length-F recipe + op ta
                                    // (jitcfg = configuration for M, twp = its per-pass twiddles)
     // blue && F = mc * p with p - 1 smooth: rader_kernel.h instead of Bluestein (specialised with hiprtc); rader_bhat = FFT_(p-1)(W_p^(g^-q)) / (p - 1),
     // rader_twp = per-pass twiddles of FFT_(p-1), rader_tab = g^i mod p (i < p - 1) followed by g^-i mod p
-    bool rader = false; RaderCfg radercfg; HostTable rader_bhat, rader_twp; std::vector<int32_t> rader_tab;
+    bool rader = false; RaderCfg radercfg; HostTable rader_bhat, rader_twp, rader_twp2; std::vector<int32_t> rader_tab;   // twp2: the passes in reverse order
     bool jit = false; JitCfg jitcfg;   // C2C slot: smooth non-power-of-two n -> specialised register kernel (jit.hip); twiddles in twp
     bool unsupported = false;      // no single-kernel fit and no usable factorisation (large prime factor)
 };
@@ -106,7 +106,7 @@ struct DevConfig {                 // device copies (typed by dtype) of one FftC
     void *cs_twlo = nullptr, *cs_twhi = nullptr;
     void *wave_tw = nullptr;
     void *tinymat[4] = {nullptr, nullptr, nullptr, nullptr};
-    void *rader_bhat = nullptr, *rader_twp = nullptr, *rader_tab = nullptr;
+    void *rader_bhat = nullptr, *rader_twp = nullptr, *rader_twp2 = nullptr, *rader_tab = nullptr;
 };
 
 enum ConfigSlot { CFG_MAIN = 0, CFG_DCT1 = 1, CFG_DCT4 = 2, CFG_COUNT = 3 };

@@ -48,7 +48,8 @@ template <typename T> struct RealArgs {
     int32_t xcd_chunk = 0;               // non-XCD kernels: XCD-aware workgroup -> tile map (device_common.h: xcd_block), 0 = identity
     int32_t stream_in = 0;               // COL kernels: 1 = streaming (nt) loads of the input: it is read once and must not
                                          // push the intermediate of a two-stage route out of the Infinity Cache
-    const int32_t *rader_tab = nullptr;  // Rader kernels (rader_kernel.h): g^i mod P (i < P - 1), then g^-i mod P; bhat = FFT_(P-1)(W_P^(g^-q)) / (P - 1)
+    const int32_t *rader_tab = nullptr;  // Rader kernels (rader_kernel.h): g^i mod P (i < P - 1), then g^-i mod P; bhat = FFT_(P-1)(W_P^(g^-q)) / (P - 1),
+                                         // twp / chirp = per-pass twiddles of FFT_(P-1) with the radix list front to back / back to front
 };
 
 struct ZiNone { static __device__ __forceinline__ int map(int p) { return p; } };

@@ -11,7 +11,8 @@
 //
 // Per lane: stage the raw lane -> LDS; PRE (realops.h) gathered through the index table straight into the first pass's
 // register pattern of MC independent FFT_M (MC * TPL threads per lane, the passes of pow2_kernel.h with any radix list);
-// * bhat, conj; one LDS exchange back into the first pass's pattern; the same passes; scatter to the Rader output order;
+// * bhat, conj in registers; the same passes in REVERSE order (they start from the pattern the first FFT ends in, so the
+// product never goes through LDS); scatter to the Rader output order;
 // for MC > 1 one radix-MC butterfly across the MC sub-transforms; Z in LDS in natural order; POST gather (realops.h).
 // FFT work per lane: 2 MC (P - 1) ~ 2 F points against Bluestein's 2 M' with M' = 2^k >= 2F - 1 (2F .. 4F), in a workgroup
 // of 1/2 .. 1/4 of the LDS.  Specialised with hiprtc per (P, MC, op, dtype, layout) at first use (jit.hip: launch_jit_rader).
@@ -27,9 +28,20 @@ constexpr int rader_inv_mod(int a, int m) {   // a^-1 mod m for coprime a, m (0 
     return 0;
 }
 
+// RL back to front: the second FFT_M runs the passes in reverse order, so that the register pattern it starts from
+// (t + q TPL + r M / R_last) IS the pattern the first one ends in -- the product with bhat never goes through LDS
+template <int... I> struct RaderSeq {};
+template <int N, int... I> struct RaderMakeSeq : RaderMakeSeq<N - 1, N - 1, I...> {};
+template <int... I> struct RaderMakeSeq<0, I...> { typedef RaderSeq<I...> type; };
+template <typename RL, typename S> struct RaderRev;
+template <typename RL, int... I> struct RaderRev<RL, RaderSeq<I...>> { typedef RadixList<RL::at(RL::NP - 1 - I)...> type; };
+
 template <typename T, int P, int MC, int TPL, int LPB, typename RL, int OP, bool COL = false> struct RaderKernel {
     static constexpr int M = P - 1, F = P * MC;
+    using RLR = typename RaderRev<RL, typename RaderMakeSeq<RL::NP>::type>::type;
     using FFT = Pow2Kernel<T, M, TPL, LPB * MC, false, RL, 0, 1, 0>;
+    using FFT2 = Pow2Kernel<T, M, TPL, LPB * MC, false, RLR, 0, 1, 0>;
+    static_assert(FFT2::E == FFT::E, "same radices, same registers");
     static constexpr int E = FFT::E;
     static constexpr int LTHREADS = TPL * MC;                       // threads of one lane
     static constexpr int THREADS = LTHREADS * LPB;
@@ -121,51 +133,39 @@ template <typename T, int P, int MC, int TPL, int LPB, typename RL, int OP, bool
             }
         // (the first exchange inside passes() starts with a barrier, so the raw lane is dead by then)
         FFT::template passes<0>(v, a.twp, sub, t);
-        // ---- * bhat (+ x0 in bin 0), conj; back into the first pass's pattern through LDS ----
+        // ---- * bhat (+ x0 in bin 0), conj: in registers, already in the first-pass pattern of the reversed radix list ----
         cpx<T> X0 = x0;
-        {
-            cpx<T> *z = (cpx<T> *)sub;
-            __syncthreads();
 #pragma unroll
-            for (int q = 0; q < NBFL; ++q)
-                if (FULLL || t + q * TPL < NBL) {
+        for (int q = 0; q < NBFL; ++q)
+            if (FULLL || t + q * TPL < NBL) {
 #pragma unroll
-                    for (int r = 0; r < RLAST; ++r) {
-                        const int o = t + q * TPL + r * NBL;
-                        cpx<T> c = cmul(v[q * RLAST + r], a.bhat[o]);
-                        if (q == 0 && r == 0) {
-                            if (t == 0) { X0 = cadd(x0, v[0]); c = cadd(c, x0); }
-                        }
-                        z[ZiPhi::map(o)] = cconj(c);
+                for (int r = 0; r < RLAST; ++r) {
+                    cpx<T> c = cmul(v[q * RLAST + r], a.bhat[t + q * TPL + r * NBL]);
+                    if (q == 0 && r == 0) {
+                        if (t == 0) { X0 = cadd(x0, v[0]); c = cadd(c, x0); }
                     }
+                    v[q * RLAST + r] = cconj(c);
                 }
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < NBF0; ++q)
-                if (FULL0 || t + q * TPL < NB0) {
-#pragma unroll
-                    for (int r = 0; r < R0; ++r) v[q * R0 + r] = z[ZiPhi::map(t + q * TPL + r * NB0)];
-                }
-        }
-        FFT::template passes<0>(v, a.twp, sub, t);
+            }
+        FFT2::template passes<0>(v, a.chirp, sub, t);       // (chirp = per-pass twiddles of the reversed list; ends in the pattern of RL's FIRST pass)
         __syncthreads();
         cpx<T> *zz = (cpx<T> *)lds;
         if constexpr (MC == 1) {
             // ---- Z[g^-k] = conj(.), Z[0] = x0 + A[0] ----
 #pragma unroll
-            for (int q = 0; q < NBFL; ++q)
-                if (FULLL || t + q * TPL < NBL) {
+            for (int q = 0; q < NBF0; ++q)
+                if (FULL0 || t + q * TPL < NB0) {
 #pragma unroll
-                    for (int r = 0; r < RLAST; ++r) zz[ZiPhi::map(ginv[t + q * TPL + r * NBL])] = cconj(v[q * RLAST + r]);
+                    for (int r = 0; r < R0; ++r) zz[ZiPhi::map(ginv[t + q * TPL + r * NB0])] = cconj(v[q * R0 + r]);
                 }
             if (t == 0) zz[0] = X0;
         } else {
             // ---- Y[n1][k2] -> LDS as [k2][n1]; radix-MC butterflies across n1; Z[(k1 C1 + k2 C2) mod F] ----
 #pragma unroll
-            for (int q = 0; q < NBFL; ++q)
-                if (FULLL || t + q * TPL < NBL) {
+            for (int q = 0; q < NBF0; ++q)
+                if (FULL0 || t + q * TPL < NB0) {
 #pragma unroll
-                    for (int r = 0; r < RLAST; ++r) zz[ginv[t + q * TPL + r * NBL] * MC + n1] = cconj(v[q * RLAST + r]);
+                    for (int r = 0; r < R0; ++r) zz[ginv[t + q * TPL + r * NB0] * MC + n1] = cconj(v[q * R0 + r]);
                 }
             if (t == 0) zz[n1] = X0;
             __syncthreads();
