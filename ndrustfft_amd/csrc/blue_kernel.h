@@ -5,8 +5,8 @@
 //   M = 2^k >= 2F - 1, bhat = FFT_M(conj chirp, wrapped) / M   (plan.hip builds both tables in long double)
 //
 // Per lane: stage raw lane -> LDS; PRE (realops.h) * chirp -> registers in the first pass's pattern, zero
-// padded; the power-of-two passes of pow2_kernel.h; * bhat and conj in registers; one LDS exchange back
-// into the first pass's pattern; the same passes again; conj * chirp -> Z in LDS (natural order, k < F);
+// padded; the power-of-two passes of pow2_kernel.h; * bhat and conj in registers; the same passes in REVERSE
+// order (they start from the pattern the first FFT ends in); conj * chirp -> Z in LDS (natural order, k < F);
 // POST gather (realops.h) -> global.  Both FFTs are forward butterflies (IFFT = conj . FFT . conj).
 // Specialised with hiprtc per (M, op, dtype, layout) at first use (jit.hip) -- the LDS kernel
 // (generic_kernel.h) runs the same algorithm with run-time radices at 4-6 % of the HBM roofline.
@@ -24,6 +24,7 @@ template <typename T, int M, int TPL, int LPB, typename RL, int OP, bool COL = f
     static constexpr bool IN_CPLX = OP == G_C2R_EVEN || OP == G_C2R_ODD || OP == G_C2C_FWD || OP == G_C2C_INV;
     static constexpr bool OUT_CPLX = OP == G_R2C_EVEN || OP == G_R2C_ODD || OP == G_C2C_FWD || OP == G_C2C_INV;
     using FFT = Pow2Kernel<T, M, TPL, LPB, false, RL, 0, 1, 0>;
+    using FFT2 = Pow2Kernel<T, M, TPL, LPB, false, RadixReversed<RL>, 0, 1, 0>;   // the passes back to front (pow2_real.h: RadixReversed)
 
     template <int STEP, typename LD, typename ST> static __device__ __forceinline__ void stage_loop(int j0, int n, LD ld, ST st) {
         constexpr int U = 8;
@@ -96,34 +97,22 @@ template <typename T, int M, int TPL, int LPB, typename RL, int OP, bool COL = f
             }
         // (the first exchange inside passes() starts with a barrier, so the raw lane is dead by then)
         FFT::template passes<0>(v, a.twp, lds, t);
-        // ---- * bhat, conj; back into the first pass's pattern through LDS ----
-        {
-            cpx<T> *z = (cpx<T> *)lds;
-            __syncthreads();
+        // ---- * bhat, conj: in registers -- the reversed pass order starts from exactly this pattern ----
 #pragma unroll
-            for (int q = 0; q < NBFL; ++q)
+        for (int q = 0; q < NBFL; ++q)
 #pragma unroll
-                for (int r = 0; r < RLAST; ++r) {
-                    const int o = t + q * TPL + r * NBL;
-                    z[ZiPhi::map(o)] = cconj(cmul(v[q * RLAST + r], a.bhat[o]));
-                }
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < NBF0; ++q)
-#pragma unroll
-                for (int r = 0; r < R0; ++r) v[q * R0 + r] = z[ZiPhi::map(t + q * TPL + r * NB0)];
-        }
-        FFT::template passes<0>(v, a.twp, lds, t);
-        // ---- Z[k] = conj(.) * chirp[k], k < F, natural order ----
+            for (int r = 0; r < RLAST; ++r) v[q * RLAST + r] = cconj(cmul(v[q * RLAST + r], a.bhat[t + q * TPL + r * NBL]));
+        FFT2::template passes<0>(v, a.twp_rev, lds, t);
+        // ---- Z[k] = conj(.) * chirp[k], k < F, natural order (the reversed list ends in the pattern of RL's first pass) ----
         __syncthreads();
         {
             cpx<T> *z = (cpx<T> *)lds;
 #pragma unroll
-            for (int q = 0; q < NBFL; ++q)
+            for (int q = 0; q < NBF0; ++q)
 #pragma unroll
-                for (int r = 0; r < RLAST; ++r) {
-                    const int o = t + q * TPL + r * NBL;
-                    if (o < F) z[ZiPhi::map(o)] = cmul(cconj(v[q * RLAST + r]), a.chirp[o]);
+                for (int r = 0; r < R0; ++r) {
+                    const int o = t + q * TPL + r * NB0;
+                    if (o < F) z[ZiPhi::map(o)] = cmul(cconj(v[q * R0 + r]), a.chirp[o]);
                 }
         }
         __syncthreads();

@@ -75,6 +75,7 @@ struct FftConfig {                 // one complex-FFT-of-length-F recipe + op ta
     // tuned power-of-two path (register-resident Stockham), when eligible
     bool pow2 = false;             // C2C slot: pow2_kernel.h ; real-op slots: pow2_real.h
     HostTable twp;                 // per-pass transposed twiddles
+    HostTable twp_rev;             // bluereg: the same for the radix list back to front (second FFT of the convolution)
     HostTable twp_col;             // C2C slot only: twiddles in the radix order of the column kernel (pow2_real.h)
     HostTable twp_narrow;          // twiddles in the radix order of the narrow (XCD-aware) column kernel
     HostTable tinymat[4];          // MAIN slot, n = 2..16: the real-data transforms as dense real matrices (tinymat_kernel.h);
@@ -106,7 +107,7 @@ struct DevConfig {                 // device copies (typed by dtype) of one FftC
     void *cs_twlo = nullptr, *cs_twhi = nullptr;
     void *wave_tw = nullptr;
     void *tinymat[4] = {nullptr, nullptr, nullptr, nullptr};
-    void *rader_bhat = nullptr, *rader_twp = nullptr, *rader_twp2 = nullptr, *rader_tab = nullptr;
+    void *rader_bhat = nullptr, *rader_twp = nullptr, *rader_twp2 = nullptr, *rader_tab = nullptr, *twp_rev = nullptr;
 };
 
 enum ConfigSlot { CFG_MAIN = 0, CFG_DCT1 = 1, CFG_DCT4 = 2, CFG_COUNT = 3 };

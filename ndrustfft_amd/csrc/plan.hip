@@ -371,7 +371,10 @@ static void add_narrow_tables(ndfft_plan *p) {
     // Bluestein lengths: the register-kernel form (blue_kernel.h) when M has an E = 8 configuration
     for (int i = 0; i < CFG_COUNT; ++i) {
         FftConfig &c = p->cfg[i];
-        if (p->has_cfg[i] && c.blue && pow2_real_config(c.M, c.jitcfg)) { c.bluereg = true; c.twp = HostTable(); pow2_real_build_twiddles(c.M, c.twp); }
+        if (p->has_cfg[i] && c.blue && pow2_real_config(c.M, c.jitcfg)) {
+            c.bluereg = true; c.twp = HostTable(); pow2_real_build_twiddles(c.M, c.twp);
+            c.twp_rev = HostTable(); build_pass_twiddles(c.twp_rev, std::vector<int>(c.jitcfg.radix.rbegin(), c.jitcfg.radix.rend()), c.M);
+        }
         // ... and, where F = (small cofactor) x (prime p with p - 1 smooth), Rader's convolution of length p - 1 instead (rader_kernel.h)
         if (p->has_cfg[i] && c.bluereg && rader_choose(p->dtype, c.F, c.radercfg)) { c.rader = true; build_rader_tables(c); }
     }
@@ -432,6 +435,7 @@ int get_dev_tables(const ndfft_plan *cplan, const DevTables **out) {
         if ((rc = upload_any(plan->dtype, c.rader_bhat, &d.rader_bhat))) return rc;
         if ((rc = upload_any(plan->dtype, c.rader_twp, &d.rader_twp))) return rc;
         if ((rc = upload_any(plan->dtype, c.rader_twp2, &d.rader_twp2))) return rc;
+        if ((rc = upload_any(plan->dtype, c.twp_rev, &d.twp_rev))) return rc;
         if (!c.rader_tab.empty()) {
             NDFFT_HIP(hipMalloc(&d.rader_tab, c.rader_tab.size() * sizeof(int32_t)));
             NDFFT_HIP(hipMemcpy(d.rader_tab, c.rader_tab.data(), c.rader_tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -500,7 +504,7 @@ int ndfft_plan_destroy(ndfft_plan *plan) {
         (void)hipSetDevice(kv.first);
         for (int i = 0; i < CFG_COUNT; ++i) {
             DevConfig &d = kv.second.cfg[i];
-            void *ptrs[] = {d.tw, d.twM, d.chirp, d.bhat, d.aux1, d.aux2, d.twp, d.twlo, d.twhi, d.twp_col, d.twp_narrow, d.cs_twlo, d.cs_twhi, d.wave_tw, d.tinymat[0], d.tinymat[1], d.tinymat[2], d.tinymat[3], d.rader_bhat, d.rader_twp, d.rader_twp2, d.rader_tab};
+            void *ptrs[] = {d.tw, d.twM, d.chirp, d.bhat, d.aux1, d.aux2, d.twp, d.twlo, d.twhi, d.twp_col, d.twp_narrow, d.cs_twlo, d.cs_twhi, d.wave_tw, d.tinymat[0], d.tinymat[1], d.tinymat[2], d.tinymat[3], d.rader_bhat, d.rader_twp, d.rader_twp2, d.rader_tab, d.twp_rev};
             for (void *q : ptrs) if (q) (void)hipFree(q);
         }
     }

@@ -48,9 +48,19 @@ template <typename T> struct RealArgs {
     int32_t xcd_chunk = 0;               // non-XCD kernels: XCD-aware workgroup -> tile map (device_common.h: xcd_block), 0 = identity
     int32_t stream_in = 0;               // COL kernels: 1 = streaming (nt) loads of the input: it is read once and must not
                                          // push the intermediate of a two-stage route out of the Infinity Cache
+    const cpx<T> *twp_rev = nullptr;     // Bluestein / Rader kernels: per-pass twiddles of the SAME radix list taken back to front (second FFT of the convolution)
     const int32_t *rader_tab = nullptr;  // Rader kernels (rader_kernel.h): g^i mod P (i < P - 1), then g^-i mod P; bhat = FFT_(P-1)(W_P^(g^-q)) / (P - 1),
-                                         // twp / chirp = per-pass twiddles of FFT_(P-1) with the radix list front to back / back to front
+                                         // twp / twp_rev = per-pass twiddles of FFT_(P-1) with the radix list front to back / back to front
 };
+
+// RL back to front: the second FFT of a convolution (Bluestein, Rader) runs the passes in reverse order, so that the register pattern it
+// starts from (t + q TPL + r M / R_last) IS the pattern the first one ends in -- the pointwise product never goes through LDS
+template <int... I> struct RevSeq {};
+template <int N, int... I> struct RevMakeSeq : RevMakeSeq<N - 1, N - 1, I...> {};
+template <int... I> struct RevMakeSeq<0, I...> { typedef RevSeq<I...> type; };
+template <typename RL, typename S> struct RevImpl;
+template <typename RL, int... I> struct RevImpl<RL, RevSeq<I...>> { typedef RadixList<RL::at(RL::NP - 1 - I)...> type; };
+template <typename RL> using RadixReversed = typename RevImpl<RL, typename RevMakeSeq<RL::NP>::type>::type;
 
 struct ZiNone { static __device__ __forceinline__ int map(int p) { return p; } };
 struct ZiPhi { static __device__ __forceinline__ int map(int p) { return p + (p >> 4); } };

@@ -28,17 +28,9 @@ constexpr int rader_inv_mod(int a, int m) {   // a^-1 mod m for coprime a, m (0 
     return 0;
 }
 
-// RL back to front: the second FFT_M runs the passes in reverse order, so that the register pattern it starts from
-// (t + q TPL + r M / R_last) IS the pattern the first one ends in -- the product with bhat never goes through LDS
-template <int... I> struct RaderSeq {};
-template <int N, int... I> struct RaderMakeSeq : RaderMakeSeq<N - 1, N - 1, I...> {};
-template <int... I> struct RaderMakeSeq<0, I...> { typedef RaderSeq<I...> type; };
-template <typename RL, typename S> struct RaderRev;
-template <typename RL, int... I> struct RaderRev<RL, RaderSeq<I...>> { typedef RadixList<RL::at(RL::NP - 1 - I)...> type; };
-
 template <typename T, int P, int MC, int TPL, int LPB, typename RL, int OP, bool COL = false> struct RaderKernel {
     static constexpr int M = P - 1, F = P * MC;
-    using RLR = typename RaderRev<RL, typename RaderMakeSeq<RL::NP>::type>::type;
+    using RLR = RadixReversed<RL>;
     using FFT = Pow2Kernel<T, M, TPL, LPB * MC, false, RL, 0, 1, 0>;
     using FFT2 = Pow2Kernel<T, M, TPL, LPB * MC, false, RLR, 0, 1, 0>;
     static_assert(FFT2::E == FFT::E, "same radices, same registers");
@@ -147,7 +139,7 @@ template <typename T, int P, int MC, int TPL, int LPB, typename RL, int OP, bool
                     v[q * RLAST + r] = cconj(c);
                 }
             }
-        FFT2::template passes<0>(v, a.chirp, sub, t);       // (chirp = per-pass twiddles of the reversed list; ends in the pattern of RL's FIRST pass)
+        FFT2::template passes<0>(v, a.twp_rev, sub, t);     // (ends in the pattern of RL's FIRST pass)
         __syncthreads();
         cpx<T> *zz = (cpx<T> *)lds;
         if constexpr (MC == 1) {
