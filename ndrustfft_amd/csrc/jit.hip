@@ -565,12 +565,13 @@ bool rader_choose(int dtype, int F, RaderCfg &rc) {
 }
 int rader_col_lanes(int dtype, const RaderCfg &rc) {
     const int lt = rc.fft.tpl * rc.mc;
-    int thr = lt * 32;
-    thr = thr > 1024 ? 1024 : (thr < 256 ? 256 : thr);
-    const int lpb = thr / lt;
+    if (const char *e = getenv("NDFFT_RADER_COL_LPB")) { const int l = atoi(e); return l * lt <= 1024 ? l : 0; }   // developer knob
+    // whole multiples of 8 adjacent lanes (64-byte rows in f64): measured 512x65536 f64 DCT-I 16 lanes 260 us (8: 284, 12: 375), 1009x16384 c128
+    // 8 lanes 207 us (9: 321), 127x131072 c64 24 lanes 87 us (8: 93, 16: 100, 32: 96)
     const size_t lane = rader_lane_lds(rc, true) * 2 * (dtype == NDFFT_F32 ? 4 : 8);
-    const int l = (int)std::min<size_t>((size_t)lpb, jit_lds_limit() / lane);
-    return l >= 8 ? l : 0;
+    for (int l : {24, 16, 8})
+        if (l * lt <= 1024 && (size_t)l * lane <= jit_lds_limit()) return l;
+    return 0;
 }
 template <typename T> int launch_jit_rader(int gop, const RaderCfg &rc, bool col, const RealArgs<T> &a, hipStream_t s) {
     if (!rtc().ok || !rader_enabled()) return NDFFT_ERR_UNSUPPORTED;

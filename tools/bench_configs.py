@@ -131,6 +131,14 @@ def main():
             run(f"long ndfft axis=1 {rows}x{n} {np.dtype(cdt).name}", ndfft, x, y, FftHandler(n, rdt), 1, x.numel(), max(a.steps // 3, 3))
         x = torch.from_numpy(synth.real_array((64, 1 << 18))).to(dev); y = torch.empty_like(x)
         run("long nddct2 axis=1 64x262144 f64", nddct2, x, y, DctHandler(1 << 18), 1, x.numel(), max(a.steps // 3, 3))
+    if a.only == "radercol":
+        x = torch.from_numpy(synth.real_array((512, 256 * 256))).to(dev); y = torch.empty_like(x)
+        run("nddct1 axis=0 512x65536 f64", nddct1, x, y, DctHandler(512), 0, x.numel(), a.steps)
+        x = torch.from_numpy(synth.complex_array((1009, 16384))).to(dev); y = torch.empty_like(x)
+        run("ndfft axis=0 1009x16384 c128", ndfft, x, y, FftHandler(1009), 0, x.numel(), a.steps)
+        x = torch.from_numpy(synth.complex_array((127, 131072), np.complex64)).to(dev); y = torch.empty_like(x)
+        run("ndfft axis=0 127x131072 c64", ndfft, x, y, FftHandler(127, np.float32), 0, x.numel(), a.steps)
+        return
     if a.only == "radersweep":
         for n, cdt, rdt in ((1009, np.complex128, np.float64), (127, np.complex128, np.float64), (511, np.complex128, np.float64), (2017, np.complex128, np.float64),
                             (4001, np.complex128, np.float64), (1009, np.complex64, np.float32)):
