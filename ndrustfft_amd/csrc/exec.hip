@@ -782,14 +782,16 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
         const bool odd_variant = gop == G_R2C_ODD || gop == G_C2R_ODD || gop == G_DCT2_ODD || gop == G_DCT3_ODD || gop == G_DCT4_ODD;
         const bool use_jit = c.jit && !c.pow2 && P.nlanes * (int64_t)c.F >= (1 << 16);
         // Bluestein lengths on the register kernel (blue_kernel.h), every op incl. the odd-n variants and row C2C
-        const bool use_blue = c.bluereg && ((P.nlanes * (int64_t)c.M >= (1 << 16) && blue_enabled()) || c.blue_reg_only);
-        const bool use_rader = use_blue && c.rader;     // Rader / Good-Thomas instead (rader_kernel.h); Bluestein stays the fallback
+        // Rader / Good-Thomas (rader_kernel.h) wherever the plan has a recipe -- also for lanes beyond Bluestein's single-launch reach
+        // (F > 4096: M' = 2^k >= 2F - 1 no longer fits, Rader's F complex elements of LDS do); Bluestein stays the fallback where it exists
+        const bool use_rader = c.rader && P.nlanes * (int64_t)c.F >= (1 << 16) && blue_enabled();
+        const bool use_blue = use_rader || (c.bluereg && ((P.nlanes * (int64_t)c.M >= (1 << 16) && blue_enabled()) || c.blue_reg_only));
         const bool have_tw = use_jit || use_blue || (is_c2c ? !c.twp_col.re.empty() : c.pow2);
         const bool row = (!is_c2c || use_blue) && P.xs == 1 && P.ys == 1 && P.b.size() <= 1;
         bool col = false, narrow = false;
         if (!row && (!odd_variant || use_blue) && P.xlen > 1 && !P.b.empty() && P.b.size() <= 2 && P.b.back().sin == 1 && P.b.back().sout == 1) {
             if (have_tw && P.b.back().shape >= 8) {
-                const int lanes = (use_jit || use_blue) ? std::max(jit_col_lanes(plan->dtype, c.jitcfg), use_rader ? rader_col_lanes(plan->dtype, c.radercfg) : 0)
+                const int lanes = (use_jit || use_blue) ? std::max((use_jit || c.bluereg) ? jit_col_lanes(plan->dtype, c.jitcfg) : 0, use_rader ? rader_col_lanes(plan->dtype, c.radercfg) : 0)
                                           : plan->dtype == NDFFT_F32 ? pow2_real_col_lanes<float>(c.F) : pow2_real_col_lanes<double>(c.F);
                 col = lanes > 0;
             }
@@ -863,7 +865,7 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
                     const int rr = launch_jit_rader<float>(gop, c.radercfg, col, r, stream);
                     if (rr != NDFFT_ERR_UNSUPPORTED) { set_last_path(col ? "rader_col" : "rader_reg"); return rr; }
                 }
-                rc2 = use_blue ? launch_jit_blue<float>(gop, c.jitcfg, col, a, stream)
+                rc2 = use_blue ? (c.bluereg ? launch_jit_blue<float>(gop, c.jitcfg, col, a, stream) : NDFFT_ERR_UNSUPPORTED)
                       : use_jit ? launch_jit_real<float>(gop, c.jitcfg, col, a, stream) : launch_pow2_real<float>(gop, a, col, stream);
             } else {
                 RealArgs<double> a; fill(a); a.scale = P.scale;
@@ -875,7 +877,7 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
                     const int rr = launch_jit_rader<double>(gop, c.radercfg, col, r, stream);
                     if (rr != NDFFT_ERR_UNSUPPORTED) { set_last_path(col ? "rader_col" : "rader_reg"); return rr; }
                 }
-                rc2 = use_blue ? launch_jit_blue<double>(gop, c.jitcfg, col, a, stream)
+                rc2 = use_blue ? (c.bluereg ? launch_jit_blue<double>(gop, c.jitcfg, col, a, stream) : NDFFT_ERR_UNSUPPORTED)
                       : use_jit ? launch_jit_real<double>(gop, c.jitcfg, col, a, stream) : launch_pow2_real<double>(gop, a, col, stream);
             }
             if (!((use_jit || use_blue) && rc2 == NDFFT_ERR_UNSUPPORTED)) {   // UNSUPPORTED from the JIT = no hiprtc / compile failed: fall through to the LDS kernel

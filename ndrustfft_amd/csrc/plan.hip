@@ -376,7 +376,8 @@ static void add_narrow_tables(ndfft_plan *p) {
             c.twp_rev = HostTable(); build_pass_twiddles(c.twp_rev, std::vector<int>(c.jitcfg.radix.rbegin(), c.jitcfg.radix.rend()), c.M);
         }
         // ... and, where F = (small cofactor) x (prime p with p - 1 smooth), Rader's convolution of length p - 1 instead (rader_kernel.h)
-        if (p->has_cfg[i] && c.bluereg && rader_choose(p->dtype, c.F, c.radercfg)) { c.rader = true; build_rader_tables(c); }
+        //     (also beyond Bluestein's single-launch reach: lanes of up to ~9600 (f64) / ~19000 (f32) elements that otherwise take the multi-pass routes)
+        if (p->has_cfg[i] && (c.blue || c.big) && c.F >= 17 && rader_choose(p->dtype, c.F, c.radercfg)) { c.rader = true; build_rader_tables(c); }
     }
     // specialised (hiprtc) register kernels for the real-data ops with a smooth non-power-of-two inner FFT
     if (p->kind != NDFFT_KIND_C2C)

@@ -139,6 +139,15 @@ def main():
         x = torch.from_numpy(synth.complex_array((127, 131072), np.complex64)).to(dev); y = torch.empty_like(x)
         run("ndfft axis=0 127x131072 c64", ndfft, x, y, FftHandler(127, np.float32), 0, x.numel(), a.steps)
         return
+    if a.only == "raderbig":
+        for rad in ("1", "0"):
+            os.environ["NDFFT_RADER"] = rad
+            for n, cdt, rdt in ((8191, np.complex128, np.float64), (7001, np.complex128, np.float64), (8191, np.complex64, np.float32), (16001, np.complex64, np.float32)):
+                rows = (1 << 24) // n
+                x = torch.from_numpy(synth.complex_array((rows, n), cdt)).to(dev); y = torch.empty_like(x)
+                run(f"raderbig[NDFFT_RADER={rad}] ndfft axis=1 {rows}x{n} {np.dtype(cdt).name}", ndfft, x, y, FftHandler(n, rdt), 1, x.numel(), max(a.steps // 4, 3))
+        del os.environ["NDFFT_RADER"]
+        return
     if a.only == "radersweep":
         for n, cdt, rdt in ((1009, np.complex128, np.float64), (127, np.complex128, np.float64), (511, np.complex128, np.float64), (2017, np.complex128, np.float64),
                             (4001, np.complex128, np.float64), (1009, np.complex64, np.float32)):
