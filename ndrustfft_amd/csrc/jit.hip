@@ -403,12 +403,14 @@ int launch_jit_regreal(int dtype, int gop, int n, int f1, int f2, bool stage, co
 
 // lanes per column tile of the specialised real-op / column kernel (0: no useful tile)
 int jit_col_lanes(int dtype, const JitCfg &cfg) {
-    int thr = cfg.tpl * 32;
-    thr = thr > 1024 ? 1024 : (thr < 256 ? 256 : thr);
-    const int lpb = thr / cfg.tpl;
+    if (const char *e = getenv("NDFFT_JIT_COL_LPB")) { const int l = atoi(e); return l * cfg.tpl <= 1024 ? l : 0; }   // developer knob
+    // 8 adjacent lanes (f32: 16 where they fit): rows of 64-128 bytes that start on a 64-byte boundary.  Measured on 2^24 points (profiles/r04/
+    // r04i_jit_col_lanes.txt): the former "as many as fit" gave 9 lanes for 1000x16384 c128 (144-byte rows) = 257 us, 8 lanes 137 us;
+    // nddct2 1000x16384 f64 150 -> 80 us; 264x65536 c128 143 -> 127 us; n = 96 unchanged.
     const size_t lane = (size_t)((cfg.n + (cfg.n >> 4) + 2) | 1) * 2 * (dtype == NDFFT_F32 ? 4 : 8);
-    const int l = (int)std::min<size_t>((size_t)lpb, jit_lds_limit() / lane);
-    return l >= 8 ? l : 0;
+    for (int l : {dtype == NDFFT_F32 ? 16 : 8, 8})
+        if (l * cfg.tpl <= 1024 && (size_t)l * lane <= jit_lds_limit()) return l;
+    return 0;
 }
 
 // RealPow2Kernel (pow2_real.h) specialised for a smooth inner FFT length cfg.n: R2C / C2R / DCT rows, and

@@ -139,6 +139,14 @@ def main():
         x = torch.from_numpy(synth.complex_array((127, 131072), np.complex64)).to(dev); y = torch.empty_like(x)
         run("ndfft axis=0 127x131072 c64", ndfft, x, y, FftHandler(127, np.float32), 0, x.numel(), a.steps)
         return
+    if a.only == "jitcol":
+        for n, cols, cdt, rdt in ((1000, 16384, np.complex128, np.float64), (1000, 16384, np.complex64, np.float32), (264, 65536, np.complex128, np.float64), (3000, 4096, np.complex128, np.float64),
+                                  (96, 131072, np.complex128, np.float64)):
+            x = torch.from_numpy(synth.complex_array((n, cols), cdt)).to(dev); y = torch.empty_like(x)
+            run(f"jitcol ndfft axis=0 {n}x{cols} {np.dtype(cdt).name}", ndfft, x, y, FftHandler(n, rdt), 0, x.numel(), a.steps)
+        x = torch.from_numpy(synth.real_array((1000, 16384))).to(dev); y = torch.empty_like(x)
+        run("jitcol nddct2 axis=0 1000x16384 f64", nddct2, x, y, DctHandler(1000), 0, x.numel(), a.steps)
+        return
     if a.only == "raderbig":
         for rad in ("1", "0"):
             os.environ["NDFFT_RADER"] = rad
