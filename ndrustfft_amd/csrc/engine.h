@@ -60,7 +60,7 @@ template <typename T> struct GenArgs {
 // plan
 // ------------------------------------------------------------------------------------------
 struct HostTable { std::vector<long double> re, im; };
-struct JitCfg { int n = 0, tpl = 0, e = 0, lpb = 1, vec = 1; bool partial = false; std::vector<int> radix; };   // partial: some pass has an incomplete last round
+struct JitCfg { int n = 0, tpl = 0, e = 0, lpb = 1, vec = 1; bool partial = false; std::vector<int> radix; int row_lpb = 0; };   // row_lpb: planned lanes per row workgroup (0 = default rule)   // partial: some pass has an incomplete last round
 // Rader / Good-Thomas recipe of rader_kernel.h: F = mc * p, p prime with p - 1 smooth; fft = register configuration of FFT_(p-1)
 struct RaderCfg { int p = 0, mc = 1; JitCfg fft; };
 }  // namespace ndfft
@@ -201,6 +201,7 @@ bool pow2_real_config(int F, JitCfg &cfg);
 template <typename T> int launch_jit_blue(int gen_op, const JitCfg &cfgM, bool col, const RealArgs<T> &a, hipStream_t s);
 // rader_kernel.h (jit.hip): recipe for an inner FFT length F with one prime factor > 13 (false: none, Bluestein stays), lanes per column tile, launch
 bool rader_choose(int dtype, int F, RaderCfg &rc);
+bool jit_choose_real(int dtype, int F, JitCfg &cfg);   // jit_choose for the real-op slots (rows of RealPow2Kernel): cost-model recipe
 int rader_col_lanes(int dtype, const RaderCfg &rc);
 template <typename T> int launch_jit_rader(int gen_op, const RaderCfg &rc, bool col, const RealArgs<T> &a, hipStream_t s);
 int launch_pack_lanes(const void *strided, void *dense, const LaneGeom &g, int64_t lanes, int64_t len, int64_t pitch, int esz, int unpack, hipStream_t s);   // big.hip

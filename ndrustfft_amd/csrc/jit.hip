@@ -117,7 +117,23 @@ static bool jit_choose_partial(int dtype, int n, JitCfg &cfg, int emax_arg = 0) 
     return true;
 }
 
+static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg &out);
+static bool jit_choose_default(int dtype, int n, JitCfg &cfg, bool allow_partial);
+// The default recipe ("fewest passes, every radix divides E") gives some lengths 20-30 elements per thread on a handful of threads
+// (F = 48: 8.6 on 2 threads, e = 24; 3000 = 10.10.10.3, e = 30).  Those measure badly -- f64 from e > 18, f32 from e > 24
+// (profiles/r04/r04j_realplan_ab.txt: nddct2 / ndfft_r2c n = 96, 120, 300, 360, 1200, 3000, 6000 gain 1.3-2.9x; recipes with e <= 12 were as good
+// or better than the model's pick) -- and are replaced by the pick of the cost model fitted for the Rader kernel (plan_fft_by_cost).
 bool jit_choose(int dtype, int n, JitCfg &cfg, bool allow_partial) {
+    static const bool on = [] { const char *e = getenv("NDFFT_JIT_REALPLAN"); return !(e && e[0] == '0'); }();
+    static const int nmax = [] { const char *e = getenv("NDFFT_JIT_REALPLAN_MAX"); return e ? atoi(e) : 8192; }();
+    if (!jit_choose_default(dtype, n, cfg, allow_partial)) return false;
+    if (!on || !allow_partial || n > nmax || cfg.e <= (dtype == NDFFT_F32 ? 24 : 18)) return true;
+    const size_t lane = (size_t)((n + (n >> 4) + 3) & ~1) * 2 * (dtype == NDFFT_F32 ? 4 : 8);
+    JitCfg alt;
+    if (plan_fft_by_cost(dtype, n, 1, lane, alt)) { alt.vec = 1; alt.row_lpb = alt.lpb; cfg = alt; }
+    return true;
+}
+static bool jit_choose_default(int dtype, int n, JitCfg &cfg, bool allow_partial) {
     // one lane's half exchange (n reals, padded) must fit the 160 KiB of LDS: n <= 19274 (f64) / 32768 (f32, capped)
     const size_t lane_lds = ((size_t)n + ((size_t)n >> 4) + 1) * (dtype == NDFFT_F32 ? 4 : 8);
     if (jit_disabled() || n < 12 || n > 32768 || lane_lds > jit_lds_limit() || pow2_supported(dtype, n)) return false;
@@ -418,7 +434,7 @@ int jit_col_lanes(int dtype, const JitCfg &cfg) {
 template <typename T> int launch_jit_real(int gop, const JitCfg &cfg, bool col, const RealArgs<T> &a, hipStream_t s) {
     if (!rtc().ok) return NDFFT_ERR_UNSUPPORTED;
     const int dtype = sizeof(T) == 4 ? NDFFT_F32 : NDFFT_F64;
-    const int lpb = col ? jit_col_lanes(dtype, cfg) : (cfg.tpl >= 256 ? 1 : std::max(1, 256 / cfg.tpl));
+    const int lpb = col ? jit_col_lanes(dtype, cfg) : cfg.row_lpb > 0 ? cfg.row_lpb : (cfg.tpl >= 256 ? 1 : std::max(1, 256 / cfg.tpl));
     if (lpb <= 0) return NDFFT_ERR_UNSUPPORTED;
     int dev = 0;
     NDFFT_HIP(hipGetDevice(&dev));
@@ -482,20 +498,10 @@ static size_t rader_lane_lds(const RaderCfg &rc, bool col) {   // complex elemen
 }
 // lanes per workgroup of the row kernel.  Measured (profiles/r04/r04d_rader_tune_lpb.txt): workgroups of ONE wave win wherever a lane needs
 // <= 64 threads (no real barriers: 127 c128 150 -> 121 us, 511 c128 125 -> 110 us), otherwise the fullest waves with the fewest of them.
+static int row_lanes_by_fill(int lt, size_t lane, int forced, double *util_out);
 static int rader_row_lanes_for(int dtype, const RaderCfg &rc, double *util_out) {
     const int forced = [] { const char *e = getenv("NDFFT_RADER_LPB"); return e ? atoi(e) : 0; }();
-    const int lt = rc.fft.tpl * rc.mc;
-    const size_t lane = rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8);
-    int best = 0; double best_score = -1.0, best_util = 0.0;
-    for (int l = 1; l <= std::max(1, 320 / lt); ++l) {
-        if (forced > 0 && l != forced) continue;
-        const int thr = l * lt, waves = (thr + 63) / 64;
-        if (thr > 1024 || (size_t)l * lane > jit_lds_limit()) break;
-        const double util = (double)thr / (64.0 * waves), score = util - 0.02 * (waves - 1);
-        if (score > best_score) { best_score = score; best = l; best_util = util; }
-    }
-    if (util_out) *util_out = best_util;
-    return best;
+    return row_lanes_by_fill(rc.fft.tpl * rc.mc, rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8), forced, util_out);
 }
 static int rader_row_lanes(int dtype, const RaderCfg &rc) { return rader_row_lanes_for(dtype, rc, nullptr); }
 
@@ -504,7 +510,26 @@ static int rader_row_lanes(int dtype, const RaderCfg &rc) { return rader_row_lan
 // workgroups, plus a penalty for many elements per thread (f64: e = 21 costs 5-20 %, e = 24 twice the time) -- fitted to the sweeps
 // under profiles/r04/r04c_rader_tune.txt and r04d_rader_tune_lpb.txt (tools/probes/rader_tune.py).
 static bool rader_plan_fft(int dtype, int M, RaderCfg &rc) {
-    const int emax = dtype == NDFFT_F32 ? 32 : 21, esoft = dtype == NDFFT_F32 ? 21 : 18;
+    return plan_fft_by_cost(dtype, M, rc.mc, rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8), rc.fft);
+}
+// lanes per workgroup for `lt` threads per lane and `lane` bytes of LDS per lane: one wave where a lane needs <= 64 threads, else the
+// fullest waves with the fewest of them (see rader_row_lanes_for)
+static int row_lanes_by_fill(int lt, size_t lane, int forced, double *util_out) {
+    int best = 0; double best_util = 0.0;
+    // one wave where a lane needs <= 64 threads (as many lanes as fill it), else about 256 threads (measured: 1008 points on 84 threads 3 lanes
+    // 156 us / 2 lanes 160 us; 1000 points on 100 threads 2 lanes 60 us / 3 lanes 79 us)
+    const int want = forced > 0 ? forced : lt <= 64 ? 64 / lt : std::max(1, 256 / lt);
+    for (int l = want; l >= 1; --l) {
+        const int thr = l * lt, waves = (thr + 63) / 64;
+        if (thr > 1024 || (size_t)l * lane > jit_lds_limit()) { if (forced > 0) break; continue; }
+        best = l; best_util = (double)thr / (64.0 * waves);
+        break;
+    }
+    if (util_out) *util_out = best_util;
+    return best;
+}
+static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg &out) {
+    const int emax = dtype == NDFFT_F32 ? 32 : 18, esoft = dtype == NDFFT_F32 ? 21 : 18;
     const double eslope = dtype == NDFFT_F32 ? 0.05 : 0.1;
     const int cand[] = {16, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
     std::vector<int> cur;
@@ -514,15 +539,14 @@ static bool rader_plan_fft(int dtype, int M, RaderCfg &rc) {
         for (int r : cur) for (int sdiv = 1; sdiv <= 4; ++sdiv) tpls.push_back((M / r + sdiv - 1) / sdiv);
         std::sort(tpls.begin(), tpls.end()); tpls.erase(std::unique(tpls.begin(), tpls.end()), tpls.end());
         for (int tpl : tpls) {
-            if (tpl < 1 || tpl * rc.mc > 1024) continue;
+            if (tpl < 1 || tpl * mc > 1024) continue;
             int e = 0; double work = 0; bool partial = false;
             for (int r : cur) { const int nb = M / r, sl = (nb + tpl - 1) / tpl; e = std::max(e, sl * r); work += (double)sl * tpl * r; if (nb % tpl) partial = true; }
             if (e > emax) continue;
-            RaderCfg t = rc; t.fft.tpl = tpl;
             double util = 0.0;
-            const int lpb = rader_row_lanes_for(dtype, t, &util);
+            const int lpb = row_lanes_by_fill(tpl * mc, lane_bytes, 0, &util);
             if (lpb <= 0) continue;
-            const int waves = (lpb * tpl * rc.mc + 63) / 64;
+            const int waves = (lpb * tpl * mc + 63) / 64;
             const double cost = work / M / util * (waves == 1 ? 0.87 : waves == 2 ? 0.95 : 1.0) + (e > esoft ? eslope * (e - esoft) : 0.0) + 0.01 * e;
             if (cost < best_cost) { best_cost = cost; best = JitCfg(); best.n = M; best.tpl = tpl; best.e = e; best.radix = cur; best.partial = partial; best.lpb = lpb; }
         }
@@ -539,9 +563,11 @@ static bool rader_plan_fft(int dtype, int M, RaderCfg &rc) {
     };
     rec(M, 16);
     if (best.radix.empty()) return false;
-    rc.fft = best;
+    out = best;
     return true;
 }
+
+bool jit_choose_real(int dtype, int F, JitCfg &cfg) { return jit_choose(dtype, F, cfg, true); }
 
 bool rader_choose(int dtype, int F, RaderCfg &rc) {
     if (jit_disabled() || F < 17) return false;

@@ -383,7 +383,7 @@ static void add_narrow_tables(ndfft_plan *p) {
     if (p->kind != NDFFT_KIND_C2C)
         for (int i = 0; i < CFG_COUNT; ++i) {
             FftConfig &c = p->cfg[i];
-            if (p->has_cfg[i] && !c.pow2 && !c.blue && c.F > 1 && jit_choose(p->dtype, c.F, c.jitcfg, true)) { c.jit = true; jit_build_twiddles(c.jitcfg, c.twp); }
+            if (p->has_cfg[i] && !c.pow2 && !c.blue && c.F > 1 && jit_choose_real(p->dtype, c.F, c.jitcfg)) { c.jit = true; jit_build_twiddles(c.jitcfg, c.twp); }
         }
     for (int i = 0; i < CFG_COUNT; ++i)
         if (p->has_cfg[i] && !p->cfg[i].blue && !p->cfg[i].big) pow2_real_build_narrow_twiddles(p->dtype, p->cfg[i].F, p->cfg[i].twp_narrow);

@@ -17,6 +17,7 @@ bool jit_choose(int, int n, JitCfg &cfg, bool allow_partial) {
     if (n == 264) { cfg.tpl = 12; cfg.radix = {11, 8, 3}; cfg.lpb = 21; } else { cfg.tpl = 14; cfg.radix = {7, 6, 5}; cfg.lpb = 18; }
     return true;
 }
+bool jit_choose_real(int dtype, int F, JitCfg &cfg) { return jit_choose(dtype, F, cfg, true); }
 void jit_build_twiddles(const JitCfg &cfg, HostTable &out) { if (cfg.n == 264) build_tw<PRL264>(out); else if (cfg.n == 210) build_tw<PRL210>(out); }
 template <typename K> __global__ void k_c2c_emul(const Pow2Args a) { K::run(a); }
 template <typename T, int N, int TPL, int LPB, typename RL> static int c2c_one(const Pow2Args &a, hipStream_t s) {

@@ -139,6 +139,31 @@ def main():
         x = torch.from_numpy(synth.complex_array((127, 131072), np.complex64)).to(dev); y = torch.empty_like(x)
         run("ndfft axis=0 127x131072 c64", ndfft, x, y, FftHandler(127, np.float32), 0, x.numel(), a.steps)
         return
+    if a.only == "c2cplan":
+        for n in (72, 80, 120, 300, 360, 600, 1200, 1500, 3000, 6000, 12000):
+            for cdt, rdt in ((np.complex128, np.float64), (np.complex64, np.float32)):
+                rows = (1 << 24) // n
+                x = torch.from_numpy(synth.complex_array((rows, n), cdt)).to(dev); y = torch.empty_like(x)
+                run(f"c2cplan ndfft axis=1 {rows}x{n} {np.dtype(cdt).name}", ndfft, x, y, FftHandler(n, rdt), 1, x.numel(), a.steps)
+        for n in (120, 300, 1500):
+            x = torch.from_numpy(synth.complex_array((n, (1 << 24) // n // 8 * 8))).to(dev); y = torch.empty_like(x)
+            run(f"c2cplan ndfft axis=0 {n}x{x.shape[1]} complex128", ndfft, x, y, FftHandler(n), 0, x.numel(), a.steps)
+        return
+    if a.only == "realplan":
+        # real-data transforms whose inner FFT is smooth but not a power of two: rows and column tiles of the specialised kernel
+        for n in (72, 96, 100, 120, 144, 200, 300, 360, 500, 1000, 1200, 2000, 3000, 6000):
+            rows = (1 << 24) // n
+            x = torch.from_numpy(synth.real_array((rows, n))).to(dev); y = torch.empty_like(x)
+            run(f"realplan nddct2 axis=1 {rows}x{n} f64", nddct2, x, y, DctHandler(n), 1, x.numel(), a.steps)
+            xf = torch.from_numpy(synth.real_array((rows, n), np.float32)).to(dev); w = torch.empty((rows, n // 2 + 1), dtype=torch.complex64, device=dev)
+            run(f"realplan ndfft_r2c axis=1 {rows}x{n} f32", ndfft_r2c, xf, w, R2cFftHandler(n, np.float32), 1, xf.numel(), a.steps)
+        for n in (100, 500, 1000):
+            cols = (1 << 24) // n
+            x = torch.from_numpy(synth.real_array((n, cols))).to(dev); y = torch.empty_like(x)
+            run(f"realplan nddct2 axis=0 {n}x{cols} f64", nddct2, x, y, DctHandler(n), 0, x.numel(), a.steps)
+            xf = torch.from_numpy(synth.real_array((n, cols), np.float32)).to(dev); w = torch.empty((n // 2 + 1, cols), dtype=torch.complex64, device=dev)
+            run(f"realplan ndfft_r2c axis=0 {n}x{cols} f32", ndfft_r2c, xf, w, R2cFftHandler(n, np.float32), 0, xf.numel(), a.steps)
+        return
     if a.only == "jitcol":
         for n, cols, cdt, rdt in ((1000, 16384, np.complex128, np.float64), (1000, 16384, np.complex64, np.float32), (264, 65536, np.complex128, np.float64), (3000, 4096, np.complex128, np.float64),
                                   (96, 131072, np.complex128, np.float64)):
