@@ -201,6 +201,7 @@ bool pow2_real_config(int F, JitCfg &cfg);
 template <typename T> int launch_jit_blue(int gen_op, const JitCfg &cfgM, bool col, const RealArgs<T> &a, hipStream_t s);
 // rader_kernel.h (jit.hip): recipe for an inner FFT length F with one prime factor > 13 (false: none, Bluestein stays), lanes per column tile, launch
 bool rader_choose(int dtype, int F, RaderCfg &rc);
+template <typename T> int launch_jit_plain(int gen_op, const JitCfg &cfg, bool col, const RealArgs<T> &a, hipStream_t s);   // plain_kernel.h: odd-n real ops, smooth F
 bool jit_choose_real(int dtype, int F, JitCfg &cfg);   // jit_choose for the real-op slots (rows of RealPow2Kernel): cost-model recipe
 int rader_col_lanes(int dtype, const RaderCfg &rc);
 template <typename T> int launch_jit_rader(int gen_op, const RaderCfg &rc, bool col, const RealArgs<T> &a, hipStream_t s);

@@ -374,6 +374,11 @@ static bool tiny_enabled() {
     return !(e && e[0] == '0');
 }
 
+// developer / test switch: NDFFT_PLAIN=0 keeps the odd-n real ops with a smooth inner FFT on the LDS kernel (read per call)
+static bool plain_enabled() {
+    const char *e = getenv("NDFFT_PLAIN");
+    return !(e && e[0] == '0');
+}
 // developer switch: NDFFT_BLUE=0 keeps Bluestein lengths on the LDS kernel
 static bool blue_enabled() {
     const char *e = getenv("NDFFT_BLUE");
@@ -786,10 +791,11 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
         // (F > 4096: M' = 2^k >= 2F - 1 no longer fits, Rader's F complex elements of LDS do); Bluestein stays the fallback where it exists
         const bool use_rader = c.rader && P.nlanes * (int64_t)c.F >= (1 << 16) && blue_enabled();
         const bool use_blue = use_rader || (c.bluereg && ((P.nlanes * (int64_t)c.M >= (1 << 16) && blue_enabled()) || c.blue_reg_only));
+        const bool use_plain = odd_variant && use_jit && !use_blue && plain_enabled();         // odd-n real ops with a smooth inner FFT: plain_kernel.h
         const bool have_tw = use_jit || use_blue || (is_c2c ? !c.twp_col.re.empty() : c.pow2);
         const bool row = (!is_c2c || use_blue) && P.xs == 1 && P.ys == 1 && P.b.size() <= 1;
         bool col = false, narrow = false;
-        if (!row && (!odd_variant || use_blue) && P.xlen > 1 && !P.b.empty() && P.b.size() <= 2 && P.b.back().sin == 1 && P.b.back().sout == 1) {
+        if (!row && (!odd_variant || use_blue || use_plain) && P.xlen > 1 && !P.b.empty() && P.b.size() <= 2 && P.b.back().sin == 1 && P.b.back().sout == 1) {
             if (have_tw && P.b.back().shape >= 8) {
                 const int lanes = (use_jit || use_blue) ? std::max((use_jit || c.bluereg) ? jit_col_lanes(plan->dtype, c.jitcfg) : 0, use_rader ? rader_col_lanes(plan->dtype, c.radercfg) : 0)
                                           : plan->dtype == NDFFT_F32 ? pow2_real_col_lanes<float>(c.F) : pow2_real_col_lanes<double>(c.F);
@@ -832,7 +838,7 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
             set_last_path("pow2_col_xcd");
             return rc2;
         }
-        if (have_tw && (!odd_variant || use_blue) && (row || col)) {
+        if (have_tw && (!odd_variant || use_blue || use_plain) && (row || col)) {
             auto fill = [&](auto &a) {
                 a.in = d_in; a.out = d_out; a.nlanes = P.nlanes;
                 a.pitch_in = P.b.empty() ? P.xlen : P.b[0].sin;
@@ -866,6 +872,7 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
                     if (rr != NDFFT_ERR_UNSUPPORTED) { set_last_path(col ? "rader_col" : "rader_reg"); return rr; }
                 }
                 rc2 = use_blue ? (c.bluereg ? launch_jit_blue<float>(gop, c.jitcfg, col, a, stream) : NDFFT_ERR_UNSUPPORTED)
+                      : use_plain ? launch_jit_plain<float>(gop, c.jitcfg, col, a, stream)
                       : use_jit ? launch_jit_real<float>(gop, c.jitcfg, col, a, stream) : launch_pow2_real<float>(gop, a, col, stream);
             } else {
                 RealArgs<double> a; fill(a); a.scale = P.scale;
@@ -878,10 +885,11 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
                     if (rr != NDFFT_ERR_UNSUPPORTED) { set_last_path(col ? "rader_col" : "rader_reg"); return rr; }
                 }
                 rc2 = use_blue ? (c.bluereg ? launch_jit_blue<double>(gop, c.jitcfg, col, a, stream) : NDFFT_ERR_UNSUPPORTED)
+                      : use_plain ? launch_jit_plain<double>(gop, c.jitcfg, col, a, stream)
                       : use_jit ? launch_jit_real<double>(gop, c.jitcfg, col, a, stream) : launch_pow2_real<double>(gop, a, col, stream);
             }
             if (!((use_jit || use_blue) && rc2 == NDFFT_ERR_UNSUPPORTED)) {   // UNSUPPORTED from the JIT = no hiprtc / compile failed: fall through to the LDS kernel
-                set_last_path(use_blue ? (col ? "blue_col" : "blue_reg") : use_jit ? (col ? "jit_col" : "jit_real") : (col ? "pow2_col" : "pow2_real"));
+                set_last_path(use_blue ? (col ? "blue_col" : "blue_reg") : use_plain ? (col ? "plain_col" : "plain_real") : use_jit ? (col ? "jit_col" : "jit_real") : (col ? "pow2_col" : "pow2_real"));
                 return rc2;
             }
         }

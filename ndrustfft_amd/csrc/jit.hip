@@ -243,8 +243,8 @@ static Entry compile_entry(const std::string &src, const std::string &what) {
     Rtc &r = rtc();
     Entry ne;
     {   // a code object compiled by an earlier process?
-        const char *hs0[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h, jit_src_realops_h, jit_src_pow2_real_h, jit_src_blue_kernel_h, jit_src_reg_kernel_h, jit_src_rader_kernel_h};
-        const std::string path = cache_path(src, hs0, 8);
+        const char *hs0[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h, jit_src_realops_h, jit_src_pow2_real_h, jit_src_blue_kernel_h, jit_src_reg_kernel_h, jit_src_rader_kernel_h, jit_src_plain_kernel_h};
+        const std::string path = cache_path(src, hs0, 9);
         std::string code;
         if (!path.empty() && read_file(path, code) && hipModuleLoadData(&ne.mod, code.data()) == hipSuccess &&
             hipModuleGetFunction(&ne.fn, ne.mod, "k_jit") == hipSuccess)
@@ -255,10 +255,10 @@ static Entry compile_entry(const std::string &src, const std::string &what) {
             if (e[0] == '1') { ne.failed = true; return ne; }
         }
     }
-    const char *hn[] = {"device_common.h", "butterflies.h", "pow2_kernel.h", "realops.h", "pow2_real.h", "blue_kernel.h", "reg_kernel.h", "rader_kernel.h"};
-    const char *hs[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h, jit_src_realops_h, jit_src_pow2_real_h, jit_src_blue_kernel_h, jit_src_reg_kernel_h, jit_src_rader_kernel_h};
+    const char *hn[] = {"device_common.h", "butterflies.h", "pow2_kernel.h", "realops.h", "pow2_real.h", "blue_kernel.h", "reg_kernel.h", "rader_kernel.h", "plain_kernel.h"};
+    const char *hs[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h, jit_src_realops_h, jit_src_pow2_real_h, jit_src_blue_kernel_h, jit_src_reg_kernel_h, jit_src_rader_kernel_h, jit_src_plain_kernel_h};
     rtcProgram prog = nullptr;
-    bool ok = r.ok && r.create(&prog, src.c_str(), "k_jit.hip", 8, hs, hn) == 0;
+    bool ok = r.ok && r.create(&prog, src.c_str(), "k_jit.hip", 9, hs, hn) == 0;
     if (ok) {
         ok = r.compile(prog, 4, (const char **)kJitOpts) == 0;
         if (!ok && getenv("NDFFT_JIT_VERBOSE")) {
@@ -278,7 +278,7 @@ static Entry compile_entry(const std::string &src, const std::string &what) {
     } else if (getenv("NDFFT_JIT_VERBOSE")) {
         fprintf(stderr, "ndfft jit: no code object for %s (hiprtc %s)\n", what.c_str(), r.ok ? "present" : "missing");
     }
-    if (ok) { const std::string path = cache_path(src, hs, 8); if (!path.empty()) write_file_atomic(path, code); }
+    if (ok) { const std::string path = cache_path(src, hs, 9); if (!path.empty()) write_file_atomic(path, code); }
     if (!ok) { (void)hipGetLastError(); ne.failed = true; }
     return ne;
 }
@@ -458,6 +458,37 @@ template <typename T> int launch_jit_real(int gop, const JitCfg &cfg, bool col, 
     NDFFT_HIP(hipModuleLaunchKernel(e.fn, (unsigned)nblk, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, s, params, nullptr));
     return NDFFT_OK;
 }
+// PlainRealKernel (plain_kernel.h): the odd-n forms of the real-data ops for a smooth inner FFT length cfg.n, rows and column tiles
+template <typename T> int launch_jit_plain(int gop, const JitCfg &cfg, bool col, const RealArgs<T> &a, hipStream_t s) {
+    if (!rtc().ok) return NDFFT_ERR_UNSUPPORTED;
+    const int dtype = sizeof(T) == 4 ? NDFFT_F32 : NDFFT_F64;
+    const int lpb = col ? jit_col_lanes(dtype, cfg) : cfg.row_lpb > 0 ? cfg.row_lpb : (cfg.tpl >= 256 ? 1 : std::max(1, 256 / cfg.tpl));
+    if (lpb <= 0) return NDFFT_ERR_UNSUPPORTED;
+    int dev = 0;
+    NDFFT_HIP(hipGetDevice(&dev));
+    const char *tn = sizeof(T) == 4 ? "float" : "double";
+    const int threads = cfg.tpl * lpb;
+    const std::string inst = std::string("PlainRealKernel<") + tn + ", " + std::to_string(cfg.n) + ", " + std::to_string(cfg.tpl) + ", " +
+                             std::to_string(lpb) + ", RadixList<" + radix_list(cfg) + ">, " + std::to_string(gop) + ", " + (col ? "true" : "false") + ">";
+    const std::string src = std::string("#include \"plain_kernel.h\"\nusing namespace ndfft;\nextern \"C\" __global__ __launch_bounds__(") +
+                            std::to_string(threads) + ") void k_jit(const RealArgs<" + tn + "> a) { " + inst + "::run(a); }\n";
+    const Entry e = get_or_compile("dev" + std::to_string(dev) + ":" + inst, src, inst);
+    if (e.failed) return NDFFT_ERR_UNSUPPORTED;
+    const int F = cfg.n;
+    const size_t lane_lds = col ? (size_t)((F + (F >> 4) + 3) | 1) : (size_t)((F + (F >> 4) + 4) & ~1);     // PlainRealKernel::LANE_LDS
+    const size_t lds = (size_t)lpb * lane_lds * 2 * sizeof(T);
+    if (lds > jit_lds_limit()) return NDFFT_ERR_UNSUPPORTED;
+    const int64_t nblk = (a.nlanes + lpb - 1) / lpb;
+    if (nblk <= 0) return NDFFT_OK;
+    if (nblk > 0x7fffffffLL) return NDFFT_ERR_UNSUPPORTED;
+    RealArgs<T> arg = a;
+    void *params[] = {(void *)&arg};
+    NDFFT_HIP(hipModuleLaunchKernel(e.fn, (unsigned)nblk, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, s, params, nullptr));
+    return NDFFT_OK;
+}
+template int launch_jit_plain<float>(int, const JitCfg &, bool, const RealArgs<float> &, hipStream_t);
+template int launch_jit_plain<double>(int, const JitCfg &, bool, const RealArgs<double> &, hipStream_t);
+
 // BlueKernel (blue_kernel.h) for Bluestein length cfgM.n = M: every op, rows and column tiles
 template <typename T> int launch_jit_blue(int gop, const JitCfg &cfg, bool col, const RealArgs<T> &a, hipStream_t s) {
     if (!rtc().ok) return NDFFT_ERR_UNSUPPORTED;

@@ -6,19 +6,22 @@
 #include "blue_kernel.h"
 #include "reg_kernel.h"
 #include "rader_kernel.h"
+#include "plain_kernel.h"
 namespace ndfft {
 // two PARTIAL-round configurations of the C2C row kernel (pow2_kernel.h: slots / full) instantiated ahead of
 // time, so that the predicated passes are exercised on the CPU: 264 = 11.8.3 on 12 threads, 210 = 7.6.5 on 14
 using PRL264 = RadixList<11, 8, 3>;
 using PRL210 = RadixList<7, 6, 5>;
+using PRL45 = RadixList<9, 5>;
 bool jit_choose(int, int n, JitCfg &cfg, bool allow_partial) {
+    if (allow_partial && n == 45) { cfg.n = 45; cfg.partial = true; cfg.vec = 1; cfg.tpl = 5; cfg.e = 10; cfg.radix = {9, 5}; cfg.lpb = 12; return true; }   // odd-n real ops (plain_kernel.h)
     if (!allow_partial || (n != 264 && n != 210)) return false;
     cfg.n = n; cfg.partial = true; cfg.vec = 1;
     if (n == 264) { cfg.tpl = 12; cfg.radix = {11, 8, 3}; cfg.lpb = 21; } else { cfg.tpl = 14; cfg.radix = {7, 6, 5}; cfg.lpb = 18; }
     return true;
 }
 bool jit_choose_real(int dtype, int F, JitCfg &cfg) { return jit_choose(dtype, F, cfg, true); }
-void jit_build_twiddles(const JitCfg &cfg, HostTable &out) { if (cfg.n == 264) build_tw<PRL264>(out); else if (cfg.n == 210) build_tw<PRL210>(out); }
+void jit_build_twiddles(const JitCfg &cfg, HostTable &out) { if (cfg.n == 264) build_tw<PRL264>(out); else if (cfg.n == 210) build_tw<PRL210>(out); else if (cfg.n == 45) build_tw<PRL45>(out); }
 template <typename K> __global__ void k_c2c_emul(const Pow2Args a) { K::run(a); }
 template <typename T, int N, int TPL, int LPB, typename RL> static int c2c_one(const Pow2Args &a, hipStream_t s) {
     using K = Pow2Kernel<T, N, TPL, LPB, true, RL, 0, 1, 1, 1>;
@@ -31,7 +34,7 @@ int launch_jit_c2c(int dtype, const JitCfg &cfg, int, const Pow2Args &a, hipStre
     if (cfg.n == 210) return dtype == NDFFT_F32 ? c2c_one<float, 210, 14, 18, PRL210>(a, s) : c2c_one<double, 210, 14, 18, PRL210>(a, s);
     return NDFFT_ERR_UNSUPPORTED;
 }
-int jit_col_lanes(int, const JitCfg &cfg) { return (cfg.n == 64 || cfg.n == 256 || cfg.n == 264 || cfg.n == 210) ? 8 : 0; }
+int jit_col_lanes(int, const JitCfg &cfg) { return (cfg.n == 64 || cfg.n == 256 || cfg.n == 264 || cfg.n == 210 || cfg.n == 45) ? 8 : 0; }
 // the same two partial-round configurations on the real-op / column kernel (pow2_real.h)
 template <typename K, typename T> __global__ void k_real_emul(const RealArgs<T> a) { K::run(a); }
 template <typename T, int F, int TPL, int LPBR, typename RL, int OP> static int real_one(bool col, const RealArgs<T> &a, hipStream_t s) {
@@ -64,6 +67,31 @@ template int launch_jit_real<float>(int, const JitCfg &, bool, const RealArgs<fl
 template int launch_jit_real<double>(int, const JitCfg &, bool, const RealArgs<double> &, hipStream_t);
 
 template <typename K, typename T> __global__ void k_blue_emul(const RealArgs<T> a) { K::run(a); }
+
+// odd-n real ops with the smooth inner FFT 45 = 9.5 (plain_kernel.h; the product specialises it with hiprtc, jit.hip: launch_jit_plain)
+template <typename T, int OP> static int plain_one(bool col, const RealArgs<T> &a, hipStream_t s) {
+    if (col) {
+        using K = PlainRealKernel<T, 45, 5, 8, PRL45, OP, true>;
+        hipLaunchKernelGGL((k_blue_emul<K, T>), dim3((unsigned)((a.nlanes + 7) / 8)), dim3(K::THREADS), K::LDS_BYTES, s, a);
+    } else {
+        using K = PlainRealKernel<T, 45, 5, 12, PRL45, OP, false>;
+        hipLaunchKernelGGL((k_blue_emul<K, T>), dim3((unsigned)((a.nlanes + 11) / 12)), dim3(K::THREADS), K::LDS_BYTES, s, a);
+    }
+    return NDFFT_OK;
+}
+template <typename T> int launch_jit_plain(int gop, const JitCfg &cfg, bool col, const RealArgs<T> &a, hipStream_t s) {
+    if (a.nlanes <= 0) return NDFFT_OK;
+    if (cfg.n != 45) return NDFFT_ERR_UNSUPPORTED;
+    switch (gop) {
+        case G_R2C_ODD: return plain_one<T, G_R2C_ODD>(col, a, s);
+        case G_C2R_ODD: return plain_one<T, G_C2R_ODD>(col, a, s);
+        case G_DCT2_ODD: return plain_one<T, G_DCT2_ODD>(col, a, s);
+        case G_DCT3_ODD: return plain_one<T, G_DCT3_ODD>(col, a, s);
+        default: return NDFFT_ERR_UNSUPPORTED;
+    }
+}
+template int launch_jit_plain<float>(int, const JitCfg &, bool, const RealArgs<float> &, hipStream_t);
+template int launch_jit_plain<double>(int, const JitCfg &, bool, const RealArgs<double> &, hipStream_t);
 
 template <typename T, int M, int TPL, typename RL, int OP> static int blue_one(bool col, const RealArgs<T> &a, hipStream_t s) {
     if (col) {

@@ -742,6 +742,21 @@ def bluestein_register_kernel(L, sizes=((17, 64), (31, 64), (97, 256), (127, 256
         del os.environ["NDFFT_RADER"]
 
 
+def odd_real_lengths(L, sizes=(45,), dct4=False):
+    """Odd-n forms of R2C / C2R / DCT-II / DCT-III (/ DCT-IV: inner FFT 2n) with a smooth n on the register kernel (plain_kernel.h), rows and column tiles."""
+    for n in sizes:
+        rows = (1 << 17) // n + 5
+        for rdt in (np.float64, np.float32):
+            names = ("ndfft_r2c", "ndifft_r2c", "nddct2", "nddct3") + (("nddct4",) if dct4 else ())
+            for name in names:
+                for norm in ("Default", "None"):
+                    assert run_case(L, name, (rows, n), 1, rdt, norm=norm, offset=n) in ("plain_real", "regreal_row"), (name, n, rdt)
+                # (a tile of 8 lanes must fit LDS: longer lanes go through the transpose route to the row kernel)
+                ok_col = ("plain_col", "regreal_col", "transpose+plain_real")
+                assert run_case(L, name, (n, rows + 3), 0, rdt, offset=n + 1) in ok_col, (name, n, rdt)
+                assert run_case(L, name, (3, n, rows // 2), 1, rdt, offset=n + 2) in ok_col, (name, n, rdt)
+
+
 def rader_kernel(L, sizes=(31, 62, 97, 511), col_max_F=128):
     """Inner FFT lengths F = (cofactor <= 16) x (prime p, p - 1 smooth) on the Rader / Good-Thomas register kernel
     (rader_kernel.h): every op family incl. the odd-n variants, both normalisations, rows and column tiles."""

@@ -50,6 +50,7 @@ def test_fuzz(L): ps.fuzz(L, seed=11, count=120, max_points=1 << 13)
 def test_bluestein_register_kernel(L): ps.bluestein_register_kernel(L)
 def test_partial_round_configs(L): ps.partial_round_configs(L)
 def test_rader_kernel(L): ps.rader_kernel(L)
+def test_odd_real_lengths(L): ps.odd_real_lengths(L)
 def test_long_lanes_four_step(L): ps.long_lanes_four_step(L, full=False)
 
 

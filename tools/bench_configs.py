@@ -139,6 +139,19 @@ def main():
         x = torch.from_numpy(synth.complex_array((127, 131072), np.complex64)).to(dev); y = torch.empty_like(x)
         run("ndfft axis=0 127x131072 c64", ndfft, x, y, FftHandler(127, np.float32), 0, x.numel(), a.steps)
         return
+    if a.only == "oddreal":
+        for v in ("1", "0"):
+            os.environ["NDFFT_PLAIN"] = v
+            for n in (63, 125, 243, 625, 1001, 3003):
+                rows = (1 << 24) // n
+                x = torch.from_numpy(synth.real_array((rows, n))).to(dev); y = torch.empty_like(x)
+                run(f"oddreal[NDFFT_PLAIN={v}] nddct2 axis=1 {rows}x{n} f64", nddct2, x, y, DctHandler(n), 1, x.numel(), a.steps)
+                xf = torch.from_numpy(synth.real_array((rows, n), np.float32)).to(dev); w = torch.empty((rows, n // 2 + 1), dtype=torch.complex64, device=dev)
+                run(f"oddreal[NDFFT_PLAIN={v}] ndfft_r2c axis=1 {rows}x{n} f32", ndfft_r2c, xf, w, R2cFftHandler(n, np.float32), 1, xf.numel(), a.steps)
+            x = torch.from_numpy(synth.real_array((625, 16384))).to(dev); y = torch.empty_like(x)
+            run(f"oddreal[NDFFT_PLAIN={v}] nddct2 axis=0 625x16384 f64", nddct2, x, y, DctHandler(625), 0, x.numel(), a.steps)
+        del os.environ["NDFFT_PLAIN"]
+        return
     if a.only == "c2cplan":
         for n in (72, 80, 120, 300, 360, 600, 1200, 1500, 3000, 6000, 12000):
             for cdt, rdt in ((np.complex128, np.float64), (np.complex64, np.float32)):
