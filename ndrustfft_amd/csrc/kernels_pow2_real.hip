@@ -163,12 +163,19 @@ template <typename T> int launch_pow2_real_narrow(int op, const RealArgs<T> &a, 
 template int launch_pow2_real_narrow<float>(int, const RealArgs<float> &, hipStream_t);
 template int launch_pow2_real_narrow<double>(int, const RealArgs<double> &, hipStream_t);
 
+// threads per row workgroup (whole lanes): a documented compile-time knob, see DESIGN.md section 6
+#ifndef NDFFT_REAL_ROW_THREADS
+#define NDFFT_REAL_ROW_THREADS 256
+#endif
 template <typename T, int F, int OP> static int launch_real_one(const RealArgs<T> &a, bool col, hipStream_t s) {
     constexpr int TPL = RealCfg<F>::TPL;
     if (!col) {
         if constexpr (OP == G_C2C_FWD || OP == G_C2C_INV) return fail(NDFFT_ERR_INVALID_ARG, "row C2C goes through k_pow2");
         else {
-            constexpr int LPB = TPL >= 256 ? 1 : 256 / TPL;
+            // one-wave workgroups for f64 and for short f32 lanes (profiles/r04/r04n_rowthr_ab.txt: nddct2 f64 n = 128..1024 0.78-0.82 -> 0.81-0.84,
+            // ndfft_r2c f32 n = 128 / 256 0.69 / 0.68 -> 0.73 / 0.71, n = 512 / 1024 lose 1-4 % and keep 256 threads)
+            constexpr int THR = (NDFFT_REAL_ROW_THREADS == 256 && (sizeof(T) == 8 || F <= 128)) ? 64 : NDFFT_REAL_ROW_THREADS;
+            constexpr int LPB = TPL >= THR ? 1 : THR / TPL;
             return launch_k<RealPow2Kernel<T, F, TPL, LPB, typename RealCfg<F>::RL, OP, false>, T>(a, LPB, s);
         }
     }
