@@ -310,13 +310,18 @@ std::string radix_list(const JitCfg &cfg) {
 }  // namespace
 
 // returns NDFFT_OK and launches, or NDFFT_ERR_UNSUPPORTED if no specialised kernel can be had (caller falls back)
-int launch_jit_c2c(int dtype, const JitCfg &cfg, int nt, const Pow2Args &a, hipStream_t s) {
+int launch_jit_c2c(int dtype, const JitCfg &cfg_in, int nt, const Pow2Args &a, hipStream_t s) {
     if (!rtc().ok) return NDFFT_ERR_UNSUPPORTED;
-    const bool vec_ok = cfg.vec == 2 && a.pitch_in % 2 == 0 && a.pitch_out % 2 == 0 && ((uintptr_t)a.in % 16) == 0 && ((uintptr_t)a.out % 16) == 0;
+    const bool vec_ok = cfg_in.vec == 2 && a.pitch_in % 2 == 0 && a.pitch_out % 2 == 0 && ((uintptr_t)a.in % 16) == 0 && ((uintptr_t)a.out % 16) == 0;
     const int vec = vec_ok ? 2 : 1;
     int dev = 0;
     NDFFT_HIP(hipGetDevice(&dev));
     const char *tn = dtype == NDFFT_F32 ? "float" : "double";
+    // one-wave workgroups where a lane needs <= 64 threads (profiles/r04/r04o_c2c_row_threads.txt: 1000 c64 0.71 -> 0.81, 1000 / 1331 / 264 / 96 c128 +3-6 %,
+    // 72 c64 0.75 -> 0.84; 120 c64 loses 7 %); 0 = the recipe's own lanes (256 threads)
+    static const int c2c_thr = [] { const char *e = getenv("NDFFT_JIT_C2C_ROW_THREADS"); return e ? atoi(e) : 64; }();
+    JitCfg cfg = cfg_in;
+    if (c2c_thr > 0 && cfg.row_lpb == 0) cfg.lpb = cfg.tpl >= c2c_thr ? 1 : std::max(1, c2c_thr / cfg.tpl);
     const int threads = cfg.tpl * cfg.lpb;
     // f32 lanes exchange whole complex elements (64-bit LDS accesses, half the LDS instructions) as long as two
     // workgroups still fit a CU, like the ahead-of-time f32 configurations (kernels_pow2.hip: Pow2Half).  Measured on
@@ -434,7 +439,10 @@ int jit_col_lanes(int dtype, const JitCfg &cfg) {
 template <typename T> int launch_jit_real(int gop, const JitCfg &cfg, bool col, const RealArgs<T> &a, hipStream_t s) {
     if (!rtc().ok) return NDFFT_ERR_UNSUPPORTED;
     const int dtype = sizeof(T) == 4 ? NDFFT_F32 : NDFFT_F64;
-    const int lpb = col ? jit_col_lanes(dtype, cfg) : cfg.row_lpb > 0 ? cfg.row_lpb : (cfg.tpl >= 256 ? 1 : std::max(1, 256 / cfg.tpl));
+    // rows: one-wave workgroups where a lane needs <= 64 threads (profiles/r04/r04o_jit_row_threads.txt: nddct2 f64 n = 72..2000 +8-21 %, ndfft_r2c f32 +1-15 %
+    // against 256-thread workgroups)
+    static const int row_thr = [] { const char *e = getenv("NDFFT_JIT_ROW_THREADS"); return e ? atoi(e) : 64; }();   // developer knob
+    const int lpb = col ? jit_col_lanes(dtype, cfg) : cfg.row_lpb > 0 ? cfg.row_lpb : (cfg.tpl >= row_thr ? 1 : std::max(1, row_thr / cfg.tpl));
     if (lpb <= 0) return NDFFT_ERR_UNSUPPORTED;
     int dev = 0;
     NDFFT_HIP(hipGetDevice(&dev));
@@ -462,7 +470,7 @@ template <typename T> int launch_jit_real(int gop, const JitCfg &cfg, bool col, 
 template <typename T> int launch_jit_plain(int gop, const JitCfg &cfg, bool col, const RealArgs<T> &a, hipStream_t s) {
     if (!rtc().ok) return NDFFT_ERR_UNSUPPORTED;
     const int dtype = sizeof(T) == 4 ? NDFFT_F32 : NDFFT_F64;
-    const int lpb = col ? jit_col_lanes(dtype, cfg) : cfg.row_lpb > 0 ? cfg.row_lpb : (cfg.tpl >= 256 ? 1 : std::max(1, 256 / cfg.tpl));
+    const int lpb = col ? jit_col_lanes(dtype, cfg) : cfg.row_lpb > 0 ? cfg.row_lpb : (cfg.tpl >= 64 ? 1 : std::max(1, 64 / cfg.tpl));
     if (lpb <= 0) return NDFFT_ERR_UNSUPPORTED;
     int dev = 0;
     NDFFT_HIP(hipGetDevice(&dev));
