@@ -52,7 +52,11 @@ namespace ndfft {
     X(8192, 512, 8, 16, 8, 8) \
     X(16384, 512, 16, 16, 8, 8)
 
-static constexpr int lpb_for(int tpl) { return tpl >= 256 ? 1 : 256 / tpl; }
+// threads per workgroup (whole lanes): a documented compile-time knob
+#ifndef NDFFT_POW2_ROW_THREADS
+#define NDFFT_POW2_ROW_THREADS 256
+#endif
+static constexpr int lpb_for(int tpl) { return tpl >= NDFFT_POW2_ROW_THREADS ? 1 : NDFFT_POW2_ROW_THREADS / tpl; }
 
 template <typename T, int N> struct Pow2Cfg;
 #define NDFFT_DEF_CFG64(N_, TPL_, ...) \
