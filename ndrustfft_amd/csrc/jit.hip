@@ -317,8 +317,8 @@ int launch_jit_c2c(int dtype, const JitCfg &cfg_in, int nt, const Pow2Args &a, h
     int dev = 0;
     NDFFT_HIP(hipGetDevice(&dev));
     const char *tn = dtype == NDFFT_F32 ? "float" : "double";
-    // one-wave workgroups where a lane needs <= 64 threads (profiles/r04/r04o_c2c_row_threads.txt: 1000 c64 0.71 -> 0.81, 1000 / 1331 / 264 / 96 c128 +3-6 %,
-    // 72 c64 0.75 -> 0.84; 120 c64 loses 7 %); 0 = the recipe's own lanes (256 threads)
+    // one-wave workgroups where a lane needs <= 64 threads: +1-4 % in alternating A-B-A-B runs (profiles/r04/r04s_abab_c2c_row.txt: 1000 / 264 / 1331 / 96 c128,
+    // 1000 c64); 0 = the recipe's own lanes (256 threads)
     static const int c2c_thr = [] { const char *e = getenv("NDFFT_JIT_C2C_ROW_THREADS"); return e ? atoi(e) : 64; }();
     JitCfg cfg = cfg_in;
     if (c2c_thr > 0 && cfg.row_lpb == 0) cfg.lpb = cfg.tpl >= c2c_thr ? 1 : std::max(1, c2c_thr / cfg.tpl);
@@ -439,8 +439,8 @@ int jit_col_lanes(int dtype, const JitCfg &cfg) {
 template <typename T> int launch_jit_real(int gop, const JitCfg &cfg, bool col, const RealArgs<T> &a, hipStream_t s) {
     if (!rtc().ok) return NDFFT_ERR_UNSUPPORTED;
     const int dtype = sizeof(T) == 4 ? NDFFT_F32 : NDFFT_F64;
-    // rows: one-wave workgroups where a lane needs <= 64 threads (profiles/r04/r04o_jit_row_threads.txt: nddct2 f64 n = 72..2000 +8-21 %, ndfft_r2c f32 +1-15 %
-    // against 256-thread workgroups)
+    // rows: one-wave workgroups where a lane needs <= 64 threads (alternating A-B-A-B runs, profiles/r04/r04s_abab_jit_row.txt: nddct2 f64 n = 100..2000 +5-19 %,
+    // ndfft_r2c f32 +2-6 % against 256-thread workgroups)
     static const int row_thr = [] { const char *e = getenv("NDFFT_JIT_ROW_THREADS"); return e ? atoi(e) : 64; }();   // developer knob
     const int lpb = col ? jit_col_lanes(dtype, cfg) : cfg.row_lpb > 0 ? cfg.row_lpb : (cfg.tpl >= row_thr ? 1 : std::max(1, row_thr / cfg.tpl));
     if (lpb <= 0) return NDFFT_ERR_UNSUPPORTED;
@@ -501,7 +501,8 @@ template int launch_jit_plain<double>(int, const JitCfg &, bool, const RealArgs<
 template <typename T> int launch_jit_blue(int gop, const JitCfg &cfg, bool col, const RealArgs<T> &a, hipStream_t s) {
     if (!rtc().ok) return NDFFT_ERR_UNSUPPORTED;
     const int dtype = sizeof(T) == 4 ? NDFFT_F32 : NDFFT_F64;
-    const int lpb = col ? jit_col_lanes(dtype, cfg) : (cfg.tpl >= 256 ? 1 : std::max(1, 256 / cfg.tpl));
+    static const int row_thr = [] { const char *e = getenv("NDFFT_BLUE_ROW_THREADS"); return e ? atoi(e) : 256; }();   // developer knob
+    const int lpb = col ? jit_col_lanes(dtype, cfg) : (cfg.tpl >= row_thr ? 1 : std::max(1, row_thr / cfg.tpl));
     if (lpb <= 0) return NDFFT_ERR_UNSUPPORTED;
     int dev = 0;
     NDFFT_HIP(hipGetDevice(&dev));

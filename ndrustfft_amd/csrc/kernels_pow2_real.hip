@@ -172,8 +172,8 @@ template <typename T, int F, int OP> static int launch_real_one(const RealArgs<T
     if (!col) {
         if constexpr (OP == G_C2C_FWD || OP == G_C2C_INV) return fail(NDFFT_ERR_INVALID_ARG, "row C2C goes through k_pow2");
         else {
-            // one-wave workgroups for f64 and for short f32 lanes (profiles/r04/r04n_rowthr_ab.txt: nddct2 f64 n = 128..1024 0.78-0.82 -> 0.81-0.84,
-            // ndfft_r2c f32 n = 128 / 256 0.69 / 0.68 -> 0.73 / 0.71, n = 512 / 1024 lose 1-4 % and keep 256 threads)
+            // one-wave workgroups for f64 and for short f32 lanes (alternating A-B-A-B runs, profiles/r04/r04s_abab_pow2real_*.txt: nddct2 f64 n = 128..1024 +2.5-6 %,
+            // cfg4 nddct2 81.4 -> 78.8 us; ndfft_r2c f32 n = 128 / 256 +3-5 %, n >= 512 no gain: they keep 256 threads)
             constexpr int THR = (NDFFT_REAL_ROW_THREADS == 256 && (sizeof(T) == 8 || F <= 128)) ? 64 : NDFFT_REAL_ROW_THREADS;
             constexpr int LPB = TPL >= THR ? 1 : THR / TPL;
             return launch_k<RealPow2Kernel<T, F, TPL, LPB, typename RealCfg<F>::RL, OP, false>, T>(a, LPB, s);
