@@ -62,7 +62,7 @@ template <typename T> struct GenArgs {
 struct HostTable { std::vector<long double> re, im; };
 struct JitCfg { int n = 0, tpl = 0, e = 0, lpb = 1, vec = 1; bool partial = false; std::vector<int> radix; int row_lpb = 0; };   // row_lpb: planned lanes per row workgroup (0 = default rule)   // partial: some pass has an incomplete last round
 // Rader / Good-Thomas recipe of rader_kernel.h: F = mc * p, p prime with p - 1 smooth; fft = register configuration of FFT_(p-1)
-struct RaderCfg { int p = 0, mc = 1; JitCfg fft; };
+struct RaderCfg { int p = 0, mc = 1, mc1 = 1, mc2 = 1; JitCfg fft; };   // mc = mc1 * mc2: cofactor as one butterfly (mc2 = 1) or a two-factor transform in registers
 }  // namespace ndfft
 struct ndfft_plan;
 namespace ndfft {   // built once in long double
@@ -96,7 +96,7 @@ struct FftConfig {                 // one complex-FFT-of-length-F recipe + op ta
                                    // (jitcfg = configuration for M, twp = its per-pass twiddles)
     // blue && F = mc * p with p - 1 smooth: rader_kernel.h instead of Bluestein (specialised with hiprtc); rader_bhat = FFT_(p-1)(W_p^(g^-q)) / (p - 1),
     // rader_twp = per-pass twiddles of FFT_(p-1), rader_tab = g^i mod p (i < p - 1) followed by g^-i mod p
-    bool rader = false; RaderCfg radercfg; HostTable rader_bhat, rader_twp, rader_twp2; std::vector<int32_t> rader_tab;   // twp2: the passes in reverse order
+    bool rader = false; RaderCfg radercfg; HostTable rader_bhat, rader_twp, rader_twp2, rader_ctw; std::vector<int32_t> rader_tab;   // twp2: the passes in reverse order
     bool jit = false; JitCfg jitcfg;   // C2C slot: smooth non-power-of-two n -> specialised register kernel (jit.hip); twiddles in twp
     bool unsupported = false;      // no single-kernel fit and no usable factorisation (large prime factor)
 };
@@ -107,7 +107,7 @@ struct DevConfig {                 // device copies (typed by dtype) of one FftC
     void *cs_twlo = nullptr, *cs_twhi = nullptr;
     void *wave_tw = nullptr;
     void *tinymat[4] = {nullptr, nullptr, nullptr, nullptr};
-    void *rader_bhat = nullptr, *rader_twp = nullptr, *rader_twp2 = nullptr, *rader_tab = nullptr, *twp_rev = nullptr;
+    void *rader_bhat = nullptr, *rader_twp = nullptr, *rader_twp2 = nullptr, *rader_tab = nullptr, *twp_rev = nullptr, *rader_ctw = nullptr;   // ctw: W_mc^k of a two-factor cofactor
 };
 
 enum ConfigSlot { CFG_MAIN = 0, CFG_DCT1 = 1, CFG_DCT4 = 2, CFG_COUNT = 3 };

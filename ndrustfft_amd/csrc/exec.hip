@@ -867,7 +867,7 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
                 a.chirp = (const cpx<float> *)d.chirp; a.bhat = (const cpx<float> *)d.bhat; a.twp_rev = (const cpx<float> *)d.twp_rev;
                 if (use_rader) {
                     RealArgs<float> r = a;
-                    r.twp = (const cpx<float> *)d.rader_twp; r.twp_rev = (const cpx<float> *)d.rader_twp2; r.bhat = (const cpx<float> *)d.rader_bhat; r.rader_tab = (const int32_t *)d.rader_tab;
+                    r.twp = (const cpx<float> *)d.rader_twp; r.twp_rev = (const cpx<float> *)d.rader_twp2; r.chirp = (const cpx<float> *)d.rader_ctw; r.bhat = (const cpx<float> *)d.rader_bhat; r.rader_tab = (const int32_t *)d.rader_tab;
                     const int rr = launch_jit_rader<float>(gop, c.radercfg, col, r, stream);
                     if (rr != NDFFT_ERR_UNSUPPORTED) { set_last_path(col ? "rader_col" : "rader_reg"); return rr; }
                 }
@@ -880,7 +880,7 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
                 a.chirp = (const double2 *)d.chirp; a.bhat = (const double2 *)d.bhat; a.twp_rev = (const double2 *)d.twp_rev;
                 if (use_rader) {
                     RealArgs<double> r = a;
-                    r.twp = (const double2 *)d.rader_twp; r.twp_rev = (const double2 *)d.rader_twp2; r.bhat = (const double2 *)d.rader_bhat; r.rader_tab = (const int32_t *)d.rader_tab;
+                    r.twp = (const double2 *)d.rader_twp; r.twp_rev = (const double2 *)d.rader_twp2; r.chirp = (const double2 *)d.rader_ctw; r.bhat = (const double2 *)d.rader_bhat; r.rader_tab = (const int32_t *)d.rader_tab;
                     const int rr = launch_jit_rader<double>(gop, c.radercfg, col, r, stream);
                     if (rr != NDFFT_ERR_UNSUPPORTED) { set_last_path(col ? "rader_col" : "rader_reg"); return rr; }
                 }

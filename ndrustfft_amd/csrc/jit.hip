@@ -117,7 +117,7 @@ static bool jit_choose_partial(int dtype, int n, JitCfg &cfg, int emax_arg = 0) 
     return true;
 }
 
-static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg &out);
+static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg &out, bool wide = false);
 static bool jit_choose_default(int dtype, int n, JitCfg &cfg, bool allow_partial);
 // The default recipe ("fewest passes, every radix divides E") gives some lengths 20-30 elements per thread on a handful of threads
 // (F = 48: 8.6 on 2 threads, e = 24; 3000 = 10.10.10.3, e = 30).  Those measure badly -- f64 from e > 18, f32 from e > 24
@@ -549,8 +549,9 @@ static int rader_row_lanes(int dtype, const RaderCfg &rc) { return rader_row_lan
 // cost = passes x (work incl. idle threads of partial rounds) / (fill of the workgroup's waves), 13 % / 5 % off for one- / two-wave
 // workgroups, plus a penalty for many elements per thread (f64: e = 21 costs 5-20 %, e = 24 twice the time) -- fitted to the sweeps
 // under profiles/r04/r04c_rader_tune.txt and r04d_rader_tune_lpb.txt (tools/probes/rader_tune.py).
-static bool rader_plan_fft(int dtype, int M, RaderCfg &rc) {
-    return plan_fft_by_cost(dtype, M, rc.mc, rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8), rc.fft);
+static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg &out, bool wide);
+static bool rader_plan_fft(int dtype, int M, RaderCfg &rc, bool wide) {
+    return plan_fft_by_cost(dtype, M, rc.mc, rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8), rc.fft, wide);
 }
 // lanes per workgroup for `lt` threads per lane and `lane` bytes of LDS per lane: one wave where a lane needs <= 64 threads, else the
 // fullest waves with the fewest of them (see rader_row_lanes_for)
@@ -568,10 +569,12 @@ static int row_lanes_by_fill(int lt, size_t lane, int forced, double *util_out) 
     if (util_out) *util_out = best_util;
     return best;
 }
-static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg &out) {
-    const int emax = dtype == NDFFT_F32 ? 32 : 18, esoft = dtype == NDFFT_F32 ? 21 : 18;
+static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg &out, bool wide) {
+    const int emax = dtype == NDFFT_F32 ? 32 : (wide ? 19 : 18), esoft = dtype == NDFFT_F32 ? 21 : 18;
     const double eslope = dtype == NDFFT_F32 ? 0.05 : 0.1;
-    const int cand[] = {16, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
+    // wide: M has one factor 17 or 19 (Rader for primes like 103, 137, 191): those radices join the list
+    std::vector<int> cand = {16, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
+    if (wide) { cand.insert(cand.begin(), 17); cand.insert(cand.begin(), 19); }
     std::vector<int> cur;
     JitCfg best; double best_cost = 1e30;
     auto eval = [&]() {
@@ -601,7 +604,7 @@ static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg
             cur.pop_back();
         }
     };
-    rec(M, 16);
+    rec(M, wide ? 19 : 16);
     if (best.radix.empty()) return false;
     out = best;
     return true;
@@ -615,8 +618,18 @@ bool rader_choose(int dtype, int F, RaderCfg &rc) {
     for (int f = 2; (int64_t)f * f <= m; ++f) while (m % f == 0) { p = f; m /= f; }
     if (m > 1) p = m;                                   // largest prime factor
     const int mc = F / p;
-    if (p <= 13 || mc > 16 || mc % p == 0) return false;
-    { int q = p - 1; for (int f : {2, 3, 5, 7, 11, 13}) while (q % f == 0) q /= f; if (q != 1) return false; }
+    if (p <= 13 || mc % p == 0) return false;
+    // cofactor: one butterfly (2..16) or two butterfly factors held in one thread's registers (w[.][mc] next to the E elements of the FFT)
+    rc.mc1 = mc; rc.mc2 = 1;
+    if (mc > 16) {
+        int n1 = 0, n2 = 0;
+        if (mc > (dtype == NDFFT_F32 ? 48 : 32) || !regfft_factor(mc, &n1, &n2) || n1 > 16 || n2 > 16) return false;
+        rc.mc1 = n1; rc.mc2 = n2;
+    }
+    // p - 1: 13-smooth, or with ONE factor 17 / 19 (a radix-17 / 19 pass: E >= 17 / 19 complex registers)
+    bool wide = false;
+    { int q = p - 1; for (int f : {2, 3, 5, 7, 11, 13}) while (q % f == 0) q /= f;
+      if (q == 17 || q == 19) wide = true; else if (q != 1) return false; }
     rc.p = p; rc.mc = mc;
     if (rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8) > jit_lds_limit()) return false;
     if (const char *e = getenv("NDFFT_RADER_CFG")) {     // developer knob (tools/probes/rader_tune.py): "tpl:r0.r1.r2" for FFT_(p-1), read per plan
@@ -629,7 +642,7 @@ bool rader_choose(int dtype, int F, RaderCfg &rc) {
         for (int r : c.radix) { const int nb = c.n / r, sl = (nb + c.tpl - 1) / c.tpl; c.e = std::max(c.e, sl * r); if (nb % c.tpl) c.partial = true; }
         return true;
     }
-    return rader_plan_fft(dtype, p - 1, rc);
+    return rader_plan_fft(dtype, p - 1, rc, wide);
 }
 int rader_col_lanes(int dtype, const RaderCfg &rc) {
     const int lt = rc.fft.tpl * rc.mc;
@@ -651,7 +664,7 @@ template <typename T> int launch_jit_rader(int gop, const RaderCfg &rc, bool col
     NDFFT_HIP(hipGetDevice(&dev));
     const char *tn = sizeof(T) == 4 ? "float" : "double";
     const int threads = lt * lpb;
-    const std::string inst = std::string("RaderKernel<") + tn + ", " + std::to_string(rc.p) + ", " + std::to_string(rc.mc) + ", " + std::to_string(rc.fft.tpl) + ", " +
+    const std::string inst = std::string("RaderKernel<") + tn + ", " + std::to_string(rc.p) + ", " + std::to_string(rc.mc1) + ", " + std::to_string(rc.mc2) + ", " + std::to_string(rc.fft.tpl) + ", " +
                              std::to_string(lpb) + ", RadixList<" + radix_list(rc.fft) + ">, " + std::to_string(gop) + ", " + (col ? "true" : "false") + ">";
     const std::string src = std::string("#include \"rader_kernel.h\"\nusing namespace ndfft;\nextern \"C\" __global__ __launch_bounds__(") +
                             std::to_string(threads) + ") void k_jit(const RealArgs<" + tn + "> a) { " + inst + "::run(a); }\n";

@@ -170,6 +170,8 @@ static void build_rader_tables(FftConfig &c) {
     for (int k = 0; k < M; ++k) { c.rader_bhat.re.push_back(br[k] / M); c.rader_bhat.im.push_back(bi[k] / M); }
     c.rader_twp = HostTable();
     build_pass_twiddles(c.rader_twp, c.radercfg.fft.radix, M);
+    c.rader_ctw = HostTable();
+    for (int k = 0; k < c.radercfg.mc; ++k) unit(c.rader_ctw, (unsigned long long)k, (unsigned long long)c.radercfg.mc);   // W_mc^k: inner twiddles of a two-factor cofactor
     c.rader_twp2 = HostTable();
     build_pass_twiddles(c.rader_twp2, std::vector<int>(c.radercfg.fft.radix.rbegin(), c.radercfg.fft.radix.rend()), M);
 }
@@ -437,6 +439,7 @@ int get_dev_tables(const ndfft_plan *cplan, const DevTables **out) {
         if ((rc = upload_any(plan->dtype, c.rader_twp, &d.rader_twp))) return rc;
         if ((rc = upload_any(plan->dtype, c.rader_twp2, &d.rader_twp2))) return rc;
         if ((rc = upload_any(plan->dtype, c.twp_rev, &d.twp_rev))) return rc;
+        if ((rc = upload_any(plan->dtype, c.rader_ctw, &d.rader_ctw))) return rc;
         if (!c.rader_tab.empty()) {
             NDFFT_HIP(hipMalloc(&d.rader_tab, c.rader_tab.size() * sizeof(int32_t)));
             NDFFT_HIP(hipMemcpy(d.rader_tab, c.rader_tab.data(), c.rader_tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -505,7 +508,7 @@ int ndfft_plan_destroy(ndfft_plan *plan) {
         (void)hipSetDevice(kv.first);
         for (int i = 0; i < CFG_COUNT; ++i) {
             DevConfig &d = kv.second.cfg[i];
-            void *ptrs[] = {d.tw, d.twM, d.chirp, d.bhat, d.aux1, d.aux2, d.twp, d.twlo, d.twhi, d.twp_col, d.twp_narrow, d.cs_twlo, d.cs_twhi, d.wave_tw, d.tinymat[0], d.tinymat[1], d.tinymat[2], d.tinymat[3], d.rader_bhat, d.rader_twp, d.rader_twp2, d.rader_tab, d.twp_rev};
+            void *ptrs[] = {d.tw, d.twM, d.chirp, d.bhat, d.aux1, d.aux2, d.twp, d.twlo, d.twhi, d.twp_col, d.twp_narrow, d.cs_twlo, d.cs_twhi, d.wave_tw, d.tinymat[0], d.tinymat[1], d.tinymat[2], d.tinymat[3], d.rader_bhat, d.rader_twp, d.rader_twp2, d.rader_tab, d.twp_rev, d.rader_ctw};
             for (void *q : ptrs) if (q) (void)hipFree(q);
         }
     }

@@ -19,6 +19,7 @@
 // The lane semantics are the reference's (src/lib.rs:313-338, 497-531, 688-741) through realops.h, exactly as in blue_kernel.h.
 #pragma once
 #include "pow2_real.h"
+#include "reg_kernel.h"
 
 namespace ndfft {
 
@@ -28,7 +29,11 @@ constexpr int rader_inv_mod(int a, int m) {   // a^-1 mod m for coprime a, m (0 
     return 0;
 }
 
-template <typename T, int P, int MC, int TPL, int LPB, typename RL, int OP, bool COL = false> struct RaderKernel {
+// MC = MC1 * MC2: the cofactor transform is one butterfly (MC2 = 1: MC = 2..16) or a two-factor Cooley-Tukey in registers (reg_kernel.h: RegFft2::fft,
+// e.g. 18 = 6 x 3, 27 = 9 x 3, 28 = 7 x 4; its twiddles W_MC^k come through a.chirp)
+template <typename T, int P, int MC1, int MC2, int TPL, int LPB, typename RL, int OP, bool COL = false> struct RaderKernel {
+    static constexpr int MC = MC1 * MC2;
+    using COF = RegFft2<T, MC1, MC2, 1, false>;
     static constexpr int M = P - 1, F = P * MC;
     using RLR = RadixReversed<RL>;
     using FFT = Pow2Kernel<T, M, TPL, LPB * MC, false, RL, 0, 1, 0>;
@@ -176,13 +181,13 @@ template <typename T, int P, int MC, int TPL, int LPB, typename RL, int OP, bool
             for (int s = 0; s < NS; ++s) {
                 const int k2 = tl + s * LTHREADS;
                 if (k2 < P) {
-                    Bfly<T, MC>::run(w[s]);
+                    COF::fft(w[s], a.chirp);                              // register slot j holds output k1 = COF::out_index(j)
                     const int kb = MC * ((k2 * MINV) % P);              // k2 C2 mod F
 #pragma unroll
-                    for (int k1 = 0; k1 < MC; ++k1) {
-                        int k = kb + P * ((k1 * PINV) % MC);            // + k1 C1 mod F
+                    for (int j = 0; j < MC; ++j) {
+                        int k = kb + P * ((COF::out_index(j) * PINV) % MC);   // + k1 C1 mod F
                         if (k >= F) k -= F;
-                        zz[ZiPhi::map(k)] = w[s][k1];
+                        zz[ZiPhi::map(k)] = w[s][j];
                     }
                 }
             }

@@ -123,29 +123,32 @@ template int launch_jit_blue<float>(int, const JitCfg &, bool, const RealArgs<fl
 template int launch_jit_blue<double>(int, const JitCfg &, bool, const RealArgs<double> &, hipStream_t);
 
 // Rader / Good-Thomas kernel (rader_kernel.h; the product specialises it with hiprtc, jit.hip: launch_jit_rader), ahead of time for
-// F = 31 and 97 (primes), 62 = 2 x 31 and 511 = 7 x 73 (cofactor butterflies); FFT_30 runs with a PARTIAL second pass (6.5 on 5 threads)
+// F = 31 and 97 (primes), 62 = 2 x 31 and 511 = 7 x 73 (cofactor butterflies), 306 = (6 x 3) x 17 (two-factor cofactor, one-pass FFT_16);
+// FFT_30 runs with a PARTIAL second pass (6.5 on 5 threads)
 bool rader_choose(int, int F, RaderCfg &rc) {
     rc.fft.vec = 1; rc.fft.lpb = 1;
-    if (F == 31 || F == 62) { rc.p = 31; rc.mc = F / 31; rc.fft.n = 30; rc.fft.tpl = 5; rc.fft.e = 10; rc.fft.radix = {6, 5}; rc.fft.partial = true; return true; }
+    if (F == 31 || F == 62) { rc.p = 31; rc.mc = F / 31; rc.mc1 = rc.mc; rc.fft.n = 30; rc.fft.tpl = 5; rc.fft.e = 10; rc.fft.radix = {6, 5}; rc.fft.partial = true; return true; }
     if (F == 97) { rc.p = 97; rc.mc = 1; rc.fft.n = 96; rc.fft.tpl = 8; rc.fft.e = 12; rc.fft.radix = {6, 4, 4}; return true; }
-    if (F == 511) { rc.p = 73; rc.mc = 7; rc.fft.n = 72; rc.fft.tpl = 6; rc.fft.e = 12; rc.fft.radix = {6, 4, 3}; return true; }
+    if (F == 511) { rc.p = 73; rc.mc = 7; rc.mc1 = 7; rc.fft.n = 72; rc.fft.tpl = 6; rc.fft.e = 12; rc.fft.radix = {6, 4, 3}; return true; }
+    if (F == 306) { rc.p = 17; rc.mc = 18; rc.mc1 = 6; rc.mc2 = 3; rc.fft.n = 16; rc.fft.tpl = 1; rc.fft.e = 16; rc.fft.radix = {16}; return true; }   // two-factor cofactor, one-pass FFT_16
     return false;
 }
 int rader_col_lanes(int, const RaderCfg &) { return 8; }
-template <typename T, int P, int MC, int TPL, typename RL, int OP> static int rader_one(bool col, const RealArgs<T> &a, hipStream_t s) {
+template <typename T, int P, int MC1, int MC2, int TPL, typename RL, int OP> static int rader_one(bool col, const RealArgs<T> &a, hipStream_t s) {
+    constexpr int MC = MC1 * MC2;
     if (col) {
-        using K = RaderKernel<T, P, MC, TPL, 8, RL, OP, true>;
+        using K = RaderKernel<T, P, MC1, MC2, TPL, 8, RL, OP, true>;
         hipLaunchKernelGGL((k_blue_emul<K, T>), dim3((unsigned)((a.nlanes + 7) / 8)), dim3(K::THREADS), K::LDS_BYTES, s, a);
     } else {
         constexpr int LPB = 256 / (TPL * MC);
-        using K = RaderKernel<T, P, MC, TPL, LPB, RL, OP, false>;
+        using K = RaderKernel<T, P, MC1, MC2, TPL, LPB, RL, OP, false>;
         hipLaunchKernelGGL((k_blue_emul<K, T>), dim3((unsigned)((a.nlanes + LPB - 1) / LPB)), dim3(K::THREADS), K::LDS_BYTES, s, a);
     }
     return NDFFT_OK;
 }
-template <typename T, int P, int MC, int TPL, typename RL> static int rader_P(int gop, bool col, const RealArgs<T> &a, hipStream_t s) {
+template <typename T, int P, int MC1, int MC2, int TPL, typename RL> static int rader_P(int gop, bool col, const RealArgs<T> &a, hipStream_t s) {
     switch (gop) {
-#define B(OP_) case OP_: return rader_one<T, P, MC, TPL, RL, OP_>(col, a, s);
+#define B(OP_) case OP_: return rader_one<T, P, MC1, MC2, TPL, RL, OP_>(col, a, s);
         B(G_C2C_FWD) B(G_C2C_INV) B(G_R2C_EVEN) B(G_R2C_ODD) B(G_C2R_EVEN) B(G_C2R_ODD) B(G_DCT1)
         B(G_DCT2_EVEN) B(G_DCT2_ODD) B(G_DCT3_EVEN) B(G_DCT3_ODD) B(G_DCT4_EVEN) B(G_DCT4_ODD)
 #undef B
@@ -155,10 +158,11 @@ template <typename T, int P, int MC, int TPL, typename RL> static int rader_P(in
 template <typename T> int launch_jit_rader(int gop, const RaderCfg &rc, bool col, const RealArgs<T> &a, hipStream_t s) {
     if (a.nlanes <= 0) return NDFFT_OK;
     { const char *e = getenv("NDFFT_RADER"); if (e && e[0] == '0') return NDFFT_ERR_UNSUPPORTED; }
-    if (rc.p == 31 && rc.mc == 1) return rader_P<T, 31, 1, 5, RadixList<6, 5>>(gop, col, a, s);
-    if (rc.p == 31 && rc.mc == 2) return rader_P<T, 31, 2, 5, RadixList<6, 5>>(gop, col, a, s);
-    if (rc.p == 97 && rc.mc == 1) return rader_P<T, 97, 1, 8, RadixList<6, 4, 4>>(gop, col, a, s);
-    if (rc.p == 73 && rc.mc == 7) return rader_P<T, 73, 7, 6, RadixList<6, 4, 3>>(gop, col, a, s);
+    if (rc.p == 31 && rc.mc == 1) return rader_P<T, 31, 1, 1, 5, RadixList<6, 5>>(gop, col, a, s);
+    if (rc.p == 31 && rc.mc == 2) return rader_P<T, 31, 2, 1, 5, RadixList<6, 5>>(gop, col, a, s);
+    if (rc.p == 97 && rc.mc == 1) return rader_P<T, 97, 1, 1, 8, RadixList<6, 4, 4>>(gop, col, a, s);
+    if (rc.p == 73 && rc.mc == 7) return rader_P<T, 73, 7, 1, 6, RadixList<6, 4, 3>>(gop, col, a, s);
+    if (rc.p == 17 && rc.mc == 18) return rader_P<T, 17, 6, 3, 1, RadixList<16>>(gop, col, a, s);
     return NDFFT_ERR_UNSUPPORTED;
 }
 template int launch_jit_rader<float>(int, const RaderCfg &, bool, const RealArgs<float> &, hipStream_t);

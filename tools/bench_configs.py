@@ -150,6 +150,24 @@ def main():
         x = torch.from_numpy(synth.complex_array((127, 131072), np.complex64)).to(dev); y = torch.empty_like(x)
         run("ndfft axis=0 127x131072 c64", ndfft, x, y, FftHandler(127, np.float32), 0, x.numel(), a.steps)
         return
+    if a.only == "rader2":
+        for rad in ("1", "0"):
+            os.environ["NDFFT_RADER"] = rad
+            for n, cdt, rdt in ((306, np.complex128, np.float64), (513, np.complex128, np.float64), (532, np.complex128, np.float64), (2336, np.complex128, np.float64),
+                                (103, np.complex128, np.float64), (137, np.complex128, np.float64), (2466, np.complex128, np.float64), (513, np.complex64, np.float32), (103, np.complex64, np.float32)):
+                rows = (1 << 24) // n
+                x = torch.from_numpy(synth.complex_array((rows, n), cdt)).to(dev); y = torch.empty_like(x)
+                run(f"rader2[NDFFT_RADER={rad}] ndfft axis=1 {rows}x{n} {np.dtype(cdt).name}", ndfft, x, y, FftHandler(n, rdt), 1, x.numel(), a.steps)
+        del os.environ["NDFFT_RADER"]
+        return
+    if a.only == "r2crows":
+        for n in (256, 1024, 8192):
+            rows = (1 << 26) // n
+            x = torch.from_numpy(synth.real_array((rows, n), np.float32)).to(dev); w = torch.empty((rows, n // 2 + 1), dtype=torch.complex64, device=dev)
+            run(f"r2crows ndfft_r2c f32 {rows}x{n}", ndfft_r2c, x, w, R2cFftHandler(n, np.float32), 1, x.numel(), a.steps)
+            xc = torch.from_numpy(synth.complex_array((rows // 2, n), np.complex64)).to(dev); yc = torch.empty_like(xc)
+            run(f"r2crows ndfft c64 {rows // 2}x{n}", ndfft, xc, yc, FftHandler(n, np.float32), 1, xc.numel(), a.steps)
+        return
     if a.only == "bluesweep":
         for n, cdt, rdt in ((59, np.complex128, np.float64), (83, np.complex128, np.float64), (227, np.complex128, np.float64), (479, np.complex128, np.float64),
                             (983, np.complex128, np.float64), (2039, np.complex128, np.float64), (227, np.complex64, np.float32), (983, np.complex64, np.float32)):
