@@ -2,7 +2,8 @@
 // length F has a prime factor > 13 (prime lane lengths, DCT-I with n-1 not smooth, ...), one pass over HBM.
 //
 //   Z[k] = chirp[k] * IFFT_M( FFT_M(z * chirp, zero padded to M) * bhat )[k],   chirp[j] = e^{-i pi j^2/F},
-//   M = 2^k >= 2F - 1, bhat = FFT_M(conj chirp, wrapped) / M   (plan.hip builds both tables in long double)
+//   M >= 2F - 1 (a power of two, or a cheaper 13-smooth length: jit.hip blue_pick_len), bhat = FFT_M(conj chirp, wrapped) / M
+//   (plan.hip builds both tables in long double)
 //
 // Per lane: stage raw lane -> LDS; PRE (realops.h) * chirp -> registers in the first pass's pattern, zero
 // padded; the power-of-two passes of pow2_kernel.h; * bhat and conj in registers; the same passes in REVERSE
@@ -17,7 +18,7 @@
 namespace ndfft {
 
 template <typename T, int M, int TPL, int LPB, typename RL, int OP, bool COL = false> struct BlueKernel {
-    static constexpr int E = M / TPL;
+    static constexpr int E = Pow2Kernel<T, M, TPL, LPB, false, RL, 0, 1, 0>::E;     // = M / TPL when every pass has whole rounds (partial rounds: pow2_kernel.h)
     static constexpr int THREADS = TPL * LPB;
     static constexpr int LANE_LDS = COL ? ((M + (M >> 4) + 2) | 1) : ((M + (M >> 4) + 3) & ~1);   // complex elements per lane
     static constexpr size_t LDS_BYTES = (size_t)LPB * LANE_LDS * 2 * sizeof(T);
@@ -85,23 +86,28 @@ template <typename T, int M, int TPL, int LPB, typename RL, int OP, bool COL = f
         }
         __syncthreads();
         // ---- PRE * chirp, zero padded, in the first pass's register pattern ----
-        constexpr int R0 = RL::at(0), NB0 = M / R0, NBF0 = E / R0;
-        constexpr int RLAST = RL::at(RL::NP - 1), NBL = M / RLAST, NBFL = E / RLAST;
+        constexpr int R0 = RL::at(0), NB0 = FFT::nbfly(0), NBF0 = FFT::slots(0);
+        constexpr int RLAST = RL::at(RL::NP - 1), NBL = FFT::nbfly(RL::NP - 1), NBFL = FFT::slots(RL::NP - 1);
+        constexpr bool FULL0 = FFT::full(0), FULLL = FFT::full(RL::NP - 1);
         cpx<T> v[E];
 #pragma unroll
         for (int q = 0; q < NBF0; ++q)
+            if (FULL0 || t + q * TPL < NB0) {
 #pragma unroll
-            for (int r = 0; r < R0; ++r) {
-                const int i = t + q * TPL + r * NB0;
-                v[q * R0 + r] = i < F ? cmul(pre(a, (const void *)lds, i), a.chirp[i]) : mk<T>((T)0, (T)0);
+                for (int r = 0; r < R0; ++r) {
+                    const int i = t + q * TPL + r * NB0;
+                    v[q * R0 + r] = i < F ? cmul(pre(a, (const void *)lds, i), a.chirp[i]) : mk<T>((T)0, (T)0);
+                }
             }
         // (the first exchange inside passes() starts with a barrier, so the raw lane is dead by then)
         FFT::template passes<0>(v, a.twp, lds, t);
         // ---- * bhat, conj: in registers -- the reversed pass order starts from exactly this pattern ----
 #pragma unroll
         for (int q = 0; q < NBFL; ++q)
+            if (FULLL || t + q * TPL < NBL) {
 #pragma unroll
-            for (int r = 0; r < RLAST; ++r) v[q * RLAST + r] = cconj(cmul(v[q * RLAST + r], a.bhat[t + q * TPL + r * NBL]));
+                for (int r = 0; r < RLAST; ++r) v[q * RLAST + r] = cconj(cmul(v[q * RLAST + r], a.bhat[t + q * TPL + r * NBL]));
+            }
         FFT2::template passes<0>(v, a.twp_rev, lds, t);
         // ---- Z[k] = conj(.) * chirp[k], k < F, natural order (the reversed list ends in the pattern of RL's first pass) ----
         __syncthreads();
@@ -109,10 +115,12 @@ template <typename T, int M, int TPL, int LPB, typename RL, int OP, bool COL = f
             cpx<T> *z = (cpx<T> *)lds;
 #pragma unroll
             for (int q = 0; q < NBF0; ++q)
+                if (FULL0 || t + q * TPL < NB0) {
 #pragma unroll
-                for (int r = 0; r < R0; ++r) {
-                    const int o = t + q * TPL + r * NB0;
-                    if (o < F) z[ZiPhi::map(o)] = cmul(cconj(v[q * R0 + r]), a.chirp[o]);
+                    for (int r = 0; r < R0; ++r) {
+                        const int o = t + q * TPL + r * NB0;
+                        if (o < F) z[ZiPhi::map(o)] = cmul(cconj(v[q * R0 + r]), a.chirp[o]);
+                    }
                 }
         }
         __syncthreads();

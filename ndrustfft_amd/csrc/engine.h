@@ -200,6 +200,9 @@ template <typename T> int launch_pow2_real_narrow(int gen_op, const RealArgs<T> 
 bool pow2_real_config(int F, JitCfg &cfg);
 template <typename T> int launch_jit_blue(int gen_op, const JitCfg &cfgM, bool col, const RealArgs<T> &a, hipStream_t s);
 // rader_kernel.h (jit.hip): recipe for an inner FFT length F with one prime factor > 13 (false: none, Bluestein stays), lanes per column tile, launch
+// Bluestein (jit.hip): convolution length for inner FFT length F -- the cheapest 13-smooth M in [2F - 1, m_pow2] by passes x M -- and the register recipe for it
+int blue_pick_len(int dtype, int F, int m_pow2);
+bool blue_plan_cfg(int dtype, int M, JitCfg &cfg);
 bool rader_choose(int dtype, int F, RaderCfg &rc);
 template <typename T> int launch_jit_plain(int gen_op, const JitCfg &cfg, bool col, const RealArgs<T> &a, hipStream_t s);   // plain_kernel.h: odd-n real ops, smooth F
 bool jit_choose_real(int dtype, int F, JitCfg &cfg);   // jit_choose for the real-op slots (rows of RealPow2Kernel): cost-model recipe

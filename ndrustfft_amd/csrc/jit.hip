@@ -117,7 +117,7 @@ static bool jit_choose_partial(int dtype, int n, JitCfg &cfg, int emax_arg = 0) 
     return true;
 }
 
-static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg &out, bool wide = false);
+static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg &out, bool wide = false, double *cost_out = nullptr);
 static bool jit_choose_default(int dtype, int n, JitCfg &cfg, bool allow_partial);
 // The default recipe ("fewest passes, every radix divides E") gives some lengths 20-30 elements per thread on a handful of threads
 // (F = 48: 8.6 on 2 threads, e = 24; 3000 = 10.10.10.3, e = 30).  Those measure badly -- f64 from e > 18, f32 from e > 24
@@ -502,7 +502,7 @@ template <typename T> int launch_jit_blue(int gop, const JitCfg &cfg, bool col, 
     if (!rtc().ok) return NDFFT_ERR_UNSUPPORTED;
     const int dtype = sizeof(T) == 4 ? NDFFT_F32 : NDFFT_F64;
     static const int row_thr = [] { const char *e = getenv("NDFFT_BLUE_ROW_THREADS"); return e ? atoi(e) : 256; }();   // developer knob
-    const int lpb = col ? jit_col_lanes(dtype, cfg) : (cfg.tpl >= row_thr ? 1 : std::max(1, row_thr / cfg.tpl));
+    const int lpb = col ? jit_col_lanes(dtype, cfg) : cfg.row_lpb > 0 ? cfg.row_lpb : (cfg.tpl >= row_thr ? 1 : std::max(1, row_thr / cfg.tpl));
     if (lpb <= 0) return NDFFT_ERR_UNSUPPORTED;
     int dev = 0;
     NDFFT_HIP(hipGetDevice(&dev));
@@ -549,9 +549,9 @@ static int rader_row_lanes(int dtype, const RaderCfg &rc) { return rader_row_lan
 // cost = passes x (work incl. idle threads of partial rounds) / (fill of the workgroup's waves), 13 % / 5 % off for one- / two-wave
 // workgroups, plus a penalty for many elements per thread (f64: e = 21 costs 5-20 %, e = 24 twice the time) -- fitted to the sweeps
 // under profiles/r04/r04c_rader_tune.txt and r04d_rader_tune_lpb.txt (tools/probes/rader_tune.py).
-static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg &out, bool wide);
+static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg &out, bool wide, double *cost_out);
 static bool rader_plan_fft(int dtype, int M, RaderCfg &rc, bool wide) {
-    return plan_fft_by_cost(dtype, M, rc.mc, rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8), rc.fft, wide);
+    return plan_fft_by_cost(dtype, M, rc.mc, rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8), rc.fft, wide, nullptr);
 }
 // lanes per workgroup for `lt` threads per lane and `lane` bytes of LDS per lane: one wave where a lane needs <= 64 threads, else the
 // fullest waves with the fewest of them (see rader_row_lanes_for)
@@ -569,7 +569,7 @@ static int row_lanes_by_fill(int lt, size_t lane, int forced, double *util_out) 
     if (util_out) *util_out = best_util;
     return best;
 }
-static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg &out, bool wide) {
+static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg &out, bool wide, double *cost_out) {
     const int emax = dtype == NDFFT_F32 ? 32 : (wide ? 19 : 18), esoft = dtype == NDFFT_F32 ? 21 : 18;
     const double eslope = dtype == NDFFT_F32 ? 0.05 : 0.1;
     // wide: M has one factor 17 or 19 (Rader for primes like 103, 137, 191): those radices join the list
@@ -607,10 +607,57 @@ static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg
     rec(M, wide ? 19 : 16);
     if (best.radix.empty()) return false;
     out = best;
+    if (cost_out) *cost_out = best_cost;
     return true;
 }
 
 bool jit_choose_real(int dtype, int F, JitCfg &cfg) { return jit_choose(dtype, F, cfg, true); }
+
+// ---- Bluestein on a smooth convolution length ---------------------------------------------------------------------------
+// fewest radices (<= 16, incl. 12) whose product is m; 99 if m is not 13-smooth
+static int min_passes(int m) {
+    static const int cand[] = {16, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
+    if (m == 1) return 0;
+    int best = 99;
+    for (int c : cand) if (m % c == 0) { const int r = min_passes(m / c); if (r + 1 < best) best = r + 1; if (best <= 1) break; }
+    return best;
+}
+int blue_pick_len(int dtype, int F, int m_pow2) {
+    static const bool on = [] { const char *e = getenv("NDFFT_BLUE_SMOOTH"); return !(e && e[0] == '0'); }();
+    if (!on || jit_disabled()) return m_pow2;
+    // shortlist by passes x length, then the register planner's own cost (passes x work / wave fill + penalties) x length decides; the power of two
+    // competes with its E = 8 recipe: passes x length (+ 5 %: a smooth length must win clearly)
+    // Measured (profiles/r04/r04y_abab_blue_smooth.txt): per point the mixed-radix passes cost about 1.3x the power-of-two E = 8 recipe, so a smooth length only
+    // pays when it is much shorter -- F = 263: M 1024 -> 550, 325 -> 211 us; F = 1283: 4096 -> 2592, 369 -> 279 us; but F = 227: 512 -> 480, 183 -> 228 us --
+    // F = 83: 256 -> 169 (0.66), 217 -> 228 us -- hence only lengths up to 0.65 x the power of two are considered.
+    std::vector<std::pair<long, int>> cands;
+    for (int m = 2 * F - 1; m < m_pow2 && 100 * (long)m <= 65 * (long)m_pow2; ++m) {
+        int q = m; for (int f : {2, 3, 5, 7, 11, 13}) while (q % f == 0) q /= f;
+        if (q != 1) continue;
+        const int np = min_passes(m);
+        if (np < 99) cands.push_back({(long)m * np, m});
+    }
+    std::sort(cands.begin(), cands.end());
+    JitCfg p2;
+    const double pow2_cost = (pow2_real_config(m_pow2, p2) ? (double)p2.radix.size() : (double)min_passes(m_pow2)) * m_pow2;
+    int best = m_pow2; double best_cost = pow2_cost * 0.95;
+    for (size_t i = 0; i < cands.size() && i < 6; ++i) {
+        const int m = cands[i].second;
+        JitCfg c; double cost = 0.0;
+        const size_t lane = (size_t)((m + (m >> 4) + 3) & ~1) * 2 * (dtype == NDFFT_F32 ? 4 : 8);
+        if (lane > jit_lds_limit() || !plan_fft_by_cost(dtype, m, 1, lane, c, false, &cost)) continue;
+        if (cost * m < best_cost) { best_cost = cost * m; best = m; }
+    }
+    return best;
+}
+bool blue_plan_cfg(int dtype, int M, JitCfg &cfg) {
+    if (jit_disabled()) return false;
+    const size_t lane = (size_t)((M + (M >> 4) + 3) & ~1) * 2 * (dtype == NDFFT_F32 ? 4 : 8);      // BlueKernel::LANE_LDS (rows)
+    if (lane > jit_lds_limit()) return false;
+    if (!plan_fft_by_cost(dtype, M, 1, lane, cfg)) return false;
+    cfg.vec = 1; cfg.row_lpb = cfg.lpb;
+    return true;
+}
 
 bool rader_choose(int dtype, int F, RaderCfg &rc) {
     if (jit_disabled() || F < 17) return false;

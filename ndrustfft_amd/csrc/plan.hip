@@ -100,7 +100,20 @@ static bool single_kernel_ok(int len, int dtype) {
 
 // chirp[j] = e^{-i pi j^2/F} (j < F) and bhat = FFT_M(conj chirp, wrapped) / M, computed in long double by an
 // iterative radix-2 FFT (per-stage twiddle tables) so that the device tables are correctly rounded
+static void dft_ld(std::vector<long double> &re, std::vector<long double> &im);
 static void build_bluestein_tables(FftConfig &c, int F, int M) {
+    if (M & (M - 1)) {      // smooth non-power-of-two M: the general long-double DFT below
+        for (int j = 0; j < F; ++j) unit(c.chirp, ((unsigned long long)j * j) % (2ull * F), 2ull * F);
+        std::vector<long double> br(M, 0.0L), bi(M, 0.0L);
+        for (int j = 0; j < F; ++j) {
+            br[j] = c.chirp.re[j]; bi[j] = -c.chirp.im[j];
+            if (j) { br[M - j] = br[j]; bi[M - j] = bi[j]; }
+        }
+        dft_ld(br, bi);
+        c.bhat.re.reserve(M); c.bhat.im.reserve(M);
+        for (int k = 0; k < M; ++k) { c.bhat.re.push_back(br[k] / M); c.bhat.im.push_back(bi[k] / M); }
+        return;
+    }
     for (int j = 0; j < F; ++j) unit(c.chirp, ((unsigned long long)j * j) % (2ull * F), 2ull * F);
     std::vector<long double> br(M, 0.0L), bi(M, 0.0L);
     for (int j = 0; j < F; ++j) {
@@ -221,7 +234,9 @@ static void build_fft(FftConfig &c, int F, int dtype) {
     c.blue = true;
     c.blue_reg_only = !blue_lds;
     c.radix.clear();
-    const int M = blue_len(F);
+    // M: the next power of two, or -- where the LDS kernel can hold it too -- a cheaper 13-smooth length >= 2F - 1 (jit.hip: blue_pick_len)
+    int M = blue_len(F);
+    if (blue_lds) { const int Ms = blue_pick_len(dtype, F, M); std::vector<int> rm; if (Ms >= 2 * F - 1 && Ms < M && factorize(Ms, rm)) M = Ms; }
     c.M = M;
     factorize(M, c.radixM);
     build_pass_twiddles(c.twM, c.radixM, M);
@@ -373,8 +388,10 @@ static void add_narrow_tables(ndfft_plan *p) {
     // Bluestein lengths: the register-kernel form (blue_kernel.h) when M has an E = 8 configuration
     for (int i = 0; i < CFG_COUNT; ++i) {
         FftConfig &c = p->cfg[i];
-        if (p->has_cfg[i] && c.blue && pow2_real_config(c.M, c.jitcfg)) {
-            c.bluereg = true; c.twp = HostTable(); pow2_real_build_twiddles(c.M, c.twp);
+        const bool m_pow2 = (c.M & (c.M - 1)) == 0;
+        if (p->has_cfg[i] && c.blue && (m_pow2 ? pow2_real_config(c.M, c.jitcfg) : blue_plan_cfg(p->dtype, c.M, c.jitcfg))) {
+            c.bluereg = true; c.twp = HostTable();
+            if (m_pow2) pow2_real_build_twiddles(c.M, c.twp); else build_pass_twiddles(c.twp, c.jitcfg.radix, c.M);
             c.twp_rev = HostTable(); build_pass_twiddles(c.twp_rev, std::vector<int>(c.jitcfg.radix.rbegin(), c.jitcfg.radix.rend()), c.M);
         }
         // ... and, where F = (small cofactor) x (prime p with p - 1 smooth), Rader's convolution of length p - 1 instead (rader_kernel.h)

@@ -21,6 +21,8 @@ bool jit_choose(int, int n, JitCfg &cfg, bool allow_partial) {
     return true;
 }
 bool jit_choose_real(int dtype, int F, JitCfg &cfg) { return jit_choose(dtype, F, cfg, true); }
+int blue_pick_len(int, int, int m_pow2) { return m_pow2; }      // the CPU build keeps Bluestein on powers of two (M = 64 and 256 are instantiated below)
+bool blue_plan_cfg(int, int, JitCfg &) { return false; }
 void jit_build_twiddles(const JitCfg &cfg, HostTable &out) { if (cfg.n == 264) build_tw<PRL264>(out); else if (cfg.n == 210) build_tw<PRL210>(out); else if (cfg.n == 45) build_tw<PRL45>(out); }
 template <typename K> __global__ void k_c2c_emul(const Pow2Args a) { K::run(a); }
 template <typename T, int N, int TPL, int LPB, typename RL> static int c2c_one(const Pow2Args &a, hipStream_t s) {

@@ -783,7 +783,7 @@ def rader_kernel(L, sizes=(31, 62, 97, 306, 511), col_max_F=128):
 
 def _bluestein_register_kernel(L, sizes, col_max_M):
     for F, M in sizes:
-        rows = (1 << 16) // M + 5
+        rows = (1 << 17) // M + 5        # (the library may pick a smooth convolution length down to M / 2: stay above its 2^16-point threshold)
         for rdt in (np.float64, np.float32):
             # C2C (n = F), odd-n real ops (inner FFT n = F; DCT-IV odd uses 2n, so it is not in this list)
             for name in ("ndfft", "ndifft", "ndfft_r2c", "ndifft_r2c", "nddct2", "nddct3"):

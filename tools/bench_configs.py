@@ -169,8 +169,9 @@ def main():
             run(f"r2crows ndfft c64 {rows // 2}x{n}", ndfft, xc, yc, FftHandler(n, np.float32), 1, xc.numel(), a.steps)
         return
     if a.only == "bluesweep":
-        for n, cdt, rdt in ((59, np.complex128, np.float64), (83, np.complex128, np.float64), (227, np.complex128, np.float64), (479, np.complex128, np.float64),
-                            (983, np.complex128, np.float64), (2039, np.complex128, np.float64), (227, np.complex64, np.float32), (983, np.complex64, np.float32)):
+        for n, cdt, rdt in ((59, np.complex128, np.float64), (83, np.complex128, np.float64), (107, np.complex128, np.float64), (227, np.complex128, np.float64), (263, np.complex128, np.float64),
+                            (479, np.complex128, np.float64), (515, np.complex128, np.float64), (983, np.complex128, np.float64), (1283, np.complex128, np.float64), (2039, np.complex128, np.float64),
+                            (227, np.complex64, np.float32), (515, np.complex64, np.float32), (983, np.complex64, np.float32)):
             rows = (1 << 24) // n
             x = torch.from_numpy(synth.complex_array((rows, n), cdt)).to(dev); y = torch.empty_like(x)
             run(f"bluesweep ndfft axis=1 {rows}x{n} {np.dtype(cdt).name}", ndfft, x, y, FftHandler(n, rdt), 1, x.numel(), a.steps)
