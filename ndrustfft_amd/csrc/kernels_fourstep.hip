@@ -18,12 +18,19 @@ NDFFT_FS(256, 32, 8, 8, 4)
 NDFFT_FS(512, 64, 8, 8, 8)
 NDFFT_FS(1024, 128, 8, 8, 4, 4)
 
+// adjacent lanes per tile (compile-time knobs, A/B in profiles/)
+#ifndef NDFFT_FS_LANES_F64
+#define NDFFT_FS_LANES_F64 8
+#endif
+#ifndef NDFFT_FS_LANES_F32
+#define NDFFT_FS_LANES_F32 16
+#endif
 template <typename T, int F> struct FsGeom {
     static constexpr int TPL = FsCfg<F>::TPL;
     // adjacent lanes per tile: 128-byte rows (8 complex f64 / 16 complex f32), at least 256 threads.  Narrower than the
     // 32-lane tiles of the general column kernels on purpose: F = 256 f64 then takes 35 KiB of LDS instead of 140 KiB,
     // four workgroups per CU instead of one (256 x 65536 c128: 251 -> see DESIGN.md section 3.5)
-    static constexpr int MINL = sizeof(T) == 8 ? 8 : 16;
+    static constexpr int MINL = sizeof(T) == 8 ? NDFFT_FS_LANES_F64 : NDFFT_FS_LANES_F32;
     static constexpr int LPB = TPL * MINL < 256 ? 256 / TPL : (TPL * MINL > 1024 ? 1024 / TPL : MINL);
     static_assert(TPL * LPB <= 1024, "workgroup too large");
 };
