@@ -117,7 +117,7 @@ static bool jit_choose_partial(int dtype, int n, JitCfg &cfg, int emax_arg = 0) 
     return true;
 }
 
-static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg &out, bool wide = false, double *cost_out = nullptr);
+static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg &out, int wide = 0, double *cost_out = nullptr);
 static bool jit_choose_default(int dtype, int n, JitCfg &cfg, bool allow_partial);
 // The default recipe ("fewest passes, every radix divides E") gives some lengths 20-30 elements per thread on a handful of threads
 // (F = 48: 8.6 on 2 threads, e = 24; 3000 = 10.10.10.3, e = 30).  Those measure badly -- f64 from e > 18, f32 from e > 24
@@ -549,8 +549,8 @@ static int rader_row_lanes(int dtype, const RaderCfg &rc) { return rader_row_lan
 // cost = passes x (work incl. idle threads of partial rounds) / (fill of the workgroup's waves), 13 % / 5 % off for one- / two-wave
 // workgroups, plus a penalty for many elements per thread (f64: e = 21 costs 5-20 %, e = 24 twice the time) -- fitted to the sweeps
 // under profiles/r04/r04c_rader_tune.txt and r04d_rader_tune_lpb.txt (tools/probes/rader_tune.py).
-static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg &out, bool wide, double *cost_out);
-static bool rader_plan_fft(int dtype, int M, RaderCfg &rc, bool wide) {
+static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg &out, int wide, double *cost_out);
+static bool rader_plan_fft(int dtype, int M, RaderCfg &rc, int wide) {
     return plan_fft_by_cost(dtype, M, rc.mc, rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8), rc.fft, wide, nullptr);
 }
 // lanes per workgroup for `lt` threads per lane and `lane` bytes of LDS per lane: one wave where a lane needs <= 64 threads, else the
@@ -569,12 +569,12 @@ static int row_lanes_by_fill(int lt, size_t lane, int forced, double *util_out) 
     if (util_out) *util_out = best_util;
     return best;
 }
-static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg &out, bool wide, double *cost_out) {
-    const int emax = dtype == NDFFT_F32 ? 32 : (wide ? 19 : 18), esoft = dtype == NDFFT_F32 ? 21 : 18;
+static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg &out, int wide, double *cost_out) {
+    const int emax = dtype == NDFFT_F32 ? 32 : (wide ? std::max(wide, 18) : 18), esoft = dtype == NDFFT_F32 ? 21 : 18;
     const double eslope = dtype == NDFFT_F32 ? 0.05 : 0.1;
-    // wide: M has one factor 17 or 19 (Rader for primes like 103, 137, 191): those radices join the list
+    // wide: M has one factor 17 or 19 (f32 also 23, 29, 31; Rader for primes like 103, 137, 191, 47, 59): that radix joins the list
     std::vector<int> cand = {16, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
-    if (wide) { cand.insert(cand.begin(), 17); cand.insert(cand.begin(), 19); }
+    if (wide) cand.insert(cand.begin(), wide);
     std::vector<int> cur;
     JitCfg best; double best_cost = 1e30;
     auto eval = [&]() {
@@ -604,7 +604,7 @@ static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg
             cur.pop_back();
         }
     };
-    rec(M, wide ? 19 : 16);
+    rec(M, wide ? wide : 16);
     if (best.radix.empty()) return false;
     out = best;
     if (cost_out) *cost_out = best_cost;
@@ -673,10 +673,14 @@ bool rader_choose(int dtype, int F, RaderCfg &rc) {
         if (mc > (dtype == NDFFT_F32 ? 48 : 32) || !regfft_factor(mc, &n1, &n2) || n1 > 16 || n2 > 16) return false;
         rc.mc1 = n1; rc.mc2 = n2;
     }
-    // p - 1: 13-smooth, or with ONE factor 17 / 19 (a radix-17 / 19 pass: E >= 17 / 19 complex registers)
-    bool wide = false;
+    // p - 1: 13-smooth, or with ONE factor 17 / 19 (f32: also 23 / 29 / 31) -- a pass of that radix, E >= that many complex registers
+    int wide = 0;
     { int q = p - 1; for (int f : {2, 3, 5, 7, 11, 13}) while (q % f == 0) q /= f;
-      if (q == 17 || q == 19) wide = true; else if (q != 1) return false; }
+      if (q == 17 || q == 19 || (dtype == NDFFT_F32 && (q == 23 || q == 29 || q == 31))) wide = q; else if (q != 1) return false;
+      // (at least 8 butterflies of the wide radix per lane, over all cofactor rows: 47 = 23 x 2 + 1 alone would run on 2 threads per lane -- 300 us against
+      //  Bluestein's 118 us for 2^24 points c64; 235 = 5 x 47: 91 against 119 us, 139 = 23 x 6 + 1: 105 against 145 us, 590 = 10 x 59: 82 against 173 us,
+      //  profiles/r04/r04za_rader_f32_wide.txt)
+      if (wide && mc * ((p - 1) / wide) < 8) return false; }
     rc.p = p; rc.mc = mc;
     if (rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8) > jit_lds_limit()) return false;
     if (const char *e = getenv("NDFFT_RADER_CFG")) {     // developer knob (tools/probes/rader_tune.py): "tpl:r0.r1.r2" for FFT_(p-1), read per plan

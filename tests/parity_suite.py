@@ -757,12 +757,12 @@ def odd_real_lengths(L, sizes=(45,), dct4=False):
                 assert run_case(L, name, (3, n, rows // 2), 1, rdt, offset=n + 2) in ok_col, (name, n, rdt)
 
 
-def rader_kernel(L, sizes=(31, 62, 97, 306, 511), col_max_F=128):
+def rader_kernel(L, sizes=(31, 62, 97, 306, 511), col_max_F=128, dtypes=(np.float64, np.float32)):
     """Inner FFT lengths F = (cofactor <= 16) x (prime p, p - 1 smooth) on the Rader / Good-Thomas register kernel
     (rader_kernel.h): every op family incl. the odd-n variants, both normalisations, rows and column tiles."""
     for F in sizes:
         rows = (1 << 17) // F + 5
-        for rdt in (np.float64, np.float32):
+        for rdt in dtypes:
             ok_row = ("rader_reg", "reg_row", "regreal_row") if F <= 96 else ("rader_reg",)
             for name in ("ndfft", "ndifft", "ndfft_r2c", "ndifft_r2c", "nddct2", "nddct3"):       # n = F (odd-n variants when F is odd)
                 if F % 2 == 0 and name in ("ndfft_r2c", "ndifft_r2c", "nddct2", "nddct3"):

@@ -150,6 +150,12 @@ def main():
         x = torch.from_numpy(synth.complex_array((127, 131072), np.complex64)).to(dev); y = torch.empty_like(x)
         run("ndfft axis=0 127x131072 c64", ndfft, x, y, FftHandler(127, np.float32), 0, x.numel(), a.steps)
         return
+    if a.only == "rader3":
+        for n in (47, 139, 235, 311, 590):
+            rows = (1 << 24) // n
+            x = torch.from_numpy(synth.complex_array((rows, n), np.complex64)).to(dev); y = torch.empty_like(x)
+            run(f"rader3 ndfft axis=1 {rows}x{n} complex64", ndfft, x, y, FftHandler(n, np.float32), 1, x.numel(), a.steps)
+        return
     if a.only == "rader2":
         for rad in ("1", "0"):
             os.environ["NDFFT_RADER"] = rad
