@@ -677,10 +677,10 @@ bool rader_choose(int dtype, int F, RaderCfg &rc) {
     int wide = 0;
     { int q = p - 1; for (int f : {2, 3, 5, 7, 11, 13}) while (q % f == 0) q /= f;
       if (q == 17 || q == 19 || (dtype == NDFFT_F32 && (q == 23 || q == 29 || q == 31))) wide = q; else if (q != 1) return false;
-      // (at least 8 butterflies of the wide radix per lane, over all cofactor rows: 47 = 23 x 2 + 1 alone would run on 2 threads per lane -- 300 us against
+      // (at least 6 butterflies of the wide radix per lane, over all cofactor rows: 47 = 23 x 2 + 1 alone would run on 2 threads per lane -- 300 us against
       //  Bluestein's 118 us for 2^24 points c64; 235 = 5 x 47: 91 against 119 us, 139 = 23 x 6 + 1: 105 against 145 us, 590 = 10 x 59: 82 against 173 us,
       //  profiles/r04/r04za_rader_f32_wide.txt)
-      if (wide && mc * ((p - 1) / wide) < 8) return false; }
+      if (wide && mc * ((p - 1) / wide) < 6) return false; }
     rc.p = p; rc.mc = mc;
     if (rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8) > jit_lds_limit()) return false;
     if (const char *e = getenv("NDFFT_RADER_CFG")) {     // developer knob (tools/probes/rader_tune.py): "tpl:r0.r1.r2" for FFT_(p-1), read per plan
