@@ -534,7 +534,8 @@ static bool rader_enabled() {   // developer / test switch: NDFFT_RADER=0 keeps 
 static size_t rader_lane_lds(const RaderCfg &rc, bool col) {   // complex elements per lane = RaderKernel::LANE_LDS
     const size_t M = (size_t)rc.p - 1, F = (size_t)rc.p * rc.mc;
     const size_t sub = M + (M >> 4) + 2, lane = std::max((size_t)rc.mc * sub, F + (F >> 4) + 3);
-    return col ? (lane | 1) : ((lane + 1) & ~(size_t)1);
+    (void)col;
+    return lane | 1;
 }
 // lanes per workgroup of the row kernel.  Measured (profiles/r04/r04d_rader_tune_lpb.txt): workgroups of ONE wave win wherever a lane needs
 // <= 64 threads (no real barriers: 127 c128 150 -> 121 us, 511 c128 125 -> 110 us), otherwise the fullest waves with the fewest of them.

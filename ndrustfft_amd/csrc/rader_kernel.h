@@ -44,7 +44,9 @@ template <typename T, int P, int MC1, int MC2, int TPL, int LPB, typename RL, in
     static constexpr int THREADS = LTHREADS * LPB;
     static constexpr int SUB_LDS = M + (M >> 4) + 2;                // complex elements of one sub-transform's exchange region
     static constexpr int LANE_MIN = (MC * SUB_LDS > F + (F >> 4) + 3) ? MC * SUB_LDS : F + (F >> 4) + 3;   // ... and the raw lane / Z
-    static constexpr int LANE_LDS = COL ? (LANE_MIN | 1) : ((LANE_MIN + 1) & ~1);
+    // odd pitch: with few threads per lane the threads of a wave sit in DIFFERENT lanes at the same offset -- an even pitch (in 16-byte elements) puts them on the same
+    // LDS banks (F = 34, 2 threads per lane, pitch 40: 16-way conflicts, nddct2 n = 68 179 us; odd pitch: see profiles/r04/r04zd_rader_pitch.txt)
+    static constexpr int LANE_LDS = LANE_MIN | 1;
     static constexpr size_t LDS_BYTES = (size_t)LPB * LANE_LDS * 2 * sizeof(T);
     static constexpr bool IN_CPLX = OP == G_C2R_EVEN || OP == G_C2R_ODD || OP == G_C2C_FWD || OP == G_C2C_INV;
     static constexpr bool OUT_CPLX = OP == G_R2C_EVEN || OP == G_R2C_ODD || OP == G_C2C_FWD || OP == G_C2C_INV;
