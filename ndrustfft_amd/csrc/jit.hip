@@ -581,6 +581,7 @@ static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg
     auto eval = [&]() {
         std::vector<int> tpls;
         for (int r : cur) for (int sdiv = 1; sdiv <= 4; ++sdiv) tpls.push_back((M / r + sdiv - 1) / sdiv);
+        if (M < 200) for (int r : cur) tpls.push_back(2 * (M / r));      // short lanes: a pass may leave half its threads idle if that buys threads for the rest
         std::sort(tpls.begin(), tpls.end()); tpls.erase(std::unique(tpls.begin(), tpls.end()), tpls.end());
         for (int tpl : tpls) {
             if (tpl < 1 || tpl * mc > 1024) continue;
@@ -591,7 +592,11 @@ static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg
             const int lpb = row_lanes_by_fill(tpl * mc, lane_bytes, 0, &util);
             if (lpb <= 0) continue;
             const int waves = (lpb * tpl * mc + 63) / 64;
-            const double cost = work / M / util * (waves == 1 ? 0.87 : waves == 2 ? 0.95 : 1.0) + (e > esoft ? eslope * (e - esoft) : 0.0) + 0.01 * e;
+            // + elements of the lane per thread beyond 4: the stage / gather / POST loops run on the lane's threads, and with few threads per lane few waves fit a
+            // CU's LDS (profiles/r04/r04ze_rader_tune_short.txt: F = 34 on 2 threads 152 us, on 8 threads 76 us; F = 31 on 5 / 10 threads 118 / 90 us)
+            // (short lanes only: the weight fades out between 128 and 512 points -- 1008 points on 84 threads and 2016 on 168 measured best, r04c / r04d)
+            const double pe = (double)(M + 1) / tpl, pw = 0.15 * std::min(1.0, std::max(0.0, (512.0 - M) / 384.0));
+            const double cost = work / M / util * (waves == 1 ? 0.87 : waves == 2 ? 0.95 : 1.0) + (e > esoft ? eslope * (e - esoft) : 0.0) + 0.01 * e + pw * std::max(0.0, pe - 4.0);
             if (cost < best_cost) { best_cost = cost; best = JitCfg(); best.n = M; best.tpl = tpl; best.e = e; best.radix = cur; best.partial = partial; best.lpb = lpb; }
         }
     };

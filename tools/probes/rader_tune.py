@@ -15,7 +15,7 @@ import synth
 from ndrustfft_amd import DctHandler, FftHandler, _lib, nddct1, ndfft
 
 RADS = (16, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2)
-LPB_SWEEP = os.environ.get("RADER_TUNE_LPB", "1") == "1"
+LPB_SWEEP = os.environ.get("RADER_TUNE_LPB", "0") == "1"
 
 
 def lists(m, maxr=16, depth=0):
@@ -39,12 +39,13 @@ def configs(M, emax):
         for r in rl:
             for s in range(1, 5):
                 tpls.add(-(-(M // r) // s))
+            tpls.add(2 * (M // r))          # half the threads idle in that pass: more threads for the stage / PRE / POST loops of short lanes
         for tpl in sorted(tpls):
             if tpl < 1 or tpl > 1024:
                 continue
             e = max(-(-(M // r) // tpl) * r for r in rl)
             work = sum(-(-(M // r) // tpl) * tpl * r for r in rl) / (M * len(rl))
-            if e <= emax and work <= 1.25:
+            if e <= emax and work <= (2.1 if M < 200 else 1.25):
                 out.append((tpl, rl, e, work))
     return out
 
@@ -64,7 +65,8 @@ def main():
     dev = torch.device("cuda:0")
     cases = [(int(x.split(":")[0]), x.split(":")[1]) for x in sys.argv[1:]] or [(1009, "c128"), (2017, "c128"), (127, "c128"), (4001, "c128"), (1009, "c64")]
     for F, kind in cases:
-        cdt, rdt = (np.complex128, np.float64) if kind == "c128" else (np.complex64, np.float32)
+        dct = kind == "dct"
+        cdt, rdt = (np.complex128, np.float64) if kind in ("c128", "dct") else (np.complex64, np.float32)
         # largest prime factor
         p, m = 1, F
         f = 2
@@ -76,12 +78,17 @@ def main():
             p = m
         M = p - 1
         rows = (1 << 24) // F
-        x = torch.from_numpy(synth.complex_array((rows, F), cdt)).to(dev)
+        if dct:
+            os.environ["NDFFT_RADER_SHORT"] = "1"
+            from ndrustfft_amd import nddct2
+            x = torch.from_numpy(synth.real_array((rows // 2, 2 * F))).to(dev)
+        else:
+            x = torch.from_numpy(synth.complex_array((rows, F), cdt)).to(dev)
         y = torch.empty_like(x)
         res = []
         mc = F // p
-        for tpl, rl, e, work in configs(M, 21 if kind == "c128" else 32):
-            if work > 1.16:
+        for tpl, rl, e, work in configs(M, 21 if kind in ("c128", "dct") else 32):
+            if work > (2.1 if M < 200 else 1.16):
                 continue
             lt = tpl * mc
             lpbs = sorted({l for l in (1, 2, 3, 4, 6, 8, 12, 16, 64 // lt, 128 // lt, 192 // lt, 256 // lt) if l >= 1 and l * lt <= 512}) if LPB_SWEEP else (0,)
@@ -91,11 +98,12 @@ def main():
                     os.environ["NDFFT_RADER_LPB"] = str(lpb)
                 else:
                     os.environ.pop("NDFFT_RADER_LPB", None)
-                h = FftHandler(F, rdt)
+                h = DctHandler(2 * F) if dct else FftHandler(F, rdt)
+                fn = (lambda: nddct2(x, y, h, 1)) if dct else (lambda: ndfft(x, y, h, 1))
                 try:
-                    ndfft(x, y, h, 1)
+                    fn()
                     path = _lib.default().last_path()
-                    t = timeit(lambda: ndfft(x, y, h, 1)) if path.startswith("rader") else float("nan")
+                    t = timeit(fn) if path.startswith("rader") else float("nan")
                 except Exception as ex:      # noqa: BLE001
                     path, t = f"error {ex}", float("nan")
                 res.append((t, tpl, rl, e, work, path, lpb))
