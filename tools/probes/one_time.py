@@ -14,7 +14,8 @@ name, n = sys.argv[1], int(sys.argv[2])
 dev = torch.device("cuda:0")
 rows = (1 << 23) // n
 if name == "ndfft":
-    x = torch.from_numpy(synth.complex_array((rows, n))).to(dev); h = FftHandler(n); f = ndfft
+    F32 = len(sys.argv) > 3 and sys.argv[3] == "f32"
+    x = torch.from_numpy(synth.complex_array((rows, n), np.complex64 if F32 else np.complex128)).to(dev); h = FftHandler(n, np.float32 if F32 else np.float64); f = ndfft
 else:
     x = torch.from_numpy(synth.real_array((rows, n))).to(dev); h = DctHandler(n); f = {"nddct2": nddct2, "nddct3": nddct3}[name]
 y = torch.empty_like(x)
