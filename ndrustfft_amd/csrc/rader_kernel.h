@@ -1,6 +1,7 @@
 // rader_kernel.h -- lengths with ONE large prime factor on the register-resident Stockham engine, without Bluestein's
-// zero padding: the inner complex FFT length is F = MC * P with P prime, P - 1 smooth, and a small cofactor MC (1..16,
-// coprime to P because P > 16).
+// zero padding: the inner complex FFT length is F = MC * P with P prime, P - 1 smooth (13-smooth, or with one factor 17 / 19 -- f32 also
+// 23 / 29 / 31 -- that gets its own pass), and a small cofactor MC: one butterfly (2..16) or a product of two (up to 32 in f64, 48 in f32);
+// MC is coprime to P because P is F's largest prime factor and divides it once.
 //
 //   Good-Thomas (no twiddles): x[(n1 P + n2 MC) mod F] -> X[(k1 C1 + k2 C2) mod F],  C1 = P (P^-1 mod MC), C2 = MC (MC^-1 mod P):
 //       X[k1, k2] = sum_n1 W_MC^(n1 k1) sum_n2 W_P^(n2 k2) x[n1, n2]
@@ -13,7 +14,8 @@
 // register pattern of MC independent FFT_M (MC * TPL threads per lane, the passes of pow2_kernel.h with any radix list);
 // * bhat, conj in registers; the same passes in REVERSE order (they start from the pattern the first FFT ends in, so the
 // product never goes through LDS); scatter to the Rader output order;
-// for MC > 1 one radix-MC butterfly across the MC sub-transforms; Z in LDS in natural order; POST gather (realops.h).
+// for MC > 1 the length-MC transforms across the MC sub-transforms (one butterfly, or two factors in registers); Z in LDS in natural
+// order; POST gather (realops.h).
 // FFT work per lane: 2 MC (P - 1) ~ 2 F points against Bluestein's 2 M' with M' = 2^k >= 2F - 1 (2F .. 4F), in a workgroup
 // of 1/2 .. 1/4 of the LDS.  Specialised with hiprtc per (P, MC, op, dtype, layout) at first use (jit.hip: launch_jit_rader).
 // The lane semantics are the reference's (src/lib.rs:313-338, 497-531, 688-741) through realops.h, exactly as in blue_kernel.h.
