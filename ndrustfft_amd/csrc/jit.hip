@@ -127,7 +127,27 @@ bool jit_choose(int dtype, int n, JitCfg &cfg, bool allow_partial) {
     static const bool on = [] { const char *e = getenv("NDFFT_JIT_REALPLAN"); return !(e && e[0] == '0'); }();
     static const int nmax = [] { const char *e = getenv("NDFFT_JIT_REALPLAN_MAX"); return e ? atoi(e) : 8192; }();
     if (!jit_choose_default(dtype, n, cfg, allow_partial)) return false;
-    if (!on || !allow_partial || n > nmax || cfg.e <= (dtype == NDFFT_F32 ? 24 : 18)) return true;
+    if (const char *e = getenv("NDFFT_JIT_CFG")) {       // developer knob: "n:tpl:r0.r1.r2[:lanes]" replaces the recipe of length n (read per plan)
+        if (atoi(e) == n && allow_partial) {
+            const char *q = strchr(e, ':');
+            JitCfg c; c.n = n; c.tpl = q ? atoi(q + 1) : 0; c.vec = 1;
+            q = q ? strchr(q + 1, ':') : nullptr;
+            int prod = 1;
+            while (q && *q && *q != '\0') { const int r = atoi(q + 1); if (r < 2) break; c.radix.push_back(r); prod *= r; const char *d = strchr(q + 1, '.'), *cl = strchr(q + 1, ':'); if (cl && (!d || cl < d)) { c.row_lpb = atoi(cl + 1); break; } q = d; }
+            if (c.tpl >= 1 && prod == n) {
+                for (int r : c.radix) { const int nb = n / r, sl = (nb + c.tpl - 1) / c.tpl; c.e = std::max(c.e, sl * r); if (nb % c.tpl) c.partial = true; }
+                c.lpb = c.row_lpb > 0 ? c.row_lpb : (c.tpl >= 64 ? 1 : std::max(1, 64 / c.tpl));
+                if (c.row_lpb == 0) c.row_lpb = c.lpb;
+                cfg = c;
+                return true;
+            }
+        }
+    }
+    // f32 lanes below 256 points are re-planned from e > 8 (A-B-A-B, profiles/r04/r04zg_abab_shortplan.txt: c64 n = 80 / 96 / 160 51.5 / 50.5 / 49.7 -> 39.6 / 38.9 / 38.2 us,
+    // ndfft_r2c f32 n = 160 / 192 / 320 +10 %, the rest within 3 %; in f64 the same rule was a wash: c128 n = 96 -6 %, nddct2 n = 192 +5 %)
+    static const bool short_too = [] { const char *e = getenv("NDFFT_JIT_REALPLAN_SHORT"); return !(e && e[0] == '0'); }();
+    const bool bad_e = cfg.e > (dtype == NDFFT_F32 ? 24 : 18) || (short_too && dtype == NDFFT_F32 && n < 256 && cfg.e > 8);
+    if (!on || !allow_partial || n > nmax || !bad_e) return true;
     const size_t lane = (size_t)((n + (n >> 4) + 3) & ~1) * 2 * (dtype == NDFFT_F32 ? 4 : 8);
     JitCfg alt;
     if (plan_fft_by_cost(dtype, n, 1, lane, alt)) { alt.vec = 1; alt.row_lpb = alt.lpb; cfg = alt; }

@@ -197,6 +197,23 @@ def main():
             run(f"oddreal[NDFFT_PLAIN={v}] nddct2 axis=0 625x16384 f64", nddct2, x, y, DctHandler(625), 0, x.numel(), a.steps)
         del os.environ["NDFFT_PLAIN"]
         return
+    if a.only == "shortplan":
+        for n in (72, 80, 96, 100, 120, 144, 160, 200, 250):
+            rows = (1 << 24) // n
+            for cdt, rdt in ((np.complex64, np.float32), (np.complex128, np.float64)):
+                x = torch.from_numpy(synth.complex_array((rows, n), cdt)).to(dev); y = torch.empty_like(x)
+                run(f"shortplan ndfft axis=1 {rows}x{n} {np.dtype(cdt).name}", ndfft, x, y, FftHandler(n, rdt), 1, x.numel(), a.steps)
+            x = torch.from_numpy(synth.real_array((rows, 2 * n))).to(dev); y = torch.empty_like(x)
+            run(f"shortplan nddct2 axis=1 {rows}x{2 * n} f64", nddct2, x, y, DctHandler(2 * n), 1, x.numel(), a.steps)
+            xf = torch.from_numpy(synth.real_array((rows, 2 * n), np.float32)).to(dev); w = torch.empty((rows, n + 1), dtype=torch.complex64, device=dev)
+            run(f"shortplan ndfft_r2c axis=1 {rows}x{2 * n} f32", ndfft_r2c, xf, w, R2cFftHandler(2 * n, np.float32), 1, xf.numel(), a.steps)
+        return
+    if a.only == "c64short":
+        for n in (72, 80, 96, 100, 120, 144, 200, 250):
+            rows = (1 << 24) // n
+            x = torch.from_numpy(synth.complex_array((rows, n), np.complex64)).to(dev); y = torch.empty_like(x)
+            run(f"c64short ndfft axis=1 {rows}x{n} complex64", ndfft, x, y, FftHandler(n, np.float32), 1, x.numel(), a.steps)
+        return
     if a.only == "c2cplan":
         for n in (72, 80, 120, 300, 360, 600, 1200, 1500, 3000, 6000, 12000):
             for cdt, rdt in ((np.complex128, np.float64), (np.complex64, np.float32)):
