@@ -614,9 +614,13 @@ static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg
             const int waves = (lpb * tpl * mc + 63) / 64;
             // + elements of the lane per thread beyond 4: the stage / gather / POST loops run on the lane's threads, and with few threads per lane few waves fit a
             // CU's LDS (profiles/r04/r04ze_rader_tune_short.txt: F = 34 on 2 threads 152 us, on 8 threads 76 us; F = 31 on 5 / 10 threads 118 / 90 us)
-            // (short lanes only: the weight fades out between 128 and 512 points -- 1008 points on 84 threads and 2016 on 168 measured best, r04c / r04d)
-            const double pe = (double)(M + 1) / tpl, pw = 0.15 * std::min(1.0, std::max(0.0, (512.0 - M) / 384.0));
-            const double cost = work / M / util * (waves == 1 ? 0.87 : waves == 2 ? 0.95 : 1.0) + (e > esoft ? eslope * (e - esoft) : 0.0) + 0.01 * e + pw * std::max(0.0, pe - 4.0);
+            // (short lanes only: the weights fade out between 128 and 256 points -- 1008 points on 84 threads and 2016 on 168 measured best, r04c / r04d;
+            //  weights fitted to that sweep by grid search: on short lanes the FFT work counts 0.3x, each lane element per thread beyond 2 costs 0.2 -- worst pick 26 % / mean 6 % off
+            //  the best configuration over its 11 cases)
+            const double sw = std::min(1.0, std::max(0.0, (256.0 - (double)(M + 1) * mc) / 128.0));   // by lane length: 1 up to 128 elements, 0 from 256 (the sweep's range)
+            const double pe = (double)(M + 1) / tpl;
+            const double cost = (1.0 - 0.7 * sw) * work / M / util * (waves == 1 ? 0.87 : waves == 2 ? 0.95 : 1.0) + (e > esoft ? eslope * (e - esoft) : 0.0) + 0.01 * e +
+                                0.2 * sw * std::max(0.0, pe - (4.0 - 2.0 * sw));
             if (cost < best_cost) { best_cost = cost; best = JitCfg(); best.n = M; best.tpl = tpl; best.e = e; best.radix = cur; best.partial = partial; best.lpb = lpb; }
         }
     };
@@ -637,7 +641,19 @@ static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg
     return true;
 }
 
-bool jit_choose_real(int dtype, int F, JitCfg &cfg) { return jit_choose(dtype, F, cfg, true); }
+// real-op slots: inner FFTs below 128 points are re-planned from e > 8 in f64 as well -- the PRE / POST loops run on the lane's threads, so short lanes want
+// more of them (nddct2 f64 n = 63: 9.7 on 9 threads 49 us, 7.3.3 on 21 threads 39 us; the even-n forms n = 144..240 moved by -1..+5 % under the same rule,
+// profiles/r04/r04zg_abab_shortplan.txt)
+bool jit_choose_real(int dtype, int F, JitCfg &cfg) {
+    if (!jit_choose(dtype, F, cfg, true)) return false;
+    static const bool on = [] { const char *e = getenv("NDFFT_JIT_REALPLAN"); return !(e && e[0] == '0'); }();
+    if (on && !getenv("NDFFT_JIT_CFG") && F < 128 && cfg.e > 8 && cfg.row_lpb == 0) {
+        const size_t lane = (size_t)((F + (F >> 4) + 3) & ~1) * 2 * (dtype == NDFFT_F32 ? 4 : 8);
+        JitCfg alt;
+        if (plan_fft_by_cost(dtype, F, 1, lane, alt)) { alt.vec = 1; alt.row_lpb = alt.lpb; cfg = alt; }
+    }
+    return true;
+}
 
 // ---- Bluestein on a smooth convolution length ---------------------------------------------------------------------------
 // fewest radices (<= 16, incl. 12) whose product is m; 99 if m is not 13-smooth
