@@ -794,10 +794,9 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
         // Bluestein lengths on the register kernel (blue_kernel.h), every op incl. the odd-n variants and row C2C
         // Rader / Good-Thomas (rader_kernel.h) wherever the plan has a recipe -- also for lanes beyond Bluestein's single-launch reach
         // (F > 4096: M' = 2^k >= 2F - 1 no longer fits, Rader's F complex elements of LDS do); Bluestein stays the fallback where it exists
-        // (the even-n DCT forms and DCT-I keep SHORT inner FFTs on Bluestein, whose M = 128 / 256 recipe is cheap per lane: after the recipe fix for short lanes
-        //  (jit.hip: pe term) a scan of n = 34..330 has nddct2 on Rader slower only below F ~ 80 -- n = 58 (F = 29) 101 against 62 us, n = 134 (F = 67) 89 against 66 us --
-        //  and ndfft_r2c nowhere, profiles/r04/r04zd_rader_short_real.txt)
-        const bool rader_long_enough = is_c2c || odd_variant || gop == G_R2C_EVEN || gop == G_C2R_EVEN || c.F >= 80 || rader_short_forced();
+        // (no length rule any more: with the short-lane recipe weights of jit.hip a scan of n = 34..260 has nddct2 on Rader at a median 1.59x over Bluestein with two lengths
+        //  7 % slower, C2C at 1.7x with none, profiles/r04/r04zd_rader_short_real.txt; NDFFT_RADER_SHORT is kept as a no-op test switch)
+        const bool rader_long_enough = true || rader_short_forced();
         const bool use_rader = c.rader && rader_long_enough && P.nlanes * (int64_t)c.F >= (1 << 16) && blue_enabled();
         const bool use_blue = use_rader || (c.bluereg && ((P.nlanes * (int64_t)c.M >= (1 << 16) && blue_enabled()) || c.blue_reg_only));
         const bool use_plain = odd_variant && use_jit && !use_blue && plain_enabled();         // odd-n real ops with a smooth inner FFT: plain_kernel.h
