@@ -374,11 +374,6 @@ static bool tiny_enabled() {
     return !(e && e[0] == '0');
 }
 
-// test switch: NDFFT_RADER_SHORT=1 runs the Rader kernel on short real-op lanes too (read per call)
-static bool rader_short_forced() {
-    const char *e = getenv("NDFFT_RADER_SHORT");
-    return e && e[0] == '1';
-}
 // developer / test switch: NDFFT_PLAIN=0 keeps the odd-n real ops with a smooth inner FFT on the LDS kernel (read per call)
 static bool plain_enabled() {
     const char *e = getenv("NDFFT_PLAIN");
@@ -795,9 +790,8 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
         // Rader / Good-Thomas (rader_kernel.h) wherever the plan has a recipe -- also for lanes beyond Bluestein's single-launch reach
         // (F > 4096: M' = 2^k >= 2F - 1 no longer fits, Rader's F complex elements of LDS do); Bluestein stays the fallback where it exists
         // (no length rule any more: with the short-lane recipe weights of jit.hip a scan of n = 34..260 has nddct2 on Rader at a median 1.59x over Bluestein with two lengths
-        //  7 % slower, C2C at 1.7x with none, profiles/r04/r04zd_rader_short_real.txt; NDFFT_RADER_SHORT is kept as a no-op test switch)
-        const bool rader_long_enough = true || rader_short_forced();
-        const bool use_rader = c.rader && rader_long_enough && P.nlanes * (int64_t)c.F >= (1 << 16) && blue_enabled();
+        //  7 % slower, C2C at 1.7x with none, profiles/r04/r04zd_rader_short_real.txt)
+        const bool use_rader = c.rader && P.nlanes * (int64_t)c.F >= (1 << 16) && blue_enabled();
         const bool use_blue = use_rader || (c.bluereg && ((P.nlanes * (int64_t)c.M >= (1 << 16) && blue_enabled()) || c.blue_reg_only));
         const bool use_plain = odd_variant && use_jit && !use_blue && plain_enabled();         // odd-n real ops with a smooth inner FFT: plain_kernel.h
         const bool have_tw = use_jit || use_blue || (is_c2c ? !c.twp_col.re.empty() : c.pow2);

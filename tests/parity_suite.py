@@ -759,16 +759,7 @@ def odd_real_lengths(L, sizes=(45,), dct4=False):
 
 def rader_kernel(L, sizes=(31, 62, 97, 306, 511), col_max_F=128, dtypes=(np.float64, np.float32)):
     """Inner FFT lengths F = (cofactor <= 16) x (prime p, p - 1 smooth) on the Rader / Good-Thomas register kernel
-    (rader_kernel.h): every op family incl. the odd-n variants, both normalisations, rows and column tiles.
-    (NDFFT_RADER_SHORT=1: the library keeps real-op lanes with a short inner FFT on Bluestein; the test wants the Rader kernel's PRE / POST forms at every size.)"""
-    os.environ["NDFFT_RADER_SHORT"] = "1"
-    try:
-        _rader_kernel(L, sizes, col_max_F, dtypes)
-    finally:
-        del os.environ["NDFFT_RADER_SHORT"]
-
-
-def _rader_kernel(L, sizes, col_max_F, dtypes):
+    (rader_kernel.h): every op family incl. the odd-n variants, both normalisations, rows and column tiles."""
     for F in sizes:
         rows = (1 << 17) // F + 5
         for rdt in dtypes:
