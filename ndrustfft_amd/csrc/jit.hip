@@ -571,27 +571,49 @@ static int rader_row_lanes(int dtype, const RaderCfg &rc) { return rader_row_lan
 // workgroups, plus a penalty for many elements per thread (f64: e = 21 costs 5-20 %, e = 24 twice the time) -- fitted to the sweeps
 // under profiles/r04/r04c_rader_tune.txt and r04d_rader_tune_lpb.txt (tools/probes/rader_tune.py).
 static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg &out, int wide, double *cost_out);
+static thread_local bool g_rader_planning = false;      // plan_fft_by_cost is called for the Rader kernel (f64 cap 21 instead of 18)
 static bool rader_plan_fft(int dtype, int M, RaderCfg &rc, int wide) {
-    return plan_fft_by_cost(dtype, M, rc.mc, rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8), rc.fft, wide, nullptr);
+    g_rader_planning = true;
+    const bool ok = plan_fft_by_cost(dtype, M, rc.mc, rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8), rc.fft, wide, nullptr);
+    g_rader_planning = false;
+    return ok;
 }
 // lanes per workgroup for `lt` threads per lane and `lane` bytes of LDS per lane: one wave where a lane needs <= 64 threads, else the
 // fullest waves with the fewest of them (see rader_row_lanes_for)
 static int row_lanes_by_fill(int lt, size_t lane, int forced, double *util_out) {
     int best = 0; double best_util = 0.0;
-    // one wave where a lane needs <= 64 threads (as many lanes as fill it), else about 256 threads (measured: 1008 points on 84 threads 3 lanes
-    // 156 us / 2 lanes 160 us; 1000 points on 100 threads 2 lanes 60 us / 3 lanes 79 us)
-    const int want = forced > 0 ? forced : lt <= 64 ? 64 / lt : std::max(1, 256 / lt);
-    for (int l = want; l >= 1; --l) {
-        const int thr = l * lt, waves = (thr + 63) / 64;
-        if (thr > 1024 || (size_t)l * lane > jit_lds_limit()) { if (forced > 0) break; continue; }
-        best = l; best_util = (double)thr / (64.0 * waves);
-        break;
+    // one wave where a lane needs <= 64 threads (as many lanes as fill it); else up to 256 threads: among the lane counts whose waves are at least 85 % as full as the
+    // fullest, the one that lets the most lanes share a CU's LDS, the smallest on a tie (measured: 1008 points on 84 threads 3 lanes 156 us / 2 lanes 160 us;
+    // 2016 points on 126 threads 1 lane 146 us / 2 lanes 185 us -- 4 lanes per CU either way, smaller workgroups win)
+    if (forced > 0 || lt <= 64) {
+        const int want = forced > 0 ? forced : 64 / lt;
+        for (int l = want; l >= 1; --l) {
+            const int thr = l * lt, waves = (thr + 63) / 64;
+            if (thr > 1024 || (size_t)l * lane > jit_lds_limit()) { if (forced > 0) break; continue; }
+            best = l; best_util = (double)thr / (64.0 * waves);
+            break;
+        }
+    } else {
+        const int lmax = std::max(1, 256 / lt);
+        double umax = 0.0;
+        for (int l = 1; l <= lmax; ++l) if ((size_t)l * lane <= jit_lds_limit()) umax = std::max(umax, (double)(l * lt) / (64.0 * ((l * lt + 63) / 64)));
+        size_t best_cu = 0;
+        for (int l = 1; l <= lmax; ++l) {
+            if ((size_t)l * lane > jit_lds_limit()) break;
+            const double util = (double)(l * lt) / (64.0 * ((l * lt + 63) / 64));
+            if (util < 0.85 * umax) continue;
+            const size_t cu = jit_lds_limit() / ((size_t)l * lane) * l;
+            if (cu > best_cu) { best_cu = cu; best = l; best_util = util; }
+        }
     }
     if (util_out) *util_out = best_util;
     return best;
 }
 static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg &out, int wide, double *cost_out) {
-    const int emax = dtype == NDFFT_F32 ? 32 : (wide ? std::max(wide, 18) : 18), esoft = dtype == NDFFT_F32 ? 21 : 18;
+    // f64 cap: 18 for the row kernels (1500 = 10.6.5.5 at e = 20 lost 10 %), 21 for the Rader kernel (mc > 0 marks it: 2016 = 16.9.7.2 on 126 threads, e = 21, 146 us
+    // against 185 us for 12.12.7.2 on 168 threads, e = 14 -- two full waves against three at 7/8)
+    const bool rader_call = g_rader_planning;
+    const int emax = dtype == NDFFT_F32 ? 32 : (wide ? std::max(wide, rader_call ? 21 : 18) : (rader_call ? 21 : 18)), esoft = dtype == NDFFT_F32 ? 21 : 18;
     const double eslope = dtype == NDFFT_F32 ? 0.05 : 0.1;
     // wide: M has one factor 17 or 19 (f32 also 23, 29, 31; Rader for primes like 103, 137, 191, 47, 59): that radix joins the list
     std::vector<int> cand = {16, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
