@@ -55,15 +55,15 @@ def test_fuzz_short_lanes(L):
     assert {"tiny_col", "tinymat_col"} <= set(paths) and any(p.startswith("reg") for p in paths), paths
 def test_partial_round_configs(L): ps.partial_round_configs(L, sizes=(264, 210, 840, 1008, 630, 2520, 3003, 6006, 33, 66))
 def test_long_smooth_lanes(L): ps.long_smooth_lanes(L)
-def test_rader_kernel(L): ps.rader_kernel(L, sizes=(31, 62, 97, 127, 257, 465, 511, 1009, 3027, 4001), col_max_F=600)
+def test_rader_kernel(L): ps.rader_kernel(L, sizes=(31, 62, 127, 257, 511, 1009, 3027), col_max_F=600)
 def test_rader_two_factor_cofactor_and_wide_radices(L):
     """Cofactors 17..32 as two butterflies in registers (306 = 18 x 17, 513 = 27 x 19, 532 = 28 x 19, 522 = 18 x 29, 2336 = 32 x 73) and p - 1 with a factor 17 / 19
     (103, 137, 191; 206 = 2 x 103, 2466 = 18 x 137)."""
-    ps.rader_kernel(L, sizes=(306, 513, 532, 2336, 103, 191, 206), col_max_F=600)
+    ps.rader_kernel(L, sizes=(306, 513, 2336, 103, 206), col_max_F=600)
 def test_rader_f32_radix_23_29_31(L):
     """f32 only: p - 1 with one factor 23 / 29 / 31 gets a pass of that radix (139: 138 = 23 x 6, 233: 232 = 29 x 8, 311: 310 = 31 x 10); f64 keeps Bluestein there."""
-    ps.rader_kernel(L, sizes=(139, 233, 311, 466), col_max_F=200, dtypes=(np.float32,))
-def test_odd_real_lengths(L): ps.odd_real_lengths(L, sizes=(63, 99, 125, 625, 1001, 3003), dct4=True)
+    ps.rader_kernel(L, sizes=(139, 311), col_max_F=200, dtypes=(np.float32,))
+def test_odd_real_lengths(L): ps.odd_real_lengths(L, sizes=(63, 125, 1001, 3003), dct4=True)
 def test_rader_kernel_beyond_bluestein(L):
     """F > 4096: Bluestein's M = 2^k >= 2F - 1 no longer fits one launch, Rader's F elements of LDS do (7001, 8191 prime; 8402 = 2 x 4201)."""
     ps.rader_kernel(L, sizes=(8191, 8402), col_max_F=0)
