@@ -33,7 +33,7 @@ def test_clone(L): ps.handler_clone_shares_plan(L)
 def test_wave_short_lanes(L): ps.wave_short_lanes(L)
 def test_tiny_lanes(L): ps.tiny_lanes(L)
 def test_reg_lanes(L): ps.reg_lanes(L)
-def test_regreal_lanes(L): ps.regreal_lanes(L)
+def test_regreal_lanes(L): ps.regreal_lanes(L, sizes=(12, 17, 18, 21, 24, 30, 42, 48), sizes_f32=(49, 64, 72))      # (every op x dtype x layout is one hiprtc compile: ~100 s for the default lists)
 def test_tinymat_lanes(L): ps.tinymat_lanes(L)
 def test_host_pipeline_pageable(L): ps.host_pipeline_pageable(L)
 def test_sharded_exec_same_device_twice(L):
