@@ -154,6 +154,11 @@ int ndfft_exec_sharded_device(const ndfft_plan *plan, int op, const void *d_in, 
  * ("pow2_reg", "generic_row", "generic_col", "generic_strided", "transpose+row", ...). */
 const char *ndfft_last_path(void);
 
+/* Diagnostic (no reference counterpart; needs no GPU): writes a text description of the recipes a handler of (kind, dtype, n) would use -- one line per
+ * inner-FFT slot: "slot=MAIN F=511 route=rader p=73 mc=7x1 M=72 tpl=9 e=9 radix=9.8 ..." -- into buf (NUL-terminated, truncated to buflen).
+ * Returns the number of bytes the full text needs (excluding the NUL), or a negative status.  Used by tests/test_plan_recipes.py. */
+int ndfft_explain_plan(int kind, int dtype, size_t n, char *buf, size_t buflen);
+
 /* ---- device memory helpers for shims that keep arrays resident between nd* calls ----------- */
 int ndfft_dev_alloc(void **d_ptr, size_t bytes);
 int ndfft_dev_free(void *d_ptr);

@@ -21,7 +21,7 @@ SYMBOLS = [
     "ndfft_abi_version", "ndfft_last_error", "ndfft_device_count", "ndfft_set_device",
     "ndfft_plan_create", "ndfft_plan_retain", "ndfft_plan_destroy", "ndfft_plan_n", "ndfft_plan_kind",
     "ndfft_plan_dtype", "ndfft_plan_lane_len_in", "ndfft_plan_lane_len_out",
-    "ndfft_exec", "ndfft_exec_device", "ndfft_exec_sharded", "ndfft_exec_sharded_device", "ndfft_last_path",
+    "ndfft_exec", "ndfft_exec_device", "ndfft_exec_sharded", "ndfft_exec_sharded_device", "ndfft_last_path", "ndfft_explain_plan",
     "ndfft_dev_alloc", "ndfft_dev_free", "ndfft_dev_upload", "ndfft_dev_download", "ndfft_dev_sync",
     "ndfft_release_workspace", "ndfft_host_alloc", "ndfft_host_free",
 ]
@@ -49,6 +49,8 @@ class Library:
         L.ndfft_abi_version.restype = i32
         L.ndfft_last_error.restype = ctypes.c_char_p
         L.ndfft_last_path.restype = ctypes.c_char_p
+        L.ndfft_explain_plan.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+        L.ndfft_explain_plan.restype = ctypes.c_int
         L.ndfft_device_count.restype = i32
         L.ndfft_set_device.argtypes = [i32]
         L.ndfft_plan_create.argtypes = [i32, i32, sz, ctypes.POINTER(vp)]
@@ -84,6 +86,14 @@ class Library:
 
     def last_path(self):
         return self.c.ndfft_last_path().decode()
+
+    def explain_plan(self, kind, dtype, n):
+        """Text description of the recipes a handler of (kind, dtype, n) would use (diagnostic; needs no GPU)."""
+        buf = ctypes.create_string_buffer(4096)
+        need = self.c.ndfft_explain_plan(kind, dtype, n, buf, len(buf))
+        if need < 0:
+            raise NdfftError(-need, self.c.ndfft_last_error().decode())
+        return buf.value.decode()
 
 
 _default = None

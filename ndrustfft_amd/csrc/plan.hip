@@ -536,6 +536,38 @@ int ndfft_plan_destroy(ndfft_plan *plan) {
     return NDFFT_OK;
 }
 
+int ndfft_explain_plan(int kind, int dtype, size_t n, char *buf, size_t buflen) {
+    clear_err();
+    if (kind < NDFFT_KIND_C2C || kind > NDFFT_KIND_DCT) return -fail(NDFFT_ERR_INVALID_ARG, "bad kind");
+    if (dtype != NDFFT_F32 && dtype != NDFFT_F64) return -fail(NDFFT_ERR_INVALID_ARG, "bad dtype");
+    if (n > (size_t)(1 << 24)) return -fail(NDFFT_ERR_UNSUPPORTED, "n > 2^24 is not supported yet");
+    ndfft_plan *p = make_plan(kind, dtype, n);      // host tables only: nothing is uploaded, no device is touched
+    std::string out;
+    auto radix = [](const std::vector<int> &r) { std::string t; for (size_t i = 0; i < r.size(); ++i) t += (i ? "." : "") + std::to_string(r[i]); return t.empty() ? std::string("-") : t; };
+    static const char *slot_name[CFG_COUNT] = {"MAIN", "DCT1", "DCT4"};
+    for (int i = 0; i < CFG_COUNT; ++i) {
+        if (!p->has_cfg[i]) continue;
+        const FftConfig &c = p->cfg[i];
+        std::string l = std::string("slot=") + slot_name[i] + " F=" + std::to_string(c.F);
+        if (c.unsupported) l += " route=unsupported";
+        else if (c.rader) l += " route=rader p=" + std::to_string(c.radercfg.p) + " mc=" + std::to_string(c.radercfg.mc1) + "x" + std::to_string(c.radercfg.mc2) + " M=" + std::to_string(c.radercfg.fft.n) +
+                               " tpl=" + std::to_string(c.radercfg.fft.tpl) + " e=" + std::to_string(c.radercfg.fft.e) + " radix=" + radix(c.radercfg.fft.radix) + " lanes=" + std::to_string(c.radercfg.fft.lpb);
+        else if (c.pow2) l += " route=pow2";
+        else if (c.jit) l += " route=jit tpl=" + std::to_string(c.jitcfg.tpl) + " e=" + std::to_string(c.jitcfg.e) + " radix=" + radix(c.jitcfg.radix) + " lanes=" + std::to_string(c.jitcfg.row_lpb);
+        else if (c.big && !c.bigblue) l += " route=four_step F1=" + std::to_string(c.F1) + " F2=" + std::to_string(c.F2);
+        else if (c.F <= 1) l += " route=trivial";
+        else if (!c.blue && !c.big) l += " route=lds radix=" + radix(c.radix);
+        if (c.blue || c.bigblue) {
+            l += std::string(c.rader ? " fallback=" : " route=") + (c.bigblue && !c.bluereg ? "blue_global" : c.bluereg ? "blue_reg" : "blue_lds") + " blueM=" + std::to_string(c.M);
+            if (c.bluereg) l += " blue_tpl=" + std::to_string(c.jitcfg.tpl) + " blue_e=" + std::to_string(c.jitcfg.e) + " blue_radix=" + radix(c.jitcfg.radix);
+        }
+        out += l + "\n";
+    }
+    ndfft_plan_destroy(p);
+    if (buf && buflen) { const size_t k = std::min(out.size(), buflen - 1); memcpy(buf, out.data(), k); buf[k] = '\0'; }
+    return (int)out.size();
+}
+
 size_t ndfft_plan_n(const ndfft_plan *plan) { return plan ? plan->n : 0; }
 int ndfft_plan_kind(const ndfft_plan *plan) { return plan ? plan->kind : -1; }
 int ndfft_plan_dtype(const ndfft_plan *plan) { return plan ? plan->dtype : -1; }
