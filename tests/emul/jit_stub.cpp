@@ -125,13 +125,14 @@ template int launch_jit_blue<float>(int, const JitCfg &, bool, const RealArgs<fl
 template int launch_jit_blue<double>(int, const JitCfg &, bool, const RealArgs<double> &, hipStream_t);
 
 // Rader / Good-Thomas kernel (rader_kernel.h; the product specialises it with hiprtc, jit.hip: launch_jit_rader), ahead of time for
-// F = 31 and 97 (primes), 62 = 2 x 31 and 511 = 7 x 73 (cofactor butterflies), 306 = (6 x 3) x 17 (two-factor cofactor, one-pass FFT_16);
+// F = 31 and 97 (primes), 62 = 2 x 31 and 511 = 7 x 73 (cofactor butterflies), 306 = (6 x 3) x 17 (two-factor cofactor, one-pass FFT_16), 103 (102 = 17 x 6: a radix-17 pass);
 // FFT_30 runs with a PARTIAL second pass (6.5 on 5 threads)
 bool rader_choose(int, int F, RaderCfg &rc) {
     rc.fft.vec = 1; rc.fft.lpb = 1;
     if (F == 31 || F == 62) { rc.p = 31; rc.mc = F / 31; rc.mc1 = rc.mc; rc.fft.n = 30; rc.fft.tpl = 5; rc.fft.e = 10; rc.fft.radix = {6, 5}; rc.fft.partial = true; return true; }
     if (F == 97) { rc.p = 97; rc.mc = 1; rc.fft.n = 96; rc.fft.tpl = 8; rc.fft.e = 12; rc.fft.radix = {6, 4, 4}; return true; }
     if (F == 511) { rc.p = 73; rc.mc = 7; rc.mc1 = 7; rc.fft.n = 72; rc.fft.tpl = 6; rc.fft.e = 12; rc.fft.radix = {6, 4, 3}; return true; }
+    if (F == 103) { rc.p = 103; rc.mc = 1; rc.fft.n = 102; rc.fft.tpl = 6; rc.fft.e = 18; rc.fft.radix = {17, 6}; rc.fft.partial = true; return true; }   // p - 1 = 17 x 6: a radix-17 pass
     if (F == 306) { rc.p = 17; rc.mc = 18; rc.mc1 = 6; rc.mc2 = 3; rc.fft.n = 16; rc.fft.tpl = 1; rc.fft.e = 16; rc.fft.radix = {16}; return true; }   // two-factor cofactor, one-pass FFT_16
     return false;
 }
@@ -165,6 +166,7 @@ template <typename T> int launch_jit_rader(int gop, const RaderCfg &rc, bool col
     if (rc.p == 97 && rc.mc == 1) return rader_P<T, 97, 1, 1, 8, RadixList<6, 4, 4>>(gop, col, a, s);
     if (rc.p == 73 && rc.mc == 7) return rader_P<T, 73, 7, 1, 6, RadixList<6, 4, 3>>(gop, col, a, s);
     if (rc.p == 17 && rc.mc == 18) return rader_P<T, 17, 6, 3, 1, RadixList<16>>(gop, col, a, s);
+    if (rc.p == 103 && rc.mc == 1) return rader_P<T, 103, 1, 1, 6, RadixList<17, 6>>(gop, col, a, s);
     return NDFFT_ERR_UNSUPPORTED;
 }
 template int launch_jit_rader<float>(int, const RaderCfg &, bool, const RealArgs<float> &, hipStream_t);

@@ -757,7 +757,7 @@ def odd_real_lengths(L, sizes=(45,), dct4=False):
                 assert run_case(L, name, (3, n, rows // 2), 1, rdt, offset=n + 2) in ok_col, (name, n, rdt)
 
 
-def rader_kernel(L, sizes=(31, 62, 97, 306, 511), col_max_F=128, dtypes=(np.float64, np.float32)):
+def rader_kernel(L, sizes=(31, 62, 97, 103, 306, 511), col_max_F=128, dtypes=(np.float64, np.float32)):
     """Inner FFT lengths F = (cofactor <= 16) x (prime p, p - 1 smooth) on the Rader / Good-Thomas register kernel
     (rader_kernel.h): every op family incl. the odd-n variants, both normalisations, rows and column tiles."""
     for F in sizes:
