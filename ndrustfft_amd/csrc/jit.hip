@@ -584,7 +584,7 @@ static int row_lanes_by_fill(int lt, size_t lane, int forced, double *util_out) 
     int best = 0; double best_util = 0.0;
     // one wave where a lane needs <= 64 threads (as many lanes as fill it); else up to 256 threads: among the lane counts whose waves are at least 85 % as full as the
     // fullest, the one that lets the most lanes share a CU's LDS, the smallest on a tie (measured: 1008 points on 84 threads 3 lanes 156 us / 2 lanes 160 us;
-    // 2016 points on 126 threads 1 lane 146 us / 2 lanes 185 us -- 4 lanes per CU either way, smaller workgroups win)
+    // 2016 points on 126 threads 1 lane 144-150 us / 2 lanes 166 us -- 4 lanes per CU either way, smaller workgroups win; profiles/r04/r04zj_abab_rader_lanes.txt)
     if (forced > 0 || lt <= 64) {
         const int want = forced > 0 ? forced : 64 / lt;
         for (int l = want; l >= 1; --l) {
