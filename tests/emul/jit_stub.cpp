@@ -21,8 +21,14 @@ bool jit_choose(int, int n, JitCfg &cfg, bool allow_partial) {
     return true;
 }
 bool jit_choose_real(int dtype, int F, JitCfg &cfg) { return jit_choose(dtype, F, cfg, true); }
-int blue_pick_len(int, int, int m_pow2) { return m_pow2; }      // the CPU build keeps Bluestein on powers of two (M = 64 and 256 are instantiated below)
-bool blue_plan_cfg(int, int, JitCfg &) { return false; }
+// the CPU build keeps Bluestein on powers of two (M = 64 and 256 are instantiated below) except for F = 263, which gets the smooth length 550 = 11.10.5 on 55 threads
+// (a PARTIAL first round: 50 butterflies of radix 11) like the product's blue_pick_len would choose
+int blue_pick_len(int, int F, int m_pow2) { return F == 263 ? 550 : m_pow2; }
+bool blue_plan_cfg(int, int M, JitCfg &cfg) {
+    if (M != 550) return false;
+    cfg = JitCfg(); cfg.n = 550; cfg.tpl = 55; cfg.e = 11; cfg.radix = {11, 10, 5}; cfg.partial = true; cfg.vec = 1; cfg.row_lpb = 4;
+    return true;
+}
 void jit_build_twiddles(const JitCfg &cfg, HostTable &out) { if (cfg.n == 264) build_tw<PRL264>(out); else if (cfg.n == 210) build_tw<PRL210>(out); else if (cfg.n == 45) build_tw<PRL45>(out); }
 template <typename K> __global__ void k_c2c_emul(const Pow2Args a) { K::run(a); }
 template <typename T, int N, int TPL, int LPB, typename RL> static int c2c_one(const Pow2Args &a, hipStream_t s) {
@@ -36,7 +42,7 @@ int launch_jit_c2c(int dtype, const JitCfg &cfg, int, const Pow2Args &a, hipStre
     if (cfg.n == 210) return dtype == NDFFT_F32 ? c2c_one<float, 210, 14, 18, PRL210>(a, s) : c2c_one<double, 210, 14, 18, PRL210>(a, s);
     return NDFFT_ERR_UNSUPPORTED;
 }
-int jit_col_lanes(int, const JitCfg &cfg) { return (cfg.n == 64 || cfg.n == 256 || cfg.n == 264 || cfg.n == 210 || cfg.n == 45) ? 8 : 0; }
+int jit_col_lanes(int, const JitCfg &cfg) { return (cfg.n == 64 || cfg.n == 256 || cfg.n == 264 || cfg.n == 210 || cfg.n == 45 || cfg.n == 550) ? 8 : 0; }
 // the same two partial-round configurations on the real-op / column kernel (pow2_real.h)
 template <typename K, typename T> __global__ void k_real_emul(const RealArgs<T> a) { K::run(a); }
 template <typename T, int F, int TPL, int LPBR, typename RL, int OP> static int real_one(bool col, const RealArgs<T> &a, hipStream_t s) {
@@ -119,6 +125,7 @@ template <typename T> int launch_jit_blue(int gop, const JitCfg &cfg, bool col, 
     if (a.nlanes <= 0) return NDFFT_OK;
     if (cfg.n == 64) return blue_M<T, 64, 8, RadixList<8, 8>>(gop, col, a, s);        // = RealCfg<64> / RealCfg<256> (kernels_pow2_real.hip)
     if (cfg.n == 256) return blue_M<T, 256, 32, RadixList<8, 8, 4>>(gop, col, a, s);
+    if (cfg.n == 550) return blue_M<T, 550, 55, RadixList<11, 10, 5>>(gop, col, a, s);
     return NDFFT_ERR_UNSUPPORTED;
 }
 template int launch_jit_blue<float>(int, const JitCfg &, bool, const RealArgs<float> &, hipStream_t);

@@ -48,6 +48,10 @@ def test_column_four_step(L): ps.column_four_step(L)
 def test_huge_prime_factors(L): ps.huge_prime_factors(L, full=False)
 def test_fuzz(L): ps.fuzz(L, seed=11, count=120, max_points=1 << 13)
 def test_bluestein_register_kernel(L): ps.bluestein_register_kernel(L)
+def test_bluestein_smooth_length_partial_rounds(L):
+    """F = 263 on the smooth convolution length 550 = 11.10.5 (55 threads, partial first round) instead of 1024: blue_kernel.h's partial-round guards and the
+    long-double DFT of the bhat table for a non-power-of-two M, on the CPU."""
+    ps.bluestein_register_kernel(L, sizes=((263, 1024),), col_max_M=1024)
 def test_partial_round_configs(L): ps.partial_round_configs(L)
 def test_rader_kernel(L): ps.rader_kernel(L)
 def test_odd_real_lengths(L): ps.odd_real_lengths(L)
