@@ -14,6 +14,7 @@ using PRL264 = RadixList<11, 8, 3>;
 using PRL210 = RadixList<7, 6, 5>;
 using PRL45 = RadixList<9, 5>;
 bool jit_choose(int, int n, JitCfg &cfg, bool allow_partial) {
+    if (allow_partial && n == 90) { cfg.n = 90; cfg.partial = true; cfg.vec = 1; cfg.tpl = 9; cfg.e = 18; cfg.radix = {10, 9}; cfg.lpb = 7; return true; }   // DCT-IV with n = 45: inner FFT 2n
     if (allow_partial && n == 45) { cfg.n = 45; cfg.partial = true; cfg.vec = 1; cfg.tpl = 5; cfg.e = 10; cfg.radix = {9, 5}; cfg.lpb = 12; return true; }   // odd-n real ops (plain_kernel.h)
     if (!allow_partial || (n != 264 && n != 210)) return false;
     cfg.n = n; cfg.partial = true; cfg.vec = 1;
@@ -29,7 +30,7 @@ bool blue_plan_cfg(int, int M, JitCfg &cfg) {
     cfg = JitCfg(); cfg.n = 550; cfg.tpl = 55; cfg.e = 11; cfg.radix = {11, 10, 5}; cfg.partial = true; cfg.vec = 1; cfg.row_lpb = 4;
     return true;
 }
-void jit_build_twiddles(const JitCfg &cfg, HostTable &out) { if (cfg.n == 264) build_tw<PRL264>(out); else if (cfg.n == 210) build_tw<PRL210>(out); else if (cfg.n == 45) build_tw<PRL45>(out); }
+void jit_build_twiddles(const JitCfg &cfg, HostTable &out) { if (cfg.n == 264) build_tw<PRL264>(out); else if (cfg.n == 210) build_tw<PRL210>(out); else if (cfg.n == 45) build_tw<PRL45>(out); else if (cfg.n == 90) build_tw<RadixList<10, 9>>(out); }
 template <typename K> __global__ void k_c2c_emul(const Pow2Args a) { K::run(a); }
 template <typename T, int N, int TPL, int LPB, typename RL> static int c2c_one(const Pow2Args &a, hipStream_t s) {
     using K = Pow2Kernel<T, N, TPL, LPB, true, RL, 0, 1, 1, 1>;
@@ -42,7 +43,7 @@ int launch_jit_c2c(int dtype, const JitCfg &cfg, int, const Pow2Args &a, hipStre
     if (cfg.n == 210) return dtype == NDFFT_F32 ? c2c_one<float, 210, 14, 18, PRL210>(a, s) : c2c_one<double, 210, 14, 18, PRL210>(a, s);
     return NDFFT_ERR_UNSUPPORTED;
 }
-int jit_col_lanes(int, const JitCfg &cfg) { return (cfg.n == 64 || cfg.n == 256 || cfg.n == 264 || cfg.n == 210 || cfg.n == 45 || cfg.n == 550) ? 8 : 0; }
+int jit_col_lanes(int, const JitCfg &cfg) { return (cfg.n == 64 || cfg.n == 256 || cfg.n == 264 || cfg.n == 210 || cfg.n == 45 || cfg.n == 550 || cfg.n == 90) ? 8 : 0; }
 // the same two partial-round configurations on the real-op / column kernel (pow2_real.h)
 template <typename K, typename T> __global__ void k_real_emul(const RealArgs<T> a) { K::run(a); }
 template <typename T, int F, int TPL, int LPBR, typename RL, int OP> static int real_one(bool col, const RealArgs<T> &a, hipStream_t s) {
@@ -87,8 +88,19 @@ template <typename T, int OP> static int plain_one(bool col, const RealArgs<T> &
     }
     return NDFFT_OK;
 }
+template <typename T> static int plain_dct4(bool col, const RealArgs<T> &a, hipStream_t s) {
+    if (col) {
+        using K = PlainRealKernel<T, 90, 9, 8, RadixList<10, 9>, G_DCT4_ODD, true>;
+        hipLaunchKernelGGL((k_blue_emul<K, T>), dim3((unsigned)((a.nlanes + 7) / 8)), dim3(K::THREADS), K::LDS_BYTES, s, a);
+    } else {
+        using K = PlainRealKernel<T, 90, 9, 7, RadixList<10, 9>, G_DCT4_ODD, false>;
+        hipLaunchKernelGGL((k_blue_emul<K, T>), dim3((unsigned)((a.nlanes + 6) / 7)), dim3(K::THREADS), K::LDS_BYTES, s, a);
+    }
+    return NDFFT_OK;
+}
 template <typename T> int launch_jit_plain(int gop, const JitCfg &cfg, bool col, const RealArgs<T> &a, hipStream_t s) {
     if (a.nlanes <= 0) return NDFFT_OK;
+    if (cfg.n == 90 && gop == G_DCT4_ODD) return plain_dct4<T>(col, a, s);
     if (cfg.n != 45) return NDFFT_ERR_UNSUPPORTED;
     switch (gop) {
         case G_R2C_ODD: return plain_one<T, G_R2C_ODD>(col, a, s);

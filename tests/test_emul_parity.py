@@ -54,7 +54,7 @@ def test_bluestein_smooth_length_partial_rounds(L):
     ps.bluestein_register_kernel(L, sizes=((263, 1024),), col_max_M=1024)
 def test_partial_round_configs(L): ps.partial_round_configs(L)
 def test_rader_kernel(L): ps.rader_kernel(L)
-def test_odd_real_lengths(L): ps.odd_real_lengths(L)
+def test_odd_real_lengths(L): ps.odd_real_lengths(L, dct4=True)
 def test_long_lanes_four_step(L): ps.long_lanes_four_step(L, full=False)
 
 
