@@ -1153,7 +1153,9 @@ class CopyPool {
                 p = q_.front(); q_.pop_front();
             }
             memcpy(p.d, p.s, p.n);
-            if (p.g->left.fetch_sub(1) == 1) { std::lock_guard<std::mutex> lk(p.g->m); p.g->cv.notify_all(); }
+            // the count changes only under the group's mutex: a waiter (whose CopyGroup lives on its stack) cannot see zero, return and
+            // destroy the group while this thread is still about to lock it
+            { std::lock_guard<std::mutex> lk(p.g->m); if (p.g->left.fetch_sub(1) == 1) p.g->cv.notify_all(); }
         }
     }
     int nthreads_ = 1;
@@ -1292,6 +1294,7 @@ int ndfft_exec(const ndfft_plan *plan, int op, const void *in, void *out, int nd
             }
         }
     }
+    if (!out_dense && (rc = ws.bounce_out[0].reserve(obytes))) return rc;   // before anything is in flight
     NDFFT_HIP(hipMemcpy(ws.stage_in.p, hin, ibytes, hipMemcpyHostToDevice));
     const char *din = (const char *)ws.stage_in.p - ilo * (int64_t)ein;
     char *dout = (char *)ws.stage_out.p - olo * (int64_t)eout;
@@ -1303,7 +1306,6 @@ int ndfft_exec(const ndfft_plan *plan, int op, const void *in, void *out, int nd
         // The output view has holes.  They belong to the caller (possibly to ANOTHER thread's &mut view of the same
         // allocation), so they are neither read nor written: the span comes back into a private pinned image and only
         // the view's own elements are copied out of it.
-        if ((rc = ws.bounce_out[0].reserve(obytes))) return rc;
         NDFFT_HIP(hipMemcpy(ws.bounce_out[0].p, ws.stage_out.p, obytes, hipMemcpyDeviceToHost));
         copy_view_elements((char *)out, (const char *)ws.bounce_out[0].p - olo * (int64_t)eout, ndim, shape_out, stride_out, eout);
     }

@@ -88,7 +88,32 @@ void emul_check_current(const void *devptr, const char *what) {
         abort();
     }
 }
+namespace { std::map<std::pair<int, int>, bool> &g_peer = *new std::map<std::pair<int, int>, bool>; std::mutex &g_peer_mu = *new std::mutex; }
+hipError_t hipDeviceCanAccessPeer(int *can, int dev, int peer) {
+    if (dev < 0 || peer < 0 || dev >= emul_device_count() || peer >= emul_device_count()) return 101;
+    *can = dev != peer;
+    return 0;
+}
+hipError_t hipDeviceEnablePeerAccess(int peer, unsigned) {
+    if (peer < 0 || peer >= emul_device_count() || peer == emul_cur_device) return 101;
+    std::lock_guard<std::mutex> g(g_peer_mu);
+    bool &on = g_peer[{emul_cur_device, peer}];
+    if (on) return hipErrorPeerAccessAlreadyEnabled;
+    on = true;
+    return 0;
+}
 hipError_t hipMemcpyPeerAsync(void *dst, int dst_dev, const void *src, int src_dev, size_t n, hipStream_t) {
+    if (dst_dev != src_dev) {
+        std::lock_guard<std::mutex> g(g_peer_mu);
+        if (!g_peer[{dst_dev, src_dev}] || !g_peer[{src_dev, dst_dev}]) {
+            fprintf(stderr, "emul: hipMemcpyPeerAsync between devices %d and %d without hipDeviceEnablePeerAccess in both directions\n", dst_dev, src_dev);
+            abort();
+        }
+    }
+    if (dst_dev != emul_cur_device && src_dev != emul_cur_device) {
+        fprintf(stderr, "emul: hipMemcpyPeerAsync: neither end (%d, %d) is the current device %d\n", dst_dev, src_dev, emul_cur_device);
+        abort();
+    }
     if (emul_device_of(dst) != dst_dev || emul_device_of(src) != src_dev) {
         fprintf(stderr, "emul: hipMemcpyPeerAsync: pointer is not on the device it is claimed to be on (dst %d vs %d, src %d vs %d)\n",
                 emul_device_of(dst), dst_dev, emul_device_of(src), src_dev);

@@ -79,6 +79,11 @@ inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 // peer copies check that each pointer lies in an allocation made on the device it is claimed to be on
 hipError_t hipMemcpyPeerAsync(void *dst, int dst_dev, const void *src, int src_dev, size_t n, hipStream_t);
 int emul_device_of(const void *p);   // device an address was hipMalloc'd on, -1 if not device memory
+// peer access: every fake device can map every other one, but a peer copy ABORTS unless access was enabled in both
+// directions first (on the MI355X such a copy would silently be staged through host memory instead of xGMI)
+enum { hipErrorPeerAccessAlreadyEnabled = 704 };
+hipError_t hipDeviceCanAccessPeer(int *can, int dev, int peer);
+hipError_t hipDeviceEnablePeerAccess(int peer, unsigned flags);
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t) { return hipMemcpy(d, s, n, k); }
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
