@@ -423,8 +423,19 @@ static int col_split(const Problem &P, const void *d_in, void *d_out, const FftC
         if (C > I) C = I;
     }
     const bool chunked = C < I;
+    // Row pitch of the intermediate.  It is OUR array, so its rows need not sit a power of two apart: tools/colprobe.hip
+    // (profiles/r05/r05a_colprobe.txt) reads 256-byte segments 8192 rows deep at 0.55 of 8 TB/s when the rows are 32 KiB apart and
+    // at 0.85 when they are 32 KiB + 512 B apart (writes 0.33 -> 0.70): a power-of-two pitch keeps every row of a column tile on
+    // the same few HBM channels.  NDFFT_CS_PAD = padding in BYTES (0 keeps dense rows); only for one outer block (the padded
+    // layout needs the (b, i) batch dimensions unmerged, and the column kernels take two).
+    int64_t pad = 0;
+    if (O == 1) {
+        static const int pad_bytes = [] { const char *e = getenv("NDFFT_CS_PAD"); return e ? atoi(e) : 0; }();   // measured on cfg3-A / cfg3-A' (profiles/r05/r05a_cs_pad_abab.txt): 0 / 256 / 512 / 1024 B all within 200-207 us: no effect, off
+        pad = pad_bytes / (int64_t)sizeof(cpx<T>);
+    }
+    const int64_t Cp = C + pad;              // pitch of one (k1, b) row of the intermediate, in complex elements
     void *S;
-    int rc = get_scratch(5, stream, (size_t)O * K1 * F2 * C * sizeof(cpx<T>), &S);
+    int rc = get_scratch(5, stream, (size_t)O * K1 * F2 * Cp * sizeof(cpx<T>), &S);
     if (rc) return rc;
     const DevTables *dt2;
     if ((rc = get_dev_tables(c.cs_sub2, &dt2))) return rc;
@@ -442,11 +453,12 @@ static int col_split(const Problem &P, const void *d_in, void *d_out, const FftC
         a.cs_k1n = K1; a.cs_f1 = F1; a.cs_n = (int)P.plan->n; a.cs_outer_in = sin_o; a.cs_outer_out = sout_o; a.cs_pitch = I;
         Problem Q;
         Q.plan = c.cs_sub1; Q.nlanes = O * F2 * Cc; Q.scale = 1.0; Q.no_xcd_map = 1;
+        const bool split_bi = chunked || pad > 0;   // (b, i) as two batch dimensions: the intermediate's rows are not back to back
         if (!c2r) {
             // A: column transform of length F1 over a = row / F2; lanes (b, i)
-            Q.op = P.op; Q.xlen = F1; Q.ylen = K1; Q.xs = (int64_t)F2 * I; Q.ys = (int64_t)F2 * Cc;
+            Q.op = P.op; Q.xlen = F1; Q.ylen = K1; Q.xs = (int64_t)F2 * I; Q.ys = (int64_t)F2 * Cp;
             { const char *e1 = getenv("NDFFT_CS_KEEP"); Q.keep_out = e1 ? atoi(e1) : chunked; const char *e2 = getenv("NDFFT_CS_NT_IN"); Q.stream_in = e2 ? atoi(e2) : 0; }
-            if (chunked) { Q.b.push_back({(int64_t)F2, I, Cc}); Q.b.push_back({Cc, 1, 1}); }
+            if (split_bi) { Q.b.push_back({(int64_t)F2, I, Cp}); Q.b.push_back({Cc, 1, 1}); }
             else {
                 if (O > 1) Q.b.push_back({O, sin_o, (int64_t)K1 * F2 * I});
                 Q.b.push_back({(int64_t)F2 * I, 1, 1});
@@ -454,16 +466,16 @@ static int col_split(const Problem &P, const void *d_in, void *d_out, const FftC
             if ((rc = dispatch(Q, in_c, S, stream))) return rc;
             // B: twiddle on load, length F2 over b, rows k1 + F1 k2 (R2C: Hermitian row map)
             a.in = S; a.out = out_c;
-            a.outer_in = (int64_t)F2 * Cc; a.outer_out = 0; a.elem_in = Cc; a.elem_out = (int64_t)F1 * I;
+            a.outer_in = (int64_t)F2 * Cp; a.outer_out = 0; a.elem_in = Cp; a.elem_out = (int64_t)F1 * I;
             if ((rc = launch_colsplit<T>(r2c ? 2 : 1, inv, a, stream))) return rc;
         } else {
             // A: Hermitian gather, inverse of length F2 over k2, conj twiddle -> S[o][k1][b][i]
             a.in = in_c; a.out = S;
-            a.outer_in = 0; a.outer_out = (int64_t)F2 * Cc; a.elem_in = I; a.elem_out = Cc;
+            a.outer_in = 0; a.outer_out = (int64_t)F2 * Cp; a.elem_in = I; a.elem_out = Cp;
             if ((rc = launch_colsplit<T>(3, true, a, stream))) return rc;
             // B: column C2R of length F1 over k1
-            Q.op = NDFFT_OP_C2R; Q.xlen = K1; Q.ylen = F1; Q.xs = (int64_t)F2 * Cc; Q.ys = (int64_t)F2 * I;
-            if (chunked) { Q.b.push_back({(int64_t)F2, Cc, I}); Q.b.push_back({Cc, 1, 1}); }
+            Q.op = NDFFT_OP_C2R; Q.xlen = K1; Q.ylen = F1; Q.xs = (int64_t)F2 * Cp; Q.ys = (int64_t)F2 * I;
+            if (split_bi) { Q.b.push_back({(int64_t)F2, Cp, I}); Q.b.push_back({Cc, 1, 1}); }
             else {
                 if (O > 1) Q.b.push_back({O, (int64_t)K1 * F2 * I, sout_o});
                 Q.b.push_back({(int64_t)F2 * I, 1, 1});

@@ -26,3 +26,10 @@ def refvec():
 def npvec():
     """numpy/scipy full-precision vectors (tests/golden/make_golden.py)."""
     return np.load(os.path.join(ROOT, "tests", "golden", "numpy_scipy_vectors.npz"))
+
+
+@pytest.fixture(scope="session")
+def blvec():
+    """Independent truths at the BASELINE lane lengths 4096 / 8192 / 16384 / 512 (tests/golden/make_golden_baseline.py):
+    numpy / scipy on every lane, long-double O(n^2) definitions on lane 0, mpmath on 12 bins of lane 0."""
+    return np.load(os.path.join(ROOT, "tests", "golden", "baseline_lengths.npz"))

@@ -141,6 +141,47 @@ def reference_examples(L, refvec):
     assert np.abs(vhat - (np.asarray(d["re"]) + 1j * np.asarray(d["im"]))).max() < d["abs_tol"]
 
 
+# ---- independent truths at the BASELINE lane lengths (tests/golden/make_golden_baseline.py) ------------------------
+def baseline_length_fixtures(L, blvec, device=None):
+    """The library under test against numpy / scipy (every lane), the long-double definition (lane 0) and mpmath (12 bins) at n = 4096 c128,
+    8192 c64 / f32 R2C / C2R, 16384, 512 DCT-I..IV -- the lengths the BASELINE configs run.  Host arrays, or torch tensors on `device`."""
+    def call(fn, x, yshape, ydt, h, axis):
+        if device is None:
+            y = np.zeros(yshape, ydt); fn(x, y, h, axis); return y
+        import torch
+        xd = torch.from_numpy(np.ascontiguousarray(x)).to(device); yd = torch.zeros(yshape, dtype=torch.from_numpy(np.zeros(1, ydt)).dtype, device=device)
+        fn(xd, yd, h, axis); return yd.cpu().numpy()
+    for n, dt in ((4096, "f64"), (8192, "f32"), (8192, "f64"), (16384, "f64"), (16384, "f32")):
+        rdt = np.float64 if dt == "f64" else np.float32; tol = TOL[np.dtype(rdt)]
+        key = f"c2c_{dt}_n{n}"; x = blvec[key + "_in"]; h = handlers.FftHandler(n, rdt, _library=L)
+        y = call(api.ndfft, x, x.shape, x.dtype, h, 1)
+        assert_close(y, blvec[key + "_fft_np"], 1, tol, f"{key} fft vs pocketfft")
+        assert_close(y[:1], blvec[key + "_fft_ld"][None, :], 1, tol, f"{key} fft vs long double")
+        b = blvec[key + "_mp_bins"]
+        assert np.abs(y[0, b] - blvec[key + "_fft_mp"]).max() <= tol * np.abs(blvec[key + "_fft_ld"]).max(), f"{key} fft vs mpmath"
+        y = call(api.ndifft, x, x.shape, x.dtype, h, 1)
+        assert_close(y, blvec[key + "_ifft_np"], 1, tol, f"{key} ifft vs pocketfft")
+        assert_close(y[:1], blvec[key + "_ifft_ld"][None, :], 1, tol, f"{key} ifft vs long double")
+    for dt in ("f32", "f64"):
+        n = 8192; m = n // 2 + 1
+        rdt = np.float64 if dt == "f64" else np.float32; tol = TOL[np.dtype(rdt)]
+        key = f"real_{dt}_n{n}"; xr, xh = blvec[key + "_r_in"], blvec[key + "_h_in"]; h = handlers.R2cFftHandler(n, rdt, _library=L)
+        y = call(api.ndfft_r2c, xr, (xr.shape[0], m), cdt_of(rdt), h, 1)
+        assert_close(y, blvec[key + "_r2c_np"], 1, tol, f"{key} r2c vs pocketfft")
+        assert_close(y[:1], blvec[key + "_r2c_ld"][None, :], 1, tol, f"{key} r2c vs long double")
+        xo = call(api.ndifft_r2c, xh, (xh.shape[0], n), rdt, h, 1)
+        assert_close(xo, blvec[key + "_c2r_np"], 1, tol, f"{key} c2r vs pocketfft")
+        assert_close(xo[:1], blvec[key + "_c2r_ld"][None, :], 1, tol, f"{key} c2r vs long double")
+        # the strided axis (cfg3-A's layout): the same lanes as columns
+        yt = call(api.ndfft_r2c, np.ascontiguousarray(xr.T), (m, xr.shape[0]), cdt_of(rdt), h, 0)
+        assert_close(yt.T, blvec[key + "_r2c_np"], 1, tol, f"{key} r2c axis 0 vs pocketfft")
+    x = blvec["dct_f64_n512_in"]; h = handlers.DctHandler(512, _library=L)
+    for k in (1, 2, 3, 4):
+        y = call(getattr(api, f"nddct{k}"), x, x.shape, x.dtype, h, 1)
+        assert_close(y, blvec[f"dct_f64_n512_dct{k}_np"], 1, 1e-10, f"dct{k} n=512 vs scipy")
+        assert_close(y[:1], blvec[f"dct_f64_n512_dct{k}_ld"][None, :], 1, 1e-10, f"dct{k} n=512 vs long double")
+
+
 # ---- committed numpy/scipy golden vectors -------------------------------------------------------
 def golden_vectors(L, npvec, dt, n):
     rdt = np.float64 if dt == "f64" else np.float32; cdt = cdt_of(rdt); tol = TOL[np.dtype(rdt)]

@@ -116,6 +116,7 @@ def test_sharded_device_resident_chunk_pipeline(L, monkeypatch):
     _dev_sharded_case(L, "nddct2", (40, 32, 3), 1, root=2, ids=[0, 1], out_view=((40, 32, 6), np.s_[:, :, ::2]), repeats=2)
 
 
+def test_baseline_length_fixtures(L, blvec): ps.baseline_length_fixtures(L, blvec)
 def test_interleaved_mut_views(L): ps.interleaved_mut_views_two_threads(L, rounds=1)
 def test_long_strided_lanes(L): ps.long_strided_lanes(L)
 def test_narrow_xcd_tiles(L): ps.narrow_xcd_tiles(L)

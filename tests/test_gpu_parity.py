@@ -81,6 +81,16 @@ def test_reference_bench_shapes(L): ps.reference_bench_shapes(L)
 def test_golden(L, npvec, dt, n): ps.golden_vectors(L, npvec, dt, n)
 
 
+def test_baseline_length_fixtures_host(L, blvec):
+    """HIP path (host arrays) against numpy / scipy, long-double definitions and mpmath at n = 4096 / 8192 / 16384 / 512: no oracle in the loop."""
+    ps.baseline_length_fixtures(L, blvec)
+
+
+def test_baseline_length_fixtures_device(L, blvec):
+    """The same through ndfft_exec_device on torch tensors (the path the roofline numbers are measured on)."""
+    ps.baseline_length_fixtures(L, blvec, device="cuda:0")
+
+
 @pytest.mark.parametrize("n", ps.SIZE_SWEEP)
 def test_sizes_f64(L, n): ps.size_sweep(L, n, np.float64)
 

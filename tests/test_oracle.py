@@ -147,6 +147,54 @@ def test_vs_numpy_scipy(npvec, dt, n):
         assert_close(xo, npvec[key + f"_dct{k}"], 1, tol * 4, f"dct{k}")
 
 
+# ---- the BASELINE lane lengths: 4096 (cfg2 / cfg5), 8192 (cfg3-A R2C / C2R f32, cfg3-B c64), 512 (cfg4 DCT), 16384 ------------------
+BL_C2C = [(4096, "f64"), (8192, "f32"), (8192, "f64"), (16384, "f64"), (16384, "f32")]
+
+
+@pytest.mark.parametrize("n,dt", BL_C2C)
+def test_baseline_lengths_c2c(blvec, n, dt):
+    """ndfft / ndifft (src/lib.rs:313-338) at the lengths the BASELINE configs run, against three independent truths."""
+    rdt = np.float64 if dt == "f64" else np.float32
+    tol = 1e-12 if dt == "f64" else 2e-5
+    key = f"c2c_{dt}_n{n}"; x = blvec[key + "_in"]
+    h = orc.FftHandler(n, rdt); y = np.zeros_like(x)
+    orc.ndfft(x, y, h, 1)
+    assert_close(y, blvec[key + "_fft_np"], 1, tol, "fft vs pocketfft")
+    assert_close(y[:1], blvec[key + "_fft_ld"][None, :], 1, tol, "fft vs long-double definition")
+    b = blvec[key + "_mp_bins"]
+    assert np.abs(y[0, b] - blvec[key + "_fft_mp"]).max() <= tol * np.abs(blvec[key + "_fft_ld"]).max(), "fft vs mpmath bins"
+    orc.ndifft(x, y, h, 1)
+    assert_close(y, blvec[key + "_ifft_np"], 1, tol, "ifft vs pocketfft")
+    assert_close(y[:1], blvec[key + "_ifft_ld"][None, :], 1, tol, "ifft vs long-double definition")
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+def test_baseline_lengths_real(blvec, dt):
+    """ndfft_r2c / ndifft_r2c (src/lib.rs:497-531) at n = 8192 (cfg3-A and the way back)."""
+    n = 8192; m = n // 2 + 1
+    rdt = np.float64 if dt == "f64" else np.float32; cdt = cdt_of(rdt)
+    tol = 1e-12 if dt == "f64" else 2e-5
+    key = f"real_{dt}_n{n}"; xr, xh = blvec[key + "_r_in"], blvec[key + "_h_in"]
+    h = orc.R2cFftHandler(n, rdt)
+    y = np.zeros((xr.shape[0], m), cdt); orc.ndfft_r2c(xr, y, h, 1)
+    assert_close(y, blvec[key + "_r2c_np"], 1, tol, "r2c vs pocketfft")
+    assert_close(y[:1], blvec[key + "_r2c_ld"][None, :], 1, tol, "r2c vs long-double definition")
+    b = blvec[key + "_mp_bins"]
+    assert np.abs(y[0, b] - blvec[key + "_r2c_mp"]).max() <= tol * np.abs(blvec[key + "_r2c_ld"]).max(), "r2c vs mpmath bins"
+    xo = np.zeros((xh.shape[0], n), rdt); orc.ndifft_r2c(xh, xo, h, 1)
+    assert_close(xo, blvec[key + "_c2r_np"], 1, tol, "c2r vs pocketfft")
+    assert_close(xo[:1], blvec[key + "_c2r_ld"][None, :], 1, tol, "c2r vs long-double definition (DC / Nyquist imaginary parts dropped)")
+
+
+def test_baseline_lengths_dct(blvec):
+    """nddct1..4 (src/lib.rs:688-741) at n = 512 (cfg4)."""
+    x = blvec["dct_f64_n512_in"]; h = orc.DctHandler(512); y = np.zeros_like(x)
+    for k in (1, 2, 3, 4):
+        getattr(orc, f"nddct{k}")(x, y, h, 1)
+        assert_close(y, blvec[f"dct_f64_n512_dct{k}_np"], 1, 4e-12, f"dct{k} vs scipy")
+        assert_close(y[:1], blvec[f"dct_f64_n512_dct{k}_ld"][None, :], 1, 4e-12, f"dct{k} vs long-double definition")
+
+
 # ---- long-double definitions ------------------------------------------------------------------
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 12, 17, 31, 37, 60, 74, 128, 221])
 def test_vs_long_double_truth(n):
