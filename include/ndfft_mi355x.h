@@ -150,6 +150,16 @@ int ndfft_exec_sharded_device(const ndfft_plan *plan, int op, const void *d_in, 
                               const int64_t *shape_out, const int64_t *stride_out,
                               int axis, int norm, double scale, int n_devices, const int *device_ids, void *stream);
 
+/* ---- where does the input of the next calls come from?  (speed only; no reference counterpart) -------------------------------
+ * The batched C2C row kernels (BASELINE configs[1] / [4]) read their input either with the default cache policy -- up to 15 %
+ * faster when the array is resident in the MI355X's 256 MiB Infinity Cache -- or with streaming loads -- 6 % faster when it comes
+ * from HBM.  AUTO (the default) decides from what this thread's own earlier calls imply: an array it read recently with the
+ * default policy is resident; an array it WROTE (outputs are stored non-temporally) or has pushed out of the cache since is
+ * not; an array it has never seen is assumed resident if it is <= 384 MiB.  A caller that knows better -- the input was just
+ * produced by another kernel, or has not been touched for a long time -- says so.  Per host thread, sticky until changed. */
+typedef enum { NDFFT_INPUT_AUTO = 0, NDFFT_INPUT_CACHED = 1, NDFFT_INPUT_COLD = 2 } ndfft_input_hint;
+int ndfft_set_input_hint(int hint);
+
 /* Name of the kernel path the last successful exec on this thread dispatched to
  * ("pow2_reg", "generic_row", "generic_col", "generic_strided", "transpose+row", ...). */
 const char *ndfft_last_path(void);

@@ -15,6 +15,7 @@ F32, F64 = 0, 1
 KIND_C2C, KIND_R2C, KIND_DCT = 0, 1, 2
 OP_C2C_FWD, OP_C2C_INV, OP_R2C, OP_C2R, OP_DCT1, OP_DCT2, OP_DCT3, OP_DCT4 = range(8)
 NORM_NONE, NORM_DEFAULT, NORM_SCALE = 0, 1, 2
+INPUT_AUTO, INPUT_CACHED, INPUT_COLD = 0, 1, 2
 
 # every symbol include/ndfft_mi355x.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -23,7 +24,7 @@ SYMBOLS = [
     "ndfft_plan_dtype", "ndfft_plan_lane_len_in", "ndfft_plan_lane_len_out",
     "ndfft_exec", "ndfft_exec_device", "ndfft_exec_sharded", "ndfft_exec_sharded_device", "ndfft_last_path", "ndfft_explain_plan",
     "ndfft_dev_alloc", "ndfft_dev_free", "ndfft_dev_upload", "ndfft_dev_download", "ndfft_dev_sync",
-    "ndfft_release_workspace", "ndfft_host_alloc", "ndfft_host_free",
+    "ndfft_release_workspace", "ndfft_host_alloc", "ndfft_host_free", "ndfft_set_input_hint",
 ]
 
 
@@ -75,6 +76,7 @@ class Library:
         L.ndfft_release_workspace.argtypes = []; L.ndfft_release_workspace.restype = ctypes.c_int
         L.ndfft_host_alloc.argtypes = [ctypes.POINTER(vp), ctypes.c_size_t]; L.ndfft_host_alloc.restype = ctypes.c_int
         L.ndfft_host_free.argtypes = [vp]; L.ndfft_host_free.restype = ctypes.c_int
+        L.ndfft_set_input_hint.argtypes = [i32]; L.ndfft_set_input_hint.restype = i32
 
     def check(self, status):
         if status == OK:

@@ -61,6 +61,9 @@ struct Pow2Args {
     int32_t logB = 0, f1 = 1;
     // XCD-aware workgroup -> lane-block map (xcd_block): 0 = identity
     int32_t xcd_chunk = 0;
+    // load policy of the input: -1 = the launcher decides by size, 0 = default policy (the input is expected in the Infinity Cache),
+    // 1 = streaming (nt) loads (the input comes from HBM) -- exec.hip: MallModel
+    int32_t stream_in = -1;
 };
 
 // arguments of the LDS-free wavefront kernel for short dense C2C lanes (wave_kernel.h)

@@ -277,7 +277,42 @@ struct Pipe {
         h2d = cmp = d2h = nullptr; ok = false;
     }
 };
+// What this thread's own calls imply about the 256 MiB Infinity Cache of the current device -- used for ONE decision, the load
+// policy of the register-resident C2C row kernels (BASELINE configs[1] / [4]):  plain loads are up to 15 % faster when the input is
+// resident in the Infinity Cache (4096 x 4096 c128: 0.86 vs 0.74 of the roofline), streaming (nt) loads 6 % faster when it comes from
+// HBM (0.74 vs 0.70).  Round 2 bet on "resident" for every input <= 384 MiB; a chain of nd* calls loses that bet at every link (the
+// output of a pass was written with nt stores, which bypass the cache).  The model tracks, per buffer this thread has transformed:
+//   * an input read with plain loads is resident until this thread's later plain reads have pushed ~256 MiB through the cache;
+//   * an input read with streaming loads, and every output (nt stores), is not resident;
+//   * a buffer the model has never seen keeps round 2's bet (plain loads up to 384 MiB) -- its producer is unknown.
+// ndfft_set_input_hint overrides it per host thread.  Speed only: either policy gives the same results.
+struct MallModel {
+    struct Entry { uintptr_t lo, hi; uint64_t stamp; bool resident; };
+    std::vector<Entry> e;
+    uint64_t clock = 0;                          // bytes this thread has read with plain loads
+    static constexpr uint64_t kCap = (uint64_t)256 << 20;
+    Entry *find(const void *p, size_t bytes) {
+        const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+        for (auto &x : e) if (lo < x.hi && x.lo < hi) return &x;
+        return nullptr;
+    }
+    // 1: streaming loads, 0: plain loads, -1: unknown buffer (the launcher decides by size)
+    int decide(const void *in, size_t bytes) {
+        if (bytes > kCap) return -1;
+        const Entry *x = find(in, bytes);
+        if (!x) return -1;
+        return (x->resident && clock - x->stamp + bytes <= kCap) ? 0 : 1;
+    }
+    void note(const void *p, size_t bytes, bool resident) {
+        const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+        for (size_t i = 0; i < e.size();) { if (lo < e[i].hi && e[i].lo < hi) e.erase(e.begin() + i); else ++i; }
+        if (resident) clock += bytes;
+        if (e.size() >= 32) e.erase(e.begin());  // oldest first
+        e.push_back({lo, hi, clock, resident});
+    }
+};
 struct DeviceWs {
+    MallModel mall;
     std::map<hipStream_t, Scratch> scratch[8];
     Staging stage_in, stage_out;
     PinnedBuf bounce_in[3], bounce_out[3];
@@ -308,6 +343,18 @@ static int current_ws(DeviceWs **out) {
     NDFFT_HIP(hipGetDevice(&dev));
     *out = &g_tws.dev[dev];
     return NDFFT_OK;
+}
+static thread_local int g_input_hint = NDFFT_INPUT_AUTO;
+// load policy for the dense C2C row kernels on input `in` (Pow2Args::stream_in), and the bookkeeping for the next call
+static int c2c_row_load_policy(const void *in, const void *out, size_t bytes) {
+    static const int force = [] { const char *e = getenv("NDFFT_STREAM_LOADS"); return e ? atoi(e) : -1; }();   // developer switch: 0 / 1 forces a policy
+    DeviceWs *ws;
+    if (current_ws(&ws)) return -1;
+    int pol = force >= 0 ? (force != 0) : g_input_hint == NDFFT_INPUT_CACHED ? 0 : g_input_hint == NDFFT_INPUT_COLD ? 1 : ws->mall.decide(in, bytes);
+    const bool nt = pol >= 0 ? pol != 0 : stream_loads_for(bytes);
+    ws->mall.note(in, bytes, !nt);
+    ws->mall.note(out, bytes, false);            // nt stores: the output bypasses the cache
+    return nt ? 1 : 0;
 }
 static int get_scratch(int which, hipStream_t s, size_t bytes, void **out) {
     DeviceWs *ws;
@@ -766,6 +813,8 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
         a.inverse = P.op == NDFFT_OP_C2C_INV;
         a.scale = P.scale;
         a.twp = dt->cfg[CFG_MAIN].twp;
+        if (a.pitch_in == (int64_t)plan->n && a.pitch_out == (int64_t)plan->n)
+            a.stream_in = c2c_row_load_policy(d_in, d_out, (size_t)P.nlanes * plan->n * 2 * real_size(plan->dtype));
         set_last_path("pow2_reg");
         return launch_pow2(plan->dtype, (int)plan->n, a, stream);
     }
@@ -780,7 +829,9 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
         a.inverse = P.op == NDFFT_OP_C2C_INV;
         a.scale = P.scale;
         a.twp = dt->cfg[CFG_MAIN].twp;
-        const int nt = stream_loads_for((size_t)P.nlanes * plan->n * 2 * real_size(plan->dtype)) ? 3 : 1;
+        const size_t bytes_c = (size_t)P.nlanes * plan->n * 2 * real_size(plan->dtype);
+        const int pol = (a.pitch_in == (int64_t)plan->n && a.pitch_out == (int64_t)plan->n) ? c2c_row_load_policy(d_in, d_out, bytes_c) : -1;
+        const int nt = (pol >= 0 ? pol != 0 : stream_loads_for(bytes_c)) ? 3 : 1;
         const int rcj = launch_jit_c2c(plan->dtype, plan->cfg[CFG_MAIN].jitcfg, nt, a, stream);
         if (rcj == NDFFT_OK) { set_last_path("jit_reg"); return NDFFT_OK; }
         if (rcj != NDFFT_ERR_UNSUPPORTED) return rcj;   // a real HIP error; UNSUPPORTED = no hiprtc / compile failed -> LDS kernel
@@ -1321,6 +1372,13 @@ int ndfft_exec(const ndfft_plan *plan, int op, const void *in, void *out, int nd
         NDFFT_HIP(hipMemcpy(ws.bounce_out[0].p, ws.stage_out.p, obytes, hipMemcpyDeviceToHost));
         copy_view_elements((char *)out, (const char *)ws.bounce_out[0].p - olo * (int64_t)eout, ndim, shape_out, stride_out, eout);
     }
+    return NDFFT_OK;
+}
+
+int ndfft_set_input_hint(int hint) {
+    clear_err();
+    if (hint < NDFFT_INPUT_AUTO || hint > NDFFT_INPUT_COLD) return fail(NDFFT_ERR_INVALID_ARG, "bad input hint");
+    g_input_hint = hint;
     return NDFFT_OK;
 }
 

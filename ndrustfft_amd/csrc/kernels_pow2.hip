@@ -138,7 +138,8 @@ template <typename T, int N, int NT, int VEC, int FL = 0> static int launch_inst
 }
 template <typename T, int N, int NT, int VEC, int FL = 0> static int launch_one(const Pow2Args &a, hipStream_t s) {
     static_assert(NT == 1, "callers name the store policy; the load policy is chosen here");
-    if (stream_loads_for((size_t)a.nlanes * N * sizeof(cpx<T>))) return launch_inst<T, N, 3, VEC, FL>(a, s);
+    const bool nt_in = a.stream_in >= 0 ? a.stream_in != 0 : stream_loads_for((size_t)a.nlanes * N * sizeof(cpx<T>));
+    if (nt_in) return launch_inst<T, N, 3, VEC, FL>(a, s);
     return launch_inst<T, N, 1, VEC, FL>(a, s);
 }
 

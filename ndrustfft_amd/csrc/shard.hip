@@ -440,7 +440,11 @@ int ndfft_exec_sharded_device(const ndfft_plan *plan, int op, const void *d_in, 
             rb.si[d] = rb.so[d] = b.hi - b.lo;
             rb.pin += b.lo * stride_in[d] * (int64_t)ein; rb.pout += b.lo * stride_out[d] * (int64_t)eout;
         }
-        fs.push_back(worker_for(b.device).submit([rb]() { return rb.dev == rb.root ? run_root_block(rb) : run_remote_block(rb); }));
+        // developer / test switch: NDFFT_SHARD_FORCE_REMOTE=1 sends the root's own blocks through the scatter / gather pipeline too, so that a
+        // one-GPU box exercises the pack / unpack kernels, the streams and the events (a peer copy to the same device is a device copy)
+        const char *fr = getenv("NDFFT_SHARD_FORCE_REMOTE");
+        const bool remote = rb.dev != rb.root || (fr && fr[0] == '1');
+        fs.push_back(worker_for(b.device).submit([rb, remote]() { return remote ? run_remote_block(rb) : run_root_block(rb); }));
     }
     return collect(fs);
 }

@@ -500,6 +500,52 @@ def sharded_exec(L, device_ids, torch_device=None):
         api.set_par_devices(None)
 
 
+def dev_sharded_case(L, name, shape, axis, root, ids, rdt=np.float64, out_view=None, in_view=None, repeats=1, sentinel=7.25):
+    """One ndfft_exec_sharded_device call on arrays resident on fake device `root`, blocks on `ids`.  out_view / in_view: (alloc_shape, index) --
+    the array is a view into a larger allocation (holes); every element outside the view must keep the sentinel."""
+    import ctypes
+    from ndrustfft_amd import api
+    sin, sout = shapes_for(name, shape, axis)
+    x = make_input(name, sin, rdt)
+    odt = cdt_of(rdt) if OPS[name][4] else np.dtype(rdt)
+    h, o = handlers_for(name, shape[axis], rdt, L)
+    yo = np.zeros(sout, odt); OPS[name][1](x, yo, o, axis)
+    # host images of the two allocations
+    if in_view is None: xa = np.ascontiguousarray(x); xv = xa
+    else:
+        xa = np.full(in_view[0], sentinel, x.dtype); xv = xa[in_view[1]]; assert xv.shape == x.shape; xv[...] = x
+    if out_view is None: ya = np.full(sout, sentinel, odt); yv = ya
+    else:
+        ya = np.full(out_view[0], sentinel, odt); yv = ya[out_view[1]]; assert yv.shape == tuple(sout)
+    opcode = {"ndfft": _lib.OP_C2C_FWD, "ndifft": _lib.OP_C2C_INV, "ndfft_r2c": _lib.OP_R2C, "ndifft_r2c": _lib.OP_C2R, "nddct1": _lib.OP_DCT1,
+              "nddct2": _lib.OP_DCT2, "nddct3": _lib.OP_DCT3, "nddct4": _lib.OP_DCT4}[name]
+    def off(v, a): return (v.__array_interface__["data"][0] - a.__array_interface__["data"][0])
+    try:
+        assert L.c.ndfft_set_device(root) == 0
+        din, dout = ctypes.c_void_p(), ctypes.c_void_p()
+        L.check(L.c.ndfft_dev_alloc(ctypes.byref(din), xa.nbytes)); L.check(L.c.ndfft_dev_alloc(ctypes.byref(dout), ya.nbytes))
+        L.check(L.c.ndfft_dev_upload(din, ctypes.c_void_p(xa.ctypes.data), xa.nbytes))
+        cids = (ctypes.c_int * len(ids))(*ids)
+        for rep in range(repeats):
+            L.check(L.c.ndfft_dev_upload(dout, ctypes.c_void_p(ya.ctypes.data), ya.nbytes))      # sentinel everywhere
+            L.check(L.c.ndfft_exec_sharded_device(
+                h._plan, opcode, ctypes.c_void_p(din.value + off(xv, xa)), ctypes.c_void_p(dout.value + off(yv, ya)), len(sin),
+                api._i64(sin), api._i64([s // xv.itemsize for s in xv.strides]), api._i64(sout), api._i64([s // yv.itemsize for s in yv.strides]),
+                axis, _lib.NORM_DEFAULT, 0.0, len(ids), cids, None))
+            assert L.last_path().startswith("sharded:"), L.last_path()
+            got = np.empty_like(ya)
+            L.check(L.c.ndfft_dev_download(ctypes.c_void_p(got.ctypes.data), dout, ya.nbytes))
+            gv = got if out_view is None else got[out_view[1]]
+            assert_close(gv, yo, axis, TOL[np.dtype(rdt)], f"sharded device-resident {name} {shape} axis {axis} rep {rep}")
+            if out_view is not None:
+                mask = np.ones(out_view[0], bool); mask[out_view[1]] = False
+                assert np.all(got[mask] == sentinel), "an element outside the output view was written"
+        L.check(L.c.ndfft_dev_free(din)); L.check(L.c.ndfft_dev_free(dout))
+    finally:
+        L.c.ndfft_set_device(0)
+
+
+
 def fuzz(L, seed, count, max_points=1 << 17, lengths=None):
     """Random op x lane length x shape x axis x dtype x norm x layout (C / F / stepped and reversed views, padded
     output views) against the oracle.  The lane lengths mix every dispatch class: powers of two, smooth,

@@ -41,79 +41,34 @@ def test_sharded_exec_three_fake_devices(L):
     assert L.c.ndfft_device_count() == 3
     ps.sharded_exec(L, [0, 1, 2])
     ps.sharded_exec(L, [2, 0])
-def _dev_sharded_case(L, name, shape, axis, root, ids, rdt=np.float64, out_view=None, in_view=None, repeats=1, sentinel=7.25):
-    """One ndfft_exec_sharded_device call on arrays resident on fake device `root`, blocks on `ids`.  out_view / in_view: (alloc_shape, index) --
-    the array is a view into a larger allocation (holes); every element outside the view must keep the sentinel."""
-    import ctypes
-    from ndrustfft_amd import api
-    sin, sout = ps.shapes_for(name, shape, axis)
-    x = ps.make_input(name, sin, rdt)
-    odt = ps.cdt_of(rdt) if ps.OPS[name][4] else np.dtype(rdt)
-    h, o = ps.handlers_for(name, shape[axis], rdt, L)
-    yo = np.zeros(sout, odt); ps.OPS[name][1](x, yo, o, axis)
-    # host images of the two allocations
-    if in_view is None: xa = np.ascontiguousarray(x); xv = xa
-    else:
-        xa = np.full(in_view[0], sentinel, x.dtype); xv = xa[in_view[1]]; assert xv.shape == x.shape; xv[...] = x
-    if out_view is None: ya = np.full(sout, sentinel, odt); yv = ya
-    else:
-        ya = np.full(out_view[0], sentinel, odt); yv = ya[out_view[1]]; assert yv.shape == tuple(sout)
-    opcode = {"ndfft": _lib.OP_C2C_FWD, "ndifft": _lib.OP_C2C_INV, "ndfft_r2c": _lib.OP_R2C, "ndifft_r2c": _lib.OP_C2R, "nddct1": _lib.OP_DCT1,
-              "nddct2": _lib.OP_DCT2, "nddct3": _lib.OP_DCT3, "nddct4": _lib.OP_DCT4}[name]
-    def off(v, a): return (v.__array_interface__["data"][0] - a.__array_interface__["data"][0])
-    try:
-        assert L.c.ndfft_set_device(root) == 0
-        din, dout = ctypes.c_void_p(), ctypes.c_void_p()
-        L.check(L.c.ndfft_dev_alloc(ctypes.byref(din), xa.nbytes)); L.check(L.c.ndfft_dev_alloc(ctypes.byref(dout), ya.nbytes))
-        L.check(L.c.ndfft_dev_upload(din, ctypes.c_void_p(xa.ctypes.data), xa.nbytes))
-        cids = (ctypes.c_int * len(ids))(*ids)
-        for rep in range(repeats):
-            L.check(L.c.ndfft_dev_upload(dout, ctypes.c_void_p(ya.ctypes.data), ya.nbytes))      # sentinel everywhere
-            L.check(L.c.ndfft_exec_sharded_device(
-                h._plan, opcode, ctypes.c_void_p(din.value + off(xv, xa)), ctypes.c_void_p(dout.value + off(yv, ya)), len(sin),
-                api._i64(sin), api._i64([s // xv.itemsize for s in xv.strides]), api._i64(sout), api._i64([s // yv.itemsize for s in yv.strides]),
-                axis, _lib.NORM_DEFAULT, 0.0, len(ids), cids, None))
-            assert L.last_path().startswith("sharded:"), L.last_path()
-            got = np.empty_like(ya)
-            L.check(L.c.ndfft_dev_download(ctypes.c_void_p(got.ctypes.data), dout, ya.nbytes))
-            gv = got if out_view is None else got[out_view[1]]
-            ps.assert_close(gv, yo, axis, ps.TOL[np.dtype(rdt)], f"sharded device-resident {name} {shape} axis {axis} rep {rep}")
-            if out_view is not None:
-                mask = np.ones(out_view[0], bool); mask[out_view[1]] = False
-                assert np.all(got[mask] == sentinel), "an element outside the output view was written"
-        L.check(L.c.ndfft_dev_free(din)); L.check(L.c.ndfft_dev_free(dout))
-    finally:
-        L.c.ndfft_set_device(0)
-
-
 def test_sharded_device_resident_interleaved_blocks(L):
     """The case round 2's advisor broke: the split dimension is NOT the outermost one in memory (axis = 0 on a C-contiguous array -- the second pass of
     fft2), so every block's address span covers nearly the whole array and interleaves with the other devices' blocks.  Blocks now travel as dense
     images (pack / unpack kernels on the root device); the emulation aborts on a peer copy without peer access.  Repeated: the old failure was a race."""
-    _dev_sharded_case(L, "ndfft", (64, 300), 0, root=1, ids=[0, 1, 2], repeats=20)
-    _dev_sharded_case(L, "ndfft", (64, 300), 0, root=0, ids=[2, 1], repeats=5)
-    _dev_sharded_case(L, "ndfft_r2c", (64, 5, 3), 0, root=2, ids=[0, 1, 2], repeats=5)
-    _dev_sharded_case(L, "ndifft_r2c", (32, 7, 9), 0, root=1, ids=[0, 1, 2], repeats=3, rdt=np.float32)
-    _dev_sharded_case(L, "nddct2", (5, 16, 33), 1, root=0, ids=[1, 2, 0], repeats=3)
-    _dev_sharded_case(L, "nddct1", (9, 6, 4), 0, root=1, ids=[2, 0], repeats=3)
+    ps.dev_sharded_case(L, "ndfft", (64, 300), 0, root=1, ids=[0, 1, 2], repeats=20)
+    ps.dev_sharded_case(L, "ndfft", (64, 300), 0, root=0, ids=[2, 1], repeats=5)
+    ps.dev_sharded_case(L, "ndfft_r2c", (64, 5, 3), 0, root=2, ids=[0, 1, 2], repeats=5)
+    ps.dev_sharded_case(L, "ndifft_r2c", (32, 7, 9), 0, root=1, ids=[0, 1, 2], repeats=3, rdt=np.float32)
+    ps.dev_sharded_case(L, "nddct2", (5, 16, 33), 1, root=0, ids=[1, 2, 0], repeats=3)
+    ps.dev_sharded_case(L, "nddct1", (9, 6, 4), 0, root=1, ids=[2, 0], repeats=3)
 
 
 def test_sharded_device_resident_views_with_holes(L):
     """Output (and input) views with holes on the device: stepped, reversed and padded views of a larger allocation; every element outside
     the view keeps its sentinel, with the holes interleaved between the blocks of different devices."""
-    _dev_sharded_case(L, "ndfft", (9, 16, 6), 1, root=1, ids=[0, 1, 2], out_view=((9, 16, 12), np.s_[:, :, ::2]), repeats=5)
-    _dev_sharded_case(L, "ndfft", (9, 16, 6), 1, root=0, ids=[1, 2], out_view=((9, 16, 12), np.s_[::-1, :, 1::2]), in_view=((18, 16, 6), np.s_[::2]), repeats=3)
-    _dev_sharded_case(L, "ndfft", (16, 40), 0, root=2, ids=[0, 1, 2], out_view=((16, 50), np.s_[:, 5:45]), repeats=5)
-    _dev_sharded_case(L, "nddct3", (12, 8), 1, root=1, ids=[0, 2], out_view=((24, 8), np.s_[1::2, :]), repeats=3)
-    _dev_sharded_case(L, "ndfft_r2c", (10, 21), 0, root=0, ids=[2, 1, 0], out_view=((6, 64), np.s_[:, 1:64:3]), repeats=3)
+    ps.dev_sharded_case(L, "ndfft", (9, 16, 6), 1, root=1, ids=[0, 1, 2], out_view=((9, 16, 12), np.s_[:, :, ::2]), repeats=5)
+    ps.dev_sharded_case(L, "ndfft", (9, 16, 6), 1, root=0, ids=[1, 2], out_view=((9, 16, 12), np.s_[::-1, :, 1::2]), in_view=((18, 16, 6), np.s_[::2]), repeats=3)
+    ps.dev_sharded_case(L, "ndfft", (16, 40), 0, root=2, ids=[0, 1, 2], out_view=((16, 50), np.s_[:, 5:45]), repeats=5)
+    ps.dev_sharded_case(L, "nddct3", (12, 8), 1, root=1, ids=[0, 2], out_view=((24, 8), np.s_[1::2, :]), repeats=3)
+    ps.dev_sharded_case(L, "ndfft_r2c", (10, 21), 0, root=0, ids=[2, 1, 0], out_view=((6, 64), np.s_[:, 1:64:3]), repeats=3)
 
 
 def test_sharded_device_resident_chunk_pipeline(L, monkeypatch):
     """Blocks cut into many pipelined chunks (scatter of chunk c+1 beside the transform of chunk c and the gather of chunk c-1; two buffer slots)."""
     monkeypatch.setenv("NDFFT_SHARD_CHUNK_KB", "4")
-    _dev_sharded_case(L, "ndfft", (61, 64), 1, root=1, ids=[0, 1, 2], repeats=2)          # contiguous spans, uneven chunks
-    _dev_sharded_case(L, "ndfft", (64, 90), 0, root=0, ids=[1, 2], repeats=2)             # packed, many chunks
-    _dev_sharded_case(L, "nddct2", (40, 32, 3), 1, root=2, ids=[0, 1], out_view=((40, 32, 6), np.s_[:, :, ::2]), repeats=2)
+    ps.dev_sharded_case(L, "ndfft", (61, 64), 1, root=1, ids=[0, 1, 2], repeats=2)          # contiguous spans, uneven chunks
+    ps.dev_sharded_case(L, "ndfft", (64, 90), 0, root=0, ids=[1, 2], repeats=2)             # packed, many chunks
+    ps.dev_sharded_case(L, "nddct2", (40, 32, 3), 1, root=2, ids=[0, 1], out_view=((40, 32, 6), np.s_[:, :, ::2]), repeats=2)
 
 
 def test_baseline_length_fixtures(L, blvec): ps.baseline_length_fixtures(L, blvec)

@@ -36,6 +36,24 @@ def test_reg_lanes(L): ps.reg_lanes(L)
 def test_regreal_lanes(L): ps.regreal_lanes(L, sizes=(12, 17, 18, 21, 24, 30, 42, 48), sizes_f32=(49, 64, 72))      # (every op x dtype x layout is one hiprtc compile: ~100 s for the default lists)
 def test_tinymat_lanes(L): ps.tinymat_lanes(L)
 def test_host_pipeline_pageable(L): ps.host_pipeline_pageable(L)
+def test_sharded_device_resident_pipeline_on_one_gpu(L, monkeypatch):
+    """ndfft_exec_sharded_device's scatter -> transform -> gather pipeline (pack / unpack kernels on the root, per-device streams, events, two buffer
+    slots) on real hardware: with one GPU per lease every block lives on the root, so NDFFT_SHARD_FORCE_REMOTE sends them through the pipeline anyway.
+    Blocks interleaved in memory (axis 0 of a C-contiguous array), output views with holes (sentinels must survive), many small chunks."""
+    monkeypatch.setenv("NDFFT_SHARD_FORCE_REMOTE", "1")
+    n = L.c.ndfft_device_count()
+    ids = list(range(n)) if n > 1 else [0, 0, 0]
+    ps.dev_sharded_case(L, "ndfft", (64, 300), 0, root=0, ids=ids, repeats=5)
+    ps.dev_sharded_case(L, "ndfft_r2c", (64, 5, 3), 0, root=0, ids=ids, repeats=3)
+    ps.dev_sharded_case(L, "ndfft", (9, 16, 6), 1, root=0, ids=ids, out_view=((9, 16, 12), np.s_[:, :, ::2]), repeats=3)
+    ps.dev_sharded_case(L, "ndfft", (9, 16, 6), 1, root=0, ids=ids, out_view=((9, 16, 12), np.s_[::-1, :, 1::2]), in_view=((18, 16, 6), np.s_[::2]), repeats=3)
+    ps.dev_sharded_case(L, "ndfft", (4096, 512), 1, root=0, ids=ids, repeats=2)                     # contiguous spans, 16 MiB
+    ps.dev_sharded_case(L, "ndfft", (512, 4096), 0, root=0, ids=ids, repeats=2)                     # packed images, 16 MiB
+    monkeypatch.setenv("NDFFT_SHARD_CHUNK_KB", "256")
+    ps.dev_sharded_case(L, "ndfft", (4096, 512), 1, root=0, ids=ids, repeats=2)                     # ~22 chunks per block through two slots
+    ps.dev_sharded_case(L, "nddct2", (300, 64, 40), 1, root=0, ids=ids, out_view=((300, 64, 80), np.s_[:, :, ::2]), repeats=2)
+
+
 def test_sharded_exec_same_device_twice(L):
     n = L.c.ndfft_device_count()
     ps.sharded_exec(L, list(range(n)) if n > 1 else [0, 0, 0], torch_device="cuda:0")
