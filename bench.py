@@ -388,15 +388,22 @@ def main():
     # ------------------------------------------------------------------ host-array API (PCIe both ways), N = 1 only
     host_api = None
     if rank == 0 and ngpu == 1 and not args.no_host_api:
+        # the caller's own pageable arrays (numpy = malloc memory), as the reference's signature hands them over (src/lib.rs:105-115):
+        #   call 1: first sighting of the arrays -> bounce-buffer pipeline;  call 2: the library registers them (hipHostRegister, once);
+        #   calls 3..: steady state, DMA straight from / to the caller's arrays.  All three are reported; none is `value`.
         yh = np.empty_like(x)
-        ndfft(x, yh, h, 1)
+        t0 = time.perf_counter(); ndfft(x, yh, h, 1); first = time.perf_counter() - t0
+        t0 = time.perf_counter(); ndfft(x, yh, h, 1); second = time.perf_counter() - t0
         t0 = time.perf_counter(); reps = 5
         for _ in range(reps):
             ndfft(x, yh, h, 1)
         hel = (time.perf_counter() - t0) / reps
         assert np.abs(yh[:4] - np.fft.fft(x[:4], axis=1)).max() / np.abs(yh[:4]).max() < 1e-10
-        host_api = {"what": "ndfft_exec on pageable host arrays (upload + transform + download), never `value`",
+        lib.c.ndfft_host_forget(None)
+        host_api = {"what": "ndfft_exec on pageable host arrays (upload + transform + download), never `value`; steady state = the same caller "
+                            "arrays again (registered by the library on their second use)",
                     "ms_per_call": round(hel * 1e3, 3), "value": round(rows * n / hel / 1e9, 3), "unit": "GFFT-points/s",
+                    "first_call_ms": round(first * 1e3, 3), "registering_call_ms": round(second * 1e3, 3),
                     "kernel_path": lib.last_path()}
 
     if rank == 0:

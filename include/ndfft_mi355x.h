@@ -183,6 +183,13 @@ int ndfft_dev_sync(void *stream);                                     /* hipStre
  * allocates pageable memory); a shim exposes it as an allocator for its array type. */
 int ndfft_host_alloc(void **h_ptr, size_t bytes);
 int ndfft_host_free(void *h_ptr);
+/* Ordinary (pageable) caller arrays -- what the reference's signature hands over, lib.rs:105-115 -- are remembered by address: the SECOND
+ * ndfft_exec on the same array registers it with the driver (hipHostRegister, ~22 ms per 512 MiB, once) and keeps the registration in an
+ * LRU (NDFFT_HOST_REG_CACHE_MB, default 4096, 0 = off); from then on calls on that array run the pinned pipeline (2 x 256 MiB: ~6.2 ms
+ * instead of 8-10 ms through bounce buffers).  One-shot arrays never pay the registration.  A caller that frees (or reallocates) such an
+ * array tells the library with ndfft_host_forget(ptr): the registration covering ptr is dropped; NULL drops all of them.  Forgetting is
+ * optional for correctness (the driver revalidates registered ranges by virtual address) but returns the pinned pages at once. */
+int ndfft_host_forget(const void *h_ptr);
 
 /* Frees the CALLING THREAD's device workspace on EVERY device it has used: the scratch arrays of the multi-pass paths (transpose route,
  * four-step, column four-step, global Bluestein) and the staging buffers of ndfft_exec.  They are otherwise

@@ -1098,6 +1098,95 @@ bool is_pinned(const void *p) {
     if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
     return a.type == hipMemoryTypeHost;
 }
+
+// ---- registration cache for the caller's own (pageable) arrays ---------------------------------------------------------
+// The reference's signature hands over ndarrays in ordinary host memory (src/lib.rs:105-115).  Pinned memory moves at the PCIe duplex
+// rate (2 x 256 MiB: 6.2 ms through the chunk pipeline) but hipHostRegister costs ~22 ms per 512 MiB, pageable memory goes through bounce
+// buffers (8-10 ms: the host memcpys bound it on a 16-CPU quota).  A caller that transforms the SAME arrays again and again -- a time
+// stepper, the reference's own benches -- should pay the registration once: the SECOND time a range is seen it is registered and kept in an
+// LRU (NDFFT_HOST_REG_CACHE_MB, default 4096; 0 disables), from then on its calls run the pinned pipeline.  One-shot arrays never pay.
+// amdgpu registers user memory by virtual address with MMU-notifier revalidation, so a range that was freed and mapped again is
+// re-pinned by the driver, not left pointing at stale pages; a caller that frees registered arrays should still say so with
+// ndfft_host_forget (it returns the pinned pages at once instead of at eviction).
+class HostRegCache {
+  public:
+    static HostRegCache &get() { static HostRegCache *c = new HostRegCache; return *c; }
+    // true: [p, p + bytes) is registered now (and held until release())
+    bool acquire(const void *p, size_t bytes) {
+        if (!limit_ || bytes < ((size_t)8 << 20)) return false;
+        const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+        std::lock_guard<std::mutex> g(mu_);
+        ++tick_;
+        R *hit = nullptr;
+        for (size_t i = 0; i < v_.size();) {
+            R &r = v_[i];
+            if (r.lo <= lo && hi <= r.hi) { hit = &r; ++i; continue; }
+            if (lo < r.hi && r.lo < hi) {                 // overlaps without containing: the caller's allocation changed
+                if (r.inuse) return false;                //   (another thread is moving data through it: leave everything alone)
+                drop(i);
+                continue;
+            }
+            ++i;
+        }
+        if (hit) {
+            hit->last = tick_;
+            if (hit->registered) { ++hit->inuse; return true; }
+            if (++hit->seen < 2) return false;
+            if (hipHostRegister((void *)hit->lo, hit->hi - hit->lo, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); hit->seen = -1000000; return false; }
+            hit->registered = true; hit->inuse = 1; reg_bytes_ += hit->hi - hit->lo;
+            const uintptr_t keep = hit->lo;               // (evict() may move entries)
+            evict(keep);
+            return true;
+        }
+        if (v_.size() >= 256) {                           // forget the oldest unregistered sighting
+            size_t o = v_.size();
+            for (size_t i = 0; i < v_.size(); ++i) if (!v_[i].registered && (o == v_.size() || v_[i].last < v_[o].last)) o = i;
+            if (o < v_.size()) v_.erase(v_.begin() + o);
+        }
+        v_.push_back({lo, hi, tick_, 1, false, 0});
+        return false;
+    }
+    void release(const void *p) {
+        const uintptr_t a = (uintptr_t)p;
+        std::lock_guard<std::mutex> g(mu_);
+        for (R &r : v_) if (r.registered && r.lo <= a && a < r.hi && r.inuse > 0) { --r.inuse; return; }
+    }
+    // p == nullptr: everything.  Returns the number of registrations given back.
+    int forget(const void *p) {
+        const uintptr_t a = (uintptr_t)p;
+        std::lock_guard<std::mutex> g(mu_);
+        int n = 0;
+        for (size_t i = 0; i < v_.size();) {
+            if ((!p || (v_[i].lo <= a && a < v_[i].hi)) && !v_[i].inuse) { n += v_[i].registered; drop(i); } else ++i;
+        }
+        return n;
+    }
+  private:
+    struct R { uintptr_t lo, hi; uint64_t last; int seen; bool registered; int inuse; };
+    HostRegCache() { const char *e = getenv("NDFFT_HOST_REG_CACHE_MB"); limit_ = (size_t)(e ? std::max(0L, atol(e)) : 4096L) << 20; }
+    void drop(size_t i) {
+        if (v_[i].registered) { (void)hipHostUnregister((void *)v_[i].lo); (void)hipGetLastError(); reg_bytes_ -= v_[i].hi - v_[i].lo; }
+        v_.erase(v_.begin() + i);
+    }
+    void evict(uintptr_t keep) {
+        while (reg_bytes_ > limit_) {
+            size_t o = v_.size();
+            for (size_t i = 0; i < v_.size(); ++i)
+                if (v_[i].registered && !v_[i].inuse && v_[i].lo != keep && (o == v_.size() || v_[i].last < v_[o].last)) o = i;
+            if (o == v_.size()) return;
+            drop(o);
+        }
+    }
+    std::mutex mu_;
+    std::vector<R> v_;
+    uint64_t tick_ = 0;
+    size_t reg_bytes_ = 0, limit_ = 0;
+};
+struct HostPin {       // one side of a call: registered for the duration of the call if the cache says so
+    const void *p = nullptr; bool held = false;
+    HostPin(const void *ptr, size_t bytes) : p(ptr) { held = HostRegCache::get().acquire(ptr, bytes); }
+    ~HostPin() { if (held) HostRegCache::get().release(p); }
+};
 int pipe_init(Pipe &p, int chunks) {
     if (!p.ok) {
         NDFFT_HIP(hipStreamCreate(&p.h2d)); NDFFT_HIP(hipStreamCreate(&p.cmp)); NDFFT_HIP(hipStreamCreate(&p.d2h));
@@ -1343,7 +1432,10 @@ int ndfft_exec(const ndfft_plan *plan, int op, const void *in, void *out, int nd
             // a chunk must stay a real problem: kernel choice depends on the size of a call (hiprtc specialisation from 2^16-2^17
             // points), so never cut below 2^18 points per chunk
             const int64_t max_chunks = std::max<int64_t>(1, (P.nlanes * std::max(P.xlen, P.ylen)) >> 18);
-            if (is_pinned(in) && is_pinned(out)) {
+            // the caller's own arrays, seen before: registered once, DMA straight from / to them from then on
+            const bool own_in = is_pinned(in), own_out = is_pinned(out);
+            HostPin pin_in(hin, own_in ? 0 : ibytes), pin_out(hout, own_out ? 0 : obytes);
+            if ((own_in || pin_in.held) && (own_out || pin_out.held)) {
                 const int chunks = (int)std::min<int64_t>(std::min<int64_t>(shape_in[0], max_chunks), e ? std::max(1, atoi(e)) : 8);
                 return exec_pinned_pipeline(ws, plan, op, hin, hout, ndim, shape_in, stride_in, shape_out, stride_out, axis, norm, scale, ein, eout, chunks);
             }
@@ -1372,6 +1464,12 @@ int ndfft_exec(const ndfft_plan *plan, int op, const void *in, void *out, int nd
         NDFFT_HIP(hipMemcpy(ws.bounce_out[0].p, ws.stage_out.p, obytes, hipMemcpyDeviceToHost));
         copy_view_elements((char *)out, (const char *)ws.bounce_out[0].p - olo * (int64_t)eout, ndim, shape_out, stride_out, eout);
     }
+    return NDFFT_OK;
+}
+
+int ndfft_host_forget(const void *h_ptr) {
+    clear_err();
+    (void)HostRegCache::get().forget(h_ptr);
     return NDFFT_OK;
 }
 

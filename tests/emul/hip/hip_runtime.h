@@ -88,6 +88,9 @@ inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t) { return hipMemcpy(d, s, n, k); }
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
 inline hipError_t hipHostFree(void *p) { free(p); return 0; }
+enum { hipHostRegisterDefault = 0 };
+inline hipError_t hipHostRegister(void *, size_t, unsigned) { return 1; }   // never "pinned" in the emulation: the bounce pipeline stays the tested path
+inline hipError_t hipHostUnregister(void *) { return 0; }
 inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return 0; }
 
 void __syncthreads();

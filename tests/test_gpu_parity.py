@@ -36,6 +36,32 @@ def test_reg_lanes(L): ps.reg_lanes(L)
 def test_regreal_lanes(L): ps.regreal_lanes(L, sizes=(12, 17, 18, 21, 24, 30, 42, 48), sizes_f32=(49, 64, 72))      # (every op x dtype x layout is one hiprtc compile: ~100 s for the default lists)
 def test_tinymat_lanes(L): ps.tinymat_lanes(L)
 def test_host_pipeline_pageable(L): ps.host_pipeline_pageable(L)
+def test_host_registration_cache(L):
+    """Caller arrays in ordinary malloc memory: the second ndfft_exec on the same arrays registers them, later calls run the pinned pipeline; results
+    identical on every path; arrays that change size at the same address, ndfft_host_forget, and a different input through the same output."""
+    import ctypes
+    n = 1024
+    x = synth.complex_array((4096, n)); yo = np.zeros_like(x); orc.ndfft_par(x, yo, orc.FftHandler(n), 1)
+    h = handlers.FftHandler(n, _library=L)
+    ys = []
+    for k in range(4):
+        y = np.zeros_like(x) if k == 0 else ys[0]
+        if k == 0: ys.append(y)
+        y[...] = 0
+        api.ndfft(x, y, h, 1)
+        assert_close(y, yo, 1, 1e-10, f"host call {k}")
+    attr_pinned = lambda a: L.c.ndfft_host_forget(ctypes.c_void_p(a.ctypes.data)) == 0
+    x2 = synth.complex_array((4096, n), offset=77); y2o = np.zeros_like(x2); orc.ndfft_par(x2, y2o, orc.FftHandler(n), 1)
+    api.ndfft(x2, ys[0], h, 1); assert_close(ys[0], y2o, 1, 1e-10, "new input, registered output")
+    assert attr_pinned(x) and attr_pinned(ys[0])
+    api.ndfft(x, ys[0], h, 1); assert_close(ys[0], yo, 1, 1e-10, "after forget")
+    # a view of the registered array (smaller range inside it) and a larger array over it
+    for k in range(3):
+        api.ndfft(x[:2048], ys[0][:2048], h, 1)
+    assert_close(ys[0][:2048], yo[:2048], 1, 1e-10, "sub-range of a seen array")
+    L.c.ndfft_host_forget(None)
+
+
 def test_sharded_device_resident_pipeline_on_one_gpu(L, monkeypatch):
     """ndfft_exec_sharded_device's scatter -> transform -> gather pipeline (pack / unpack kernels on the root, per-device streams, events, two buffer
     slots) on real hardware: with one GPU per lease every block lives on the root, so NDFFT_SHARD_FORCE_REMOTE sends them through the pipeline anyway.
