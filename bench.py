@@ -388,22 +388,32 @@ def main():
     # ------------------------------------------------------------------ host-array API (PCIe both ways), N = 1 only
     host_api = None
     if rank == 0 and ngpu == 1 and not args.no_host_api:
-        # the caller's own pageable arrays (numpy = malloc memory), as the reference's signature hands them over (src/lib.rs:105-115):
-        #   call 1: first sighting of the arrays -> bounce-buffer pipeline;  call 2: the library registers them (hipHostRegister, once);
-        #   calls 3..: steady state, DMA straight from / to the caller's arrays.  All three are reported; none is `value`.
+        # the caller's own pageable arrays (numpy = malloc memory), as the reference's signature hands them over (src/lib.rs:105-115).
+        # Default configuration: pinned bounce buffers filled by a host copy pool (`ms_per_call`).  With the opt-in registration cache
+        # (ndfft_host_reg_cache: a caller that owns its arrays' lifetimes) the library registers an array on its second use and later
+        # calls DMA straight from / to it (`registered`).  Neither is `value`.
         yh = np.empty_like(x)
         t0 = time.perf_counter(); ndfft(x, yh, h, 1); first = time.perf_counter() - t0
-        t0 = time.perf_counter(); ndfft(x, yh, h, 1); second = time.perf_counter() - t0
         t0 = time.perf_counter(); reps = 5
         for _ in range(reps):
             ndfft(x, yh, h, 1)
         hel = (time.perf_counter() - t0) / reps
         assert np.abs(yh[:4] - np.fft.fft(x[:4], axis=1)).max() / np.abs(yh[:4]).max() < 1e-10
-        lib.c.ndfft_host_forget(None)
-        host_api = {"what": "ndfft_exec on pageable host arrays (upload + transform + download), never `value`; steady state = the same caller "
-                            "arrays again (registered by the library on their second use)",
+        lib.check(lib.c.ndfft_host_reg_cache(4 << 30))
+        t0 = time.perf_counter(); ndfft(x, yh, h, 1); r1 = time.perf_counter() - t0      # first sighting: bounce buffers
+        t0 = time.perf_counter(); ndfft(x, yh, h, 1); r2 = time.perf_counter() - t0      # second sighting: registers both arrays
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ndfft(x, yh, h, 1)
+        rel = (time.perf_counter() - t0) / reps
+        assert np.abs(yh[:4] - np.fft.fft(x[:4], axis=1)).max() / np.abs(yh[:4]).max() < 1e-10
+        lib.check(lib.c.ndfft_host_reg_cache(0))                                          # drops the registrations before numpy frees the arrays
+        host_api = {"what": "ndfft_exec on pageable host arrays (upload + transform + download), never `value`",
                     "ms_per_call": round(hel * 1e3, 3), "value": round(rows * n / hel / 1e9, 3), "unit": "GFFT-points/s",
-                    "first_call_ms": round(first * 1e3, 3), "registering_call_ms": round(second * 1e3, 3),
+                    "first_call_ms": round(first * 1e3, 3),
+                    "registered": {"what": "opt-in registration cache (ndfft_host_reg_cache): same caller arrays, registered by the library on their second use",
+                                   "steady_state_ms_per_call": round(rel * 1e3, 3), "value": round(rows * n / rel / 1e9, 3),
+                                   "first_sighting_ms": round(r1 * 1e3, 3), "registering_call_ms": round(r2 * 1e3, 3)},
                     "kernel_path": lib.last_path()}
 
     if rank == 0:

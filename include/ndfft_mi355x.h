@@ -183,12 +183,15 @@ int ndfft_dev_sync(void *stream);                                     /* hipStre
  * allocates pageable memory); a shim exposes it as an allocator for its array type. */
 int ndfft_host_alloc(void **h_ptr, size_t bytes);
 int ndfft_host_free(void *h_ptr);
-/* Ordinary (pageable) caller arrays -- what the reference's signature hands over, lib.rs:105-115 -- are remembered by address: the SECOND
- * ndfft_exec on the same array registers it with the driver (hipHostRegister, ~22 ms per 512 MiB, once) and keeps the registration in an
- * LRU (NDFFT_HOST_REG_CACHE_MB, default 4096, 0 = off); from then on calls on that array run the pinned pipeline (2 x 256 MiB: ~6.2 ms
- * instead of 8-10 ms through bounce buffers).  One-shot arrays never pay the registration.  A caller that frees (or reallocates) such an
- * array tells the library with ndfft_host_forget(ptr): the registration covering ptr is dropped; NULL drops all of them.  Forgetting is
- * optional for correctness (the driver revalidates registered ranges by virtual address) but returns the pinned pages at once. */
+/* Registration cache for ordinary (pageable) caller arrays -- what the reference's signature hands over, lib.rs:105-115.  OPT-IN:
+ * ndfft_host_reg_cache(max_bytes) (or NDFFT_HOST_REG_CACHE_MB) switches it on with an LRU budget, 0 switches it off and drops every
+ * registration.  When on, the SECOND ndfft_exec on the same array registers it with the driver (hipHostRegister, once) and later calls on
+ * it run the pinned pipeline (2 x 256 MiB: ~6.2 ms instead of 8-10 ms through bounce buffers); one-shot arrays never pay.
+ * Contract: before freeing (or reallocating) an array that has been through ndfft_exec, call ndfft_host_forget(ptr) -- the registration
+ * covering ptr is dropped; NULL drops all.  A registration that outlives its array makes HIP reject later copies from the reused
+ * addresses ("invalid argument"), in this library (which recovers: it forgets the range and retries through the bounce buffers) and in any
+ * other code of the process (which does not) -- hence off by default. */
+int ndfft_host_reg_cache(size_t max_bytes);
 int ndfft_host_forget(const void *h_ptr);
 
 /* Frees the CALLING THREAD's device workspace on EVERY device it has used: the scratch arrays of the multi-pass paths (transpose route,

@@ -1104,10 +1104,13 @@ bool is_pinned(const void *p) {
 // rate (2 x 256 MiB: 6.2 ms through the chunk pipeline) but hipHostRegister costs ~22 ms per 512 MiB, pageable memory goes through bounce
 // buffers (8-10 ms: the host memcpys bound it on a 16-CPU quota).  A caller that transforms the SAME arrays again and again -- a time
 // stepper, the reference's own benches -- should pay the registration once: the SECOND time a range is seen it is registered and kept in an
-// LRU (NDFFT_HOST_REG_CACHE_MB, default 4096; 0 disables), from then on its calls run the pinned pipeline.  One-shot arrays never pay.
-// amdgpu registers user memory by virtual address with MMU-notifier revalidation, so a range that was freed and mapped again is
-// re-pinned by the driver, not left pointing at stale pages; a caller that frees registered arrays should still say so with
-// ndfft_host_forget (it returns the pinned pages at once instead of at eviction).
+// LRU, from then on its calls run the pinned pipeline.  One-shot arrays never pay.
+// OPT-IN (ndfft_host_reg_cache / NDFFT_HOST_REG_CACHE_MB, default 0 = off), because a registration outlives the array: when the caller
+// frees a registered array and the allocator hands the addresses out again, HIP still treats them as the old pinned object and EVERY copy
+// from or to them -- this library's, torch's, the caller's own -- fails with "invalid argument" (seen on the MI355X with numpy arrays in
+// the first version, which had the cache on by default).  This library recovers (it forgets the range and retries through the bounce
+// buffers) but cannot protect other code, so only a caller that owns its arrays' lifetimes should switch it on, and call
+// ndfft_host_forget before freeing them.
 class HostRegCache {
   public:
     static HostRegCache &get() { static HostRegCache *c = new HostRegCache; return *c; }
@@ -1163,7 +1166,15 @@ class HostRegCache {
     }
   private:
     struct R { uintptr_t lo, hi; uint64_t last; int seen; bool registered; int inuse; };
-    HostRegCache() { const char *e = getenv("NDFFT_HOST_REG_CACHE_MB"); limit_ = (size_t)(e ? std::max(0L, atol(e)) : 4096L) << 20; }
+    HostRegCache() { const char *e = getenv("NDFFT_HOST_REG_CACHE_MB"); limit_ = (size_t)(e ? std::max(0L, atol(e)) : 0L) << 20; }
+  public:
+    void set_limit(size_t bytes) {
+        std::lock_guard<std::mutex> g(mu_);
+        limit_ = bytes;
+        if (!bytes) { for (size_t i = 0; i < v_.size();) { if (!v_[i].inuse) drop(i); else ++i; } }
+        else evict(0);
+    }
+  private:
     void drop(size_t i) {
         if (v_[i].registered) { (void)hipHostUnregister((void *)v_[i].lo); (void)hipGetLastError(); reg_bytes_ -= v_[i].hi - v_[i].lo; }
         v_.erase(v_.begin() + i);
@@ -1434,10 +1445,23 @@ int ndfft_exec(const ndfft_plan *plan, int op, const void *in, void *out, int nd
             const int64_t max_chunks = std::max<int64_t>(1, (P.nlanes * std::max(P.xlen, P.ylen)) >> 18);
             // the caller's own arrays, seen before: registered once, DMA straight from / to them from then on
             const bool own_in = is_pinned(in), own_out = is_pinned(out);
-            HostPin pin_in(hin, own_in ? 0 : ibytes), pin_out(hout, own_out ? 0 : obytes);
-            if ((own_in || pin_in.held) && (own_out || pin_out.held)) {
-                const int chunks = (int)std::min<int64_t>(std::min<int64_t>(shape_in[0], max_chunks), e ? std::max(1, atoi(e)) : 8);
-                return exec_pinned_pipeline(ws, plan, op, hin, hout, ndim, shape_in, stride_in, shape_out, stride_out, axis, norm, scale, ein, eout, chunks);
+            bool retry_unpinned = false;
+            {
+                HostPin pin_in(hin, own_in ? 0 : ibytes), pin_out(hout, own_out ? 0 : obytes);
+                if ((own_in || pin_in.held) && (own_out || pin_out.held)) {
+                    const int chunks = (int)std::min<int64_t>(std::min<int64_t>(shape_in[0], max_chunks), e ? std::max(1, atoi(e)) : 8);
+                    const int rcp = exec_pinned_pipeline(ws, plan, op, hin, hout, ndim, shape_in, stride_in, shape_out, stride_out, axis, norm, scale, ein, eout, chunks);
+                    // A registration made by the cache can be stale: the caller freed the array and the allocator handed the same addresses out
+                    // again (seen on the MI355X with numpy arrays: hipMemcpyAsync then fails with "invalid argument" -- before anything has been
+                    // written to the caller's output).  Forget both ranges and run this call through the bounce buffers instead.
+                    if (rcp == NDFFT_OK || rcp != NDFFT_ERR_HIP || !(pin_in.held || pin_out.held)) return rcp;
+                    retry_unpinned = true;
+                }
+            }
+            if (retry_unpinned) {
+                (void)hipGetLastError();
+                HostRegCache::get().forget(hin); HostRegCache::get().forget(hout);
+                clear_err();
             }
             const char *hp = getenv("NDFFT_HOST_PIPE");
             const bool force = hp && hp[0] == '1';            // tests: pipeline small calls too
@@ -1450,13 +1474,21 @@ int ndfft_exec(const ndfft_plan *plan, int op, const void *in, void *out, int nd
         }
     }
     if (!out_dense && (rc = ws.bounce_out[0].reserve(obytes))) return rc;   // before anything is in flight
-    NDFFT_HIP(hipMemcpy(ws.stage_in.p, hin, ibytes, hipMemcpyHostToDevice));
+    // (a copy that fails may have met a stale cached registration over the caller's array -- see HostRegCache: forget it and try once more)
+    auto copy_host = [](void *dst, const void *src, size_t bytes, hipMemcpyKind kind, const void *host_side) -> int {
+        if (hipMemcpy(dst, src, bytes, kind) == hipSuccess) return NDFFT_OK;
+        (void)hipGetLastError();
+        if (!HostRegCache::get().forget(host_side)) return fail(NDFFT_ERR_HIP, "hipMemcpy between the caller's array and the device failed");
+        NDFFT_HIP(hipMemcpy(dst, src, bytes, kind));
+        return NDFFT_OK;
+    };
+    if ((rc = copy_host(ws.stage_in.p, hin, ibytes, hipMemcpyHostToDevice, hin))) return rc;
     const char *din = (const char *)ws.stage_in.p - ilo * (int64_t)ein;
     char *dout = (char *)ws.stage_out.p - olo * (int64_t)eout;
     rc = dispatch_peeled(P, din, dout, ein, eout, (hipStream_t) nullptr);
     if (rc) { (void)hipStreamSynchronize(nullptr); return rc; }
     if (out_dense) {
-        NDFFT_HIP(hipMemcpy(hout, ws.stage_out.p, obytes, hipMemcpyDeviceToHost));   // synchronises with the kernel
+        if ((rc = copy_host(hout, ws.stage_out.p, obytes, hipMemcpyDeviceToHost, hout))) return rc;   // synchronises with the kernel
     } else {
         // The output view has holes.  They belong to the caller (possibly to ANOTHER thread's &mut view of the same
         // allocation), so they are neither read nor written: the span comes back into a private pinned image and only
@@ -1464,6 +1496,12 @@ int ndfft_exec(const ndfft_plan *plan, int op, const void *in, void *out, int nd
         NDFFT_HIP(hipMemcpy(ws.bounce_out[0].p, ws.stage_out.p, obytes, hipMemcpyDeviceToHost));
         copy_view_elements((char *)out, (const char *)ws.bounce_out[0].p - olo * (int64_t)eout, ndim, shape_out, stride_out, eout);
     }
+    return NDFFT_OK;
+}
+
+int ndfft_host_reg_cache(size_t max_bytes) {
+    clear_err();
+    HostRegCache::get().set_limit(max_bytes);
     return NDFFT_OK;
 }
 

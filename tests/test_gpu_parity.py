@@ -43,6 +43,7 @@ def test_host_registration_cache(L):
     n = 1024
     x = synth.complex_array((4096, n)); yo = np.zeros_like(x); orc.ndfft_par(x, yo, orc.FftHandler(n), 1)
     h = handlers.FftHandler(n, _library=L)
+    L.check(L.c.ndfft_host_reg_cache(1 << 30))                   # opt-in
     ys = []
     for k in range(4):
         y = np.zeros_like(x) if k == 0 else ys[0]
@@ -59,7 +60,15 @@ def test_host_registration_cache(L):
     for k in range(3):
         api.ndfft(x[:2048], ys[0][:2048], h, 1)
     assert_close(ys[0][:2048], yo[:2048], 1, 1e-10, "sub-range of a seen array")
-    L.c.ndfft_host_forget(None)
+    # the hazard the cache is opt-in for: arrays freed while registered, their addresses handed out again -- the library must recover
+    for rep in range(4):
+        a = synth.complex_array((4096, n), offset=rep); b = np.zeros_like(a)
+        for k in range(3):
+            api.ndfft(a, b, h, 1)
+        bo = np.zeros_like(a); orc.ndfft_par(a, bo, orc.FftHandler(n), 1)
+        assert_close(b, bo, 1, 1e-10, f"freed and reallocated arrays, round {rep}")
+        del a, b
+    L.check(L.c.ndfft_host_reg_cache(0))
 
 
 def test_sharded_device_resident_pipeline_on_one_gpu(L, monkeypatch):
