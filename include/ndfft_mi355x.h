@@ -188,9 +188,10 @@ int ndfft_host_free(void *h_ptr);
  * registration.  When on, the SECOND ndfft_exec on the same array registers it with the driver (hipHostRegister, once) and later calls on
  * it run the pinned pipeline (2 x 256 MiB: ~6.2 ms instead of 8-10 ms through bounce buffers); one-shot arrays never pay.
  * Contract: before freeing (or reallocating) an array that has been through ndfft_exec, call ndfft_host_forget(ptr) -- the registration
- * covering ptr is dropped; NULL drops all.  A registration that outlives its array makes HIP reject later copies from the reused
- * addresses ("invalid argument"), in this library (which recovers: it forgets the range and retries through the bounce buffers) and in any
- * other code of the process (which does not) -- hence off by default. */
+ * covering ptr is dropped; NULL drops all.  A registration that outlives its array makes later copies from the reused addresses fail
+ * ("invalid argument": this library then forgets the range and retries through the bounce buffers) or ABORT inside the HIP runtime
+ * (measured on the MI355X, ROCm 7.2), in this library and in any other code of the process -- hence off by default, and only for
+ * callers that own their arrays' lifetimes. */
 int ndfft_host_reg_cache(size_t max_bytes);
 int ndfft_host_forget(const void *h_ptr);
 

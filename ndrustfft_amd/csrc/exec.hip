@@ -1107,10 +1107,10 @@ bool is_pinned(const void *p) {
 // LRU, from then on its calls run the pinned pipeline.  One-shot arrays never pay.
 // OPT-IN (ndfft_host_reg_cache / NDFFT_HOST_REG_CACHE_MB, default 0 = off), because a registration outlives the array: when the caller
 // frees a registered array and the allocator hands the addresses out again, HIP still treats them as the old pinned object and EVERY copy
-// from or to them -- this library's, torch's, the caller's own -- fails with "invalid argument" (seen on the MI355X with numpy arrays in
-// the first version, which had the cache on by default).  This library recovers (it forgets the range and retries through the bounce
-// buffers) but cannot protect other code, so only a caller that owns its arrays' lifetimes should switch it on, and call
-// ndfft_host_forget before freeing them.
+// from or to them -- this library's, torch's, the caller's own -- fails with "invalid argument" or aborts inside the HIP runtime (both seen
+// on the MI355X with numpy arrays in the first version, which had the cache on by default).  This library recovers from the error form
+// (it forgets the range and retries through the bounce buffers) but cannot protect other code nor survive the abort, so only a caller that
+// owns its arrays' lifetimes should switch it on, and it must call ndfft_host_forget before freeing them.
 class HostRegCache {
   public:
     static HostRegCache &get() { static HostRegCache *c = new HostRegCache; return *c; }
