@@ -259,6 +259,16 @@ def main():
         dist.all_reduce(one)                        # an RCCL collective: every rank is really there
         ranks_seen = int(one[0])
 
+    # which physical GPU each rank drives (name, PCI bus id, UUID): a SCALE run must show N DISTINCT devices
+    pr = torch.cuda.get_device_properties(local_rank)
+    me = {"rank": rank, "local_rank": local_rank, "name": pr.name,
+          "pci": f"{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', -1):02x}:{getattr(pr, 'pci_device_id', -1):02x}",
+          "uuid": str(getattr(pr, "uuid", "")), "hip_visible_devices": os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", ""))}
+    devices = [me]
+    if use_dist and world > 1:
+        devices = [None] * world
+        dist.all_gather_object(devices, me)
+
     n = args.n
     rows = args.rows
     h = FftHandler(n)
@@ -447,7 +457,8 @@ def main():
         out = {
             "metric": "GFFT-points/s, batched 1-D C2C FFT f64 along the contiguous axis (+ achieved HBM GB/s vs roofline)",
             "value": round(points / el / 1e9, 3), "unit": "GFFT-points/s",
-            "n_gpus": ngpu, "ranks_seen": ranks_seen, "steps": primary_steps, "warmup": args.warmup,
+            "n_gpus": ngpu, "ranks_seen": ranks_seen, "devices": devices, "distinct_devices": len({d["uuid"] or d["pci"] for d in devices}),
+            "steps": primary_steps, "warmup": args.warmup,
             "ms_per_step": round(el / primary_steps * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
