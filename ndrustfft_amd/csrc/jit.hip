@@ -230,16 +230,37 @@ std::string cache_dir() {
     return d;
 }
 uint64_t fnv1a(uint64_t h, const char *p, size_t n) { for (size_t i = 0; i < n; ++i) { h ^= (unsigned char)p[i]; h *= 1099511628211ull; } return h; }
+std::string cache_name(const std::string &src, const char *const *hs, int nh);
 std::string cache_path(const std::string &src, const char *const *hs, int nh) {
     const std::string d = cache_dir();
     if (d.empty()) return "";
+    return d + cache_name(src, hs, nh);
+}
+std::string cache_name(const std::string &src, const char *const *hs, int nh) {
     uint64_t h = 1469598103934665603ull;
     h = fnv1a(h, src.data(), src.size());
     for (int i = 0; i < nh; ++i) h = fnv1a(h, hs[i], strlen(hs[i]));
     for (const char *o : kJitOpts) h = fnv1a(h, o, strlen(o));
     char name[40];
     snprintf(name, sizeof name, "/%016llx.hsaco", (unsigned long long)h);
-    return d + name;
+    return name;
+}
+// A second, READ-ONLY location is looked up after the user's cache: <directory of this library>/jit_prebuilt (NDFFT_JIT_PREBUILT
+// overrides; "0" disables).  It ships code objects for the reference's own test / bench / example lengths (3, 6, 264, 129, 265, 513,
+// 1025 -- tools/prebuild_jit.py writes it on an MI355X), so that a first nd* call on those never waits ~0.5 s for hiprtc.  Same file
+// names (hash of source + headers + options): an object built from other kernel text is simply not found.
+std::string prebuilt_path(const std::string &cache_file_path_or_name) {
+    static const std::string dir = [] {
+        if (const char *e = getenv("NDFFT_JIT_PREBUILT")) return (!e[0] || !strcmp(e, "0")) ? std::string() : std::string(e);
+        Dl_info info;
+        if (!dladdr((const void *)&fnv1a, &info) || !info.dli_fname) return std::string();
+        std::string p = info.dli_fname;
+        const size_t k = p.find_last_of('/');
+        return (k == std::string::npos ? std::string(".") : p.substr(0, k)) + "/jit_prebuilt";
+    }();
+    if (dir.empty()) return "";
+    const size_t k = cache_file_path_or_name.find_last_of('/');
+    return dir + "/" + (k == std::string::npos ? cache_file_path_or_name : cache_file_path_or_name.substr(k + 1));
 }
 bool read_file(const std::string &path, std::string &out) {
     FILE *f = fopen(path.c_str(), "rb");
@@ -267,6 +288,12 @@ static Entry compile_entry(const std::string &src, const std::string &what) {
         const std::string path = cache_path(src, hs0, 9);
         std::string code;
         if (!path.empty() && read_file(path, code) && hipModuleLoadData(&ne.mod, code.data()) == hipSuccess &&
+            hipModuleGetFunction(&ne.fn, ne.mod, "k_jit") == hipSuccess)
+            return ne;
+        (void)hipGetLastError();
+        ne = Entry();
+        const std::string pre = prebuilt_path(cache_name(src, hs0, 9));    // shipped with the library
+        if (!pre.empty() && read_file(pre, code) && hipModuleLoadData(&ne.mod, code.data()) == hipSuccess &&
             hipModuleGetFunction(&ne.fn, ne.mod, "k_jit") == hipSuccess)
             return ne;
         (void)hipGetLastError();
@@ -428,9 +455,12 @@ int launch_jit_regreal(int dtype, int gop, int n, int f1, int f2, bool stage, co
     const char *tn = dtype == NDFFT_F32 ? "float" : "double";
     const std::string inst = std::string("RegReal<") + tn + ", " + std::to_string(gop) + ", " + std::to_string(n) + ", " + std::to_string(f1) + ", " +
                              std::to_string(f2) + ", " + std::to_string(lanes) + ", " + (stage ? "true" : "false") + ">";
-    const std::string src = std::string("#include \"reg_kernel.h\"\nusing namespace ndfft;\nextern \"C\" __global__ __launch_bounds__(") +
+    // developer switch (read per call): NDFFT_REPRO_MASKED_TAIL=1 builds the predicated-tail form of the staging loads -- see reg_kernel.h
+    const char *rp = getenv("NDFFT_REPRO_MASKED_TAIL");
+    const bool repro = rp && rp[0] == '1';
+    const std::string src = std::string(repro ? "#define NDFFT_REPRO_MASKED_TAIL 1\n" : "") + "#include \"reg_kernel.h\"\nusing namespace ndfft;\nextern \"C\" __global__ __launch_bounds__(" +
                             std::to_string(lanes) + ") void k_jit(const RegRealArgs a) { " + inst + "::run(a); }\n";
-    const Entry e = get_or_compile("dev" + std::to_string(dev) + ":" + inst, src, inst);
+    const Entry e = get_or_compile("dev" + std::to_string(dev) + ":" + inst + (repro ? ":masked-tail" : ""), src, inst);
     if (e.failed) return NDFFT_ERR_UNSUPPORTED;
     const int64_t nblk = (a.t.nlanes + lanes - 1) / lanes;
     if (nblk <= 0) return NDFFT_OK;

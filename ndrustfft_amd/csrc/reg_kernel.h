@@ -162,8 +162,17 @@ template <typename T, int OP, int N, int F1, int F2, int LANES, bool STAGE> stru
             const int64_t c0 = (int64_t)blockIdx.x * THREADS * NI, total = a.nlanes * NI;
             const T *in = (const T *)a.in + c0;
             const int last = (int)std_min64(total - c0, (int64_t)THREADS * NI) - 1;
+#ifdef NDFFT_REPRO_MASKED_TAIL
+            // REPRODUCER ONLY (tools/repro_masked_tail.py, NDFFT_REPRO_MASKED_TAIL=1): the tail workgroup PREDICATES its loads, the form this
+            // kernel was first written in.  On the MI355X (ROCm 7.2, hiprtc) every lane of the last workgroup came out wrong for n = 40 and 48
+            // in f64 -- the raw lane lives partly in AGPRs there (256 VGPRs + AGPR spill) and the exec-masked loads into those registers lost
+            // their values.  The product clamps the addresses instead (below): every thread executes every load.
+#pragma unroll
+            for (int k = 0; k < NI; ++k) { const int g = threadIdx.x + k * THREADS; raw[k] = (T)0; if (g <= last) raw[k] = in[g]; }
+#else
 #pragma unroll
             for (int k = 0; k < NI; ++k) { const int g = threadIdx.x + k * THREADS; raw[k] = in[g < last ? g : last]; }
+#endif
 #pragma unroll
             for (int k = 0; k < NI; ++k) { const int g = threadIdx.x + k * THREADS; lds[(g / NI) * PI_ + g % NI] = raw[k]; }
             __syncthreads();
