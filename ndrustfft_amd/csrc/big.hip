@@ -75,7 +75,7 @@ int launch_blue_stage(int stage, cpx<T> *dst, int64_t pitch_dst, const cpx<T> *s
 template int launch_blue_stage<float>(int, cpx<float> *, int64_t, const cpx<float> *, int64_t, int64_t, int, int, const cpx<float> *, const cpx<float> *, int, float, hipStream_t);
 template int launch_blue_stage<double>(int, double2 *, int64_t, const double2 *, int64_t, int64_t, int, int, const double2 *, const double2 *, int, double, hipStream_t);
 
-template <typename T, int OP> __global__ __launch_bounds__(256) void k_big_pre(const RealArgs<T> a, cpx<T> *z) {
+template <typename T, int OP> __global__ __launch_bounds__(256) void k_big_pre(const RealArgs<T> a, cpx<T> *z, int conj_z) {
     constexpr bool in_cplx = OP == G_C2R_EVEN || OP == G_C2R_ODD;
     const int64_t total = a.nlanes * a.F;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -85,6 +85,7 @@ template <typename T, int OP> __global__ __launch_bounds__(256) void k_big_pre(c
         if constexpr (OP == G_R2C_EVEN) v = ((const cpx<T> *)raw)[k];
         else if constexpr (OP == G_R2C_ODD) v = mk<T>(((const T *)raw)[k], (T)0);
         else v = pre_elem<T, OP, ZiNone>(a, raw, k);
+        if (conj_z) v.y = -v.y;
         z[i] = v;
     }
 }
@@ -126,10 +127,10 @@ int launch_pack_lanes(const void *strided, void *dense, const LaneGeom &g, int64
 #define NDFFT_BIG_OPS(X) X(G_R2C_EVEN) X(G_R2C_ODD) X(G_C2R_EVEN) X(G_C2R_ODD) X(G_DCT1) X(G_DCT2_EVEN) X(G_DCT2_ODD) \
     X(G_DCT3_EVEN) X(G_DCT3_ODD) X(G_DCT4_EVEN) X(G_DCT4_ODD)
 
-template <typename T> int launch_big_pre(int op, const RealArgs<T> &a, cpx<T> *z, hipStream_t s) {
+template <typename T> int launch_big_pre(int op, const RealArgs<T> &a, cpx<T> *z, hipStream_t s, int conj_z) {
     const unsigned grid = (unsigned)std::min<int64_t>((a.nlanes * a.F + 255) / 256, 8192);
     switch (op) {
-#define NDFFT_C(OP) case OP: hipLaunchKernelGGL((k_big_pre<T, OP>), dim3(grid), dim3(256), 0, s, a, z); break;
+#define NDFFT_C(OP) case OP: hipLaunchKernelGGL((k_big_pre<T, OP>), dim3(grid), dim3(256), 0, s, a, z, conj_z); break;
         NDFFT_BIG_OPS(NDFFT_C)
 #undef NDFFT_C
         default: return fail(NDFFT_ERR_INVALID_ARG, "big pre: bad op");
@@ -148,8 +149,8 @@ template <typename T> int launch_big_post(int op, const RealArgs<T> &a, const cp
     NDFFT_HIP(hipGetLastError());
     return NDFFT_OK;
 }
-template int launch_big_pre<float>(int, const RealArgs<float> &, cpx<float> *, hipStream_t);
-template int launch_big_pre<double>(int, const RealArgs<double> &, double2 *, hipStream_t);
+template int launch_big_pre<float>(int, const RealArgs<float> &, cpx<float> *, hipStream_t, int);
+template int launch_big_pre<double>(int, const RealArgs<double> &, double2 *, hipStream_t, int);
 template int launch_big_post<float>(int, const RealArgs<float> &, const cpx<float> *, hipStream_t);
 template int launch_big_post<double>(int, const RealArgs<double> &, const double2 *, hipStream_t);
 

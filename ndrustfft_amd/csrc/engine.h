@@ -225,7 +225,7 @@ template <typename T>
 int launch_blue_stage(int stage, cpx<T> *dst, int64_t pitch_dst, const cpx<T> *src, int64_t pitch_src, int64_t lanes, int F, int M,
                       const cpx<T> *chirp, const cpx<T> *bhat, int inverse, T scale, hipStream_t s);   // 0 pre, 1 mid, 2 post (big.hip)
 template <typename T>
-int launch_big_pre(int gen_op, const RealArgs<T> &a, cpx<T> *z, hipStream_t s);    // raw lanes (a.in, a.pitch_in) -> z[lane][F]
+int launch_big_pre(int gen_op, const RealArgs<T> &a, cpx<T> *z, hipStream_t s, int conj_z = 0);    // raw lanes (a.in, a.pitch_in) -> z[lane][F] (conj_z: its conjugate)
 template <typename T>
 int launch_big_post(int gen_op, const RealArgs<T> &a, const cpx<T> *z, hipStream_t s);   // z[lane][F] -> a.out
 size_t generic_max_len(size_t csize);   // longest complex FFT the single-launch LDS kernel can hold

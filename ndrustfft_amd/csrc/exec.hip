@@ -667,9 +667,26 @@ static int dispatch_big(const Problem &P, const void *d_in, void *d_out, const D
     void *z;
     int rc;
     if ((rc = get_scratch(4, stream, (size_t)(P.nlanes * c.F) * sizeof(cpx<T>), &z))) return rc;
-    if ((rc = launch_big_pre<T>(gop, a, (cpx<T> *)z, stream))) return rc;
-    if ((rc = big_fft<T>(c, d, (const cpx<T> *)z, c.F, (cpx<T> *)z, c.F, P.nlanes, false, (T)1, stream))) return rc;
-    rc = launch_big_post<T>(gop, a, (const cpx<T> *)z, stream);
+    // Two of the ops need only ONE of the elementwise passes over global memory (round 3):
+    //   R2C, even n: the PRE fold is z[i] = (x[2i], x[2i+1]) -- the raw real lane read as complex.  The FFT takes the input array itself.
+    //   C2R, even n: the POST is x[2k] = Re, x[2k+1] = -Im of the forward FFT of conj(Zt) -- i.e. the inverse-by-conjugation of Zt written
+    //                into the real output lane read as complex.  PRE emits Zt, the FFT runs as an inverse and stores the result itself.
+    const bool cplx_view_ok = [&] {   // a real lane can be addressed as complex elements: even pitch, complex-aligned base
+        const void *p = gop == G_R2C_EVEN ? d_in : (const void *)d_out;
+        const int64_t pitch = gop == G_R2C_EVEN ? pin : pout;
+        return pitch % 2 == 0 && (uintptr_t)p % sizeof(cpx<T>) == 0;
+    }();
+    if (gop == G_R2C_EVEN && cplx_view_ok) {
+        if ((rc = big_fft<T>(c, d, (const cpx<T> *)d_in, pin / 2, (cpx<T> *)z, c.F, P.nlanes, false, (T)1, stream))) return rc;
+        rc = launch_big_post<T>(gop, a, (const cpx<T> *)z, stream);
+    } else if (gop == G_C2R_EVEN && cplx_view_ok) {
+        if ((rc = launch_big_pre<T>(gop, a, (cpx<T> *)z, stream, 1))) return rc;
+        rc = big_fft<T>(c, d, (const cpx<T> *)z, c.F, (cpx<T> *)d_out, pout / 2, P.nlanes, true, (T)1, stream);
+    } else {
+        if ((rc = launch_big_pre<T>(gop, a, (cpx<T> *)z, stream))) return rc;
+        if ((rc = big_fft<T>(c, d, (const cpx<T> *)z, c.F, (cpx<T> *)z, c.F, P.nlanes, false, (T)1, stream))) return rc;
+        rc = launch_big_post<T>(gop, a, (const cpx<T> *)z, stream);
+    }
     set_last_path(c.bigblue ? "blue_global" : "four_step");
     return rc;
 }

@@ -706,7 +706,9 @@ def long_lanes_four_step(L, full=True):
              ("nddct3", (2, 12000), 1, np.float64, "four_step"), ("nddct1", (2, 10001), 1, np.float64, "four_step"),
              ("nddct4", (2, 12000), 1, np.float64, "four_step"), ("ndfft", (2, 65536), 1, np.float32, "four_step"),
              ("ndfft", (20000, 3), 0, np.float64, "transpose+four_step"), ("ndfft_r2c", (2, 9999), 1, np.float64, "four_step"),
-             ("nddct2", (2, 9999), 1, np.float32, "four_step")]
+             ("nddct2", (2, 9999), 1, np.float32, "four_step"),
+             # R2C without its PRE pass / C2R without its POST pass (the real lane addressed as complex), two-pass power-of-two route
+             ("ndfft_r2c", (2, 1 << 17), 1, np.float32, "four_step"), ("ndifft_r2c", (3, 1 << 17), 1, np.float64, "four_step")]
     if full:
         cases += [("ndfft", (2, 1 << 20), 1, np.float64, "four_step"), ("ndfft", (2, 1 << 20), 1, np.float32, "four_step"), ("ndifft", (3, 1 << 19), 1, np.float32, "four_step"), ("ndifft", (1, 1 << 22), 1, np.float32, "four_step"),
                   ("nddct2", (3, 1 << 18), 1, np.float64, "four_step"), ("ndfft_r2c", (2, 3 * (1 << 17)), 1, np.float32, "four_step")]
@@ -714,6 +716,7 @@ def long_lanes_four_step(L, full=True):
         assert run_case(L, name, shape, axis, rdt) == want, (name, shape)
     # the power-of-two lengths above took the two-pass form (column load / row store, then twiddled column pass); the
     # three-pass form they replace stays covered, and both directions / norms of the new one on an odd lane count
+    assert run_case(L, "ndifft_r2c", (2, 1 << 16), 1, np.float32, norm="None") == "four_step"
     for name in ("ndfft", "ndifft"):
         for norm in ("Default", "None"):
             assert run_case(L, name, (3, 32768), 1, np.float64, norm=norm) == "four_step"
