@@ -396,5 +396,11 @@ inline void set_par_devices(std::vector<int> ids) { detail::par_devices_ref() = 
 
 /// Frees the calling thread's device scratch and staging buffers (the engine keeps them for reuse).
 inline void release_workspace() { detail::check(ndfft_release_workspace()); }
+// Opt-in: the library registers a caller-owned host array on its second use and DMAs straight from / to it afterwards.  Call
+// host_forget(ptr) before freeing such an array (include/ndfft_mi355x.h: ndfft_host_reg_cache).
+inline void host_reg_cache(size_t max_bytes) { detail::check(ndfft_host_reg_cache(max_bytes)); }
+inline void host_forget(const void *ptr) { detail::check(ndfft_host_forget(ptr)); }
+// Where the input of this thread's next device-resident calls comes from (speed only): NDFFT_INPUT_AUTO / _CACHED / _COLD
+inline void set_input_hint(int hint) { detail::check(ndfft_set_input_hint(hint)); }
 
 }  // namespace ndrustfft

@@ -74,4 +74,9 @@ extern "C" {
     /// pinned host memory: ndfft_exec on arrays that both live in it overlaps upload, transform and download
     pub fn ndfft_host_alloc(h_ptr: *mut *mut c_void, bytes: usize) -> c_int;
     pub fn ndfft_host_free(h_ptr: *mut c_void) -> c_int;
+    /// opt-in registration cache for the caller's own (pageable) arrays; `ndfft_host_forget` BEFORE such an array is freed
+    pub fn ndfft_host_reg_cache(max_bytes: usize) -> c_int;
+    pub fn ndfft_host_forget(h_ptr: *const c_void) -> c_int;
+    /// 0 = auto (the library's Infinity-Cache model), 1 = the input is cache-resident, 2 = it comes from HBM; per host thread
+    pub fn ndfft_set_input_hint(hint: c_int) -> c_int;
 }

@@ -257,7 +257,7 @@ transform!(/// DCT-IV along `axis`.
 /// Device-resident arrays: keep the `work` array of a multi-axis transform (examples/fft2.rs:23-27 in the
 /// reference) in HBM between the axis passes instead of crossing PCIe twice per call.
 /// No counterpart in ndrustfft; the functions mirror the host ones (same names, same handlers, same axis
-/// semantics) on `DeviceArray`s.  `Normalization::Custom` needs host lanes and is rejected here.
+/// semantics) on `DeviceArray`s.  `Normalization::Custom` is a host function: it costs one round trip of the array it acts on.
 pub mod device {
     use super::*;
 
@@ -303,30 +303,74 @@ pub mod device {
         fn drop(&mut self) { unsafe { ffi::ndfft_dev_free(self.ptr) }; }
     }
 
+    impl<A: Copy + Zero> DeviceArray<A> {
+        /// `Normalization::Custom(f)` is a host function: the array makes one round trip through host memory, `f` runs on every
+        /// lane along `axis` there (the same `apply_custom` the host functions use), and the result is uploaded again.
+        fn map_lanes_on_host(&self, axis: usize, f: fn(&mut [A])) -> DeviceArray<A> {
+            let len: usize = self.shape.iter().product();
+            let mut host = ndarray::ArrayD::<A>::from_elem(ndarray::IxDyn(&self.shape), A::zero());
+            check(unsafe { ffi::ndfft_dev_sync(std::ptr::null_mut()) });
+            check(unsafe { ffi::ndfft_dev_download(host.as_mut_ptr() as *mut c_void, self.ptr, len * std::mem::size_of::<A>()) });
+            apply_custom(&mut host, axis, f);
+            DeviceArray::from_host(&host)
+        }
+    }
+
+    fn exec_device<T: FftNum + FloatConst, A, B>(plan: &Plan, op: c_int, input: &DeviceArray<A>, output: &mut DeviceArray<B>, axis: usize, mode: c_int)
+    where A: Copy, B: Copy {
+        let (si, sti) = input.geom();
+        let (so, sto) = output.geom();
+        check(unsafe {
+            ffi::ndfft_exec_device(plan.0, op, input.ptr, output.ptr, si.len() as c_int, si.as_ptr(), sti.as_ptr(),
+                                   so.as_ptr(), sto.as_ptr(), axis as c_int, mode, 0.0, std::ptr::null_mut())
+        });
+    }
+
+    // the same three application points as the host functions (`transform_body!`): ignored / after / before
     macro_rules! device_transform {
-        ($name:ident, $a:ty, $b:ty, $h:ident, $op:expr) => {
+        ($name:ident, $a:ty, $b:ty, $h:ident, $op:expr, ignored) => {
             /// Device-resident twin of the host function of the same name (asynchronous on the null stream).
             pub fn $name<T: FftNum + FloatConst>(input: &DeviceArray<$a>, output: &mut DeviceArray<$b>, handler: &$h<T>, axis: usize) {
-                let mode = match handler.norm {
-                    Normalization::None => ffi::NDFFT_NORM_NONE,
-                    Normalization::Default => ffi::NDFFT_NORM_DEFAULT,
-                    Normalization::Custom(_) => panic!("Normalization::Custom needs host lanes: use the host functions"),
-                };
-                let (si, sti) = input.geom();
-                let (so, sto) = output.geom();
-                check(unsafe {
-                    ffi::ndfft_exec_device(handler.plan.0, $op, input.ptr, output.ptr, si.len() as c_int, si.as_ptr(), sti.as_ptr(),
-                                           so.as_ptr(), sto.as_ptr(), axis as c_int, mode, 0.0, std::ptr::null_mut())
-                });
+                check_axis(output.shape.len(), axis);
+                let mode = match handler.norm { Normalization::Default => ffi::NDFFT_NORM_DEFAULT, _ => ffi::NDFFT_NORM_NONE };
+                exec_device::<T, $a, $b>(&handler.plan, $op, input, output, axis, mode);
+            }
+        };
+        ($name:ident, $a:ty, $b:ty, $h:ident, $op:expr, after) => {
+            /// Device-resident twin of the host function of the same name.  `Normalization::Custom` runs on the host, on the OUTPUT
+            /// lanes after the transform (src/lib.rs:326-330): one extra round trip of the output array.
+            pub fn $name<T: FftNum + FloatConst>(input: &DeviceArray<$a>, output: &mut DeviceArray<$b>, handler: &$h<T>, axis: usize) {
+                check_axis(output.shape.len(), axis);
+                let mode = match handler.norm { Normalization::Default => ffi::NDFFT_NORM_DEFAULT, _ => ffi::NDFFT_NORM_NONE };
+                exec_device::<T, $a, $b>(&handler.plan, $op, input, output, axis, mode);
+                if let Normalization::Custom(f) = handler.norm {
+                    let fixed = output.map_lanes_on_host(axis, f);
+                    *output = fixed;
+                }
+            }
+        };
+        ($name:ident, $a:ty, $b:ty, $h:ident, $op:expr, before) => {
+            /// Device-resident twin of the host function of the same name.  `Normalization::Custom` runs on the host, on a copy of the
+            /// INPUT lanes before the transform (src/lib.rs:511-515, 692-696): one extra round trip of the input array.
+            pub fn $name<T: FftNum + FloatConst>(input: &DeviceArray<$a>, output: &mut DeviceArray<$b>, handler: &$h<T>, axis: usize) {
+                check_axis(output.shape.len(), axis);
+                if let Normalization::Custom(f) = handler.norm {
+                    let staged = input.map_lanes_on_host(axis, f);
+                    exec_device::<T, $a, $b>(&handler.plan, $op, &staged, output, axis, ffi::NDFFT_NORM_NONE);
+                    check(unsafe { ffi::ndfft_dev_sync(std::ptr::null_mut()) });   // `staged` is freed on return
+                } else {
+                    let mode = match handler.norm { Normalization::Default => ffi::NDFFT_NORM_DEFAULT, _ => ffi::NDFFT_NORM_NONE };
+                    exec_device::<T, $a, $b>(&handler.plan, $op, input, output, axis, mode);
+                }
             }
         };
     }
-    device_transform!(ndfft, Complex<T>, Complex<T>, FftHandler, ffi::NDFFT_OP_C2C_FWD);
-    device_transform!(ndifft, Complex<T>, Complex<T>, FftHandler, ffi::NDFFT_OP_C2C_INV);
-    device_transform!(ndfft_r2c, T, Complex<T>, R2cFftHandler, ffi::NDFFT_OP_R2C);
-    device_transform!(ndifft_r2c, Complex<T>, T, R2cFftHandler, ffi::NDFFT_OP_C2R);
-    device_transform!(nddct1, T, T, DctHandler, ffi::NDFFT_OP_DCT1);
-    device_transform!(nddct2, T, T, DctHandler, ffi::NDFFT_OP_DCT2);
-    device_transform!(nddct3, T, T, DctHandler, ffi::NDFFT_OP_DCT3);
-    device_transform!(nddct4, T, T, DctHandler, ffi::NDFFT_OP_DCT4);
+    device_transform!(ndfft, Complex<T>, Complex<T>, FftHandler, ffi::NDFFT_OP_C2C_FWD, ignored);
+    device_transform!(ndifft, Complex<T>, Complex<T>, FftHandler, ffi::NDFFT_OP_C2C_INV, after);
+    device_transform!(ndfft_r2c, T, Complex<T>, R2cFftHandler, ffi::NDFFT_OP_R2C, ignored);
+    device_transform!(ndifft_r2c, Complex<T>, T, R2cFftHandler, ffi::NDFFT_OP_C2R, before);
+    device_transform!(nddct1, T, T, DctHandler, ffi::NDFFT_OP_DCT1, before);
+    device_transform!(nddct2, T, T, DctHandler, ffi::NDFFT_OP_DCT2, before);
+    device_transform!(nddct3, T, T, DctHandler, ffi::NDFFT_OP_DCT3, before);
+    device_transform!(nddct4, T, T, DctHandler, ffi::NDFFT_OP_DCT4, before);
 }
