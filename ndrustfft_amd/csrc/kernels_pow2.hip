@@ -121,11 +121,18 @@ bool stream_loads_for(size_t in_bytes) {
     return in_bytes > ((size_t)384 << 20);
 }
 
-template <typename T, int N, int NT, int VEC, int FL = 0> static int launch_inst(const Pow2Args &a0, hipStream_t s) {
+// Position-split exchange (pow2_kernel.h: PSPLIT = 2) for the lengths whose lane fills a CU's LDS: two workgroups per CU instead of one.
+// NDFFT_PSPLIT=1 / 2 forces it off / on for n = 8192 and 16384 (A/B runs); default: the measured choice below.
+// Measured A-B-A-B on 2^24 points (profiles/r05/r05d_psplit_abab.txt): c64 n = 16384 65.5 -> 56.5 us (0.51 -> 0.59 of 8 TB/s), c64 n = 8192 51.8 -> 48.0 us
+// (0.65 -> 0.70); c128 n = 16384 unchanged (126 VGPRs x 1024 threads: registers, not LDS, keep it at one workgroup per CU), c128 n = 8192 -2 %.
+template <typename T, int N> struct Pow2PSplit { static constexpr int value = (sizeof(T) == 4 && N >= 8192) ? 2 : 1; };
+static int psplit_override() { static const int v = [] { const char *e = getenv("NDFFT_PSPLIT"); return e ? atoi(e) : 0; }(); return v; }
+
+template <typename T, int N, int NT, int VEC, int FL, int PS> static int launch_inst_ps(const Pow2Args &a0, hipStream_t s) {
     constexpr int TPL = Pow2Cfg<T, N>::TPL, LPB = lpb_for(TPL);
     // FLAGS bit 4 from n = 4096: late passes whose twiddle table exceeds 32 KiB load W^k, W^2k, W^4k (, W^8k) and build
     // the other powers (2-4 % on the instruction-bound long kernels; two extra roundings on those twiddles)
-    using K = Pow2Kernel<T, N, TPL, LPB, Pow2Half<T, N>::value, typename Pow2Cfg<T, N>::RL, FL | (N >= 4096 ? 16 : 0), 1, NT, VEC>;
+    using K = Pow2Kernel<T, N, TPL, LPB, Pow2Half<T, N>::value, typename Pow2Cfg<T, N>::RL, FL | (N >= 4096 ? 16 : 0), 1, NT, VEC, PS>;
     NDFFT_ENSURE_LDS_ATTR((k_pow2<K>));
     const int64_t nblk = (a0.nlanes + LPB - 1) / LPB;
     if (nblk <= 0) return NDFFT_OK;
@@ -135,6 +142,15 @@ template <typename T, int N, int NT, int VEC, int FL = 0> static int launch_inst
     hipLaunchKernelGGL(k_pow2<K>, dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, a);
     NDFFT_HIP(hipGetLastError());
     return NDFFT_OK;
+}
+template <typename T, int N, int NT, int VEC, int FL = 0> static int launch_inst(const Pow2Args &a, hipStream_t s) {
+    if constexpr (N >= 8192) {   // both forms exist for the two longest lengths
+        const int ov = psplit_override();
+        const int ps = ov == 1 || ov == 2 ? ov : Pow2PSplit<T, N>::value;
+        return ps == 2 ? launch_inst_ps<T, N, NT, VEC, FL, 2>(a, s) : launch_inst_ps<T, N, NT, VEC, FL, 1>(a, s);
+    } else {
+        return launch_inst_ps<T, N, NT, VEC, FL, 1>(a, s);
+    }
 }
 template <typename T, int N, int NT, int VEC, int FL = 0> static int launch_one(const Pow2Args &a, hipStream_t s) {
     static_assert(NT == 1, "callers name the store policy; the load policy is chosen here");

@@ -75,7 +75,11 @@ template <typename T, bool NT> __device__ __forceinline__ void gstore(cpx<T> *p,
 // VEC = 2 (f32 only): global loads/stores move TWO adjacent complex elements (16 B) per lane; the
 //   first and last pass then own adjacent butterfly pairs j = 2t, 2t+1 instead of j = t, t+TPL.
 //   Needs E/R >= 2 in those passes, even lane pitches and 16-byte aligned bases (checked on the host).
-template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS = 0, int MINW = 1, int NT = 1, int VEC = 1> struct Pow2Kernel {
+// PSPLIT = 2: every exchange runs in TWO position rounds through a buffer of N / 2 elements -- round A moves the elements whose Stockham
+//   position is below N / 2 (written by the butterflies j < N / (2 R), read as r < R' / 2 by every thread), round B the rest.  Twice the
+//   barriers, half the LDS: n = 16384 then takes 70 KiB per lane instead of 139 KiB, i.e. TWO workgroups per CU, so that one lane's load /
+//   store phases overlap the other's exchanges (round 3; needs whole butterfly rounds and power-of-two sizes).
+template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS = 0, int MINW = 1, int NT = 1, int VEC = 1, int PSPLIT = 1> struct Pow2Kernel {
     static constexpr int MIN_WAVES = MINW;
     // Pass p has N / R_p butterflies, dealt to the TPL threads of the lane in SLOTS(p) rounds: j = t + q TPL.
     // When TPL does not divide N / R_p the last round is PARTIAL (threads with j >= N / R_p idle): that is what
@@ -86,7 +90,8 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
     static constexpr int calc_e() { int e = 0; for (int p = 0; p < RL::NP; ++p) { const int x = slots(p) * RL::at(p); if (x > e) e = x; } return e; }
     static constexpr int E = calc_e();                                     // = N / TPL when every pass is full
     static constexpr int THREADS = TPL * LPB;
-    static constexpr int LANE_LDS = N + (N >> NDFFT_PHI_SHIFT) + 1;                      // padded elements per lane
+    static_assert(PSPLIT == 1 || PSPLIT == 2, "PSPLIT is 1 or 2");
+    static constexpr int LANE_LDS = N / PSPLIT + ((N / PSPLIT) >> NDFFT_PHI_SHIFT) + 1;   // padded elements per lane
     static constexpr size_t LDS_BYTES = (size_t)LPB * LANE_LDS * (HALF ? sizeof(T) : 2 * sizeof(T));
 
     // butterfly index owned by thread t, slot q, in pass P
@@ -136,13 +141,55 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
                 T *s = (T *)lds;
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
+                    // (PSPLIT = 2: round A's values wait in `keep` -- every thread still owns unwritten round-B values in v)
+                    T keep[PSPLIT == 2 ? NBF2 * (R2 / 2) : 1];
+#pragma unroll
+                    for (int ps = 0; ps < PSPLIT; ++ps) {
+                        __syncthreads();
+#pragma unroll
+                        for (int q = 0; q < NBF; ++q) {
+                            const int j = jof<P>(t, q), k = kmod<Ns>(j), o = (j - k) * R + k - ps * (N / 2), po = phi(o);
+                            if ((FULL || j < NB) && (PSPLIT == 1 || (j < NB / 2) == (ps == 0))) {
+#pragma unroll
+                                for (int r = 0; r < R; ++r) s[phi_at<Ns>(o, po, r)] = half ? v[q * R + r].y : v[q * R + r].x;
+                            }
+                        }
+                        __syncthreads();
+#pragma unroll
+                        for (int q = 0; q < NBF2; ++q) {
+                            const int j = jof<P + 1>(t, q), pj = phi(j);
+                            if (FULL2 || j < NB2) {
+#pragma unroll
+                                for (int r = 0; r < R2 / PSPLIT; ++r) {
+                                    const T x = s[phi_at<NB2>(j, pj, r)];     // round B: position j + (r + R2 / 2) NB2 - N / 2 = j + r NB2
+                                    if constexpr (PSPLIT == 2) {
+                                        if (ps == 0) { keep[q * (R2 / 2) + r] = x; continue; }
+                                    }
+                                    const int rr = r + ps * (R2 / 2);
+                                    if (half) v[q * R2 + rr].y = x; else v[q * R2 + rr].x = x;
+                                }
+                            }
+                        }
+                    }
+                    if constexpr (PSPLIT == 2) {
+#pragma unroll
+                        for (int q = 0; q < NBF2; ++q)
+#pragma unroll
+                            for (int r = 0; r < R2 / 2; ++r) { if (half) v[q * R2 + r].y = keep[q * (R2 / 2) + r]; else v[q * R2 + r].x = keep[q * (R2 / 2) + r]; }
+                    }
+                }
+            } else {
+                cpx<T> *s = (cpx<T> *)lds;
+                cpx<T> keep[PSPLIT == 2 ? NBF2 * (R2 / 2) : 1];
+#pragma unroll
+                for (int ps = 0; ps < PSPLIT; ++ps) {
                     __syncthreads();
 #pragma unroll
                     for (int q = 0; q < NBF; ++q) {
-                        const int j = jof<P>(t, q), k = kmod<Ns>(j), o = (j - k) * R + k, po = phi(o);
-                        if (FULL || j < NB) {
+                        const int j = jof<P>(t, q), k = kmod<Ns>(j), o = (j - k) * R + k - ps * (N / 2), po = phi(o);
+                        if ((FULL || j < NB) && (PSPLIT == 1 || (j < NB / 2) == (ps == 0))) {
 #pragma unroll
-                            for (int r = 0; r < R; ++r) s[phi_at<Ns>(o, po, r)] = half ? v[q * R + r].y : v[q * R + r].x;
+                            for (int r = 0; r < R; ++r) s[phi_at<Ns>(o, po, r)] = v[q * R + r];
                         }
                     }
                     __syncthreads();
@@ -151,32 +198,21 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
                         const int j = jof<P + 1>(t, q), pj = phi(j);
                         if (FULL2 || j < NB2) {
 #pragma unroll
-                            for (int r = 0; r < R2; ++r) {
-                                const T x = s[phi_at<NB2>(j, pj, r)];
-                                if (half) v[q * R2 + r].y = x; else v[q * R2 + r].x = x;
+                            for (int r = 0; r < R2 / PSPLIT; ++r) {
+                                const cpx<T> x = s[phi_at<NB2>(j, pj, r)];
+                                if constexpr (PSPLIT == 2) {
+                                    if (ps == 0) { keep[q * (R2 / 2) + r] = x; continue; }
+                                }
+                                v[q * R2 + r + ps * (R2 / 2)] = x;
                             }
                         }
                     }
                 }
-            } else {
-                cpx<T> *s = (cpx<T> *)lds;
-                __syncthreads();
+                if constexpr (PSPLIT == 2) {
 #pragma unroll
-                for (int q = 0; q < NBF; ++q) {
-                    const int j = jof<P>(t, q), k = kmod<Ns>(j), o = (j - k) * R + k, po = phi(o);
-                    if (FULL || j < NB) {
+                    for (int q = 0; q < NBF2; ++q)
 #pragma unroll
-                        for (int r = 0; r < R; ++r) s[phi_at<Ns>(o, po, r)] = v[q * R + r];
-                    }
-                }
-                __syncthreads();
-#pragma unroll
-                for (int q = 0; q < NBF2; ++q) {
-                    const int j = jof<P + 1>(t, q), pj = phi(j);
-                    if (FULL2 || j < NB2) {
-#pragma unroll
-                        for (int r = 0; r < R2; ++r) v[q * R2 + r] = s[phi_at<NB2>(j, pj, r)];
-                    }
+                        for (int r = 0; r < R2 / 2; ++r) v[q * R2 + r] = keep[q * (R2 / 2) + r];
                 }
             }
             passes<P + 1>(v, twp, lds, t);
