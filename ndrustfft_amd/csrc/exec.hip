@@ -283,7 +283,7 @@ struct Pipe {
 // HBM (0.74 vs 0.70).  Round 2 bet on "resident" for every input <= 384 MiB; a chain of nd* calls loses that bet at every link (the
 // output of a pass was written with nt stores, which bypass the cache).  The model tracks, per buffer this thread has transformed:
 //   * an input read with plain loads is resident until this thread's later plain reads have pushed ~256 MiB through the cache;
-//   * an input read with streaming loads, and every output (nt stores), is not resident;
+//   * an input read with streaming loads, and every output larger than 64 MiB (nt stores), is not resident;
 //   * a buffer the model has never seen keeps round 2's bet (plain loads up to 384 MiB) -- its producer is unknown.
 // ndfft_set_input_hint overrides it per host thread.  Speed only: either policy gives the same results.
 struct MallModel {
@@ -353,7 +353,9 @@ static int c2c_row_load_policy(const void *in, const void *out, size_t bytes) {
     int pol = force >= 0 ? (force != 0) : g_input_hint == NDFFT_INPUT_CACHED ? 0 : g_input_hint == NDFFT_INPUT_COLD ? 1 : ws->mall.decide(in, bytes);
     const bool nt = pol >= 0 ? pol != 0 : stream_loads_for(bytes);
     ws->mall.note(in, bytes, !nt);
-    ws->mall.note(out, bytes, false);            // nt stores: the output bypasses the cache
+    // nt stores: a large output bypasses the cache (fft -> ifft on 4096 x 4096 c128: the second pass is 3-5 % faster with streaming loads); a small
+    // one is still found there (1024 x 4096, 64 MiB: plain loads 2-3 % faster) -- tools/probes/chain_hint.py, profiles/r05/r05d_chain_hint.txt
+    ws->mall.note(out, bytes, bytes <= ((size_t)64 << 20));
     return nt ? 1 : 0;
 }
 static int get_scratch(int which, hipStream_t s, size_t bytes, void **out) {
