@@ -435,13 +435,19 @@ def main():
             try:
                 tdata = json.load(open(tj))
                 traffic = tdata.get(f"{rows}x{n}")
+                # the counters were collected for a particular kernel text: if the kernel sources have changed since, say so instead of
+                # quoting stale bytes (tools/pmc_source_sha.py prints the hash that tools/prof_bench.sh stores beside the counters)
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import pmc_source_sha
+                if tdata.get("kernel_source_sha") != pmc_source_sha.sha():
+                    traffic = None
                 traffic_src = tdata.get("source", "profiles/pmc_traffic.json (tools/pmc_traffic.sh: separate FETCH_SIZE / WRITE_SIZE "
                                                   "--pmc passes of this bench command, x2 gfx950 read correction)")
             except Exception:
                 traffic = None
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": traffic_src if traffic is not None else None,
+                "traffic_source": traffic_src if traffic is not None else "no PMC run on record for the current kernel sources (profiles/pmc_traffic.json is for older kernel text)",
                 "traffic_note": "PMC bytes from an EARLIER profiling run of this command (not measured by this process); "
                                 "FETCH_SIZE counts Infinity-Cache hits too" if traffic is not None else None,
                 "kernel": "k_pow2<double,4096>", "algorithmic_bytes_per_launch": bytes_per_launch,

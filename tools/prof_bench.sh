@@ -39,5 +39,21 @@ for ph in ("primary", "cold", "strong"):
         v["hbm_traffic_bytes_per_launch"] = v["read_bytes_x2_corrected"] + v["write_bytes"]
 json.dump(res, open(f"{out}/pmc_bench_summary.json", "w"), indent=1)
 print(json.dumps(res, indent=1)[:5000])
+# the file bench.py quotes `roofline.traffic` from, stamped with the hash of the kernel text these counters belong to
+import os, subprocess
+root = os.environ.get("GRAFT_REPO_ROOT", ".")
+def pick(ph, grid_lanes):
+    best = None
+    for k, v in res.get(ph, {}).items():
+        if "Pow2Kernel<double, 4096" in k and v["launches"]:
+            best = v["hbm_traffic_bytes_per_launch"]
+    return best
+tag = os.path.basename(out)
+tj = {"4096x4096": pick("primary", 4096), "4096x4096_cold_rotating": pick("cold", 4096), "65536x4096": pick("strong", 65536),
+      "kernel_source_sha": subprocess.check_output(["python3", os.path.join(root, "tools", "pmc_source_sha.py")], text=True).strip(),
+      "source": f"profiles/r05/{tag}_pmc_bench_summary.json (tools/prof_bench.sh {tag} pmc: separate FETCH_SIZE / WRITE_SIZE --pmc passes of `bench.py --profile-phase ...`, "
+                "x2 gfx950 read correction on FETCH_SIZE; kernel k_pow2<Pow2Kernel<double,4096,512,...>>)"}
+json.dump(tj, open(f"{out}/pmc_traffic.json", "w"), indent=1)
+print(json.dumps(tj, indent=1))
 PY
 fi
