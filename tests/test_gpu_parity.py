@@ -36,6 +36,34 @@ def test_reg_lanes(L): ps.reg_lanes(L)
 def test_regreal_lanes(L): ps.regreal_lanes(L, sizes=(12, 17, 18, 21, 24, 30, 42, 48), sizes_f32=(49, 64, 72))      # (every op x dtype x layout is one hiprtc compile: ~100 s for the default lists)
 def test_tinymat_lanes(L): ps.tinymat_lanes(L)
 def test_host_pipeline_pageable(L): ps.host_pipeline_pageable(L)
+def test_prebuilt_jit_objects_serve_reference_lengths():
+    """The code objects shipped beside the library (ndrustfft_amd/csrc/jit_prebuilt, tools/prebuild_jit.py) must serve the reference's own bench lengths
+    without hiprtc: a fresh process with the user cache disabled and compilation forbidden still takes the specialised kernels.  Fails when the kernel
+    headers have changed since the set was built (regenerate it on an MI355X)."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from ndrustfft_amd import DctHandler, FftHandler, _lib, nddct1, ndfft
+n = 264
+x = torch.zeros((n, n), dtype=torch.complex128, device="cuda:0"); y = torch.empty_like(x)
+ndfft(x, y, FftHandler(n), 0); p1 = _lib.default().last_path()
+xr = torch.zeros((265, 265), dtype=torch.float64, device="cuda:0"); yr = torch.empty_like(xr)
+nddct1(xr, yr, DctHandler(265), 0); p2 = _lib.default().last_path()
+xb = torch.zeros((4096, n), dtype=torch.complex128, device="cuda:0"); yb = torch.empty_like(xb)
+ndfft(xb, yb, FftHandler(n), 1); p3 = _lib.default().last_path()
+torch.cuda.synchronize()
+print("PATHS", p1, p2, p3)
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, NDFFT_JIT_CACHE="0", NDFFT_JIT_NOCOMPILE="1")
+    env.pop("NDFFT_JIT_PREBUILT", None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("PATHS")][-1].split()
+    assert line[1:] == ["jit_col", "jit_col", "jit_reg"], f"prebuilt code objects missing or stale (paths {line[1:]}): run tools/prebuild_jit.py on an MI355X"
+
+
 def test_masked_tail_loads_reproducer(L):
     """RegReal's tail workgroup clamps its staging addresses because predicated loads into AGPR-spilled registers lost values on the
     MI355X (n = 40, 48 in f64).  The product form must be right; the predicated form (tools/repro_masked_tail.py, NDFFT_REPRO_MASKED_TAIL=1) is built
