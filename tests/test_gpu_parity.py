@@ -42,6 +42,9 @@ def test_prebuilt_jit_objects_serve_reference_lengths():
     headers have changed since the set was built (regenerate it on an MI355X)."""
     import subprocess
     import sys
+    pre = os.path.join(ROOT, "ndrustfft_amd", "csrc", "jit_prebuilt")
+    if not os.path.isdir(pre) or not any(f.endswith(".hsaco") for f in os.listdir(pre)):
+        pytest.skip("no prebuilt code objects in this tree (tools/prebuild_jit.py writes them on an MI355X)")
     code = r"""
 import sys, numpy as np, torch
 sys.path.insert(0, %r); sys.path.insert(0, %r)
