@@ -30,7 +30,13 @@ template <typename T, int F> struct FsGeom {
     // adjacent lanes per tile: 128-byte rows (8 complex f64 / 16 complex f32), at least 256 threads.  Narrower than the
     // 32-lane tiles of the general column kernels on purpose: F = 256 f64 then takes 35 KiB of LDS instead of 140 KiB,
     // four workgroups per CU instead of one (256 x 65536 c128: 251 -> see DESIGN.md section 3.5)
-    static constexpr int MINL = sizeof(T) == 8 ? NDFFT_FS_LANES_F64 : NDFFT_FS_LANES_F32;
+#ifndef NDFFT_FS_LANES_F64_1024
+#define NDFFT_FS_LANES_F64_1024 NDFFT_FS_LANES_F64
+#endif
+#ifndef NDFFT_FS_LANES_F32_1024
+#define NDFFT_FS_LANES_F32_1024 NDFFT_FS_LANES_F32
+#endif
+    static constexpr int MINL = F == 1024 ? (sizeof(T) == 8 ? NDFFT_FS_LANES_F64_1024 : NDFFT_FS_LANES_F32_1024) : (sizeof(T) == 8 ? NDFFT_FS_LANES_F64 : NDFFT_FS_LANES_F32);
     static constexpr int LPB = TPL * MINL < 256 ? 256 / TPL : (TPL * MINL > 1024 ? 1024 / TPL : MINL);
     static_assert(TPL * LPB <= 1024, "workgroup too large");
 };
