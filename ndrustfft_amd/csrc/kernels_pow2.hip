@@ -139,7 +139,9 @@ template <typename T, int N, int NT, int VEC, int FL, int PS> static int launch_
     if (nblk > 0x7fffffffLL) return fail(NDFFT_ERR_UNSUPPORTED, "too many lanes for one launch");
     Pow2Args a = a0;
     a.xcd_chunk = xcd_chunk_for((size_t)LPB * N * sizeof(cpx<T>), nblk);
-    hipLaunchKernelGGL(k_pow2<K>, dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, a);
+    // developer knob (A/B only): extra dynamic LDS per workgroup = fewer resident workgroups per CU
+    static const size_t pad = [] { const char *e = getenv("NDFFT_POW2_LDS_PAD_KB"); return e ? (size_t)atoi(e) << 10 : (size_t)0; }();
+    hipLaunchKernelGGL(k_pow2<K>, dim3((unsigned)nblk), dim3(K::THREADS), std::min(K::LDS_BYTES + pad, (size_t)160 * 1024), s, a);
     NDFFT_HIP(hipGetLastError());
     return NDFFT_OK;
 }
