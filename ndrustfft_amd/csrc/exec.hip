@@ -345,8 +345,11 @@ static int current_ws(DeviceWs **out) {
     return NDFFT_OK;
 }
 static thread_local int g_input_hint = NDFFT_INPUT_AUTO;
+static bool F_nt_ok(int F) { return F >= 64; }   // (short lanes: the staging loads are not 16-byte vectors on every path)
 // load policy for the dense C2C row kernels on input `in` (Pow2Args::stream_in), and the bookkeeping for the next call
-static int c2c_row_load_policy(const void *in, const void *out, size_t bytes) {
+static int row_load_policy(const void *in, size_t bytes, const void *out, size_t out_bytes);
+static int c2c_row_load_policy(const void *in, const void *out, size_t bytes) { return row_load_policy(in, bytes, out, bytes); }
+static int row_load_policy(const void *in, size_t bytes, const void *out, size_t out_bytes) {
     static const int force = [] { const char *e = getenv("NDFFT_STREAM_LOADS"); return e ? atoi(e) : -1; }();   // developer switch: 0 / 1 forces a policy
     DeviceWs *ws;
     if (current_ws(&ws)) return -1;
@@ -355,7 +358,7 @@ static int c2c_row_load_policy(const void *in, const void *out, size_t bytes) {
     ws->mall.note(in, bytes, !nt);
     // nt stores: a large output bypasses the cache (fft -> ifft on 4096 x 4096 c128: the second pass is 3-5 % faster with streaming loads); a small
     // one is still found there (1024 x 4096, 64 MiB: plain loads 2-3 % faster) -- tools/probes/chain_hint.py, profiles/r05/r05d_chain_hint.txt
-    ws->mall.note(out, bytes, bytes <= ((size_t)64 << 20));
+    ws->mall.note(out, out_bytes, out_bytes <= ((size_t)64 << 20));
     return nt ? 1 : 0;
 }
 static int get_scratch(int which, hipStream_t s, size_t bytes, void **out) {
@@ -936,6 +939,9 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
                 a.vec_in = !col && ((uintptr_t)d_in % 16 == 0) && ((size_t)a.pitch_in * es_in) % 16 == 0;
                 a.xcd_remap = 0; a.keep_out = P.keep_out; a.stream_in = P.stream_in; a.xcd_chunk = P.no_xcd_map ? 0 : -1;
                 const size_t es_out = (op_out_cplx(P.op) ? 2 : 1) * real_size(plan->dtype);
+                // dense rows of the ahead-of-time real-op kernels (BASELINE configs[3]): load policy from the Infinity-Cache model, as for the C2C rows
+                if (!col && !use_jit && !use_blue && !use_plain && a.pitch_in == P.xlen && a.pitch_out == P.ylen && F_nt_ok(c.F))
+                    a.stream_in = row_load_policy(d_in, (size_t)P.nlanes * P.xlen * es_in, d_out, (size_t)P.nlanes * P.ylen * es_out) == 1;
                 a.vec_out = !col && ((uintptr_t)d_out % 16 == 0) && ((size_t)a.pitch_out * es_out) % 16 == 0;
                 // R2C rows with dense output lanes: the workgroup stores its lanes as one contiguous chunk (pow2_real.h: chunk_out)
                 // Measured (profiles/r03j, 2^24 points f32): n = 96 / 100 48 -> 37 / 32 -> 30 us, powers of two 128..1024 +4 %; n = 500 / 1000 and

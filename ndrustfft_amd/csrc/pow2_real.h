@@ -46,8 +46,8 @@ template <typename T> struct RealArgs {
     int32_t chunk_out = 0;               // row R2C: output lanes are dense (pitch == F + 1) and the array is 16-byte aligned: the workgroup's
                                          // output lanes form ONE contiguous chunk, staged in LDS and stored with coalesced 16-byte accesses
     int32_t xcd_chunk = 0;               // non-XCD kernels: XCD-aware workgroup -> tile map (device_common.h: xcd_block), 0 = identity
-    int32_t stream_in = 0;               // COL kernels: 1 = streaming (nt) loads of the input: it is read once and must not
-                                         // push the intermediate of a two-stage route out of the Infinity Cache
+    int32_t stream_in = 0;               // 1 = streaming (nt) loads of the input.  COL kernels: it is read once and must not push the intermediate of a
+                                         // two-stage route out of the Infinity Cache; row kernels (16-byte staging loads): the input comes from HBM
     const cpx<T> *twp_rev = nullptr;     // Bluestein / Rader kernels: per-pass twiddles of the SAME radix list taken back to front (second FFT of the convolution)
     const int32_t *rader_tab = nullptr;  // Rader kernels (rader_kernel.h): g^i mod P (i < P - 1), then g^-i mod P; bhat = FFT_(P-1)(W_P^(g^-q)) / (P - 1),
                                          // twp / twp_rev = per-pass twiddles of FFT_(P-1) with the radix list front to back / back to front
@@ -216,7 +216,8 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                 cpx<T> *raw = (cpx<T> *)lds;
                 if (sizeof(T) == 4 && a.vec_in) {   // two c64 per 16-byte load
                     const int nv = a.n_in >> 1;
-                    stage_loop<TPL>(t, nv, [&](int j) { return ((const vec4f *)in)[j]; }, [&](int j, vec4f v) { ((vec4f *)raw)[j] = v; });
+                    if (a.stream_in) stage_loop<TPL>(t, nv, [&](int j) { return __builtin_nontemporal_load((const vec4f *)in + j); }, [&](int j, vec4f v) { ((vec4f *)raw)[j] = v; });
+                    else stage_loop<TPL>(t, nv, [&](int j) { return ((const vec4f *)in)[j]; }, [&](int j, vec4f v) { ((vec4f *)raw)[j] = v; });
                     for (int j = 2 * nv + t; j < a.n_in; j += TPL) raw[j] = in[j];
                 } else {
                     stage_loop<TPL>(t, a.n_in, [&](int j) { return in[j]; }, [&](int j, cpx<T> v) { raw[j] = v; });
@@ -227,7 +228,9 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                 if (a.vec_in) {                      // 2 doubles / 4 floats per 16-byte load
                     constexpr int W = 16 / sizeof(T);
                     const int nv = a.n_in / W;
-                    stage_loop<TPL>(t, nv, [&](int j) { return ((const vec4f *)in)[j]; }, [&](int j, vec4f v) { ((vec4f *)raw)[j] = v; });
+                    // (stream_in: the input comes from HBM, not from the Infinity Cache -- exec.hip: MallModel)
+                    if (a.stream_in) stage_loop<TPL>(t, nv, [&](int j) { return __builtin_nontemporal_load((const vec4f *)in + j); }, [&](int j, vec4f v) { ((vec4f *)raw)[j] = v; });
+                    else stage_loop<TPL>(t, nv, [&](int j) { return ((const vec4f *)in)[j]; }, [&](int j, vec4f v) { ((vec4f *)raw)[j] = v; });
                     for (int j = W * nv + t; j < a.n_in; j += TPL) raw[j] = in[j];
                 } else {
                     stage_loop<TPL>(t, a.n_in, [&](int j) { return in[j]; }, [&](int j, T v) { raw[j] = v; });
