@@ -942,6 +942,9 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
                 // dense rows of the ahead-of-time real-op kernels (BASELINE configs[3]): load policy from the Infinity-Cache model, as for the C2C rows
                 if (!col && !use_jit && !use_blue && !use_plain && a.pitch_in == P.xlen && a.pitch_out == P.ylen && F_nt_ok(c.F))
                     a.stream_in = row_load_policy(d_in, (size_t)P.nlanes * P.xlen * es_in, d_out, (size_t)P.nlanes * P.ylen * es_out) == 1;
+                // column tiles of a caller's array (not the stages of col_split / the four-step, which set their own policy): the same model
+                if (col && !P.no_xcd_map && !P.stream_in && !P.keep_out)
+                    a.stream_in = row_load_policy(d_in, (size_t)P.nlanes * P.xlen * es_in, d_out, (size_t)P.nlanes * P.ylen * es_out) == 1;
                 a.vec_out = !col && ((uintptr_t)d_out % 16 == 0) && ((size_t)a.pitch_out * es_out) % 16 == 0;
                 // R2C rows with dense output lanes: the workgroup stores its lanes as one contiguous chunk (pow2_real.h: chunk_out)
                 // Measured (profiles/r03j, 2^24 points f32): n = 96 / 100 48 -> 37 / 32 -> 30 us, powers of two 128..1024 +4 %; n = 500 / 1000 and

@@ -4,7 +4,7 @@ for rep in 1 2; do
   for sl in auto 0; do
     echo "== NDFFT_STREAM_LOADS=$sl"
     if [ $sl == auto ]; then unset NDFFT_STREAM_LOADS; else export NDFFT_STREAM_LOADS=$sl; fi
-    python tools/bench_configs.py --only cfg4 --steps 40 2>&1 | python tools/probes/show.py /dev/stdin | grep "axis=2"
-    python tools/bench_configs.py --only cfg4 --steps 40 --pairs 6 2>&1 | python tools/probes/show.py /dev/stdin | grep "axis=2"
+    python tools/bench_configs.py --only cfg4 --steps 40 2>&1 | python tools/probes/show.py /dev/stdin | grep -E "axis=[012] "
+    python tools/bench_configs.py --only cfg4 --steps 40 --pairs 6 2>&1 | python tools/probes/show.py /dev/stdin | grep -E "axis=[012] "
   done
 done
