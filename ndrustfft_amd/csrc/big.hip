@@ -124,6 +124,39 @@ int launch_pack_lanes(const void *strided, void *dense, const LaneGeom &g, int64
     return NDFFT_OK;
 }
 
+// POST for the ops whose outputs come in spectrum pairs (k, F - k): R2C, DCT-I, DCT-II.  One thread reads Z[k] and Z[F - k] ONCE and writes every output
+// derived from them (k_big_post above reads each Z element twice and, for DCT-II, multiplies each twiddle twice: 99 us for 64 x 262144 f64, this form: see DESIGN 3.5).
+template <typename T, int OP> __global__ __launch_bounds__(256) void k_big_post_pair(const RealArgs<T> a, const cpx<T> *z) {
+    const int F = a.F, half = F / 2 + 1;
+    const int64_t total = a.nlanes * half;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t lane = i / half; const int k = (int)(i - lane * half), kf = F - k;
+        const cpx<T> *res = z + lane * F;
+        cpx<T> xk, xf;
+        r2c_split_pair<T, ZiNone>(res, k, F, a.aux1[k], xk, xf);
+        if constexpr (OP == G_R2C_EVEN) {
+            cpx<T> *out = (cpx<T> *)a.out + lane * a.pitch_out;
+            out[k] = xk;
+            if (kf != k) out[kf] = xf;
+        } else if constexpr (OP == G_DCT1) {
+            T *out = (T *)a.out + lane * a.pitch_out;
+            out[k] = (T)0.5 * xk.x;
+            if (kf != k) out[kf] = (T)0.5 * xf.x;
+        } else {   // G_DCT2_EVEN: y[k] = Re(X[k] c_k), y[n - k] = -Im(X[k] c_k)
+            T *out = (T *)a.out + lane * a.pitch_out;
+            const int n = 2 * F;
+            const cpx<T> tk = cmul(xk, a.aux2[k]);
+            out[k] = tk.x;
+            if (k > 0) out[n - k] = -tk.y;
+            if (kf != k) {
+                const cpx<T> tf = cmul(xf, a.aux2[kf]);
+                out[kf] = tf.x;
+                if (kf < F) out[n - kf] = -tf.y;
+            }
+        }
+    }
+}
+
 #define NDFFT_BIG_OPS(X) X(G_R2C_EVEN) X(G_R2C_ODD) X(G_C2R_EVEN) X(G_C2R_ODD) X(G_DCT1) X(G_DCT2_EVEN) X(G_DCT2_ODD) \
     X(G_DCT3_EVEN) X(G_DCT3_ODD) X(G_DCT4_EVEN) X(G_DCT4_ODD)
 
@@ -139,6 +172,14 @@ template <typename T> int launch_big_pre(int op, const RealArgs<T> &a, cpx<T> *z
     return NDFFT_OK;
 }
 template <typename T> int launch_big_post(int op, const RealArgs<T> &a, const cpx<T> *z, hipStream_t s) {
+    if (op == G_R2C_EVEN || op == G_DCT1 || op == G_DCT2_EVEN) {
+        const unsigned gp = (unsigned)std::min<int64_t>((a.nlanes * (a.F / 2 + 1) + 255) / 256, 16384);
+        if (op == G_R2C_EVEN) hipLaunchKernelGGL((k_big_post_pair<T, G_R2C_EVEN>), dim3(gp), dim3(256), 0, s, a, z);
+        else if (op == G_DCT1) hipLaunchKernelGGL((k_big_post_pair<T, G_DCT1>), dim3(gp), dim3(256), 0, s, a, z);
+        else hipLaunchKernelGGL((k_big_post_pair<T, G_DCT2_EVEN>), dim3(gp), dim3(256), 0, s, a, z);
+        NDFFT_HIP(hipGetLastError());
+        return NDFFT_OK;
+    }
     const unsigned grid = (unsigned)std::min<int64_t>((a.nlanes * a.n_out + 255) / 256, 8192);
     switch (op) {
 #define NDFFT_C(OP) case OP: hipLaunchKernelGGL((k_big_post<T, OP>), dim3(grid), dim3(256), 0, s, a, z); break;
