@@ -159,6 +159,9 @@ int ndfft_exec_sharded_device(const ndfft_plan *plan, int op, const void *d_in, 
  * produced by another kernel, or has not been touched for a long time -- says so.  Per host thread, sticky until changed. */
 typedef enum { NDFFT_INPUT_AUTO = 0, NDFFT_INPUT_CACHED = 1, NDFFT_INPUT_COLD = 2 } ndfft_input_hint;
 int ndfft_set_input_hint(int hint);
+/* Diagnostic: the load policy the last ndfft_exec_device on this thread ran with -- 0 default policy, 1 streaming loads, -1 the kernel it
+ * dispatched to has a fixed policy.  Used by the tests of the residency model. */
+int ndfft_last_input_policy(void);
 
 /* Name of the kernel path the last successful exec on this thread dispatched to
  * ("pow2_reg", "generic_row", "generic_col", "generic_strided", "transpose+row", ...). */

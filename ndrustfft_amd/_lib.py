@@ -24,7 +24,7 @@ SYMBOLS = [
     "ndfft_plan_dtype", "ndfft_plan_lane_len_in", "ndfft_plan_lane_len_out",
     "ndfft_exec", "ndfft_exec_device", "ndfft_exec_sharded", "ndfft_exec_sharded_device", "ndfft_last_path", "ndfft_explain_plan",
     "ndfft_dev_alloc", "ndfft_dev_free", "ndfft_dev_upload", "ndfft_dev_download", "ndfft_dev_sync",
-    "ndfft_release_workspace", "ndfft_host_alloc", "ndfft_host_free", "ndfft_set_input_hint", "ndfft_host_forget", "ndfft_host_reg_cache",
+    "ndfft_release_workspace", "ndfft_host_alloc", "ndfft_host_free", "ndfft_set_input_hint", "ndfft_host_forget", "ndfft_host_reg_cache", "ndfft_last_input_policy",
 ]
 
 
@@ -79,6 +79,7 @@ class Library:
         L.ndfft_set_input_hint.argtypes = [i32]; L.ndfft_set_input_hint.restype = i32
         L.ndfft_host_forget.argtypes = [vp]; L.ndfft_host_forget.restype = i32
         L.ndfft_host_reg_cache.argtypes = [sz]; L.ndfft_host_reg_cache.restype = i32
+        L.ndfft_last_input_policy.argtypes = []; L.ndfft_last_input_policy.restype = i32
 
     def check(self, status):
         if status == OK:

@@ -345,6 +345,7 @@ static int current_ws(DeviceWs **out) {
     return NDFFT_OK;
 }
 static thread_local int g_input_hint = NDFFT_INPUT_AUTO;
+static thread_local int g_last_policy = -1;       // load policy the last call on this thread asked the model for (diagnostic)
 static bool F_nt_ok(int F) { return F >= 64; }   // (short lanes: the staging loads are not 16-byte vectors on every path)
 // load policy for the dense C2C row kernels on input `in` (Pow2Args::stream_in), and the bookkeeping for the next call
 static int row_load_policy(const void *in, size_t bytes, const void *out, size_t out_bytes);
@@ -355,6 +356,7 @@ static int row_load_policy(const void *in, size_t bytes, const void *out, size_t
     if (current_ws(&ws)) return -1;
     int pol = force >= 0 ? (force != 0) : g_input_hint == NDFFT_INPUT_CACHED ? 0 : g_input_hint == NDFFT_INPUT_COLD ? 1 : ws->mall.decide(in, bytes);
     const bool nt = pol >= 0 ? pol != 0 : stream_loads_for(bytes);
+    g_last_policy = nt ? 1 : 0;
     ws->mall.note(in, bytes, !nt);
     // nt stores: a large output bypasses the cache (fft -> ifft on 4096 x 4096 c128: the second pass is 3-5 % faster with streaming loads); a small
     // one is still found there (1024 x 4096, 64 MiB: plain loads 2-3 % faster) -- tools/probes/chain_hint.py, profiles/r05/r05d_chain_hint.txt
@@ -1416,6 +1418,7 @@ int ndfft_exec_device(const ndfft_plan *plan, int op, const void *d_in, void *d_
                       const int64_t *shape_in, const int64_t *stride_in, const int64_t *shape_out,
                       const int64_t *stride_out, int axis, int norm, double scale, void *stream) {
     clear_err();
+    g_last_policy = -1;
     Problem P;
     bool nothing;
     int rc = prepare(plan, op, ndim, shape_in, stride_in, shape_out, stride_out, axis, norm, scale, P, nothing);
@@ -1538,6 +1541,8 @@ int ndfft_host_forget(const void *h_ptr) {
     (void)HostRegCache::get().forget(h_ptr);
     return NDFFT_OK;
 }
+
+int ndfft_last_input_policy(void) { return g_last_policy; }
 
 int ndfft_set_input_hint(int hint) {
     clear_err();

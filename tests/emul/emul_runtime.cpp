@@ -123,6 +123,30 @@ hipError_t hipMemcpyPeerAsync(void *dst, int dst_dev, const void *src, int src_d
     return 0;
 }
 
+// ---- hipHostRegister: ranges of ordinary host memory the library has "pinned" ------------------------------------------------
+namespace { std::map<char *, size_t> &g_reg = *new std::map<char *, size_t>; std::mutex &g_reg_mu = *new std::mutex; }
+hipError_t hipHostRegister(void *p, size_t n, unsigned) {
+    std::lock_guard<std::mutex> g(g_reg_mu);
+    for (auto &kv : g_reg) if ((char *)p < kv.first + kv.second && kv.first < (char *)p + n) return 712;   // hipErrorHostMemoryAlreadyRegistered
+    g_reg[(char *)p] = n;
+    return 0;
+}
+hipError_t hipHostUnregister(void *p) {
+    std::lock_guard<std::mutex> g(g_reg_mu);
+    return g_reg.erase((char *)p) ? 0 : 713;
+}
+bool emul_host_registered(const void *p) {
+    std::lock_guard<std::mutex> g(g_reg_mu);
+    for (auto &kv : g_reg) if ((const char *)p >= kv.first && (const char *)p < kv.first + kv.second) return true;
+    return false;
+}
+extern "C" size_t emul_host_registered_bytes() {
+    std::lock_guard<std::mutex> g(g_reg_mu);
+    size_t b = 0;
+    for (auto &kv : g_reg) b += kv.second;
+    return b;
+}
+
 void __syncthreads() {
     // yield; the scheduler resumes fibers round-robin, so returning here means every live fiber
     // of the block has reached a barrier (or finished) since we left

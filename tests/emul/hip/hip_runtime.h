@@ -64,9 +64,11 @@ typedef void *hipEvent_t;
 enum { hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipMemoryTypeHost = 1 };
 struct hipPointerAttribute_t { int type; int device; };
 int emul_device_of(const void *p);   // device an address was hipMalloc'd on, -1 if not device memory
+bool emul_host_registered(const void *p);     // inside a range registered with hipHostRegister (emul_runtime.cpp)
 inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *p) {
     const int d = emul_device_of(p);
-    if (d < 0) return 1;                       // plain host memory: no pointer is ever "pinned" in the emulation
+    if (d < 0 && emul_host_registered(p)) { a->type = hipMemoryTypeHost; a->device = 0; return 0; }
+    if (d < 0) return 1;                       // plain host memory: not "pinned" unless registered
     a->type = 2; a->device = d;
     return 0;
 }
@@ -89,8 +91,11 @@ inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
 inline hipError_t hipHostFree(void *p) { free(p); return 0; }
 enum { hipHostRegisterDefault = 0 };
-inline hipError_t hipHostRegister(void *, size_t, unsigned) { return 1; }   // never "pinned" in the emulation: the bounce pipeline stays the tested path
-inline hipError_t hipHostUnregister(void *) { return 0; }
+// registrations are tracked (emul_runtime.cpp) so that the registration cache of ndfft_exec and the pinned pipeline behind it run on the CPU container;
+// overlapping an existing registration fails, as on the real runtime
+hipError_t hipHostRegister(void *p, size_t n, unsigned flags);
+hipError_t hipHostUnregister(void *p);
+extern "C" size_t emul_host_registered_bytes();
 inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return 0; }
 
 void __syncthreads();

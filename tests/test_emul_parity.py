@@ -10,6 +10,7 @@ import pytest
 import parity_suite as ps
 from helpers import GOLDEN_SIZES
 from ndrustfft_amd import _lib
+from ndrustfft_amd import api as api_mod, handlers as handlers_mod
 
 EMUL_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emul")
 
@@ -72,6 +73,86 @@ def test_sharded_device_resident_chunk_pipeline(L, monkeypatch):
 
 
 def test_baseline_length_fixtures(L, blvec): ps.baseline_length_fixtures(L, blvec)
+def test_infinity_cache_residency_model(L):
+    """exec.hip: MallModel through ndfft_last_input_policy (device-resident arrays on the emulation): an unknown input keeps the size rule (plain loads); the same
+    input again is resident (plain); an output of more than 64 MiB was written with nt stores and is cold (streaming) when it becomes an input; inputs pushed out
+    by ~256 MiB of later plain reads turn cold; a small output stays resident; ndfft_set_input_hint overrides; other kernels report -1."""
+    import ctypes
+    n = 64
+    h = handlers_mod.FftHandler(n, _library=L)
+    def dev_buf(rows):
+        p = ctypes.c_void_p(); L.check(L.c.ndfft_dev_alloc(ctypes.byref(p), rows * n * 16)); return p
+    def fft(src, dst, rows, op=_lib.OP_C2C_FWD):
+        os.environ["NDFFT_WAVE"] = "0"          # n = 64 on the register row kernel (pow2_reg), the one the model serves
+        try:
+            L.check(L.c.ndfft_exec_device(h._plan, op, src, dst, 2, api_mod._i64((rows, n)), api_mod._i64((n, 1)), api_mod._i64((rows, n)), api_mod._i64((n, 1)), 1, _lib.NORM_DEFAULT, 0.0, None))
+        finally:
+            del os.environ["NDFFT_WAVE"]
+        assert L.last_path() == "pow2_reg", L.last_path()
+        return L.c.ndfft_last_input_policy()
+    big = (72 << 20) // (n * 16)                 # 72 MiB arrays: outputs above the 64 MiB line
+    a, b, c = dev_buf(big), dev_buf(big), dev_buf(big)
+    small = (8 << 20) // (n * 16)
+    s1, s2 = dev_buf(small), dev_buf(small)
+    try:
+        assert fft(a, b, big) == 0               # never seen: size rule -> plain
+        assert fft(a, b, big) == 0               # read a moment ago with plain loads: resident
+        assert fft(b, c, big) == 1               # b is an output of > 64 MiB (nt stores): cold
+        assert fft(b, c, big) == 1               # ... and streaming loads do not make it resident
+        assert fft(s1, s2, small) == 0 and fft(s2, s1, small) == 0      # small outputs stay in the cache
+        L.check(L.c.ndfft_set_input_hint(_lib.INPUT_CACHED)); assert fft(b, c, big) == 0
+        L.check(L.c.ndfft_set_input_hint(_lib.INPUT_COLD)); assert fft(a, b, big) == 1
+        L.check(L.c.ndfft_set_input_hint(_lib.INPUT_AUTO))
+        assert fft(a, c, big) == 1               # the COLD call above read a with streaming loads: not resident any more
+        # eviction: a is made resident, then four other 72 MiB inputs go through the cache with plain loads
+        L.check(L.c.ndfft_set_input_hint(_lib.INPUT_CACHED)); fft(a, c, big); L.check(L.c.ndfft_set_input_hint(_lib.INPUT_AUTO))
+        assert fft(a, c, big) == 0
+        others = [dev_buf(big) for _ in range(4)]
+        for o in others: assert fft(o, c, big) == 0
+        assert fft(a, c, big) == 1, "288 MiB of plain reads since a was last read: evicted"
+        for o in others: L.check(L.c.ndfft_dev_free(o))
+    finally:
+        L.c.ndfft_set_input_hint(_lib.INPUT_AUTO)
+        for p in (a, b, c, s1, s2): L.check(L.c.ndfft_dev_free(p))
+
+
+def test_host_registration_cache_lru(L):
+    """ndfft_host_reg_cache on the CPU container (the emulation tracks hipHostRegister ranges): nothing is registered while the cache is off or on an
+    array's first use; the second use registers input and output and the call runs the pinned pipeline with identical results; a sub-view of a
+    registered array is served by its registration; the byte budget evicts the least recently used arrays; forget / switching off drop everything."""
+    import ctypes
+    import synth
+    from ndrustfft_amd import api, handlers
+    from oracle import oracle_ctypes as orc
+    reg = lambda: L.c.emul_host_registered_bytes()
+    L.c.emul_host_registered_bytes.restype = ctypes.c_size_t
+    n = 1024; h = handlers.FftHandler(n, _library=L); o = orc.FftHandler(n)
+    def pair(k):
+        x = synth.complex_array((520, n), offset=1000 * k); y = np.zeros_like(x); yo = np.zeros_like(x); orc.ndfft(x, yo, o, 1)
+        return x, y, yo
+    x0, y0, yo0 = pair(0)
+    api.ndfft(x0, y0, h, 1); api.ndfft(x0, y0, h, 1)
+    assert reg() == 0, "cache is off by default"
+    L.check(L.c.ndfft_host_reg_cache(3 * x0.nbytes))                      # room for three arrays
+    try:
+        api.ndfft(x0, y0, h, 1); assert reg() == 0                        # first sighting
+        y0[...] = 0; api.ndfft(x0, y0, h, 1); assert reg() == 2 * x0.nbytes   # second: both registered, pinned pipeline
+        assert np.abs(y0 - yo0).max() <= 1e-10 * np.abs(yo0).max()
+        y0[...] = 0; api.ndfft(x0[:260], y0[:260], h, 1); assert reg() == 2 * x0.nbytes
+        assert np.abs(y0[:260] - yo0[:260]).max() <= 1e-10 * np.abs(yo0).max()
+        x1, y1, yo1 = pair(1)
+        for _ in range(3): api.ndfft(x1, y1, h, 1)
+        assert np.abs(y1 - yo1).max() <= 1e-10 * np.abs(yo1).max()
+        assert reg() <= 3 * x0.nbytes, "the byte budget evicts the least recently used registrations"
+        assert L.c.ndfft_host_forget(ctypes.c_void_p(x1.ctypes.data)) == 0 and L.c.ndfft_host_forget(ctypes.c_void_p(y1.ctypes.data)) == 0
+        before = reg()
+        api.ndfft(x1, y1, h, 1); assert reg() == before                   # forgotten: back to a first sighting
+        assert np.abs(y1 - yo1).max() <= 1e-10 * np.abs(yo1).max()
+    finally:
+        L.check(L.c.ndfft_host_reg_cache(0))
+    assert reg() == 0
+
+
 def test_interleaved_mut_views(L): ps.interleaved_mut_views_two_threads(L, rounds=1)
 def test_long_strided_lanes(L): ps.long_strided_lanes(L)
 def test_narrow_xcd_tiles(L): ps.narrow_xcd_tiles(L)
