@@ -260,14 +260,23 @@ def main():
         ranks_seen = int(one[0])
 
     # which physical GPU each rank drives (name, PCI bus id, UUID): a SCALE run must show N DISTINCT devices
-    pr = torch.cuda.get_device_properties(local_rank)
-    me = {"rank": rank, "local_rank": local_rank, "name": pr.name,
-          "pci": f"{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', -1):02x}:{getattr(pr, 'pci_device_id', -1):02x}",
-          "uuid": str(getattr(pr, "uuid", "")), "hip_visible_devices": os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", ""))}
+    me = {"rank": rank, "local_rank": local_rank}
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        me.update({"name": pr.name,
+                   "pci": "%04x:%02x:%02x" % (int(getattr(pr, "pci_domain_id", 0)), int(getattr(pr, "pci_bus_id", 0)), int(getattr(pr, "pci_device_id", 0))),
+                   "uuid": str(getattr(pr, "uuid", "")),
+                   "hip_visible_devices": os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", ""))})
+    except Exception as ex:                              # a diagnostic must never cost the bench line
+        me["error"] = repr(ex)[:120]
     devices = [me]
     if use_dist and world > 1:
-        devices = [None] * world
-        dist.all_gather_object(devices, me)
+        try:
+            got = [None] * world
+            dist.all_gather_object(got, me)
+            devices = got
+        except Exception as ex:
+            me["gather_error"] = repr(ex)[:120]
 
     n = args.n
     rows = args.rows
@@ -463,7 +472,7 @@ def main():
         out = {
             "metric": "GFFT-points/s, batched 1-D C2C FFT f64 along the contiguous axis (+ achieved HBM GB/s vs roofline)",
             "value": round(points / el / 1e9, 3), "unit": "GFFT-points/s",
-            "n_gpus": ngpu, "ranks_seen": ranks_seen, "devices": devices, "distinct_devices": len({d["uuid"] or d["pci"] for d in devices}),
+            "n_gpus": ngpu, "ranks_seen": ranks_seen, "devices": devices, "distinct_devices": len({d.get("uuid") or d.get("pci") or d["rank"] for d in devices}),
             "steps": primary_steps, "warmup": args.warmup,
             "ms_per_step": round(el / primary_steps * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
