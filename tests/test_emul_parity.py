@@ -159,6 +159,12 @@ def test_narrow_xcd_tiles(L): ps.narrow_xcd_tiles(L)
 def test_column_four_step(L): ps.column_four_step(L)
 def test_huge_prime_factors(L): ps.huge_prime_factors(L, full=False)
 def test_fuzz(L): ps.fuzz(L, seed=11, count=120, max_points=1 << 13)
+def test_fuzz_streaming_loads(L):
+    L.check(L.c.ndfft_set_input_hint(_lib.INPUT_COLD))
+    try:
+        ps.fuzz(L, seed=17, count=60, max_points=1 << 13)
+    finally:
+        L.check(L.c.ndfft_set_input_hint(_lib.INPUT_AUTO))
 def test_bluestein_register_kernel(L): ps.bluestein_register_kernel(L)
 def test_bluestein_smooth_length_partial_rounds(L):
     """F = 263 on the smooth convolution length 550 = 11.10.5 (55 threads, partial first round) instead of 1024: blue_kernel.h's partial-round guards and the

@@ -161,6 +161,16 @@ def test_huge_prime_factors(L): ps.huge_prime_factors(L)
 def test_fuzz(L):
     paths = ps.fuzz(L, seed=7, count=400)
     assert len(paths) >= 8, paths
+def test_fuzz_streaming_loads(L):
+    """The input hint COLD sends every kernel that has a streaming-load form down it (C2C rows, real-op rows with 16-byte staging, column tiles): same parity bar."""
+    L.check(L.c.ndfft_set_input_hint(_lib.INPUT_COLD))
+    try:
+        paths = ps.fuzz(L, seed=13, count=250)
+        assert len(paths) >= 8, paths
+        ps.pow2_real_sizes(L, sizes=(64, 512, 4096), dtypes=(np.float64, np.float32))
+        ps.baseline_length_fixtures(L, np.load(os.path.join(ROOT, "tests", "golden", "baseline_lengths.npz")), device="cuda:0")
+    finally:
+        L.check(L.c.ndfft_set_input_hint(_lib.INPUT_AUTO))
 def test_fuzz_short_lanes(L):
     """the same fuzz restricted to lanes of <= 100 points with enough lanes to reach the plan-time specialisations: wavefront,
     thread-per-lane (tiny / tinymat / reg / regreal) and their fallbacks, in every layout the fuzz generates"""
