@@ -278,19 +278,24 @@ struct Pipe {
     }
 };
 // What this thread's own calls imply about the 256 MiB Infinity Cache of the current device -- used for ONE decision, the load
-// policy of the register-resident C2C row kernels (BASELINE configs[1] / [4]):  plain loads are up to 15 % faster when the input is
-// resident in the Infinity Cache (4096 x 4096 c128: 0.86 vs 0.74 of the roofline), streaming (nt) loads 6 % faster when it comes from
-// HBM (0.74 vs 0.70).  Round 2 bet on "resident" for every input <= 384 MiB; a chain of nd* calls loses that bet at every link (the
-// output of a pass was written with nt stores, which bypass the cache).  The model tracks, per buffer this thread has transformed:
-//   * an input read with plain loads is resident until this thread's later plain reads have pushed ~256 MiB through the cache;
-//   * an input read with streaming loads, and every output larger than 64 MiB (nt stores), is not resident;
-//   * a buffer the model has never seen keeps round 2's bet (plain loads up to 384 MiB) -- its producer is unknown.
-// ndfft_set_input_hint overrides it per host thread.  Speed only: either policy gives the same results.
+// policy of the row / column-tile kernels that have a streaming-load form (BASELINE configs[1], [3], [4]): plain loads are up to 15 %
+// faster when the input is resident in the Infinity Cache (4096 x 4096 c128: 0.86 vs 0.74 of the roofline), streaming (nt) loads 6 %
+// faster when it comes from HBM (0.74 vs 0.70).  Round 2 bet on "resident" for every input <= 384 MiB; a chain of nd* calls loses that bet
+// at every link (the output of a pass was written with nt stores, which bypass the cache).  The model is an LRU stack distance per buffer
+// this thread has transformed:
+//   * a buffer this thread WROTE as an output of more than 64 MiB is cold (nt stores) -> streaming loads when it becomes an input;
+//   * a buffer it READ before (with either policy), or wrote as a small output, is worth plain loads iff the bytes this thread has moved
+//     through the cache since (all inputs, small outputs) plus its own size fit ~256 MiB: a re-read input then is, or becomes, resident;
+//     six rotating 256 MiB inputs never are (streaming loads for all of them);
+//   * a buffer the model has never seen keeps round 2's size rule (plain loads up to 384 MiB) -- its producer is unknown.
+// A stale entry (the allocator reused the addresses for something a foreign kernel produced) costs one call: after that the buffer is "read".
+// ndfft_set_input_hint overrides the model per host thread.  Speed only: either policy gives the same results.
 struct MallModel {
-    struct Entry { uintptr_t lo, hi; uint64_t stamp; bool resident; };
+    enum State { READ = 0, OUT_SMALL = 1, OUT_COLD = 2 };
+    struct Entry { uintptr_t lo, hi; uint64_t stamp; int state; };
     std::vector<Entry> e;
-    uint64_t clock = 0;                          // bytes this thread has read with plain loads
-    static constexpr uint64_t kCap = (uint64_t)256 << 20;
+    uint64_t clock = 0;                          // bytes this thread has moved through the cache's address stream (inputs read, small outputs)
+    static constexpr uint64_t kCap = (uint64_t)256 << 20, kSmallOut = (uint64_t)64 << 20;
     Entry *find(const void *p, size_t bytes) {
         const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
         for (auto &x : e) if (lo < x.hi && x.lo < hi) return &x;
@@ -301,15 +306,18 @@ struct MallModel {
         if (bytes > kCap) return -1;
         const Entry *x = find(in, bytes);
         if (!x) return -1;
-        return (x->resident && clock - x->stamp + bytes <= kCap) ? 0 : 1;
+        if (x->state == OUT_COLD) return 1;
+        return clock - x->stamp + bytes <= kCap ? 0 : 1;
     }
-    void note(const void *p, size_t bytes, bool resident) {
+    void put(const void *p, size_t bytes, int state, bool through_cache) {
         const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
         for (size_t i = 0; i < e.size();) { if (lo < e[i].hi && e[i].lo < hi) e.erase(e.begin() + i); else ++i; }
-        if (resident) clock += bytes;
+        if (through_cache) clock += bytes;
         if (e.size() >= 32) e.erase(e.begin());  // oldest first
-        e.push_back({lo, hi, clock, resident});
+        e.push_back({lo, hi, clock, state});
     }
+    void note_read(const void *p, size_t bytes) { put(p, bytes, READ, true); }
+    void note_write(const void *p, size_t bytes) { if (bytes <= kSmallOut) put(p, bytes, OUT_SMALL, true); else put(p, bytes, OUT_COLD, false); }
 };
 struct DeviceWs {
     MallModel mall;
@@ -357,10 +365,10 @@ static int row_load_policy(const void *in, size_t bytes, const void *out, size_t
     int pol = force >= 0 ? (force != 0) : g_input_hint == NDFFT_INPUT_CACHED ? 0 : g_input_hint == NDFFT_INPUT_COLD ? 1 : ws->mall.decide(in, bytes);
     const bool nt = pol >= 0 ? pol != 0 : stream_loads_for(bytes);
     g_last_policy = nt ? 1 : 0;
-    ws->mall.note(in, bytes, !nt);
+    ws->mall.note_read(in, bytes);
     // nt stores: a large output bypasses the cache (fft -> ifft on 4096 x 4096 c128: the second pass is 3-5 % faster with streaming loads); a small
     // one is still found there (1024 x 4096, 64 MiB: plain loads 2-3 % faster) -- tools/probes/chain_hint.py, profiles/r05/r05d_chain_hint.txt
-    ws->mall.note(out, out_bytes, out_bytes <= ((size_t)64 << 20));
+    ws->mall.note_write(out, out_bytes);
     return nt ? 1 : 0;
 }
 static int get_scratch(int which, hipStream_t s, size_t bytes, void **out) {
