@@ -146,7 +146,7 @@ template <typename T, int N, int NT, int VEC, int FL, int PS> static int launch_
     return NDFFT_OK;
 }
 template <typename T, int N, int NT, int VEC, int FL = 0> static int launch_inst(const Pow2Args &a, hipStream_t s) {
-    if constexpr (N >= 8192) {   // both forms exist for the two longest lengths
+    if constexpr (N >= 8192) {   // both forms exist for the two longest lengths (shorter ones: within +-2 % either way, profiles/r05/r05k_psplit_1024_4096.txt)
         const int ov = psplit_override();
         const int ps = ov == 1 || ov == 2 ? ov : Pow2PSplit<T, N>::value;
         return ps == 2 ? launch_inst_ps<T, N, NT, VEC, FL, 2>(a, s) : launch_inst_ps<T, N, NT, VEC, FL, 1>(a, s);
