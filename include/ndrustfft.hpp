@@ -292,7 +292,7 @@ void transform(int op, const ArrayView<const In> &input, ArrayView<Out> &output,
 // ---- device-resident arrays: keep `work` arrays in HBM between axis passes ----------
 // DeviceArray<A> owns a C-layout array in device memory.  The nd* overloads on DeviceArray go through
 // ndfft_exec_device (asynchronous on the default stream); upload()/download() are the only PCIe traffic.
-// Normalization::Custom is a host function and is rejected on this path.
+// Normalization::Custom is a host function: on this path it costs one round trip of the array it acts on.
 template <typename A> class DeviceArray {
   public:
     DeviceArray() = default;
@@ -335,22 +335,54 @@ template <typename A> class DeviceArray {
 };
 
 namespace detail {
+// Normalization::Custom is a host function: the array it acts on makes one round trip through host memory (the same
+// for_each_lane the host functions use), at the reference's application point -- before the transform on the input lanes
+// (C2R, DCT: lib.rs:511-515, 692-696) or after it on the output lanes (C2C inverse: lib.rs:326-330).
+template <typename A> void custom_on_device(void *dptr, const std::vector<std::int64_t> &shape, std::size_t len, std::size_t axis, void (*fn)(A *, std::size_t),
+                                            void *dst_dptr) {
+    std::vector<A> host(len);
+    check(ndfft_dev_sync(nullptr));
+    check(ndfft_dev_download(host.data(), dptr, len * sizeof(A)));
+    for_each_lane<A>(host.data(), shape, axis, fn);
+    check(ndfft_dev_upload(dst_dptr, host.data(), len * sizeof(A)));
+}
 template <typename In, typename Out, typename NormT>
 void transform_device(int op, const DeviceArray<In> &input, DeviceArray<Out> &output, ndfft_plan *plan,
-                      const Normalization<NormT> &norm, bool norm_applies, std::size_t axis, bool par = false) {
+                      const Normalization<NormT> &norm, bool norm_applies, bool norm_is_pre, std::size_t axis, bool par = false) {
     if (input.shape().size() != output.shape().size()) throw Error(NDFFT_ERR_INVALID_ARG, "input and output must have the same dimensionality D");
-    if (norm.kind == Normalization<NormT>::Custom && norm_applies)
-        throw Error(NDFFT_ERR_INVALID_ARG, "Normalization::Custom is a host function: not available on device-resident arrays");
+    const bool custom = norm.kind == Normalization<NormT>::Custom && norm_applies;
     const int mode = norm.kind == Normalization<NormT>::Default ? NDFFT_NORM_DEFAULT : NDFFT_NORM_NONE;
     if (axis > 0x7fffffffu) throw Panic(NDFFT_ERR_AXIS, "index out of bounds");
-    const std::vector<int> &ids = par_devices_ref();
-    if (par && ids.size() > 1) {   // scatter / transform / gather over xGMI, host-less
-        check(ndfft_exec_sharded_device(plan, op, input.ptr(), output.ptr(), (int)input.shape().size(), input.shape().data(), input.strides().data(),
-                                        output.shape().data(), output.strides().data(), (int)axis, mode, 0.0, (int)ids.size(), ids.data(), nullptr));
-        return;
+    const void *in_ptr = input.ptr();
+    void *staged = nullptr;
+    if (custom && norm_is_pre) {
+        if constexpr (std::is_same<In, NormT>::value) {
+            if (axis < input.shape().size()) {
+                std::size_t len = 1;
+                for (auto e : input.shape()) len *= (std::size_t)e;
+                check(ndfft_dev_alloc(&staged, len * sizeof(In)));
+                custom_on_device<In>(input.ptr(), input.shape(), len, axis, norm.fn, staged);
+                in_ptr = staged;
+            }
+        }
     }
-    check(ndfft_exec_device(plan, op, input.ptr(), output.ptr(), (int)input.shape().size(), input.shape().data(), input.strides().data(),
-                            output.shape().data(), output.strides().data(), (int)axis, mode, 0.0, nullptr));
+    const std::vector<int> &ids = par_devices_ref();
+    int st;
+    if (par && ids.size() > 1)   // scatter / transform / gather over xGMI, host-less
+        st = ndfft_exec_sharded_device(plan, op, in_ptr, output.ptr(), (int)input.shape().size(), input.shape().data(), input.strides().data(),
+                                       output.shape().data(), output.strides().data(), (int)axis, mode, 0.0, (int)ids.size(), ids.data(), nullptr);
+    else
+        st = ndfft_exec_device(plan, op, in_ptr, output.ptr(), (int)input.shape().size(), input.shape().data(), input.strides().data(),
+                               output.shape().data(), output.strides().data(), (int)axis, mode, 0.0, nullptr);
+    if (staged) { (void)ndfft_dev_sync(nullptr); (void)ndfft_dev_free(staged); }
+    check(st);
+    if (custom && !norm_is_pre) {
+        if constexpr (std::is_same<Out, NormT>::value) {
+            std::size_t len = 1;
+            for (auto e : output.shape()) len *= (std::size_t)e;
+            custom_on_device<Out>(output.ptr(), output.shape(), len, axis, norm.fn, output.ptr());
+        }
+    }
 }
 }  // namespace detail
 
@@ -374,11 +406,11 @@ void transform_device(int op, const DeviceArray<In> &input, DeviceArray<Out> &ou
     }                                                                                                        \
     template <typename T>                                                                                    \
     void NAME(const DeviceArray<IN> &input, DeviceArray<OUT> &output, const HANDLER<T> &handler, std::size_t axis) { \
-        detail::transform_device<IN, OUT, NORMT>(OP, input, output, handler.plan(), handler.norm(), APPLIES, axis);   \
+        detail::transform_device<IN, OUT, NORMT>(OP, input, output, handler.plan(), handler.norm(), APPLIES, PRE, axis);   \
     }                                                                                                        \
     template <typename T>                                                                                    \
     void NAME##_par(const DeviceArray<IN> &input, DeviceArray<OUT> &output, const HANDLER<T> &handler, std::size_t axis) { \
-        detail::transform_device<IN, OUT, NORMT>(OP, input, output, handler.plan(), handler.norm(), APPLIES, axis, true); \
+        detail::transform_device<IN, OUT, NORMT>(OP, input, output, handler.plan(), handler.norm(), APPLIES, PRE, axis, true); \
     }
 
 NDRUSTFFT_DEFINE(ndfft, Complex<T>, Complex<T>, FftHandler, NDFFT_OP_C2C_FWD, Complex<T>, false, false)       // lib.rs:350-372

@@ -156,6 +156,25 @@ static void device_resident_fft2() {   // examples/fft2.rs with the work array k
     ndfft_r2c(dx, w1, hr, 1); ndfft(w1, w2, hc, 0); ndifft(w2, w3, hc, 0); ndifft_r2c(w3, dy, hr, 1);
     approx_eq(dy.to_host().to_logical(), d, 1e-10);
 }
+static void my_norm_real(double *data, std::size_t len) { const double n = 3. / (double)len; for (std::size_t i = 0; i < len; ++i) data[i] *= n; }
+static void device_resident_custom_norm() {   // examples/fft_norm.rs on DeviceArrays: Normalization::Custom runs on the host at the reference's points
+    auto v = Array<C>::from({3}, cplx_of({1., 2., 3.}));
+    auto dv = DeviceArray<C>::from_host(v);
+    DeviceArray<C> dvhat({3}), dv2({3});
+    auto handler = FftHandler<double>(3).normalization(Normalization<C>::custom(my_norm));
+    ndfft(dv, dvhat, handler, 0); ndifft(dvhat, dv2, handler, 0);                       // AFTER, on the output lanes (lib.rs:326-330)
+    approx_eq_complex(dv2.to_host().to_logical(), {2., 4., 6.}, {2., 4., 6.}, 1e-12);
+    // BEFORE, on the input lanes of a DCT (lib.rs:692-696): same result as the host function, on a 2-D array along both axes
+    std::vector<double> d(5 * 8); for (int i = 0; i < 40; ++i) d[i] = std::cos(0.3 * i) + 0.1 * i;
+    auto x = Array<double>::from({5, 8}, d);
+    for (std::size_t axis = 0; axis < 2; ++axis) {
+        auto hd = DctHandler<double>(axis == 0 ? 5 : 8).normalization(Normalization<double>::custom(my_norm_real));
+        auto yh = Array<double>::zeros({5, 8}); nddct2(x, yh, hd, axis);
+        auto dx = DeviceArray<double>::from_host(x); DeviceArray<double> dy({5, 8});
+        nddct2(dx, dy, hd, axis);
+        approx_eq(dy.to_host().to_logical(), yh.to_logical(), 1e-12);
+    }
+}
 static void par_over_devices() {   // `_par` = create_transform_par! (lib.rs:169-238): lanes handed to the workers -- here GPUs
     const int ndev = ndfft_device_count();
     std::vector<int> ids;
@@ -220,7 +239,8 @@ int main(int argc, char **argv) {
         {"test_dct4", test_dct<4, false>}, {"test_dct4_par", test_dct<4, true>},
         {"example_fft2", example_fft2}, {"example_rfft2", example_rfft2}, {"example_fft_norm", example_fft_norm},
         {"readme_r2c_6x4", readme_r2c_6x4}, {"panics", panics}, {"f32_and_clone", f32_and_clone},
-        {"device_resident_fft2", device_resident_fft2}, {"par_over_devices", par_over_devices},
+        {"device_resident_fft2", device_resident_fft2}, {"device_resident_custom_norm", device_resident_custom_norm},
+        {"par_over_devices", par_over_devices},
     };
     int bad = 0;
     for (const T &t : tests) {
