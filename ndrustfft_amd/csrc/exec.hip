@@ -1154,9 +1154,10 @@ class HostRegCache {
     static HostRegCache &get() { static HostRegCache *c = new HostRegCache; return *c; }
     // true: [p, p + bytes) is registered now (and held until release())
     bool acquire(const void *p, size_t bytes) {
-        if (!limit_ || bytes < ((size_t)8 << 20)) return false;
+        if (bytes < ((size_t)8 << 20)) return false;
         const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
         std::lock_guard<std::mutex> g(mu_);
+        if (!limit_) return false;
         ++tick_;
         R *hit = nullptr;
         for (size_t i = 0; i < v_.size();) {
