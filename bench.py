@@ -77,8 +77,11 @@ def cpu_baseline(n, rows, budget_s=12.0):
     from oracle import oracle_ctypes as orc
     x = synth.complex_array((rows, n))
     y = np.zeros_like(x)
+    # timed with the restatement compiled for THIS host (-O3 -march=native) when that builds and still agrees with numpy; the parity tests keep -O2
+    flags = orc.use_fast_build() or "-O2"
     h = orc.FftHandler(n)
     orc.ndfft_par(x, y, h, 1)                      # warm
+    assert np.abs(y[:2] - np.fft.fft(x[:2], axis=1)).max() / np.abs(y[:2]).max() < 1e-12
     t0 = time.perf_counter(); reps = 0
     while True:
         orc.ndfft_par(x, y, h, 1); reps += 1
@@ -87,7 +90,7 @@ def cpu_baseline(n, rows, budget_s=12.0):
             break
     pts = rows * n * reps
     out = {"value": round(pts / el / 1e9, 4), "unit": "GFFT-points/s", "cores": orc.num_threads(), "kind": "port",
-           "cpu_model": cpu_model(),
+           "cpu_model": cpu_model(), "build": "gcc " + flags,
            "sample": f"{reps} x ndfft_par axis=1 on {rows}x{n} Complex<f64> (oracle/ndfft_oracle.c, OpenMP over lanes, "
                      f"{el:.1f} s; scalar C restatement of ndrustfft _par, NOT rustfft -- a lower bound on the reference's CPU speed)"}
     try:

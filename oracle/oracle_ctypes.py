@@ -44,6 +44,20 @@ def build(force=False):
 _lib = None
 
 
+def use_fast_build():
+    """bench.py's cpu_baseline leg only: (re)bind this module to the -O3 -march=native build of the same sources, built here and now for this host
+    (oracle/Makefile: fast).  Returns the compiler flags on success, None if it cannot be built or loaded (the -O2 build stays bound)."""
+    global _SO, _lib
+    fast = os.path.join(_HERE, "_build", "libndfft_oracle_fast.so")
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "fast"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        ctypes.CDLL(fast)
+    except Exception:
+        return None
+    _SO, _lib = fast, None
+    return "-O3 -march=native -funroll-loops"
+
+
 def lib():
     global _lib
     if _lib is None:
