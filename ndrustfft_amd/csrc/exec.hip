@@ -15,6 +15,9 @@
 #include <map>
 #include <string>
 #include <type_traits>
+#if defined(__x86_64__) && !defined(NDFFT_NO_NT_COPY)
+#include <immintrin.h>   // host-side streaming copy of the bounce pipeline (bulk_copy)
+#endif
 
 #include "engine.h"
 #include "pow2_real.h"
@@ -1308,6 +1311,30 @@ static int exec_pinned_pipeline(DeviceWs &ws, const ndfft_plan *plan, int op, co
 // chunks between the caller's arrays and three pinned slots per direction while the DMA engines move the previous
 // chunks, so upload, transform and download overlap for ANY host array (ndarray allocates pageable memory).
 namespace {
+// Bulk host copy with streaming (non-temporal) stores: the pieces the pool moves (a few MiB each) are below glibc's own non-temporal threshold, so plain
+// memcpy reads the destination lines before overwriting them (three memory transfers per byte instead of two).  AVX2 only where the CPU has it;
+// NDFFT_COPY_NT=0 keeps memcpy.  Host code only.
+#if defined(__x86_64__) && !defined(NDFFT_NO_NT_COPY)
+__attribute__((target("avx2"))) void copy_nt_avx2(char *d, const char *s, size_t n) {
+    while (n && ((uintptr_t)d & 31)) { *d++ = *s++; --n; }
+    size_t k = n / 128;
+    for (; k; --k, d += 128, s += 128) {
+        const __m256i a = _mm256_loadu_si256((const __m256i *)s), b = _mm256_loadu_si256((const __m256i *)(s + 32));
+        const __m256i c = _mm256_loadu_si256((const __m256i *)(s + 64)), e = _mm256_loadu_si256((const __m256i *)(s + 96));
+        _mm256_stream_si256((__m256i *)d, a); _mm256_stream_si256((__m256i *)(d + 32), b);
+        _mm256_stream_si256((__m256i *)(d + 64), c); _mm256_stream_si256((__m256i *)(d + 96), e);
+    }
+    _mm_sfence();
+    n &= 127;
+    if (n) memcpy(d, s, n);
+}
+void bulk_copy(char *d, const char *s, size_t n) {
+    static const bool nt = [] { const char *e = getenv("NDFFT_COPY_NT"); return !(e && e[0] == '0') && __builtin_cpu_supports("avx2"); }();
+    if (nt && n >= ((size_t)256 << 10)) copy_nt_avx2(d, s, n); else memcpy(d, s, n);
+}
+#else
+void bulk_copy(char *d, const char *s, size_t n) { memcpy(d, s, n); }
+#endif
 struct CopyGroup { std::atomic<int> left{0}; std::mutex m; std::condition_variable cv; };
 class CopyPool {
   public:
@@ -1354,7 +1381,7 @@ class CopyPool {
                 cv_.wait(lk, [this] { return !q_.empty(); });
                 p = q_.front(); q_.pop_front();
             }
-            memcpy(p.d, p.s, p.n);
+            bulk_copy(p.d, p.s, p.n);
             // the count changes only under the group's mutex: a waiter (whose CopyGroup lives on its stack) cannot see zero, return and
             // destroy the group while this thread is still about to lock it
             { std::lock_guard<std::mutex> lk(p.g->m); if (p.g->left.fetch_sub(1) == 1) p.g->cv.notify_all(); }
