@@ -1,0 +1,111 @@
+// col_direct.h -- LANE-FASTEST register kernel for the passes of the four-step routes whose tile is a set of ADJACENT lanes with a strided
+// transform axis (complex lanes, power-of-two F = 64..1024).
+//
+// The column kernels of pow2_real.h stage the whole F x LPB complex tile in LDS twice (raw tile in, natural-order result out) because their
+// thread map is lane-major (thread = lane * TPL + t): a wavefront then owns ONE lane, and only an LDS transpose makes its global accesses
+// contiguous.  Here thread = t * LPB + lane: a wavefront owns one butterfly slot of LPB adjacent lanes, so
+//   * the loads go global -> registers directly, already in the first pass's pattern (element t + q TPL + r F/R0 of LPB adjacent lanes =
+//     one 128-byte row segment per (q, r)), with all E of them in flight;
+//   * the passes are pow2_kernel.h's with the HALF exchange (real parts, then imaginary parts, through F reals per lane);
+//   * the stores go registers -> global directly in the last pass's pattern -- as rows k of adjacent lanes (column store) or, for the
+//     transposing first pass of the row four-step, as runs of consecutive k of one lane (a wavefront writes 64 / LPB consecutive elements of
+//     LPB lanes: whole 128-byte lines for c128).
+// LDS per tile: LPB x (F + F/16 + 1) x sizeof(T) -- a quarter of the staged tile plus exchange of the lane-major kernel for the same lanes
+// (F = 512 c128, 8 lanes: 17 KiB instead of 70 KiB; F = 1024: 34 KiB instead of 139 KiB), no staging barriers, two LDS round trips fewer.
+#pragma once
+#include "pow2_real.h"
+
+namespace ndfft {
+
+// MODE (the CS numbering of pow2_real.h):
+//   0  first pass of the row four-step: column load, ROW store (lane L -> out + L pitch_out)
+//   4  second pass of the row four-step: twiddle W_N^(j k1) on load (k1 = the inner index), column store at row k2
+//   5  second pass of the REAL four-step, R2C: half spectrum, the mirrored half conjugated into place (pow2_real.h CS = 5)
+//   6  the same with the DCT-II post-twiddle: two real outputs per element (CS = 6)
+template <typename T, int F, int TPL, int LPB, typename RL, int OP, int MODE> struct ColDirectKernel {
+    static_assert(OP == G_C2C_FWD || OP == G_C2C_INV, "complex lanes only");
+    static_assert(MODE == 0 || MODE == 4 || ((MODE == 5 || MODE == 6) && OP == G_C2C_FWD), "bad mode");
+    using FFT = Pow2Kernel<T, F, TPL, LPB, true, RL, 0, 1, 0>;
+    static constexpr int E = FFT::E, THREADS = TPL * LPB;
+    static_assert(E * TPL == F, "whole butterfly rounds only");
+    static constexpr size_t LDS_BYTES = FFT::LDS_BYTES;
+
+    static __device__ __forceinline__ void run(const RealArgs<T> &a) {
+        extern __shared__ __attribute__((aligned(16))) char smem[];
+        const int cl = threadIdx.x % LPB, t = threadIdx.x / LPB;
+        // (xcd_chunk: runs of consecutive tiles on one XCD, so that lines shared by neighbouring tiles -- the mirrored index N1 - k1 is shifted
+        //  by one element, real outputs are half lines -- merge in that XCD's L2 when they are written with plain stores: keep_out)
+        const int64_t L = (int64_t)xcd_block(blockIdx.x, gridDim.x, a.xcd_chunk) * LPB + cl;
+        const int64_t o = L / a.inner;
+        const int k1 = (int)(L - o * a.inner);
+        // (MODE 5 / 6: the inner index runs over a pitch padded to whole 128-byte lines; k1 > N1/2 is padding)
+        const bool live = L < a.nlanes && (MODE < 5 || 2 * k1 <= a.cs_f1);
+        char *lds = smem + (size_t)cl * FFT::LANE_LDS * sizeof(T);
+        cpx<T> v[E];
+        {
+            constexpr int R0 = RL::at(0), NB0 = F / R0, NBF0 = FFT::slots(0);
+            const cpx<T> *in = (const cpx<T> *)a.in + o * a.outer_in + k1;
+#pragma unroll
+            for (int q = 0; q < NBF0; ++q)
+#pragma unroll
+                for (int r = 0; r < R0; ++r) {
+                    const int i = t + q * TPL + r * NB0;
+                    if (live) v[q * R0 + r] = a.stream_in ? gload<T, true>(in + (int64_t)i * a.elem_in) : in[(int64_t)i * a.elem_in];
+                    else v[q * R0 + r] = mk<T>((T)0, (T)0);
+                }
+            if constexpr (OP == G_C2C_INV) {
+#pragma unroll
+                for (int i = 0; i < E; ++i) v[i].y = -v[i].y;
+            }
+            if constexpr (MODE >= 4) {   // W_N^(i k1), after the conjugation: the same table serves both directions
+                const int mask = (1 << a.cs_logB) - 1;
+#pragma unroll
+                for (int q = 0; q < NBF0; ++q)
+#pragma unroll
+                    for (int r = 0; r < R0; ++r) {
+                        const int m = (t + q * TPL + r * NB0) * k1;
+                        v[q * R0 + r] = cmul(v[q * R0 + r], cmul(a.cs_twhi[m >> a.cs_logB], a.cs_twlo[m & mask]));
+                    }
+            }
+        }
+        FFT::template passes<0>(v, a.twp, lds, t);
+        if (!live) return;
+        constexpr int RL_ = RL::at(RL::NP - 1), NBL = F / RL_, NBFL = FFT::slots(RL::NP - 1);
+        if constexpr (OP == G_C2C_INV) {
+#pragma unroll
+            for (int i = 0; i < E; ++i) { v[i].x *= a.scale; v[i].y *= -a.scale; }   // conj + normalisation (src/lib.rs:326-330)
+        }
+#pragma unroll
+        for (int q = 0; q < NBFL; ++q)
+#pragma unroll
+            for (int r = 0; r < RL_; ++r) {
+                const int kq = t + q * TPL + r * NBL;
+                cpx<T> val = v[q * RL_ + r];
+                if constexpr (MODE == 0) {
+                    cpx<T> *out = (cpx<T> *)a.out + L * a.pitch_out + kq;
+                    if (a.keep_out) *out = val; else gstore<T, true>(out, val);
+                } else if constexpr (MODE == 4) {
+                    gstore<T, true>((cpx<T> *)a.out + o * a.outer_out + k1 + (int64_t)kq * a.elem_out, val);
+                } else {
+                    int kk = k1, r2 = kq;
+                    bool mir = false;
+                    if (k1 == 0) { if (kq > F / 2) continue; }
+                    else if (2 * k1 == a.cs_f1) { if (kq >= F / 2) continue; }
+                    else if (kq >= F / 2) { kk = a.cs_f1 - k1; r2 = F - 1 - kq; val.y = -val.y; mir = true; }
+                    const int64_t k = kk + (int64_t)a.cs_f1 * r2;   // 0..n/2, every value once
+                    const int64_t ob = o * a.outer_out;
+                    if constexpr (MODE == 5) {
+                        if ((mir && a.keep_out) || (a.keep_out & 2)) ((cpx<T> *)a.out)[ob + k] = val; else gstore<T, true>((cpx<T> *)a.out + ob + k, val);
+                    } else {
+                        const cpx<T> tk = cmul(val, a.aux2[k]);
+                        T *out = (T *)a.out + ob;
+                        const T y0 = tk.x * a.scale, y1 = -tk.y * a.scale;
+                        if ((mir && a.keep_out) || (a.keep_out & 2)) out[k] = y0; else __builtin_nontemporal_store(y0, out + k);
+                        if (k > 0 && 2 * k < a.cs_n) { if ((!mir && a.keep_out) || (a.keep_out & 2)) out[a.cs_n - k] = y1; else __builtin_nontemporal_store(y1, out + (a.cs_n - k)); }
+                    }
+                }
+            }
+    }
+};
+
+}  // namespace ndfft

@@ -91,6 +91,12 @@ struct FftConfig {                 // one complex-FFT-of-length-F recipe + op ta
     bool cs = false; int cs_F1 = 0, cs_F2 = 0, cs_logB = 0;
     ndfft_plan *cs_sub1 = nullptr, *cs_sub2 = nullptr;
     HostTable cs_twlo, cs_twhi;    // W_n^m for m < n, split like twlo / twhi
+    // long CONTIGUOUS real-data lanes (MAIN slot of R2C and DCT plans, big, n a power of two): REAL four-step n = rfs_N1 * rfs_N2
+    // (exec.hip: real_fourstep) -- a real FFT of length N1 over the strided index, then complex FFTs of length N2 on the half
+    // spectrum; rfs_sub1 = R2C plan of length N1, rfs_sub2 = C2C plan of length N2, twiddles W_n^m split like twlo / twhi
+    bool rfs = false; int rfs_N1 = 0, rfs_N2 = 0, rfs_logB = 0;
+    ndfft_plan *rfs_sub1 = nullptr, *rfs_sub2 = nullptr;
+    HostTable rfs_twlo, rfs_twhi;
     bool blue_reg_only = false;    // M exceeds the LDS kernel's reach: only the register kernel can run it
     bool bluereg = false;          // blue && M has a register-kernel configuration: blue_kernel.h, specialised with hiprtc
                                    // (jitcfg = configuration for M, twp = its per-pass twiddles)
@@ -105,6 +111,7 @@ struct DevConfig {                 // device copies (typed by dtype) of one FftC
     void *tw = nullptr, *twM = nullptr, *chirp = nullptr, *bhat = nullptr, *aux1 = nullptr, *aux2 = nullptr, *twp = nullptr;
     void *twlo = nullptr, *twhi = nullptr, *twp_col = nullptr, *twp_narrow = nullptr;
     void *cs_twlo = nullptr, *cs_twhi = nullptr;
+    void *rfs_twlo = nullptr, *rfs_twhi = nullptr;
     void *wave_tw = nullptr;
     void *tinymat[4] = {nullptr, nullptr, nullptr, nullptr};
     void *rader_bhat = nullptr, *rader_twp = nullptr, *rader_twp2 = nullptr, *rader_tab = nullptr, *twp_rev = nullptr, *rader_ctw = nullptr;   // ctw: W_mc^k of a two-factor cofactor
@@ -216,6 +223,10 @@ template <typename T> int launch_colsplit(int cs, bool inverse, const RealArgs<T
 // kernels_fourstep.hip : the two passes of the row four-step on the column kernels (no transpose launch)
 bool fourstep_supported(int F);
 template <typename T> int launch_fourstep(int pass, int F, bool inverse, const RealArgs<T> &a, hipStream_t s);
+// kernels_fourstep_real.hip : the passes of the REAL four-step (stage: 1 = real column FFT, row store; 2 = twiddled column pass
+// writing the half spectrum (R2C) ; 3 = the same writing DCT-II outputs)
+bool fourstep_real_supported(int N1, int N2);
+template <typename T> int launch_fourstep_real(int stage, int F, const RealArgs<T> &a, hipStream_t s);
 
 // big.hip : four-step pieces for lanes that do not fit LDS
 template <typename T>

@@ -420,6 +420,12 @@ static bool fourstep2_enabled() {
     return !(e && e[0] == '0');
 }
 
+// developer / test switch: NDFFT_REAL_FOURSTEP=0 keeps long real-data lanes on the packed complex four-step with separate PRE / POST passes
+static int real_fourstep_enabled() {
+    const char *e = getenv("NDFFT_REAL_FOURSTEP");
+    return e ? atoi(e) : 1;
+}
+
 // largest handler length the thread-per-lane real-op register kernels take (raw lane + Z + outputs in registers)
 static int regreal_max_n(int f64) {
     static const int m32 = [] { const char *e = getenv("NDFFT_REGREAL_MAX_F32"); return e ? atoi(e) : 72; }();   // f32 n = 64: 0.66 vs 0.50; n = 96 / 100: 0.39 / 0.37 vs 0.41 / 0.49
@@ -664,6 +670,45 @@ static int gen_op_of(int op, int n, int *slot) {
     }
 }
 
+// REAL four-step for long contiguous real-data lanes, n = N1 * N2 a power of two (plan.hip: add_real_fourstep), R2C and DCT-II:
+//   (1) real FFTs of length N1 over the strided index n1 of x[n1 N2 + n2] (DCT-II: of Makhoul's permutation of x, gathered by the load),
+//       half spectrum stored transposed, s[lane][n2][k1], k1 = 0..N1/2
+//   (2) complex FFTs of length N2 over n2 with the twiddle W_n^(n2 k1) fused into the load; X[k1 + N1 k2] and, for the other half of every
+//       lane, conj at the mirrored index -- the half spectrum 0..n/2 exactly once; DCT-II multiplies by e^(-i pi k / 2n) and writes y[k], y[n-k]
+// Two passes and an intermediate of n/2 + N2 complex per lane; the packed complex four-step needs a split pass (and a Makhoul pass) around its two.
+template <typename T>
+static int real_fourstep(const Problem &P, int gop, const FftConfig &c, const DevConfig &d, const void *d_in, void *d_out, int64_t pin, int64_t pout, hipStream_t stream) {
+    const int N1 = c.rfs_N1, N2 = c.rfs_N2;
+    // k1 = 0..N1/2 of the intermediate on a pitch of whole 128-byte lines (the tiles of pass 2 are 128 bytes of adjacent k1 wide: with the
+    // natural pitch N1/2 + 1 every tile row would straddle two lines shared with a tile on another XCD)
+    const int K = (N1 / 2 + 1 + (int)(128 / sizeof(cpx<T>)) - 1) & ~((int)(128 / sizeof(cpx<T>)) - 1);
+    const int64_t n = (int64_t)N1 * N2, B = P.nlanes;
+    const DevTables *dt1, *dt2;
+    int rc;
+    if ((rc = get_dev_tables(c.rfs_sub1, &dt1)) || (rc = get_dev_tables(c.rfs_sub2, &dt2))) return rc;
+    void *s1;
+    if ((rc = get_scratch(4, stream, (size_t)(B * N2 * K) * sizeof(cpx<T>), &s1))) return rc;
+    RealArgs<T> a;
+    a.pitch_in = 0; a.vec_in = 0; a.vec_out = 0; a.xcd_remap = 0; a.keep_out = 0; a.stream_in = 0; a.chunk_out = 0;
+    a.aux2 = nullptr; a.chirp = nullptr; a.bhat = nullptr;
+    a.cs_twlo = (const cpx<T> *)d.rfs_twlo; a.cs_twhi = (const cpx<T> *)d.rfs_twhi; a.cs_logB = c.rfs_logB;
+    a.cs_k1n = 1; a.cs_f1 = N1; a.cs_n = (int)n; a.cs_outer_in = 0; a.cs_outer_out = 0; a.cs_pitch = 0;
+    // pass 1: lanes (l, n2), real input
+    a.in = d_in; a.out = s1; a.nlanes = B * N2; a.n = N1; a.F = N1 / 2; a.n_in = N1; a.n_out = N1 / 2 + 1; a.scale = (T)1;
+    a.inner = N2; a.outer_in = pin; a.outer_out = 0; a.elem_in = N2; a.elem_out = 0; a.pitch_out = K;
+    a.aux1 = (const cpx<T> *)dt1->cfg[CFG_MAIN].aux1; a.twp = (const cpx<T> *)dt1->cfg[CFG_MAIN].twp;
+    a.makhoul = gop == G_DCT2_EVEN ? 1 : 0;
+    if ((rc = launch_fourstep_real<T>(1, N1 / 2, a, stream))) return rc;
+    // pass 2: lanes (l, k1)
+    a.makhoul = 0;
+    { static const int mp = [] { const char *e = getenv("NDFFT_RFS_MIRROR_PLAIN"); return e ? atoi(e) : 1; }(); a.keep_out = mp; }
+    { static const int xc = [] { const char *e = getenv("NDFFT_RFS_XCD_CHUNK"); return e ? atoi(e) : 8; }(); a.xcd_chunk = xc; }
+    a.in = s1; a.out = d_out; a.nlanes = B * K; a.n = N2; a.F = N2; a.n_in = N2; a.n_out = N2; a.scale = (T)P.scale;
+    a.inner = K; a.outer_in = (int64_t)N2 * K; a.outer_out = pout; a.elem_in = K; a.elem_out = 0; a.pitch_out = 0;
+    a.aux1 = nullptr; a.aux2 = (const cpx<T> *)d.aux2; a.twp = (const cpx<T> *)dt2->cfg[CFG_MAIN].twp_col;
+    return launch_fourstep_real<T>(gop == G_DCT2_EVEN ? 3 : 2, N2, a, stream);
+}
+
 // contiguous lanes whose inner FFT does not fit one workgroup's LDS
 template <typename T>
 static int dispatch_big(const Problem &P, const void *d_in, void *d_out, const DevTables &dt, hipStream_t stream) {
@@ -676,6 +721,13 @@ static int dispatch_big(const Problem &P, const void *d_in, void *d_out, const D
     if (gop == G_C2C_FWD || gop == G_C2C_INV) {
         int rc0 = big_fft<T>(c, d, (const cpx<T> *)d_in, pin, (cpx<T> *)d_out, pout, P.nlanes, gop == G_C2C_INV, (T)P.scale, stream);
         set_last_path(c.bigblue ? "blue_global" : "four_step");
+        return rc0;
+    }
+    // (f32 R2C keeps the packed route: 90 us vs 100 us for 64 x 262144 -- its two complex passes run at twice the element rate of f64's;
+    //  NDFFT_REAL_FOURSTEP=2 forces the real four-step for every eligible call)
+    if (c.rfs && (gop == G_DCT2_EVEN || (gop == G_R2C_EVEN && P.scale == 1.0 && (sizeof(T) == 8 || real_fourstep_enabled() == 2))) && real_fourstep_enabled()) {
+        const int rc0 = real_fourstep<T>(P, gop, c, d, d_in, d_out, pin, pout, stream);
+        set_last_path("real_four_step");
         return rc0;
     }
     RealArgs<T> a;

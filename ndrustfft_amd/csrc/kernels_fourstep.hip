@@ -5,7 +5,8 @@
 //   pass 2  s[n2][k1]: FFTs of length F2 over n2 (stride F1, adjacent k1 contiguous), twiddle W_F^(n2 k1) on load,
 //           stored at k1 + F1 k2 = natural order (column store)                                     -- CS = 4 kernels
 // Replaces transpose -> row FFT -> twiddle -> transpose -> row FFT -> transpose (six passes) and the three-pass form.
-#include "pow2_real.h"
+#include "col_direct.h"
+#include <cstdlib>
 
 namespace ndfft {
 
@@ -54,12 +55,33 @@ template <typename T, int F, int OP, int CS, bool ROWOUT> static int launch_fs(c
     return NDFFT_OK;
 }
 
+// the lane-fastest register kernels of col_direct.h for the same two passes: measured SLOWER here (32 x 2^20 c64 388 -> 526 us, c128 560 -> 580 us:
+// profiles/r06), so they run only when NDFFT_FS_DIRECT=1 asks for them (parity tests do); the real four-step's second pass uses them for f64
+static bool fs_direct() {
+    const char *e = getenv("NDFFT_FS_DIRECT");   // (read per call: the parity tests switch it)
+    return e && e[0] == '1';
+}
+template <typename T, int F, int OP, int MODE> static int launch_fsd(const RealArgs<T> &a, hipStream_t s) {
+    constexpr int LPB = FsGeom<T, F>::LPB;
+    using K = ColDirectKernel<T, F, FsCfg<F>::TPL, LPB, typename FsCfg<F>::RL, OP, MODE>;
+    const int64_t nblk = (a.nlanes + LPB - 1) / LPB;
+    if (nblk <= 0) return NDFFT_OK;
+    if (nblk > 0x7fffffffLL) return fail(NDFFT_ERR_UNSUPPORTED, "too many lanes for one launch");
+    hipLaunchKernelGGL((k_pow2_real<K, T>), dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, a);
+    NDFFT_HIP(hipGetLastError());
+    return NDFFT_OK;
+}
+
 bool fourstep_supported(int F) { return F == 64 || F == 128 || F == 256 || F == 512 || F == 1024; }
 
 // pass = 1: column load / row store; pass = 2: twiddle by the inner index on load, column store
 template <typename T> int launch_fourstep(int pass, int F, bool inverse, const RealArgs<T> &a, hipStream_t s) {
 #define NDFFT_FS_CASE(F_)                                                                                              \
     case F_:                                                                                                           \
+        if (fs_direct()) {                                                                                             \
+            if (pass == 1) return inverse ? launch_fsd<T, F_, G_C2C_INV, 0>(a, s) : launch_fsd<T, F_, G_C2C_FWD, 0>(a, s); \
+            return inverse ? launch_fsd<T, F_, G_C2C_INV, 4>(a, s) : launch_fsd<T, F_, G_C2C_FWD, 4>(a, s);            \
+        }                                                                                                              \
         if (pass == 1) return inverse ? launch_fs<T, F_, G_C2C_INV, 0, true>(a, s) : launch_fs<T, F_, G_C2C_FWD, 0, true>(a, s); \
         return inverse ? launch_fs<T, F_, G_C2C_INV, 4, false>(a, s) : launch_fs<T, F_, G_C2C_FWD, 4, false>(a, s);
     switch (F) {

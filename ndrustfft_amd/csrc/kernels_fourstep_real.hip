@@ -1,0 +1,105 @@
+// kernels_fourstep_real.hip -- the passes of the REAL row four-step for long contiguous real-data lanes (exec.hip: real_fourstep).
+// n = N1 * N2 real points per lane, x[n1 N2 + n2]:
+//   stage 1  real FFTs of length N1 over n1 (stride N2, adjacent n2 contiguous: column LOAD; DCT-II: through Makhoul's permutation),
+//            half spectrum k1 = 0..N1/2 stored TRANSPOSED as s[n2][k1] (every lane one contiguous run: ROW store)      -- R2C ROWOUT kernels
+//   stage 2  s[n2][k1]: complex FFTs of length N2 over n2 (stride N1/2 + 1, adjacent k1 contiguous), twiddle W_n^(n2 k1) on load;
+//            X[k1 + N1 k2] for k <= n/2, the other half of every lane conjugated into its mirrored place                -- CS = 5 kernels
+//   stage 3  the same with the DCT-II post-twiddle fused: two real outputs per spectrum element                          -- CS = 6 kernels
+// Replaces (packed complex four-step of length n/2 = two passes) + (split pass) [+ (Makhoul pass)]: 3 (R2C) or 4 (DCT-II) passes
+// over global memory become 2.  Reference semantics: R2cFftHandler / DctHandler accept any n (src/lib.rs:477, 665).
+#include "col_direct.h"
+#include <cstdlib>
+
+namespace ndfft {
+
+// the E = 8 configurations of kernels_pow2_real.hip (same tables as kernels_fourstep.hip)
+template <int F> struct RfsCfg;
+#define NDFFT_RFS(F_, TPL_, ...) template <> struct RfsCfg<F_> { static constexpr int TPL = TPL_; using RL = RadixList<__VA_ARGS__>; };
+NDFFT_RFS(64, 8, 8, 8)
+NDFFT_RFS(128, 16, 8, 4, 4)
+NDFFT_RFS(256, 32, 8, 8, 4)
+NDFFT_RFS(512, 64, 8, 8, 8)
+NDFFT_RFS(1024, 128, 8, 8, 4, 4)
+
+// adjacent lanes per tile.  Stage 1 reads REAL rows: 16 doubles / 32 floats = 128 bytes (compile-time knobs, A/B in profiles/);
+// stages 2 / 3 read complex rows like the complex four-step (8 c128 / 16 c64)
+#ifndef NDFFT_RFS_LANES1_F64
+#define NDFFT_RFS_LANES1_F64 16
+#endif
+#ifndef NDFFT_RFS_LANES1_F32
+#define NDFFT_RFS_LANES1_F32 32
+#endif
+#ifndef NDFFT_RFS_LANES2_F64
+#define NDFFT_RFS_LANES2_F64 8
+#endif
+#ifndef NDFFT_RFS_LANES2_F32
+#define NDFFT_RFS_LANES2_F32 16
+#endif
+template <typename T, int F, int STAGE> struct RfsGeom {
+    static constexpr int TPL = RfsCfg<F>::TPL;
+    static constexpr int WANT = STAGE == 1 ? (sizeof(T) == 8 ? NDFFT_RFS_LANES1_F64 : NDFFT_RFS_LANES1_F32) : (sizeof(T) == 8 ? NDFFT_RFS_LANES2_F64 : NDFFT_RFS_LANES2_F32);
+    // at most 1024 threads, at least 256; tiles above 80 KiB of LDS (one workgroup per CU) are halved down to 8 lanes
+    static constexpr size_t LANE_BYTES = (size_t)((F + (F >> 4) + 2) | 1) * 2 * sizeof(T);
+    static constexpr int L0 = WANT * TPL > 1024 ? 1024 / TPL : WANT;
+    static constexpr int L1 = (L0 > 8 && L0 * LANE_BYTES > 80 * 1024) ? L0 / 2 : L0;
+    static constexpr int L2 = (L1 > 8 && L1 * LANE_BYTES > 80 * 1024) ? L1 / 2 : L1;
+    static constexpr int LPB = TPL * L2 < 256 ? 256 / TPL : L2;
+    static_assert(TPL * LPB <= 1024, "workgroup too large");
+};
+
+template <typename T, int F, int STAGE> static int launch_rfs(const RealArgs<T> &a, hipStream_t s) {
+    constexpr int LPB = RfsGeom<T, F, STAGE>::LPB;
+    using K = typename cond_type<STAGE == 1,
+                                 RealPow2Kernel<T, F, RfsCfg<F>::TPL, LPB, typename RfsCfg<F>::RL, G_R2C_EVEN, true, false, 0, true>,
+                                 RealPow2Kernel<T, F, RfsCfg<F>::TPL, LPB, typename RfsCfg<F>::RL, G_C2C_FWD, true, false, STAGE == 2 ? 5 : 6, false>>::type;
+    static_assert(K::LDS_BYTES <= 160 * 1024, "tile does not fit LDS");
+    NDFFT_ENSURE_LDS_ATTR((k_pow2_real<K, T>));
+    const int64_t nblk = (a.nlanes + LPB - 1) / LPB;
+    if (nblk <= 0) return NDFFT_OK;
+    if (nblk > 0x7fffffffLL) return fail(NDFFT_ERR_UNSUPPORTED, "too many lanes for one launch");
+    hipLaunchKernelGGL((k_pow2_real<K, T>), dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, a);
+    NDFFT_HIP(hipGetLastError());
+    return NDFFT_OK;
+}
+
+// stages 2 / 3 on the lane-fastest register kernels of col_direct.h: f64 by default (64 x 262144 nddct2 187 -> 155 us with runs of tiles per XCD
+// and plain stores at shared lines), f32 stays on the staged column kernels above (120 vs 127 us); NDFFT_FS_DIRECT=0 / 1 forces one form
+template <typename T> static bool rfs_direct() {
+    const char *e = getenv("NDFFT_FS_DIRECT");   // (read per call: the parity tests switch it)
+    return e ? e[0] == '1' : sizeof(T) == 8;
+}
+template <typename T, int F, int STAGE> static int launch_rfsd(const RealArgs<T> &a, hipStream_t s) {
+    constexpr int LPB = RfsGeom<T, F, STAGE>::LPB;
+    using K = ColDirectKernel<T, F, RfsCfg<F>::TPL, LPB, typename RfsCfg<F>::RL, G_C2C_FWD, STAGE == 2 ? 5 : 6>;
+    const int64_t nblk = (a.nlanes + LPB - 1) / LPB;
+    if (nblk <= 0) return NDFFT_OK;
+    if (nblk > 0x7fffffffLL) return fail(NDFFT_ERR_UNSUPPORTED, "too many lanes for one launch");
+    hipLaunchKernelGGL((k_pow2_real<K, T>), dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, a);
+    NDFFT_HIP(hipGetLastError());
+    return NDFFT_OK;
+}
+
+// N1 = real length of stage 1 (inner complex FFT N1 / 2), N2 = complex length of stage 2
+bool fourstep_real_supported(int N1, int N2) {
+    auto ok = [](int F) { return F == 64 || F == 128 || F == 256 || F == 512 || F == 1024; };
+    return N1 % 2 == 0 && ok(N1 / 2) && ok(N2);
+}
+
+// stage 1: F = N1 / 2; stages 2, 3: F = N2
+template <typename T> int launch_fourstep_real(int stage, int F, const RealArgs<T> &a, hipStream_t s) {
+#define NDFFT_RFS_CASE(F_)                                       \
+    case F_:                                                     \
+        if (stage == 1) return launch_rfs<T, F_, 1>(a, s);       \
+        if (rfs_direct<T>()) return stage == 2 ? launch_rfsd<T, F_, 2>(a, s) : launch_rfsd<T, F_, 3>(a, s); \
+        if (stage == 2) return launch_rfs<T, F_, 2>(a, s);       \
+        return launch_rfs<T, F_, 3>(a, s);
+    switch (F) {
+        NDFFT_RFS_CASE(64) NDFFT_RFS_CASE(128) NDFFT_RFS_CASE(256) NDFFT_RFS_CASE(512) NDFFT_RFS_CASE(1024)
+        default: return fail(NDFFT_ERR_UNSUPPORTED, "real four-step: unsupported factor");
+    }
+#undef NDFFT_RFS_CASE
+}
+template int launch_fourstep_real<float>(int, int, const RealArgs<float> &, hipStream_t);
+template int launch_fourstep_real<double>(int, int, const RealArgs<double> &, hipStream_t);
+
+}  // namespace ndfft

@@ -4,6 +4,7 @@
 // afterwards, so one plan can be shared by any number of host threads (lib.rs:192-194).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <tuple>
 
@@ -69,6 +70,7 @@ static bool factorize(int F, std::vector<int> &radix) {
 static ndfft_plan *make_plan(int kind, int dtype, size_t n);
 static void add_narrow_tables(ndfft_plan *p);
 static void add_colsplit(ndfft_plan *p);
+static void add_real_fourstep(ndfft_plan *p);
 
 // per-pass transposed twiddles of the LDS Stockham kernel: for pass p (radix R, Ns = product of the
 // earlier radices) the block  tw_p[(r-1) Ns + k] = e^{-2 pi i r k/(Ns R)},  r in [1,R), k in [0,Ns);
@@ -359,6 +361,7 @@ static ndfft_plan *make_plan(int kind, int dtype, size_t n) {
     build_tiny_mats(p);
     add_narrow_tables(p);
     add_colsplit(p);
+    add_real_fourstep(p);
     return p;
 }
 
@@ -382,6 +385,31 @@ static void add_colsplit(ndfft_plan *p) {
     const int64_t B = 1ll << c.cs_logB;
     for (int64_t k = 0; k < B && k < (int64_t)n; ++k) unit(c.cs_twlo, k, n);
     for (int64_t k = 0; k * B < (int64_t)n; ++k) unit(c.cs_twhi, k * B, n);
+}
+
+// REAL four-step for long contiguous real-data lanes (R2C and DCT plans, MAIN slot, n = 2^e too long for one launch):
+// n = N1 * N2, a real FFT of length N1 = 2^a over the strided index n1 (inner complex FFT N1/2 = 64..1024), then complex FFTs of length
+// N2 = 2^b (64..1024) over n2 for k1 = 0..N1/2 only.  Half the intermediate of the complex four-step on the packed lane, and no
+// separate split pass: two passes over global memory instead of three (R2C) or four (DCT-II).
+static void add_real_fourstep(ndfft_plan *p) {
+    if (p->kind != NDFFT_KIND_R2C && p->kind != NDFFT_KIND_DCT) return;
+    const size_t n = p->n;
+    FftConfig &c = p->cfg[CFG_MAIN];
+    if (n == 0 || (n & (n - 1)) || !p->has_cfg[CFG_MAIN] || !c.big || c.bigblue) return;
+    int e = 0; while (((size_t)1 << e) < n) ++e;
+    // (measured at n = 2^18, 64 lanes: f64 N1 = 512 (R2C 123 us; 1024: 139 us), f32 DCT-II N1 = 1024 (113 us; 512: 127 us) -- profiles/r06)
+    int a = std::min(11, std::max(7, (e + 1) / 2 + (p->dtype == NDFFT_F32 ? 1 : 0)));
+    if (e - a < 6) a = e - 6;
+    if (const char *k = getenv("NDFFT_RFS_LOGN1")) { const int v = atoi(k); if (v >= 7 && v <= 11) a = v; }   // developer knob (A/B of the split)
+    const int b = e - a;
+    if (b < 6 || b > 10 || !fourstep_real_supported(1 << a, 1 << b)) return;
+    c.rfs = true; c.rfs_N1 = 1 << a; c.rfs_N2 = 1 << b;
+    c.rfs_sub1 = make_plan(NDFFT_KIND_R2C, p->dtype, (size_t)c.rfs_N1);
+    c.rfs_sub2 = make_plan(NDFFT_KIND_C2C, p->dtype, (size_t)c.rfs_N2);
+    c.rfs_logB = (e + 1) / 2;
+    const int64_t B = 1ll << c.rfs_logB;
+    for (int64_t k = 0; k < B && k < (int64_t)n; ++k) unit(c.rfs_twlo, k, n);
+    for (int64_t k = 0; k * B < (int64_t)n; ++k) unit(c.rfs_twhi, k * B, n);
 }
 
 static void add_narrow_tables(ndfft_plan *p) {
@@ -448,6 +476,8 @@ int get_dev_tables(const ndfft_plan *cplan, const DevTables **out) {
         if ((rc = upload_any(plan->dtype, c.twhi, &d.twhi))) return rc;
         if ((rc = upload_any(plan->dtype, c.cs_twlo, &d.cs_twlo))) return rc;
         if ((rc = upload_any(plan->dtype, c.cs_twhi, &d.cs_twhi))) return rc;
+        if ((rc = upload_any(plan->dtype, c.rfs_twlo, &d.rfs_twlo))) return rc;
+        if ((rc = upload_any(plan->dtype, c.rfs_twhi, &d.rfs_twhi))) return rc;
         if ((rc = upload_any(plan->dtype, c.twp_col, &d.twp_col))) return rc;
         if ((rc = upload_any(plan->dtype, c.twp_narrow, &d.twp_narrow))) return rc;
         if ((rc = upload_any(plan->dtype, c.wave_tw, &d.wave_tw))) return rc;
@@ -525,13 +555,14 @@ int ndfft_plan_destroy(ndfft_plan *plan) {
         (void)hipSetDevice(kv.first);
         for (int i = 0; i < CFG_COUNT; ++i) {
             DevConfig &d = kv.second.cfg[i];
-            void *ptrs[] = {d.tw, d.twM, d.chirp, d.bhat, d.aux1, d.aux2, d.twp, d.twlo, d.twhi, d.twp_col, d.twp_narrow, d.cs_twlo, d.cs_twhi, d.wave_tw, d.tinymat[0], d.tinymat[1], d.tinymat[2], d.tinymat[3], d.rader_bhat, d.rader_twp, d.rader_twp2, d.rader_tab, d.twp_rev, d.rader_ctw};
+            void *ptrs[] = {d.tw, d.twM, d.chirp, d.bhat, d.aux1, d.aux2, d.twp, d.twlo, d.twhi, d.twp_col, d.twp_narrow, d.cs_twlo, d.cs_twhi, d.rfs_twlo, d.rfs_twhi, d.wave_tw, d.tinymat[0], d.tinymat[1], d.tinymat[2], d.tinymat[3], d.rader_bhat, d.rader_twp, d.rader_twp2, d.rader_tab, d.twp_rev, d.rader_ctw};
             for (void *q : ptrs) if (q) (void)hipFree(q);
         }
     }
     (void)hipSetDevice(cur);
     for (int i = 0; i < CFG_COUNT; ++i) { ndfft_plan_destroy(plan->cfg[i].sub1); ndfft_plan_destroy(plan->cfg[i].sub2);
-                                          ndfft_plan_destroy(plan->cfg[i].cs_sub1); ndfft_plan_destroy(plan->cfg[i].cs_sub2); }
+                                          ndfft_plan_destroy(plan->cfg[i].cs_sub1); ndfft_plan_destroy(plan->cfg[i].cs_sub2);
+                                          ndfft_plan_destroy(plan->cfg[i].rfs_sub1); ndfft_plan_destroy(plan->cfg[i].rfs_sub2); }
     delete plan;
     return NDFFT_OK;
 }
@@ -554,7 +585,8 @@ int ndfft_explain_plan(int kind, int dtype, size_t n, char *buf, size_t buflen) 
                                " tpl=" + std::to_string(c.radercfg.fft.tpl) + " e=" + std::to_string(c.radercfg.fft.e) + " radix=" + radix(c.radercfg.fft.radix) + " lanes=" + std::to_string(c.radercfg.fft.lpb);
         else if (c.pow2) l += " route=pow2";
         else if (c.jit) l += " route=jit tpl=" + std::to_string(c.jitcfg.tpl) + " e=" + std::to_string(c.jitcfg.e) + " radix=" + radix(c.jitcfg.radix) + " lanes=" + std::to_string(c.jitcfg.row_lpb);
-        else if (c.big && !c.bigblue) l += " route=four_step F1=" + std::to_string(c.F1) + " F2=" + std::to_string(c.F2);
+        else if (c.big && !c.bigblue) l += " route=four_step F1=" + std::to_string(c.F1) + " F2=" + std::to_string(c.F2) +
+                                           (c.rfs ? " real_four_step=" + std::to_string(c.rfs_N1) + "x" + std::to_string(c.rfs_N2) : std::string());
         else if (c.F <= 1) l += " route=trivial";
         else if (!c.blue && !c.big) l += " route=lds radix=" + radix(c.radix);
         if (c.blue || c.bigblue) {

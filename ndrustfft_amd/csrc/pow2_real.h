@@ -49,6 +49,8 @@ template <typename T> struct RealArgs {
     int32_t stream_in = 0;               // 1 = streaming (nt) loads of the input.  COL kernels: it is read once and must not push the intermediate of a
                                          // two-stage route out of the Infinity Cache; row kernels (16-byte staging loads): the input comes from HBM
     const cpx<T> *twp_rev = nullptr;     // Bluestein / Rader kernels: per-pass twiddles of the SAME radix list taken back to front (second FFT of the convolution)
+    int32_t makhoul = 0;                 // ROWOUT kernels with real input (first pass of the REAL four-step, exec.hip: real_fourstep): 1 = the lane is read through
+                                         // Makhoul's permutation v[m] = x[2m] (m < n/2), v[m] = x[2(n-1-m)+1] otherwise (DCT-II, n = this->n * inner)
     const int32_t *rader_tab = nullptr;  // Rader kernels (rader_kernel.h): g^i mod P (i < P - 1), then g^-i mod P; bhat = FFT_(P-1)(W_P^(g^-q)) / (P - 1),
                                          // twp / twp_rev = per-pass twiddles of FFT_(P-1) with the radix list front to back / back to front
 };
@@ -90,11 +92,16 @@ struct ZiPhi { static __device__ __forceinline__ int map(int p) { return p + (p 
 //           DC and Nyquist dropped, src/lib.rs:514-518), conj twiddle on store into the scratch array
 //   CS = 4  second pass of the ROW four-step (exec.hip: big_fft): lanes (L, k1) with k1 the INNER (contiguous) index;
 //           twiddle W_N^(j k1) on load, ordinary column store (row k2, adjacent k1 contiguous = natural order k1 + F1 k2)
-// ROWOUT (COL, C2C): column load, ROW store -- the tile is read with lanes fastest and every lane is written as one
-// contiguous run (pitch_out): the transposing first pass of the row four-step.
+//   CS = 5  second pass of the REAL row four-step (exec.hip: real_fourstep), R2C: lanes (L, k1), k1 = 0..N1/2 the inner index, loaded like
+//           CS = 4; every element of the half spectrum X[0..n/2] is written once, as Z[k1 + N1 k2] or as its conjugate at the mirrored index
+//           (the rule of CS = 2), adjacent k1 contiguous
+//   CS = 6  the same for DCT-II: y[k] = Re(X[k] c_k) scale, y[n-k] = -Im(X[k] c_k) scale (c_k = aux2[k], src/lib.rs:700-710 through Makhoul)
+// ROWOUT (COL, C2C or R2C): column load, ROW store -- the tile is read with lanes fastest and every lane is written as one
+// contiguous run (pitch_out): the transposing first pass of the row four-step (R2C: of the real four-step, n_out = F + 1 per lane).
 template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = false, bool XCD = false, int CS = 0, bool ROWOUT = false> struct RealPow2Kernel {
     static_assert(CS == 0 || (COL && !XCD && (OP == G_C2C_FWD || OP == G_C2C_INV)), "CS kernels are column C2C kernels");
-    static_assert(!ROWOUT || (COL && !XCD && CS == 0 && (OP == G_C2C_FWD || OP == G_C2C_INV)), "ROWOUT is a column-load C2C kernel");
+    static_assert(!ROWOUT || (COL && !XCD && CS == 0 && (OP == G_C2C_FWD || OP == G_C2C_INV || OP == G_R2C_EVEN)), "ROWOUT is a column-load C2C / R2C kernel");
+    static_assert(CS < 5 || OP == G_C2C_FWD, "CS = 5 / 6 are forward kernels");
     // strided staging loop with U independent global loads in flight per thread before the first LDS store
     // (a plain `for (j) dst[j] = in[j * stride]` leaves one or two loads outstanding: latency-bound)
     template <int STEP, typename LD, typename ST> static __device__ __forceinline__ void stage_loop(int j0, int n, LD ld, ST st) {
@@ -176,13 +183,14 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
             // thread -> (lane cl = tid % LPB fastest, element j = tid / LPB)
             const int cl = threadIdx.x % LPB, j0 = threadIdx.x / LPB;
             const int64_t L = lane0 + cl;
-            if (L < a.nlanes) {
+            // (CS = 5 / 6: the inner index k1 runs over a pitch padded to whole 128-byte lines; lanes k1 > N1/2 are padding)
+            if (L < a.nlanes && (CS < 5 || 2 * (L % a.inner) <= a.cs_f1)) {
                 const int64_t base = (L / a.inner) * a.outer_in + (L % a.inner);
                 char *dst = smem + (size_t)cl * LANE_LDS * 2 * sizeof(T);
                 constexpr int STEP = THREADS / LPB;
-                if constexpr (CS == 1 || CS == 2 || CS == 4) {
+                if constexpr (CS == 1 || CS == 2 || CS >= 4) {
                     const cpx<T> *in = (const cpx<T> *)a.in + base;
-                    const int k1 = CS == 4 ? (int)(L % a.inner) : (int)((L / a.inner) % a.cs_k1n);
+                    const int k1 = CS >= 4 ? (int)(L % a.inner) : (int)((L / a.inner) % a.cs_k1n);
                     struct VW { cpx<T> v, w; };
                     stage_loop<STEP>(j0, a.n_in,
                         [&](int j) { VW r; r.v = in[(int64_t)j * a.elem_in]; r.w = cs_tw(a, j * k1); return r; },
@@ -205,7 +213,19 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                     else stage_loop<STEP>(j0, a.n_in, [&](int j) { return in[(int64_t)j * a.elem_in]; }, [&](int j, cpx<T> v) { ((cpx<T> *)dst)[j] = v; });
                 } else {
                     const T *in = (const T *)a.in + base;
-                    if (a.stream_in) stage_loop<STEP>(j0, a.n_in, [&](int j) { return __builtin_nontemporal_load(in + (int64_t)j * a.elem_in); }, [&](int j, T v) { ((T *)dst)[j] = v; });
+                    bool gathered = false;
+                    if constexpr (ROWOUT) {
+                        if (a.makhoul) {   // element j of lane (o, n2) is v[m], m = j inner + n2, of the n = this->n * inner long lane o
+                            const T *lane_o = (const T *)a.in + (L / a.inner) * a.outer_in;
+                            const int64_t m0 = L % a.inner, nn = (int64_t)a.n * a.inner;
+                            stage_loop<STEP>(j0, a.n_in,
+                                [&](int j) { const int64_t m = (int64_t)j * a.inner + m0; return lane_o[2 * j < a.n ? 2 * m : 2 * (nn - 1 - m) + 1]; },
+                                [&](int j, T v) { ((T *)dst)[j] = v; });
+                            gathered = true;
+                        }
+                    }
+                    if (gathered) {}
+                    else if (a.stream_in) stage_loop<STEP>(j0, a.n_in, [&](int j) { return __builtin_nontemporal_load(in + (int64_t)j * a.elem_in); }, [&](int j, T v) { ((T *)dst)[j] = v; });
                     else stage_loop<STEP>(j0, a.n_in, [&](int j) { return in[(int64_t)j * a.elem_in]; }, [&](int j, T v) { ((T *)dst)[j] = v; });
                 }
             }
@@ -342,6 +362,30 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                         else if (q >= F / 2) { kk = a.cs_f1 - k1; r2 = F - 1 - q; val.y = -val.y; }
                     }
                     if (!skip) gstore<T, true>(out + (int64_t)kk * a.cs_pitch + (int64_t)r2 * a.elem_out, val);
+                }
+            } else if constexpr (CS == 5 || CS == 6) {
+                const int k1 = (int)(L % a.inner);
+                if (2 * k1 > a.cs_f1) return;
+                const int64_t ob = (L / a.inner) * a.outer_out;   // output lane o
+                for (int q = j0; q < F; q += THREADS / LPB) {
+                    cpx<T> val = post_cplx<T, OP, ZiPhi>(a, res, q);
+                    int kk = k1, r2 = q;
+                    bool mir = false;
+                    if (k1 == 0) { if (q > F / 2) continue; }
+                    else if (2 * k1 == a.cs_f1) { if (q >= F / 2) continue; }
+                    else if (q >= F / 2) { kk = a.cs_f1 - k1; r2 = F - 1 - q; val.y = -val.y; mir = true; }
+                    const int64_t k = kk + (int64_t)a.cs_f1 * r2;   // 0..n/2, every value once
+                    // the tile's 128 bytes of adjacent k1 land on one line at k, but on TWO lines at the mirrored index N1 - k1 (shifted by one
+                    // element): keep_out = 1 writes those with plain stores so that the L2 merges the pieces of neighbouring tiles
+                    if constexpr (CS == 5) {
+                        if (mir && a.keep_out) ((cpx<T> *)a.out)[ob + k] = val; else gstore<T, true>((cpx<T> *)a.out + ob + k, val);
+                    } else {
+                        const cpx<T> tk = cmul(val, a.aux2[k]);
+                        T *out = (T *)a.out + ob;
+                        const T y0 = tk.x * a.scale, y1 = -tk.y * a.scale;
+                        if (mir && a.keep_out) out[k] = y0; else __builtin_nontemporal_store(y0, out + k);
+                        if (k > 0 && 2 * k < a.cs_n) { if (!mir && a.keep_out) out[a.cs_n - k] = y1; else __builtin_nontemporal_store(y1, out + (a.cs_n - k)); }
+                    }
                 }
             } else if constexpr (CS == 3) {
                 const int k1 = (int)((L / a.inner) % a.cs_k1n);

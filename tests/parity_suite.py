@@ -711,9 +711,37 @@ def long_lanes_four_step(L, full=True):
              ("ndfft_r2c", (2, 1 << 17), 1, np.float32, "four_step"), ("ndifft_r2c", (3, 1 << 17), 1, np.float64, "four_step")]
     if full:
         cases += [("ndfft", (2, 1 << 20), 1, np.float64, "four_step"), ("ndfft", (2, 1 << 20), 1, np.float32, "four_step"), ("ndifft", (3, 1 << 19), 1, np.float32, "four_step"), ("ndifft", (1, 1 << 22), 1, np.float32, "four_step"),
-                  ("nddct2", (3, 1 << 18), 1, np.float64, "four_step"), ("ndfft_r2c", (2, 3 * (1 << 17)), 1, np.float32, "four_step")]
+                  ("nddct2", (3, 1 << 18), 1, np.float64, "real_four_step"), ("ndfft_r2c", (2, 3 * (1 << 17)), 1, np.float32, "four_step")]
     for name, shape, axis, rdt, want in cases:
         assert run_case(L, name, shape, axis, rdt) == want, (name, shape)
+    # REAL four-step (round 3): R2C (f64) and DCT-II of power-of-two lanes in two passes -- real FFTs of length N1 over the strided index, row store of the
+    # half spectrum, then twiddled complex FFTs of length N2 writing X[k] / conj at the mirrored index (DCT-II: y[k], y[n-k]); staged and lane-fastest
+    # kernels for pass 2, the packed route it replaces, and f32 R2C forced through it
+    def with_env(env, fn):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try: return fn()
+        finally:
+            for k, v in old.items():
+                if v is None: del os.environ[k]
+                else: os.environ[k] = v
+    for norm in ("Default", "None"):
+        assert run_case(L, "ndfft_r2c", (2, 1 << 16), 1, np.float64, norm=norm) == "real_four_step"
+        assert run_case(L, "nddct2", (3, 1 << 16), 1, np.float64, norm=norm) == "real_four_step"
+        assert run_case(L, "nddct2", (2, 1 << 17), 1, np.float32, norm=norm) == "real_four_step"
+    for direct in ("0", "1"):
+        for name, shape, rdt in (("ndfft_r2c", (3, 1 << 16), np.float64), ("nddct2", (2, 1 << 16), np.float64), ("nddct2", (1, 1 << 17), np.float32), ("ndfft_r2c", (2, 1 << 17), np.float32),
+                                 ("ndfft", (2, 32768), np.float64), ("ndifft", (3, 65536), np.float32)):
+            want = "four_step" if name in ("ndfft", "ndifft") else "real_four_step"
+            assert with_env({"NDFFT_FS_DIRECT": direct, "NDFFT_REAL_FOURSTEP": "2"}, lambda: run_case(L, name, shape, 1, rdt)) == want, (name, shape, direct)
+    for name, rdt in (("ndfft_r2c", np.float64), ("nddct2", np.float64), ("nddct2", np.float32)):
+        assert with_env({"NDFFT_REAL_FOURSTEP": "0"}, lambda: run_case(L, name, (2, 1 << 16 if rdt is np.float64 else 1 << 17), 1, rdt)) == "four_step"
+    if full:
+        for a in ("8", "10", "11"):   # other splits n = N1 * N2 (developer knob of the plan)
+            assert with_env({"NDFFT_RFS_LOGN1": a}, lambda: run_case(L, "nddct2", (2, 1 << 18), 1, np.float64)) == "real_four_step"
+            assert with_env({"NDFFT_RFS_LOGN1": a}, lambda: run_case(L, "ndfft_r2c", (3, 1 << 18), 1, np.float64)) == "real_four_step"
+        assert run_case(L, "ndfft_r2c", (5, 1 << 21), 1, np.float64) == "real_four_step"
+        assert run_case(L, "nddct2", (2, 1 << 21), 1, np.float32) == "real_four_step"
     # the power-of-two lengths above took the two-pass form (column load / row store, then twiddled column pass); the
     # three-pass form they replace stays covered, and both directions / norms of the new one on an odd lane count
     assert run_case(L, "ndifft_r2c", (2, 1 << 16), 1, np.float32, norm="None") == "four_step"

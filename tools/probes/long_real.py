@@ -19,10 +19,13 @@ for rdt, cdt in ((np.float64, np.complex128), (np.float32, np.complex64)):
     x = torch.randn((L, n), dtype=tr, device=dev); y = torch.empty_like(x)
     xh = torch.randn((L, n // 2 + 1), dtype=tc, device=dev)
     hd = DctHandler(n, rdt); hr = R2cFftHandler(n, rdt)
+    only = os.environ.get("LONG_REAL_ONLY", "").split(",") if os.environ.get("LONG_REAL_ONLY") else None
     for name, fn, a, b, h in (("nddct2", nddct2, x, y, hd), ("nddct3", nddct3, x, y, hd), ("nddct4", nddct4, x, y, hd), ("ndfft_r2c", ndfft_r2c, x, xh, hr), ("ndifft_r2c", ndifft_r2c, xh, y, hr)):
+        if only and name not in only: continue
         us = t(fn, a, b, h, 1)
         nbytes = a.numel() * a.element_size() + b.numel() * b.element_size()
         print(f"{name:11s} {np.dtype(rdt).name} {L}x{n}: {us:8.1f} us  {nbytes / us / 1e3 / 8000:.3f} of 8 TB/s  path={_lib.default().last_path()}", flush=True)
+    if only and "ndfft" not in only: continue
     xc = torch.randn((32, 1 << 20), dtype=tc, device=dev); yc = torch.empty_like(xc)
     us = t(ndfft, xc, yc, FftHandler(1 << 20, rdt), 1)
     print(f"ndfft       {np.dtype(cdt).name} 32x{1 << 20}: {us:8.1f} us  {2 * xc.numel() * xc.element_size() / us / 1e3 / 8000:.3f} of 8 TB/s", flush=True)
