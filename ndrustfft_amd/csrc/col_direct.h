@@ -22,13 +22,59 @@ namespace ndfft {
 //   4  second pass of the row four-step: twiddle W_N^(j k1) on load (k1 = the inner index), column store at row k2
 //   5  second pass of the REAL four-step, R2C: half spectrum, the mirrored half conjugated into place (pow2_real.h CS = 5)
 //   6  the same with the DCT-II post-twiddle: two real outputs per element (CS = 6)
+//   7  FIRST pass of the inverse real four-step, C2R: lanes (o, k1), k1 = 0..N1/2; element k2 is Xh[k1 + N1 k2] of the Hermitian extension (read at
+//      the mirrored index and conjugated beyond n/2; scaled, imaginary parts of DC and Nyquist dropped: src/lib.rs:511-521), unnormalised inverse FFT
+//      over k2, times W_n^(-n2 k1), ROW store s[(o, k1)][n2] -- the column C2R kernels of length N1 finish the lane (exec.hip: real_fourstep_inv)
+//   8  the same for DCT-III: the element is V[k] = 0.5 s (x[k] - i x[n-k]) e^(+i pi k / 2n) built from two real loads (realops.h: G_DCT3_EVEN)
 template <typename T, int F, int TPL, int LPB, typename RL, int OP, int MODE> struct ColDirectKernel {
     static_assert(OP == G_C2C_FWD || OP == G_C2C_INV, "complex lanes only");
-    static_assert(MODE == 0 || MODE == 4 || ((MODE == 5 || MODE == 6) && OP == G_C2C_FWD), "bad mode");
+    static_assert(MODE == 0 || MODE == 4 || ((MODE >= 5 && MODE <= 8) && OP == G_C2C_FWD), "bad mode");
     using FFT = Pow2Kernel<T, F, TPL, LPB, true, RL, 0, 1, 0>;
     static constexpr int E = FFT::E, THREADS = TPL * LPB;
     static_assert(E * TPL == F, "whole butterfly rounds only");
     static constexpr size_t LDS_BYTES = FFT::LDS_BYTES;
+
+    // MODE 7 / 8 (see above)
+    static __device__ __forceinline__ void run_inv(const RealArgs<T> &a, int64_t L, int64_t o, int k1, bool live, int t, char *lds) {
+        cpx<T> v[E];
+        constexpr int R0 = RL::at(0), NB0 = F / R0, NBF0 = FFT::slots(0);
+        const int64_t nn = a.cs_n;
+        const T hs = (T)0.5 * a.scale;
+#pragma unroll
+        for (int q = 0; q < NBF0; ++q)
+#pragma unroll
+            for (int r = 0; r < R0; ++r) {
+                cpx<T> x = mk<T>((T)0, (T)0);
+                if (live) {
+                    const int64_t k = k1 + (int64_t)a.cs_f1 * (t + q * TPL + r * NB0);
+                    const bool mir = 2 * k > nn;
+                    const int64_t src = mir ? nn - k : k;
+                    if constexpr (MODE == 7) {
+                        x = ((const cpx<T> *)a.in)[o * a.outer_in + src];
+                        x.x *= a.scale; x.y *= a.scale;
+                        if (src == 0 || 2 * src == nn) x.y = (T)0;
+                    } else {
+                        const T *xr = (const T *)a.in + o * a.outer_in;
+                        x = cmul(mk<T>(xr[src] * hs, src ? -xr[nn - src] * hs : (T)0), cconj(a.aux2[src]));
+                    }
+                    if (!mir) x.y = -x.y;   // conj of the Hermitian extension (mirrored elements are conjugates already): inverse FFT by forward butterflies
+                }
+                v[q * R0 + r] = x;
+            }
+        FFT::template passes<0>(v, a.twp, lds, t);
+        if (!live) return;
+        constexpr int RL_ = RL::at(RL::NP - 1), NBL = F / RL_, NBFL = FFT::slots(RL::NP - 1);
+        const int mask = (1 << a.cs_logB) - 1;
+        cpx<T> *out = (cpx<T> *)a.out + (o * a.cs_k1n + k1) * a.pitch_out;
+#pragma unroll
+        for (int q = 0; q < NBFL; ++q)
+#pragma unroll
+            for (int r = 0; r < RL_; ++r) {
+                const int kq = t + q * TPL + r * NBL, m = kq * k1;
+                const cpx<T> u = cmul(v[q * RL_ + r], cmul(a.cs_twhi[m >> a.cs_logB], a.cs_twlo[m & mask]));
+                out[kq] = mk<T>(u.x, -u.y);   // conj(r W^(n2 k1)) = IFFT value times W^(-n2 k1); plain store: the next launch re-reads it
+            }
+    }
 
     static __device__ __forceinline__ void run(const RealArgs<T> &a) {
         extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -40,6 +86,7 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, int MODE> st
         const int k1 = (int)(L - o * a.inner);
         // (MODE 5 / 6: the inner index runs over a pitch padded to whole 128-byte lines; k1 > N1/2 is padding)
         const bool live = L < a.nlanes && (MODE < 5 || 2 * k1 <= a.cs_f1);
+        if constexpr (MODE >= 7) { run_inv(a, L, o, k1, live, t, smem + (size_t)cl * FFT::LANE_LDS * sizeof(T)); return; }
         char *lds = smem + (size_t)cl * FFT::LANE_LDS * sizeof(T);
         cpx<T> v[E];
         {

@@ -37,6 +37,7 @@ struct Problem {
     int keep_out = 0;            // column kernels: cache-allocating stores (the output is re-read right away, col_split)
     int stream_in = 0;           // column kernels: streaming loads (the input must not evict a cache-resident intermediate)
     int no_xcd_map = 0;          // column kernels: identity workgroup -> tile map (the stages of col_split: the map cost 7-20 us there)
+    int makhoul_out = 0;         // column C2R kernels: outputs through the inverse of Makhoul's permutation (last pass of real_fourstep_inv, DCT-III)
 };
 
 static size_t real_size(int dtype) { return dtype == NDFFT_F32 ? 4 : 8; }
@@ -421,9 +422,9 @@ static bool fourstep2_enabled() {
 }
 
 // developer / test switch: NDFFT_REAL_FOURSTEP=0 keeps long real-data lanes on the packed complex four-step with separate PRE / POST passes
-static int real_fourstep_enabled() {
+static bool real_fourstep_enabled() {
     const char *e = getenv("NDFFT_REAL_FOURSTEP");
-    return e ? atoi(e) : 1;
+    return !(e && e[0] == '0');
 }
 
 // largest handler length the thread-per-lane real-op register kernels take (raw lane + Z + outputs in registers)
@@ -709,6 +710,41 @@ static int real_fourstep(const Problem &P, int gop, const FftConfig &c, const De
     return launch_fourstep_real<T>(gop == G_DCT2_EVEN ? 3 : 2, N2, a, stream);
 }
 
+// The inverse direction of the real four-step, C2R and DCT-III:
+//   (1) for k1 = 0..N1/2: the elements Xh[k1 + N1 k2] of the Hermitian extension (DCT-III: V[k] built from x[k], x[n-k]), unnormalised inverse FFT of
+//       length N2 over k2, times W_n^(-n2 k1), stored as s[lane][k1][n2]
+//   (2) column C2R of length N1 over k1 for every n2 (the ordinary column kernel: adjacent n2 contiguous on both sides) -> x[n1 N2 + n2]
+//       (DCT-III: written through the inverse of Makhoul's permutation)
+template <typename T>
+static int real_fourstep_inv(const Problem &P, int gop, const FftConfig &c, const DevConfig &d, const void *d_in, void *d_out, int64_t pin, int64_t pout, hipStream_t stream) {
+    const int N1 = c.rfs_N1, N2 = c.rfs_N2, Kx = N1 / 2 + 1;
+    const int Kp = (Kx + (int)(128 / sizeof(cpx<T>)) - 1) & ~((int)(128 / sizeof(cpx<T>)) - 1);   // lanes per o, padded: every tile starts on a 128-byte line of the input
+    const int64_t n = (int64_t)N1 * N2, B = P.nlanes;
+    const DevTables *dt2;
+    int rc;
+    if ((rc = get_dev_tables(c.rfs_sub2, &dt2))) return rc;
+    void *s1;
+    if ((rc = get_scratch(4, stream, (size_t)(B * Kx * N2) * sizeof(cpx<T>), &s1))) return rc;
+    RealArgs<T> a;
+    a.pitch_in = 0; a.vec_in = 0; a.vec_out = 0; a.xcd_remap = 0; a.keep_out = 0; a.stream_in = 0; a.chunk_out = 0; a.xcd_chunk = 0; a.makhoul = 0;
+    a.aux1 = nullptr; a.aux2 = (const cpx<T> *)d.aux2; a.chirp = nullptr; a.bhat = nullptr;
+    a.cs_twlo = (const cpx<T> *)d.rfs_twlo; a.cs_twhi = (const cpx<T> *)d.rfs_twhi; a.cs_logB = c.rfs_logB;
+    a.cs_k1n = Kx; a.cs_f1 = N1; a.cs_n = (int)n; a.cs_outer_in = 0; a.cs_outer_out = 0; a.cs_pitch = 0;
+    a.in = d_in; a.out = s1; a.nlanes = B * Kp; a.n = N2; a.F = N2; a.n_in = N2; a.n_out = N2; a.scale = (T)P.scale;
+    a.inner = Kp; a.outer_in = pin; a.outer_out = 0; a.elem_in = N1; a.elem_out = 0; a.pitch_out = N2;
+    a.twp = (const cpx<T> *)dt2->cfg[CFG_MAIN].twp_col;
+    // runs of consecutive tiles per XCD: the mirrored index N1 - k1 is shifted by one element against the tile grid (and DCT-III's real rows are
+    // half lines), so neighbouring tiles share every line
+    { static const int xc = [] { const char *e = getenv("NDFFT_RFS_XCD_CHUNK"); return e ? atoi(e) : 8; }(); a.xcd_chunk = xc; }
+    if ((rc = launch_fourstep_real<T>(gop == G_DCT3_EVEN ? 5 : 4, N2, a, stream))) return rc;
+    Problem Q;
+    Q.plan = c.rfs_sub1; Q.op = NDFFT_OP_C2R; Q.xlen = Kx; Q.ylen = N1; Q.xs = N2; Q.ys = N2; Q.nlanes = B * N2; Q.scale = 1.0;
+    if (B > 1) Q.b.push_back({B, (int64_t)Kx * N2, pout});
+    Q.b.push_back({(int64_t)N2, 1, 1});
+    Q.no_xcd_map = 1; Q.makhoul_out = gop == G_DCT3_EVEN ? 1 : 0;
+    return dispatch(Q, s1, d_out, stream);
+}
+
 // contiguous lanes whose inner FFT does not fit one workgroup's LDS
 template <typename T>
 static int dispatch_big(const Problem &P, const void *d_in, void *d_out, const DevTables &dt, hipStream_t stream) {
@@ -723,10 +759,13 @@ static int dispatch_big(const Problem &P, const void *d_in, void *d_out, const D
         set_last_path(c.bigblue ? "blue_global" : "four_step");
         return rc0;
     }
-    // (f32 R2C keeps the packed route: 90 us vs 100 us for 64 x 262144 -- its two complex passes run at twice the element rate of f64's;
-    //  NDFFT_REAL_FOURSTEP=2 forces the real four-step for every eligible call)
-    if (c.rfs && (gop == G_DCT2_EVEN || (gop == G_R2C_EVEN && P.scale == 1.0 && (sizeof(T) == 8 || real_fourstep_enabled() == 2))) && real_fourstep_enabled()) {
+    if (c.rfs && (gop == G_DCT2_EVEN || (gop == G_R2C_EVEN && P.scale == 1.0)) && real_fourstep_enabled()) {
         const int rc0 = real_fourstep<T>(P, gop, c, d, d_in, d_out, pin, pout, stream);
+        set_last_path("real_four_step");
+        return rc0;
+    }
+    if (c.rfs && (gop == G_C2R_EVEN || gop == G_DCT3_EVEN) && real_fourstep_enabled()) {
+        const int rc0 = real_fourstep_inv<T>(P, gop, c, d, d_in, d_out, pin, pout, stream);
         set_last_path("real_four_step");
         return rc0;
     }
@@ -1003,6 +1042,7 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
                 const size_t es_in = (op_in_cplx(P.op) ? 2 : 1) * real_size(plan->dtype);
                 a.vec_in = !col && ((uintptr_t)d_in % 16 == 0) && ((size_t)a.pitch_in * es_in) % 16 == 0;
                 a.xcd_remap = 0; a.keep_out = P.keep_out; a.stream_in = P.stream_in; a.xcd_chunk = P.no_xcd_map ? 0 : -1;
+                a.makhoul = col ? P.makhoul_out : 0;
                 const size_t es_out = (op_out_cplx(P.op) ? 2 : 1) * real_size(plan->dtype);
                 // dense rows of the ahead-of-time real-op kernels (BASELINE configs[3]): load policy from the Infinity-Cache model, as for the C2C rows
                 if (!col && !use_jit && !use_blue && !use_plain && a.pitch_in == P.xlen && a.pitch_out == P.ylen && F_nt_ok(c.F))

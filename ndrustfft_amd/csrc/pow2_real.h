@@ -50,7 +50,8 @@ template <typename T> struct RealArgs {
                                          // two-stage route out of the Infinity Cache; row kernels (16-byte staging loads): the input comes from HBM
     const cpx<T> *twp_rev = nullptr;     // Bluestein / Rader kernels: per-pass twiddles of the SAME radix list taken back to front (second FFT of the convolution)
     int32_t makhoul = 0;                 // ROWOUT kernels with real input (first pass of the REAL four-step, exec.hip: real_fourstep): 1 = the lane is read through
-                                         // Makhoul's permutation v[m] = x[2m] (m < n/2), v[m] = x[2(n-1-m)+1] otherwise (DCT-II, n = this->n * inner)
+                                         // Makhoul's permutation v[m] = x[2m] (m < n/2), v[m] = x[2(n-1-m)+1] otherwise (DCT-II, n = this->n * inner);
+                                         // column C2R kernels (last pass of the inverse real four-step, DCT-III): 1 = the outputs are written through its inverse
     const int32_t *rader_tab = nullptr;  // Rader kernels (rader_kernel.h): g^i mod P (i < P - 1), then g^-i mod P; bhat = FFT_(P-1)(W_P^(g^-q)) / (P - 1),
                                          // twp / twp_rev = per-pass twiddles of FFT_(P-1) with the radix list front to back / back to front
 };
@@ -167,6 +168,16 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
         // (not in the CS / ROWOUT stage kernels: they never use the map, and the extra scalar code changed the register
         //  allocation of the CS = 3 kernel from 85 to 76 VGPRs -- fewer staging loads in flight, 67 -> 76 us per launch)
         if constexpr (!XCD && CS == 0 && !ROWOUT) tile = xcd_block(blockIdx.x, gridDim.x, a.xcd_chunk);
+        if constexpr (COL && !XCD && CS == 0 && (ROWOUT ? OP == G_R2C_EVEN : OP == G_C2R_EVEN)) {
+            // Makhoul's permutation interleaves a tile (lanes n2) with its MIRROR tile (lanes inner - 1 - n2) in every line of the caller's array: one
+            // uses the even elements, the other the odd ones.  The two run back to back on one XCD (blocks b and b + 8), so the shared lines are
+            // fetched / merged once in that XCD's L2.  (inner / LPB tiles per lane, a multiple of 16; otherwise the identity)
+            const int64_t tpo = a.inner / LPB;
+            if (a.makhoul && a.inner % LPB == 0 && tpo % 16 == 0) {
+                const int64_t o_ = tile / tpo, u = tile % tpo, g = u >> 4, w = u & 15, p = 8 * g + (w & 7);
+                tile = o_ * tpo + (w < 8 ? p : tpo - 1 - p);
+            }
+        }
         if constexpr (XCD) {
             const int64_t nb64 = (int64_t)gridDim.x & ~(int64_t)63;
             if (a.xcd_remap && tile < nb64) {   // b = 8 q + x  ->  tile = 8 (8 (q / 8) + x) + q % 8
@@ -400,6 +411,17 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                 }
             } else {
                 T *out = (T *)a.out + base;
+                if constexpr (OP == G_C2R_EVEN && !XCD) {
+                    if (a.makhoul) {   // last pass of the inverse real four-step, DCT-III: element q of lane (o, n2) is v[m], m = q inner + n2 -> y[2m] / y[2(n-1-m)+1]
+                        T *lane_o = (T *)a.out + (L / a.inner) * a.outer_out;
+                        const int64_t m0 = L % a.inner, nn = (int64_t)a.n_out * a.inner;
+                        for (int q = j0; q < a.n_out; q += THREADS / LPB) {
+                            const int64_t m = (int64_t)q * a.inner + m0;
+                            lane_o[2 * q < a.n_out ? 2 * m : 2 * (nn - 1 - m) + 1] = post_real<T, OP, ZiPhi>(a, res, q);
+                        }
+                        return;
+                    }
+                }
                 for (int q = j0; q < a.n_out; q += THREADS / LPB) {
                     const T val = post_real<T, OP, ZiPhi>(a, res, q);
                     // narrow tiles write 8-32 byte pieces of lines shared with neighbouring tiles: keep them

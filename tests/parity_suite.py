@@ -708,7 +708,7 @@ def long_lanes_four_step(L, full=True):
              ("ndfft", (20000, 3), 0, np.float64, "transpose+four_step"), ("ndfft_r2c", (2, 9999), 1, np.float64, "four_step"),
              ("nddct2", (2, 9999), 1, np.float32, "four_step"),
              # R2C without its PRE pass / C2R without its POST pass (the real lane addressed as complex), two-pass power-of-two route
-             ("ndfft_r2c", (2, 1 << 17), 1, np.float32, "four_step"), ("ndifft_r2c", (3, 1 << 17), 1, np.float64, "four_step")]
+             ("ndfft_r2c", (2, 1 << 17), 1, np.float32, "real_four_step"), ("ndifft_r2c", (3, 1 << 17), 1, np.float64, "real_four_step")]
     if full:
         cases += [("ndfft", (2, 1 << 20), 1, np.float64, "four_step"), ("ndfft", (2, 1 << 20), 1, np.float32, "four_step"), ("ndifft", (3, 1 << 19), 1, np.float32, "four_step"), ("ndifft", (1, 1 << 22), 1, np.float32, "four_step"),
                   ("nddct2", (3, 1 << 18), 1, np.float64, "real_four_step"), ("ndfft_r2c", (2, 3 * (1 << 17)), 1, np.float32, "four_step")]
@@ -726,25 +726,33 @@ def long_lanes_four_step(L, full=True):
                 if v is None: del os.environ[k]
                 else: os.environ[k] = v
     for norm in ("Default", "None"):
-        assert run_case(L, "ndfft_r2c", (2, 1 << 16), 1, np.float64, norm=norm) == "real_four_step"
-        assert run_case(L, "nddct2", (3, 1 << 16), 1, np.float64, norm=norm) == "real_four_step"
-        assert run_case(L, "nddct2", (2, 1 << 17), 1, np.float32, norm=norm) == "real_four_step"
-    for direct in ("0", "1"):
+        for name in ("ndfft_r2c", "ndifft_r2c", "nddct2", "nddct3"):
+            assert run_case(L, name, (2, 1 << 16), 1, np.float64, norm=norm) == "real_four_step", name
+            assert run_case(L, name, (3, 1 << 17), 1, np.float32, norm=norm) == "real_four_step", name
+    for direct in ("0", "1"):   # pass 2 of the forward direction on the staged / the lane-fastest kernels; the same switch for the complex four-step
         for name, shape, rdt in (("ndfft_r2c", (3, 1 << 16), np.float64), ("nddct2", (2, 1 << 16), np.float64), ("nddct2", (1, 1 << 17), np.float32), ("ndfft_r2c", (2, 1 << 17), np.float32),
                                  ("ndfft", (2, 32768), np.float64), ("ndifft", (3, 65536), np.float32)):
             want = "four_step" if name in ("ndfft", "ndifft") else "real_four_step"
-            assert with_env({"NDFFT_FS_DIRECT": direct, "NDFFT_REAL_FOURSTEP": "2"}, lambda: run_case(L, name, shape, 1, rdt)) == want, (name, shape, direct)
-    for name, rdt in (("ndfft_r2c", np.float64), ("nddct2", np.float64), ("nddct2", np.float32)):
+            assert with_env({"NDFFT_FS_DIRECT": direct}, lambda: run_case(L, name, shape, 1, rdt)) == want, (name, shape, direct)
+    for name, rdt in (("ndfft_r2c", np.float64), ("nddct2", np.float64), ("nddct2", np.float32), ("ndifft_r2c", np.float64), ("nddct3", np.float32)):   # the packed route stays covered
         assert with_env({"NDFFT_REAL_FOURSTEP": "0"}, lambda: run_case(L, name, (2, 1 << 16 if rdt is np.float64 else 1 << 17), 1, rdt)) == "four_step"
+    # a lane count that leaves a partial tile in every pass, an output pitch larger than the lane, DCT types without a real four-step (I, IV) on the same length
+    for name in ("ndfft_r2c", "ndifft_r2c", "nddct2", "nddct3"):
+        assert run_case(L, name, (5, 1 << 16), 1, np.float64, offset=3) == "real_four_step", name
+    assert run_case(L, "nddct4", (2, 1 << 16), 1, np.float64) == "four_step"
     if full:
         for a in ("8", "10", "11"):   # other splits n = N1 * N2 (developer knob of the plan)
-            assert with_env({"NDFFT_RFS_LOGN1": a}, lambda: run_case(L, "nddct2", (2, 1 << 18), 1, np.float64)) == "real_four_step"
-            assert with_env({"NDFFT_RFS_LOGN1": a}, lambda: run_case(L, "ndfft_r2c", (3, 1 << 18), 1, np.float64)) == "real_four_step"
+            for name in ("nddct2", "nddct3", "ndfft_r2c", "ndifft_r2c"):
+                assert with_env({"NDFFT_RFS_LOGN1": a}, lambda: run_case(L, name, (2, 1 << 18), 1, np.float64)) == "real_four_step", (name, a)
         assert run_case(L, "ndfft_r2c", (5, 1 << 21), 1, np.float64) == "real_four_step"
+        assert run_case(L, "ndifft_r2c", (3, 1 << 20), 1, np.float32) == "real_four_step"
         assert run_case(L, "nddct2", (2, 1 << 21), 1, np.float32) == "real_four_step"
+        assert run_case(L, "nddct3", (2, 1 << 19), 1, np.float64) == "real_four_step"
+        assert run_case(L, "nddct2", (130, 1 << 16), 1, np.float64) == "real_four_step"     # more lanes than one group of XCD runs
+        assert run_case(L, "nddct3", (130, 1 << 16), 1, np.float32) == "real_four_step"
     # the power-of-two lengths above took the two-pass form (column load / row store, then twiddled column pass); the
     # three-pass form they replace stays covered, and both directions / norms of the new one on an odd lane count
-    assert run_case(L, "ndifft_r2c", (2, 1 << 16), 1, np.float32, norm="None") == "four_step"
+    assert run_case(L, "ndifft_r2c", (2, 1 << 16), 1, np.float32, norm="None") == "real_four_step"
     for name in ("ndfft", "ndifft"):
         for norm in ("Default", "None"):
             assert run_case(L, name, (3, 32768), 1, np.float64, norm=norm) == "four_step"
