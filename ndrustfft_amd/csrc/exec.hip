@@ -601,6 +601,8 @@ static int big_fft(const FftConfig &c, const DevConfig &d, const cpx<T> *zin, in
         a.aux1 = nullptr; a.aux2 = nullptr; a.chirp = nullptr; a.bhat = nullptr;
         a.cs_twlo = (const cpx<T> *)d.twlo; a.cs_twhi = (const cpx<T> *)d.twhi; a.cs_logB = c.logB;
         a.cs_k1n = 1; a.cs_f1 = F1; a.cs_n = (int)F; a.cs_outer_in = 0; a.cs_outer_out = 0; a.cs_pitch = 0;
+        // (used by the half-line tiles only, F = 1024 f32 -- pow2_real.h; 32 x 2^20 c64: 403 -> 354 us, profiles/r06)
+        { static const int xc = [] { const char *e = getenv("NDFFT_FS_XCD_CHUNK"); return e ? atoi(e) : 32; }(); a.xcd_chunk = xc; }
         // pass 1: lanes (l, n2)
         a.in = zin; a.out = s1; a.nlanes = L * F2; a.n = F1; a.F = F1; a.n_in = F1; a.n_out = F1; a.scale = (T)1;
         a.inner = F2; a.outer_in = pitch_in; a.outer_out = 0; a.elem_in = F2; a.elem_out = 0; a.pitch_out = F1;

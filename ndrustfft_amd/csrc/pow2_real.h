@@ -168,6 +168,9 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
         // (not in the CS / ROWOUT stage kernels: they never use the map, and the extra scalar code changed the register
         //  allocation of the CS = 3 kernel from 85 to 76 VGPRs -- fewer staging loads in flight, 67 -> 76 us per launch)
         if constexpr (!XCD && CS == 0 && !ROWOUT) tile = xcd_block(blockIdx.x, gridDim.x, a.xcd_chunk);
+        // passes of the row four-step whose tile rows are HALF a line (F = 1024 f32: 8 lanes x 8 bytes): runs of consecutive tiles per XCD, so that the
+        // two tiles sharing every line meet in one L2 (only these instantiations: the map costs registers in the others, see above)
+        if constexpr ((CS == 4 || (ROWOUT && OP != G_R2C_EVEN)) && LPB * 2 * sizeof(T) < 128) tile = xcd_block(blockIdx.x, gridDim.x, a.xcd_chunk);
         if constexpr (COL && !XCD && CS == 0 && (ROWOUT ? OP == G_R2C_EVEN : OP == G_C2R_EVEN)) {
             // Makhoul's permutation interleaves a tile (lanes n2) with its MIRROR tile (lanes inner - 1 - n2) in every line of the caller's array: one
             // uses the even elements, the other the odd ones.  The two run back to back on one XCD (blocks b and b + 8), so the shared lines are
