@@ -95,6 +95,7 @@ struct FftConfig {                 // one complex-FFT-of-length-F recipe + op ta
     // (exec.hip: real_fourstep) -- a real FFT of length N1 over the strided index, then complex FFTs of length N2 on the half
     // spectrum; rfs_sub1 = R2C plan of length N1, rfs_sub2 = C2C plan of length N2, twiddles W_n^m split like twlo / twhi
     bool rfs = false; int rfs_N1 = 0, rfs_N2 = 0, rfs_logB = 0;
+    int rfs_ops = 0;               // ops for which it measured faster than the packed route: 1 = R2C, 2 = C2R, 4 = DCT-II, 8 = DCT-III
     ndfft_plan *rfs_sub1 = nullptr, *rfs_sub2 = nullptr;
     HostTable rfs_twlo, rfs_twhi;
     bool blue_reg_only = false;    // M exceeds the LDS kernel's reach: only the register kernel can run it

@@ -422,9 +422,10 @@ static bool fourstep2_enabled() {
 }
 
 // developer / test switch: NDFFT_REAL_FOURSTEP=0 keeps long real-data lanes on the packed complex four-step with separate PRE / POST passes
-static bool real_fourstep_enabled() {
+// (2 = for every eligible op, also where the plan's table says the packed route is faster: parity tests)
+static int real_fourstep_enabled() {
     const char *e = getenv("NDFFT_REAL_FOURSTEP");
-    return !(e && e[0] == '0');
+    return e ? atoi(e) : 1;
 }
 
 // largest handler length the thread-per-lane real-op register kernels take (raw lane + Z + outputs in registers)
@@ -761,12 +762,13 @@ static int dispatch_big(const Problem &P, const void *d_in, void *d_out, const D
         set_last_path(c.bigblue ? "blue_global" : "four_step");
         return rc0;
     }
-    if (c.rfs && (gop == G_DCT2_EVEN || (gop == G_R2C_EVEN && P.scale == 1.0)) && real_fourstep_enabled()) {
+    const int rfs_on = real_fourstep_enabled(), rfs_ops = rfs_on == 2 ? 15 : (rfs_on ? c.rfs_ops : 0);
+    if (c.rfs && ((gop == G_DCT2_EVEN && (rfs_ops & 4)) || (gop == G_R2C_EVEN && P.scale == 1.0 && (rfs_ops & 1)))) {
         const int rc0 = real_fourstep<T>(P, gop, c, d, d_in, d_out, pin, pout, stream);
         set_last_path("real_four_step");
         return rc0;
     }
-    if (c.rfs && (gop == G_C2R_EVEN || gop == G_DCT3_EVEN) && real_fourstep_enabled()) {
+    if (c.rfs && ((gop == G_C2R_EVEN && (rfs_ops & 2)) || (gop == G_DCT3_EVEN && (rfs_ops & 8)))) {
         const int rc0 = real_fourstep_inv<T>(P, gop, c, d, d_in, d_out, pin, pout, stream);
         set_last_path("real_four_step");
         return rc0;

@@ -397,9 +397,17 @@ static void add_real_fourstep(ndfft_plan *p) {
     FftConfig &c = p->cfg[CFG_MAIN];
     if (n == 0 || (n & (n - 1)) || !p->has_cfg[CFG_MAIN] || !c.big || c.bigblue) return;
     int e = 0; while (((size_t)1 << e) < n) ++e;
-    // (measured at n = 2^18, 64 lanes: f64 N1 = 512 (R2C 123 us; 1024: 139 us), f32 DCT-II N1 = 1024 (113 us; 512: 127 us) -- profiles/r06)
-    int a = std::min(11, std::max(7, (e + 1) / 2 + (p->dtype == NDFFT_F32 ? 1 : 0)));
+    // The split and the ops that take this route, from the sweep over n = 2^16..2^21 at 2^24 points per array (profiles/r06/r06l_*, r06m_*):
+    //   f64: N1 = 2^ceil(e/2), but N1 = 2048 rather than N2 = 1024 at e = 20; faster than the packed route for every op and length (1.02-1.7 x)
+    //   f32: N1 = 1024 from e = 17 up (2048 at e = 21); R2C only up to e = 18, C2R and DCT-II up to e = 20, DCT-III always (the packed route's
+    //        complex passes run at twice f64's element rate, so its extra pass costs less)
+    const bool f32 = p->dtype == NDFFT_F32;
+    int a = f32 ? std::min(10, (e + 1) / 2 + 1) : (e + 1) / 2;
+    if (e == 20 && !f32) a = 11;
+    a = std::min(11, std::max(7, a));
+    if (e - a > 10) a = e - 10;
     if (e - a < 6) a = e - 6;
+    c.rfs_ops = f32 ? ((e <= 18 ? 1 : 0) | (e <= 20 ? 2 | 4 : 0) | 8) : 15;
     if (const char *k = getenv("NDFFT_RFS_LOGN1")) { const int v = atoi(k); if (v >= 7 && v <= 11) a = v; }   // developer knob (A/B of the split)
     const int b = e - a;
     if (b < 6 || b > 10 || !fourstep_real_supported(1 << a, 1 << b)) return;
@@ -586,7 +594,7 @@ int ndfft_explain_plan(int kind, int dtype, size_t n, char *buf, size_t buflen) 
         else if (c.pow2) l += " route=pow2";
         else if (c.jit) l += " route=jit tpl=" + std::to_string(c.jitcfg.tpl) + " e=" + std::to_string(c.jitcfg.e) + " radix=" + radix(c.jitcfg.radix) + " lanes=" + std::to_string(c.jitcfg.row_lpb);
         else if (c.big && !c.bigblue) l += " route=four_step F1=" + std::to_string(c.F1) + " F2=" + std::to_string(c.F2) +
-                                           (c.rfs ? " real_four_step=" + std::to_string(c.rfs_N1) + "x" + std::to_string(c.rfs_N2) : std::string());
+                                           (c.rfs ? " real_four_step=" + std::to_string(c.rfs_N1) + "x" + std::to_string(c.rfs_N2) + " ops=" + std::to_string(c.rfs_ops) : std::string());
         else if (c.F <= 1) l += " route=trivial";
         else if (!c.blue && !c.big) l += " route=lds radix=" + radix(c.radix);
         if (c.blue || c.bigblue) {
