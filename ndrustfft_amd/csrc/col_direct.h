@@ -26,9 +26,11 @@ namespace ndfft {
 //      the mirrored index and conjugated beyond n/2; scaled, imaginary parts of DC and Nyquist dropped: src/lib.rs:511-521), unnormalised inverse FFT
 //      over k2, times W_n^(-n2 k1), ROW store s[(o, k1)][n2] -- the column C2R kernels of length N1 finish the lane (exec.hip: real_fourstep_inv)
 //   8  the same for DCT-III: the element is V[k] = 0.5 s (x[k] - i x[n-k]) e^(+i pi k / 2n) built from two real loads (realops.h: G_DCT3_EVEN)
+//   9  second pass of the fused DCT-IV four-step: as mode 4, then y[2k] = Re(Z[k] c_k), y[n-1-2k] = -Im(Z[k] c_k), k = k1 + F1 k2 (c_k = aux2[k]; src/lib.rs:726-741
+//      through realops.h: G_DCT4_EVEN); a tile writes the even (or odd) reals of its lines, its mirror tile the others: mirror_pair_tile
 template <typename T, int F, int TPL, int LPB, typename RL, int OP, int MODE> struct ColDirectKernel {
     static_assert(OP == G_C2C_FWD || OP == G_C2C_INV, "complex lanes only");
-    static_assert(MODE == 0 || MODE == 4 || ((MODE >= 5 && MODE <= 8) && OP == G_C2C_FWD), "bad mode");
+    static_assert(MODE == 0 || MODE == 4 || ((MODE >= 5 && MODE <= 9) && OP == G_C2C_FWD), "bad mode");
     using FFT = Pow2Kernel<T, F, TPL, LPB, true, RL, 0, 1, 0>;
     static constexpr int E = FFT::E, THREADS = TPL * LPB;
     static_assert(E * TPL == F, "whole butterfly rounds only");
@@ -81,12 +83,14 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, int MODE> st
         const int cl = threadIdx.x % LPB, t = threadIdx.x / LPB;
         // (xcd_chunk: runs of consecutive tiles on one XCD, so that lines shared by neighbouring tiles -- the mirrored index N1 - k1 is shifted
         //  by one element, real outputs are half lines -- merge in that XCD's L2 when they are written with plain stores: keep_out)
-        const int64_t L = (int64_t)xcd_block(blockIdx.x, gridDim.x, a.xcd_chunk) * LPB + cl;
+        int64_t tile = xcd_block(blockIdx.x, gridDim.x, a.xcd_chunk);
+        if constexpr (MODE == 9) { if (a.inner % LPB == 0) tile = mirror_pair_tile(blockIdx.x, a.inner / LPB); }
+        const int64_t L = tile * LPB + cl;
         const int64_t o = L / a.inner;
         const int k1 = (int)(L - o * a.inner);
         // (MODE 5 / 6: the inner index runs over a pitch padded to whole 128-byte lines; k1 > N1/2 is padding)
-        const bool live = L < a.nlanes && (MODE < 5 || 2 * k1 <= a.cs_f1);
-        if constexpr (MODE >= 7) { run_inv(a, L, o, k1, live, t, smem + (size_t)cl * FFT::LANE_LDS * sizeof(T)); return; }
+        const bool live = L < a.nlanes && (MODE < 5 || MODE == 9 || 2 * k1 <= a.cs_f1);
+        if constexpr (MODE == 7 || MODE == 8) { run_inv(a, L, o, k1, live, t, smem + (size_t)cl * FFT::LANE_LDS * sizeof(T)); return; }
         char *lds = smem + (size_t)cl * FFT::LANE_LDS * sizeof(T);
         cpx<T> v[E];
         {
@@ -133,6 +137,12 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, int MODE> st
                     if (a.keep_out) *out = val; else gstore<T, true>(out, val);
                 } else if constexpr (MODE == 4) {
                     gstore<T, true>((cpx<T> *)a.out + o * a.outer_out + k1 + (int64_t)kq * a.elem_out, val);
+                } else if constexpr (MODE == 9) {
+                    const int64_t k = k1 + (int64_t)a.cs_f1 * kq;
+                    const cpx<T> tk = cmul(val, a.aux2[k]);
+                    T *out = (T *)a.out + o * a.outer_out;
+                    out[2 * k] = tk.x;                       // plain stores: the mirror tile completes every line in the same L2
+                    out[(int64_t)a.cs_n - 1 - 2 * k] = -tk.y;
                 } else {
                     int kk = k1, r2 = kq;
                     bool mir = false;

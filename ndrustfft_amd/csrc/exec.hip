@@ -748,6 +748,35 @@ static int real_fourstep_inv(const Problem &P, int gop, const FftConfig &c, cons
     return dispatch(Q, s1, d_out, stream);
 }
 
+// DCT-IV of a long even lane, n = 2 F, F = F1 * F2 powers of two: the complex four-step of length F with the fold z[j] = (x[2j] + i x[n-1-2j]) s w_j built by
+// pass 1's load and the outputs y[2k] = Re(Z[k] c_k), y[n-1-2k] = -Im(Z[k] c_k) written by pass 2's store -- two passes instead of four.
+template <typename T>
+static int dct4_fourstep(const Problem &P, const FftConfig &c, const DevConfig &d, const void *d_in, void *d_out, int64_t pin, int64_t pout, hipStream_t stream) {
+    const int F1 = c.F1, F2 = c.F2;
+    const int64_t F = (int64_t)F1 * F2, B = P.nlanes;
+    const DevTables *dt1, *dt2;
+    int rc;
+    if ((rc = get_dev_tables(c.sub1, &dt1)) || (rc = get_dev_tables(c.sub2, &dt2))) return rc;
+    void *s1;
+    if ((rc = get_scratch(2, stream, (size_t)(B * F) * sizeof(cpx<T>), &s1))) return rc;
+    RealArgs<T> a;
+    a.pitch_in = 0; a.vec_in = 0; a.vec_out = 0; a.xcd_remap = 0; a.keep_out = 1; a.stream_in = 0; a.chunk_out = 0; a.xcd_chunk = 0;
+    a.aux1 = (const cpx<T> *)d.aux1; a.aux2 = (const cpx<T> *)d.aux2; a.chirp = nullptr; a.bhat = nullptr;
+    a.cs_twlo = (const cpx<T> *)d.twlo; a.cs_twhi = (const cpx<T> *)d.twhi; a.cs_logB = c.logB;
+    a.cs_k1n = 1; a.cs_f1 = F1; a.cs_n = (int)(2 * F); a.cs_outer_in = 0; a.cs_outer_out = 0; a.cs_pitch = 0;
+    // pass 1: lanes (l, n2) of the REAL input
+    a.in = d_in; a.out = s1; a.nlanes = B * F2; a.n = F1; a.F = F1; a.n_in = F1; a.n_out = F1; a.scale = (T)P.scale;
+    a.inner = F2; a.outer_in = pin; a.outer_out = 0; a.elem_in = F2; a.elem_out = 0; a.pitch_out = F1;
+    a.twp = (const cpx<T> *)dt1->cfg[CFG_MAIN].twp_col; a.makhoul = 2;
+    if ((rc = launch_fourstep<T>(1, F1, false, a, stream))) return rc;
+    // pass 2: lanes (l, k1), real output
+    a.makhoul = 0; a.keep_out = 0;
+    a.in = s1; a.out = d_out; a.nlanes = B * F1; a.n = F2; a.F = F2; a.n_in = F2; a.n_out = F2; a.scale = (T)1;
+    a.inner = F1; a.outer_in = F; a.outer_out = pout; a.elem_in = F1; a.elem_out = 0; a.pitch_out = 0;
+    a.twp = (const cpx<T> *)dt2->cfg[CFG_MAIN].twp_col;
+    return launch_fourstep_real<T>(6, F2, a, stream);
+}
+
 // contiguous lanes whose inner FFT does not fit one workgroup's LDS
 template <typename T>
 static int dispatch_big(const Problem &P, const void *d_in, void *d_out, const DevTables &dt, hipStream_t stream) {
@@ -765,6 +794,12 @@ static int dispatch_big(const Problem &P, const void *d_in, void *d_out, const D
     const int rfs_on = real_fourstep_enabled(), rfs_ops = rfs_on == 2 ? 15 : (rfs_on ? c.rfs_ops : 0);
     if (c.rfs && ((gop == G_DCT2_EVEN && (rfs_ops & 4)) || (gop == G_R2C_EVEN && P.scale == 1.0 && (rfs_ops & 1)))) {
         const int rc0 = real_fourstep<T>(P, gop, c, d, d_in, d_out, pin, pout, stream);
+        set_last_path("real_four_step");
+        return rc0;
+    }
+    if (gop == G_DCT4_EVEN && rfs_on && c.big && !c.bigblue && fourstep_supported(c.F1) && fourstep_supported(c.F2) && !c.sub1->cfg[CFG_MAIN].twp_col.re.empty() &&
+        !c.sub2->cfg[CFG_MAIN].twp_col.re.empty() && fourstep2_enabled()) {
+        const int rc0 = dct4_fourstep<T>(P, c, d, d_in, d_out, pin, pout, stream);
         set_last_path("real_four_step");
         return rc0;
     }

@@ -78,7 +78,7 @@ bool fourstep_supported(int F) { return F == 64 || F == 128 || F == 256 || F == 
 template <typename T> int launch_fourstep(int pass, int F, bool inverse, const RealArgs<T> &a, hipStream_t s) {
 #define NDFFT_FS_CASE(F_)                                                                                              \
     case F_:                                                                                                           \
-        if (fs_direct()) {                                                                                             \
+        if (fs_direct() && !a.makhoul) {   /* (the fused DCT-IV first pass exists in the staged form only) */                \
             if (pass == 1) return inverse ? launch_fsd<T, F_, G_C2C_INV, 0>(a, s) : launch_fsd<T, F_, G_C2C_FWD, 0>(a, s); \
             return inverse ? launch_fsd<T, F_, G_C2C_INV, 4>(a, s) : launch_fsd<T, F_, G_C2C_FWD, 4>(a, s);            \
         }                                                                                                              \

@@ -8,6 +8,8 @@
 // and the inverse direction (C2R, DCT-III), whose LAST pass is the ordinary column C2R kernel of length N1 (kernels_pow2_real.hip):
 //   stage 4  X[k1 + N1 k2], k1 = 0..N1/2 (Hermitian gather): inverse FFTs of length N2 over k2, times W_n^(-n2 k1), row store s[k1][n2]   -- col_direct.h mode 7
 //   stage 5  the same with DCT-III's pre-twiddle V[k] built from x[k], x[n-k] on load                                                       -- col_direct.h mode 8
+// and the second pass of the fused DCT-IV four-step (exec.hip: dct4_fourstep; its first pass is kernels_fourstep.hip's with makhoul = 2):
+//   stage 6  twiddled complex FFTs of length F2, y[2k] = Re(Z[k] c_k), y[n-1-2k] = -Im(Z[k] c_k)                                           -- col_direct.h mode 9
 // Replaces (packed complex four-step of length n/2 = two passes) + (split pass) [+ (Makhoul pass)]: 3 (R2C) or 4 (DCT-II) passes
 // over global memory become 2.  Reference semantics: R2cFftHandler / DctHandler accept any n (src/lib.rs:477, 665).
 #include "col_direct.h"
@@ -73,7 +75,7 @@ template <typename T> static bool rfs_direct() {
 }
 template <typename T, int F, int STAGE> static int launch_rfsd(const RealArgs<T> &a, hipStream_t s) {
     constexpr int LPB = RfsGeom<T, F, 2>::LPB;
-    using K = ColDirectKernel<T, F, RfsCfg<F>::TPL, LPB, typename RfsCfg<F>::RL, G_C2C_FWD, STAGE + 3>;   // stages 2..5 = modes 5..8
+    using K = ColDirectKernel<T, F, RfsCfg<F>::TPL, LPB, typename RfsCfg<F>::RL, G_C2C_FWD, STAGE + 3>;   // stages 2..6 = modes 5..9
     const int64_t nblk = (a.nlanes + LPB - 1) / LPB;
     if (nblk <= 0) return NDFFT_OK;
     if (nblk > 0x7fffffffLL) return fail(NDFFT_ERR_UNSUPPORTED, "too many lanes for one launch");
@@ -93,6 +95,7 @@ template <typename T> int launch_fourstep_real(int stage, int F, const RealArgs<
 #define NDFFT_RFS_CASE(F_)                                       \
     case F_:                                                     \
         if (stage == 4) return launch_rfsd<T, F_, 4>(a, s);      \
+        if (stage == 6) return launch_rfsd<T, F_, 6>(a, s);      \
         if (stage == 5) return launch_rfsd<T, F_, 5>(a, s);      \
         if (stage == 1) return launch_rfs<T, F_, 1>(a, s);       \
         if (rfs_direct<T>()) return stage == 2 ? launch_rfsd<T, F_, 2>(a, s) : launch_rfsd<T, F_, 3>(a, s); \

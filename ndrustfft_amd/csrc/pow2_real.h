@@ -51,7 +51,8 @@ template <typename T> struct RealArgs {
     const cpx<T> *twp_rev = nullptr;     // Bluestein / Rader kernels: per-pass twiddles of the SAME radix list taken back to front (second FFT of the convolution)
     int32_t makhoul = 0;                 // ROWOUT kernels with real input (first pass of the REAL four-step, exec.hip: real_fourstep): 1 = the lane is read through
                                          // Makhoul's permutation v[m] = x[2m] (m < n/2), v[m] = x[2(n-1-m)+1] otherwise (DCT-II, n = this->n * inner);
-                                         // column C2R kernels (last pass of the inverse real four-step, DCT-III): 1 = the outputs are written through its inverse
+                                         // column C2R kernels (last pass of the inverse real four-step, DCT-III): 1 = the outputs are written through its inverse;
+                                         // ROWOUT C2C kernels: 2 = first pass of the fused DCT-IV four-step (the load builds z from the real lane)
     const int32_t *rader_tab = nullptr;  // Rader kernels (rader_kernel.h): g^i mod P (i < P - 1), then g^-i mod P; bhat = FFT_(P-1)(W_P^(g^-q)) / (P - 1),
                                          // twp / twp_rev = per-pass twiddles of FFT_(P-1) with the radix list front to back / back to front
 };
@@ -64,6 +65,15 @@ template <int... I> struct RevMakeSeq<0, I...> { typedef RevSeq<I...> type; };
 template <typename RL, typename S> struct RevImpl;
 template <typename RL, int... I> struct RevImpl<RL, RevSeq<I...>> { typedef RadixList<RL::at(RL::NP - 1 - I)...> type; };
 template <typename RL> using RadixReversed = typename RevImpl<RL, typename RevMakeSeq<RL::NP>::type>::type;
+
+// Tiles whose lines interleave with their MIRROR tile (Makhoul's permutation, DCT-IV's even / odd halves: one tile uses the even elements of a line, the
+// tile of the mirrored lanes the odd ones): the two run back to back on one XCD (blocks b and b + 8), so the shared lines are fetched / merged once in
+// that XCD's L2.  tpo = tiles per outer index, a multiple of 16; otherwise the identity.  Placement only: any bijection gives the same results.
+__device__ __forceinline__ int64_t mirror_pair_tile(int64_t tile, int64_t tpo) {
+    if (tpo <= 0 || tpo % 16) return tile;
+    const int64_t o_ = tile / tpo, u = tile % tpo, g = u >> 4, w = u & 15, p = 8 * g + (w & 7);
+    return o_ * tpo + (w < 8 ? p : tpo - 1 - p);
+}
 
 struct ZiNone { static __device__ __forceinline__ int map(int p) { return p; } };
 struct ZiPhi { static __device__ __forceinline__ int map(int p) { return p + (p >> 4); } };
@@ -171,22 +181,9 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
         // passes of the row four-step whose tile rows are HALF a line (F = 1024 f32: 8 lanes x 8 bytes): runs of consecutive tiles per XCD, so that the
         // two tiles sharing every line meet in one L2 (only these instantiations: the map costs registers in the others, see above)
         if constexpr ((CS == 4 || (ROWOUT && OP != G_R2C_EVEN)) && LPB * 2 * sizeof(T) < 128) tile = xcd_block(blockIdx.x, gridDim.x, a.xcd_chunk);
-        if constexpr (COL && !XCD && CS == 0 && (ROWOUT ? OP == G_R2C_EVEN : OP == G_C2R_EVEN)) {
-            // Makhoul's permutation interleaves a tile (lanes n2) with its MIRROR tile (lanes inner - 1 - n2) in every line of the caller's array: one
-            // uses the even elements, the other the odd ones.  The two run back to back on one XCD (blocks b and b + 8), so the shared lines are
-            // fetched / merged once in that XCD's L2.  (inner / LPB tiles per lane, a multiple of 16; otherwise the identity)
-            const int64_t tpo = a.inner / LPB;
-            if (a.makhoul && a.inner % LPB == 0 && tpo % 16 == 0) {
-                const int64_t o_ = tile / tpo, u = tile % tpo, g = u >> 4, w = u & 15, p = 8 * g + (w & 7);
-                tile = o_ * tpo + (w < 8 ? p : tpo - 1 - p);
-            }
-        }
-        if constexpr (XCD) {
-            const int64_t nb64 = (int64_t)gridDim.x & ~(int64_t)63;
-            if (a.xcd_remap && tile < nb64) {   // b = 8 q + x  ->  tile = 8 (8 (q / 8) + x) + q % 8
-                const int64_t q = tile >> 3, x = tile & 7;
-                tile = 8 * (8 * (q >> 3) + x) + (q & 7);
-            }
+        if constexpr (COL && !XCD && CS == 0 && (ROWOUT ? (OP == G_R2C_EVEN || OP == G_C2C_FWD) : OP == G_C2R_EVEN)) {
+            // Makhoul's permutation / DCT-IV's fold: see mirror_pair_tile (inner / LPB tiles per lane)
+            if (a.makhoul && a.inner % LPB == 0) tile = mirror_pair_tile(tile, a.inner / LPB);
         }
         const int64_t lane0 = tile * LPB;
         const int64_t lane = lane0 + ll;
@@ -223,7 +220,21 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                         });
                 } else if constexpr (IN_CPLX) {
                     const cpx<T> *in = (const cpx<T> *)a.in + base;
-                    if (a.stream_in) stage_loop<STEP>(j0, a.n_in, [&](int j) { return gload<T, true>(in + (int64_t)j * a.elem_in); }, [&](int j, cpx<T> v) { ((cpx<T> *)dst)[j] = v; });
+                    bool folded = false;
+                    if constexpr (ROWOUT && OP == G_C2C_FWD) {
+                        if (a.makhoul == 2) {   // first pass of the fused DCT-IV four-step: element j of lane (o, n2) is z[jj] = (x[2 jj] + i x[n-1-2 jj]) s e^(-i pi (4 jj + 1) / 4n),
+                                                // jj = j inner + n2, built from the REAL lane o of n = 2 this->n inner points (realops.h: G_DCT4_EVEN)
+                            const T *lane_o = (const T *)a.in + (L / a.inner) * a.outer_in;
+                            const int64_t m0 = L % a.inner, nn = 2 * (int64_t)a.n * a.inner;
+                            struct XW { T x0, x1; cpx<T> w; };
+                            stage_loop<STEP>(j0, a.n_in,
+                                [&](int j) { const int64_t jj = (int64_t)j * a.inner + m0; XW r; r.x0 = lane_o[2 * jj]; r.x1 = lane_o[nn - 1 - 2 * jj]; r.w = a.aux1[jj]; return r; },
+                                [&](int j, XW r) { ((cpx<T> *)dst)[j] = cmul(mk<T>(r.x0 * a.scale, r.x1 * a.scale), r.w); });
+                            folded = true;
+                        }
+                    }
+                    if (folded) {}
+                    else if (a.stream_in) stage_loop<STEP>(j0, a.n_in, [&](int j) { return gload<T, true>(in + (int64_t)j * a.elem_in); }, [&](int j, cpx<T> v) { ((cpx<T> *)dst)[j] = v; });
                     else stage_loop<STEP>(j0, a.n_in, [&](int j) { return in[(int64_t)j * a.elem_in]; }, [&](int j, cpx<T> v) { ((cpx<T> *)dst)[j] = v; });
                 } else {
                     const T *in = (const T *)a.in + base;

@@ -739,7 +739,13 @@ def long_lanes_four_step(L, full=True):
     # a lane count that leaves a partial tile in every pass, an output pitch larger than the lane, DCT types without a real four-step (I, IV) on the same length
     for name in ("ndfft_r2c", "ndifft_r2c", "nddct2", "nddct3"):
         assert run_case(L, name, (5, 1 << 16), 1, np.float64, offset=3) == "real_four_step", name
-    assert run_case(L, "nddct4", (2, 1 << 16), 1, np.float64) == "four_step"
+    # DCT-IV: the complex four-step of length n/2 with its fold built by pass 1's load and its outputs written by pass 2's store (two passes instead of four)
+    for norm in ("Default", "None"):
+        assert run_case(L, "nddct4", (3, 1 << 16), 1, np.float64, norm=norm) == "real_four_step"
+        assert run_case(L, "nddct4", (2, 1 << 17), 1, np.float32, norm=norm) == "real_four_step"
+    assert with_env({"NDFFT_FS_DIRECT": "1"}, lambda: run_case(L, "nddct4", (2, 1 << 16), 1, np.float64)) == "real_four_step"
+    assert with_env({"NDFFT_REAL_FOURSTEP": "0"}, lambda: run_case(L, "nddct4", (2, 1 << 16), 1, np.float64)) == "four_step"
+    assert run_case(L, "nddct1", (2, (1 << 16) + 1), 1, np.float64) == "four_step"     # DCT-I keeps the packed route
     if full:
         for a in ("8", "10", "11"):   # other splits n = N1 * N2 (developer knob of the plan)
             for name in ("nddct2", "nddct3", "ndfft_r2c", "ndifft_r2c"):
@@ -753,6 +759,8 @@ def long_lanes_four_step(L, full=True):
         for name in ("nddct2", "ndfft_r2c", "ndifft_r2c"):
             assert with_env({"NDFFT_REAL_FOURSTEP": "2"}, lambda: run_case(L, name, (2, 1 << 21), 1, np.float32)) == "real_four_step", name
         assert run_case(L, "nddct3", (2, 1 << 19), 1, np.float64) == "real_four_step"
+        assert run_case(L, "nddct4", (2, 1 << 21), 1, np.float64) == "real_four_step"
+        assert run_case(L, "nddct4", (130, 1 << 16), 1, np.float32) == "real_four_step"
         assert run_case(L, "nddct2", (130, 1 << 16), 1, np.float64) == "real_four_step"     # more lanes than one group of XCD runs
         assert run_case(L, "nddct3", (130, 1 << 16), 1, np.float32) == "real_four_step"
     # the power-of-two lengths above took the two-pass form (column load / row store, then twiddled column pass); the

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np, torch
-    from ndrustfft_amd import DctHandler, R2cFftHandler, _lib, nddct2, nddct3, ndfft_r2c, ndifft_r2c
+    from ndrustfft_amd import DctHandler, R2cFftHandler, _lib, nddct2, nddct3, nddct4, ndfft_r2c, ndifft_r2c
     dev = torch.device("cuda:0")
     def t(fn, *a, steps=10):
         for _ in range(3): fn(*a)
@@ -24,7 +24,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             x = torch.randn((L, n), dtype=tr, device=dev); y = torch.empty_like(x)
             xh = torch.randn((L, n // 2 + 1), dtype=tc, device=dev)
             hd = DctHandler(n, rdt); hr = R2cFftHandler(n, rdt)
-            for name, fn, a, b, h in (("nddct2", nddct2, x, y, hd), ("nddct3", nddct3, x, y, hd), ("ndfft_r2c", ndfft_r2c, x, xh, hr), ("ndifft_r2c", ndifft_r2c, xh, y, hr)):
+            for name, fn, a, b, h in (("nddct2", nddct2, x, y, hd), ("nddct3", nddct3, x, y, hd), ("nddct4", nddct4, x, y, hd), ("ndfft_r2c", ndfft_r2c, x, xh, hr), ("ndifft_r2c", ndifft_r2c, xh, y, hr)):
+                if os.environ.get("SWEEP_OPS") and name not in os.environ["SWEEP_OPS"].split(","): continue
                 us = t(fn, a, b, h, 1)
                 out[f"{name} {np.dtype(rdt).name} {L}x2^{e}"] = (round(us, 1), _lib.default().last_path())
     print("RESULT " + json.dumps(out))
