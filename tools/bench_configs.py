@@ -141,7 +141,13 @@ def main():
             x = torch.from_numpy(synth.complex_array((rows, n), cdt)).to(dev); y = torch.empty_like(x)
             run(f"long ndfft axis=1 {rows}x{n} {np.dtype(cdt).name}", ndfft, x, y, FftHandler(n, rdt), 1, x.numel(), max(a.steps // 3, 3))
         x = torch.from_numpy(synth.real_array((64, 1 << 18))).to(dev); y = torch.empty_like(x)
-        run("long nddct2 axis=1 64x262144 f64", nddct2, x, y, DctHandler(1 << 18), 1, x.numel(), max(a.steps // 3, 3))
+        hd = DctHandler(1 << 18)
+        run("long nddct2 axis=1 64x262144 f64", nddct2, x, y, hd, 1, x.numel(), max(a.steps // 3, 3))
+        run("long nddct3 axis=1 64x262144 f64", nddct3, x, y, hd, 1, x.numel(), max(a.steps // 3, 3))
+        run("long nddct4 axis=1 64x262144 f64", nddct4, x, y, hd, 1, x.numel(), max(a.steps // 3, 3))
+        xh = torch.from_numpy(synth.complex_array((64, (1 << 17) + 1))).to(dev); hr = R2cFftHandler(1 << 18)
+        run("long ndfft_r2c axis=1 64x262144 f64", ndfft_r2c, x, xh, hr, 1, (x.numel() + 2 * xh.numel()) // 2, max(a.steps // 3, 3))
+        run("long ndifft_r2c axis=1 64x262144 f64", ndifft_r2c, xh, y, hr, 1, (x.numel() + 2 * xh.numel()) // 2, max(a.steps // 3, 3))
     if a.only == "radercol":
         x = torch.from_numpy(synth.real_array((512, 256 * 256))).to(dev); y = torch.empty_like(x)
         run("nddct1 axis=0 512x65536 f64", nddct1, x, y, DctHandler(512), 0, x.numel(), a.steps)
