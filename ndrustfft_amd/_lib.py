@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libndfft_mi355x.so")
+LIB_PATH = os.environ.get("NDFFT_MI355X_LIB") or os.path.join(_HERE, "csrc", "libndfft_mi355x.so")   # (the variable: developer A/B builds)
 
 OK, ERR_INVALID_ARG, ERR_SIZE_MISMATCH, ERR_SHAPE_MISMATCH, ERR_AXIS, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE, ERR_ALLOC = range(9)
 F32, F64 = 0, 1
