@@ -696,6 +696,35 @@ def pow2_real_sizes(L, sizes=(64, 128, 256, 512, 1024, 2048, 4096, 8192), dtypes
             assert run_case(L, "nddct1", (5, F + 1), 1, rdt, offset=F) == "pow2_real", ("nddct1", F)
 
 
+def long_lanes_padded_views(L):
+    """The two-pass long-lane routes (real four-step both directions, fused DCT-IV) on views with an offset and a pitch larger than the lane, odd in elements:
+    results against numpy / scipy, and every element outside the output view keeps its sentinel."""
+    import scipy.fft
+    n = 1 << 16
+    rng = np.random.default_rng(5)
+    for rdt, tol in ((np.float64, 1e-10), (np.float32, 2e-4)):
+        cdt = cdt_of(rdt)
+        big = rng.standard_normal((3, n + 11)).astype(rdt); x = big[:, 3:3 + n]
+        ybig = np.full((3, n + 7), 7.5, rdt); y = ybig[:, 5:5 + n]
+        hd = handlers.DctHandler(n, rdt, _library=L)
+        for name, fn, t in (("nddct2", api.nddct2, 2), ("nddct3", api.nddct3, 3), ("nddct4", api.nddct4, 4)):
+            ybig[:] = 7.5; fn(x, y, hd, 1)
+            assert L.last_path() == "real_four_step", (name, L.last_path())
+            ref = scipy.fft.dct(x.astype(np.float64), type=t, axis=1)
+            err = np.abs(y - ref).max() / np.abs(ref).max()
+            assert err < tol and np.all(ybig[:, :5] == 7.5) and np.all(ybig[:, 5 + n:] == 7.5), (name, err)
+        hr = handlers.R2cFftHandler(n, rdt, _library=L)
+        cbig = np.full((3, n // 2 + 1 + 5), 1.5 + 2.5j, cdt); c = cbig[:, 2:2 + n // 2 + 1]
+        api.ndfft_r2c(x, c, hr, 1)
+        assert L.last_path() == "real_four_step", L.last_path()
+        ref = np.fft.rfft(x.astype(np.float64), axis=1); err = np.abs(c - ref).max() / np.abs(ref).max()
+        assert err < tol and np.all(cbig[:, :2] == 1.5 + 2.5j) and np.all(cbig[:, 2 + n // 2 + 1:] == 1.5 + 2.5j), err
+        ybig[:] = 7.5; api.ndifft_r2c(c, y, hr, 1)
+        assert L.last_path() == "real_four_step", L.last_path()
+        err = np.abs(y - x).max() / np.abs(x).max()
+        assert err < tol and np.all(ybig[:, :5] == 7.5) and np.all(ybig[:, 5 + n:] == 7.5), err
+
+
 def long_lanes_four_step(L, full=True):
     """Lanes longer than one workgroup's LDS: four-step on the row kernels (any op, C2C inverse scaling,
     non-power-of-two splits, strided axis through the transpose route); and the documented refusal."""

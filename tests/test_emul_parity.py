@@ -176,6 +176,7 @@ def test_partial_round_configs(L): ps.partial_round_configs(L)
 def test_rader_kernel(L): ps.rader_kernel(L)
 def test_odd_real_lengths(L): ps.odd_real_lengths(L, dct4=True)
 def test_long_lanes_four_step(L): ps.long_lanes_four_step(L, full=False)
+def test_long_lanes_padded_views(L): ps.long_lanes_padded_views(L)
 
 
 @pytest.mark.parametrize("dt", ["f64", "f32"])

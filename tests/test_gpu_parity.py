@@ -193,6 +193,8 @@ def test_rader_kernel_beyond_bluestein(L):
 def test_bluestein_register_kernel(L):
     ps.bluestein_register_kernel(L, sizes=((17, 64), (31, 64), (97, 256), (127, 256), (511, 1024), (1009, 2048), (2039, 4096), (4093, 8192)), col_max_M=1024)
 def test_long_lanes_four_step(L): ps.long_lanes_four_step(L, full=True)
+@pytest.mark.gpu
+def test_long_lanes_padded_views(L): ps.long_lanes_padded_views(L)
 def test_pow2_real_sizes(L): ps.pow2_real_sizes(L)
 def test_jit_specialised_sizes(L): ps.jit_specialised_sizes(L)
 def test_pow2_col_sizes(L): ps.pow2_col_sizes(L)
