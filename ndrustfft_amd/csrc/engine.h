@@ -225,7 +225,7 @@ template <typename T> int launch_colsplit(int cs, bool inverse, const RealArgs<T
 bool fourstep_supported(int F);
 template <typename T> int launch_fourstep(int pass, int F, bool inverse, const RealArgs<T> &a, hipStream_t s);
 // kernels_fourstep_real.hip : the passes of the REAL four-step (stage: 1 = real column FFT, row store; 2 = twiddled column pass
-// writing the half spectrum (R2C) ; 3 = the same writing DCT-II outputs ; 4 / 5 = first pass of the inverse direction, C2R / DCT-III ; 6 = second pass of the fused DCT-IV four-step)
+// writing the half spectrum (R2C) ; 3 = the same writing DCT-II outputs ; 4 / 5 = first pass of the inverse direction, C2R / DCT-III ; 6 = second pass of the fused DCT-IV four-step ; 7 = last pass of the inverse direction, column C2R)
 bool fourstep_real_supported(int N1, int N2);
 template <typename T> int launch_fourstep_real(int stage, int F, const RealArgs<T> &a, hipStream_t s);
 

@@ -740,6 +740,16 @@ static int real_fourstep_inv(const Problem &P, int gop, const FftConfig &c, cons
     // half lines), so neighbouring tiles share every line
     { static const int xc = [] { const char *e = getenv("NDFFT_RFS_XCD_CHUNK"); return e ? atoi(e) : 8; }(); a.xcd_chunk = xc; }
     if ((rc = launch_fourstep_real<T>(gop == G_DCT3_EVEN ? 5 : 4, N2, a, stream))) return rc;
+    if (const char *e = getenv("NDFFT_RFS_C2R_TILE"); !(e && e[0] == '0')) {   // the column C2R kernel on 128-byte tiles (0: the general column kernel through dispatch())
+        const DevTables *dt1;
+        if ((rc = get_dev_tables(c.rfs_sub1, &dt1))) return rc;
+        a.xcd_chunk = 0; a.keep_out = 0;
+        a.in = s1; a.out = d_out; a.nlanes = B * N2; a.n = N1; a.F = N1 / 2; a.n_in = Kx; a.n_out = N1; a.scale = (T)1;
+        a.inner = N2; a.outer_in = (int64_t)Kx * N2; a.outer_out = pout; a.elem_in = N2; a.elem_out = N2; a.pitch_in = 0; a.pitch_out = 0;
+        a.aux1 = (const cpx<T> *)dt1->cfg[CFG_MAIN].aux1; a.twp = (const cpx<T> *)dt1->cfg[CFG_MAIN].twp;
+        a.makhoul = gop == G_DCT3_EVEN ? 1 : 0;
+        return launch_fourstep_real<T>(7, N1 / 2, a, stream);
+    }
     Problem Q;
     Q.plan = c.rfs_sub1; Q.op = NDFFT_OP_C2R; Q.xlen = Kx; Q.ylen = N1; Q.xs = N2; Q.ys = N2; Q.nlanes = B * N2; Q.scale = 1.0;
     if (B > 1) Q.b.push_back({B, (int64_t)Kx * N2, pout});

@@ -84,16 +84,32 @@ template <typename T, int F, int STAGE> static int launch_rfsd(const RealArgs<T>
     return NDFFT_OK;
 }
 
+// last pass of the inverse direction: the column C2R kernel of length N1 = 2 F on tiles of 128-byte real rows (16 f64 / 32 f32 lanes, halved above 80 KiB) --
+// the general column kernels (kernels_pow2_real.hip) use 32-lane tiles, 140 KiB = one workgroup per CU at F = 256 f64
+template <typename T, int F> static int launch_rfs_c2r(const RealArgs<T> &a, hipStream_t s) {
+    constexpr int LPB = RfsGeom<T, F, 1>::LPB;
+    using K = RealPow2Kernel<T, F, RfsCfg<F>::TPL, LPB, typename RfsCfg<F>::RL, G_C2R_EVEN, true, false, 0, false>;
+    static_assert(K::LDS_BYTES <= 160 * 1024, "tile does not fit LDS");
+    NDFFT_ENSURE_LDS_ATTR((k_pow2_real<K, T>));
+    const int64_t nblk = (a.nlanes + LPB - 1) / LPB;
+    if (nblk <= 0) return NDFFT_OK;
+    if (nblk > 0x7fffffffLL) return fail(NDFFT_ERR_UNSUPPORTED, "too many lanes for one launch");
+    hipLaunchKernelGGL((k_pow2_real<K, T>), dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, a);
+    NDFFT_HIP(hipGetLastError());
+    return NDFFT_OK;
+}
+
 // N1 = real length of stage 1 (inner complex FFT N1 / 2), N2 = complex length of stage 2
 bool fourstep_real_supported(int N1, int N2) {
     auto ok = [](int F) { return F == 64 || F == 128 || F == 256 || F == 512 || F == 1024; };
     return N1 % 2 == 0 && ok(N1 / 2) && ok(N2);
 }
 
-// stage 1: F = N1 / 2; stages 2, 3: F = N2
+// stages 1, 7: F = N1 / 2; the others: F = N2
 template <typename T> int launch_fourstep_real(int stage, int F, const RealArgs<T> &a, hipStream_t s) {
 #define NDFFT_RFS_CASE(F_)                                       \
     case F_:                                                     \
+        if (stage == 7) return launch_rfs_c2r<T, F_>(a, s);      \
         if (stage == 4) return launch_rfsd<T, F_, 4>(a, s);      \
         if (stage == 6) return launch_rfsd<T, F_, 6>(a, s);      \
         if (stage == 5) return launch_rfsd<T, F_, 5>(a, s);      \

@@ -80,6 +80,9 @@ template <typename K, typename T> static int launch_k(const RealArgs<T> &a, int 
 #ifndef NDFFT_COL_LANES_F32
 #define NDFFT_COL_LANES_F32 32
 #endif
+#ifndef NDFFT_COL_LANES_F64
+#define NDFFT_COL_LANES_F64 32
+#endif
 // threads of a COL workgroup: aim at 32 adjacent lanes per tile row, at most 1024 threads
 static constexpr int col_threads(int tpl, int lanes) { return tpl * lanes > 1024 ? 1024 : (tpl * lanes < 256 ? 256 : tpl * lanes); }
 // Rows of a column tile should be 256 bytes wide: tools/tilecopy.hip (profiles/r02t_tilecopy.txt) copies 128-row tiles whose
@@ -88,9 +91,13 @@ static constexpr int col_threads(int tpl, int lanes) { return tpl * lanes > 1024
 // tile still fits (REAL = the op reads or writes real lanes); everything else keeps 32 lanes (256 B for c64 / f64, 512 B for c128).
 template <typename T, int F, bool REAL = false> struct ColGeom {
     static constexpr int TPL = RealCfg<F>::TPL;
-    static constexpr int WANT = (sizeof(T) == 4 && REAL) ? 2 * NDFFT_COL_LANES_F32 : (sizeof(T) == 4 ? NDFFT_COL_LANES_F32 : 32);
-    static constexpr int LPB = col_threads(TPL, WANT) / TPL;
-    static constexpr size_t LDS = (size_t)LPB * (((F + (F >> 4) + 2) | 1)) * 2 * sizeof(T);
+    static constexpr int WANT = (sizeof(T) == 4 && REAL) ? 2 * NDFFT_COL_LANES_F32 : (sizeof(T) == 4 ? NDFFT_COL_LANES_F32 : NDFFT_COL_LANES_F64);
+    static constexpr int LPB0 = col_threads(TPL, WANT) / TPL;
+    static constexpr size_t LANE_BYTES = (size_t)(((F + (F >> 4) + 2) | 1)) * 2 * sizeof(T);
+    // f64, F = 256: 32 lanes are 140 KiB = ONE 1024-thread workgroup per CU; 16 lanes (two of 512 threads) measure 2.6-5 % faster on the strided axes of
+    // cfg4 (89.5 / 91.8 -> 87.1 us) and 15 % as the last pass of the inverse real four-step (profiles/r06/r06s_*, r06t_*)
+    static constexpr int LPB = (sizeof(T) == 8 && LPB0 >= 32 && LPB0 * LANE_BYTES > 80 * 1024) ? LPB0 / 2 : LPB0;
+    static constexpr size_t LDS = (size_t)LPB * LANE_BYTES;
     static constexpr bool OK = LPB >= 8 && LDS <= 160 * 1024;
 };
 
