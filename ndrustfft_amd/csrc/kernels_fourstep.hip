@@ -31,8 +31,10 @@ template <typename T, int F> struct FsGeom {
     // adjacent lanes per tile: 128-byte rows (8 complex f64 / 16 complex f32), at least 256 threads.  Narrower than the
     // 32-lane tiles of the general column kernels on purpose: F = 256 f64 then takes 35 KiB of LDS instead of 140 KiB,
     // four workgroups per CU instead of one (256 x 65536 c128: 251 -> see DESIGN.md section 3.5)
+    // F = 1024 c128: 4 lanes (64-byte rows, 70 KiB = two workgroups per CU) since the half-line tiles run in XCD runs (pow2_real.h): 32 x 2^20 c128
+    // 591 -> 569 us (profiles/r06/r06u_*; without the runs the same tiles lost 15 %: profiles/r05/r05g_*)
 #ifndef NDFFT_FS_LANES_F64_1024
-#define NDFFT_FS_LANES_F64_1024 NDFFT_FS_LANES_F64
+#define NDFFT_FS_LANES_F64_1024 4
 #endif
 #ifndef NDFFT_FS_LANES_F32_1024
 #define NDFFT_FS_LANES_F32_1024 NDFFT_FS_LANES_F32
