@@ -94,9 +94,19 @@ template <typename T, int F, bool REAL = false> struct ColGeom {
     static constexpr int WANT = (sizeof(T) == 4 && REAL) ? 2 * NDFFT_COL_LANES_F32 : (sizeof(T) == 4 ? NDFFT_COL_LANES_F32 : NDFFT_COL_LANES_F64);
     static constexpr int LPB0 = col_threads(TPL, WANT) / TPL;
     static constexpr size_t LANE_BYTES = (size_t)(((F + (F >> 4) + 2) | 1)) * 2 * sizeof(T);
-    // f64, F = 256: 32 lanes are 140 KiB = ONE 1024-thread workgroup per CU; 16 lanes (two of 512 threads) measure 2.6-5 % faster on the strided axes of
-    // cfg4 (89.5 / 91.8 -> 87.1 us) and 15 % as the last pass of the inverse real four-step (profiles/r06/r06s_*, r06t_*)
-    static constexpr int LPB = (sizeof(T) == 8 && LPB0 >= 32 && LPB0 * LANE_BYTES > 80 * 1024) ? LPB0 / 2 : LPB0;
+    // A tile above 80 KiB is ONE 1024-thread workgroup per CU: nothing runs while it loads or stores.  f64 tiles are halved down to 8 lanes:
+    //   F = 256 (32 -> 16 lanes): the strided axes of cfg4 89.5 / 91.8 -> 87.1 us, the last pass of the inverse real four-step -15 % (profiles/r06/r06s_*, r06t_*)
+    //   F = 512 (16 -> 8 lanes):  ndfft axis 0 of 512 x 32768 c128 117 -> 87 us (0.57 -> 0.77), nddct2 / ndfft_r2c axis 0 of 1024 x 16384 f64 71 / 64 -> 57 / 50 us
+    //                             although their real rows are 64 bytes then (profiles/r06/r06v_*)
+    // f32 tiles (F = 256 real ops: 64 lanes, 140 KiB) measured the same halved or not and stay.
+#ifndef NDFFT_COL_HALVE_MIN_LANES_F64
+#define NDFFT_COL_HALVE_MIN_LANES_F64 16
+#endif
+#ifndef NDFFT_COL_HALVE_MIN_LANES_F32
+#define NDFFT_COL_HALVE_MIN_LANES_F32 1000
+#endif
+    static constexpr int HALVE_FROM = sizeof(T) == 8 ? NDFFT_COL_HALVE_MIN_LANES_F64 : NDFFT_COL_HALVE_MIN_LANES_F32;
+    static constexpr int LPB = (LPB0 >= HALVE_FROM && LPB0 * LANE_BYTES > 80 * 1024) ? LPB0 / 2 : LPB0;
     static constexpr size_t LDS = (size_t)LPB * LANE_BYTES;
     static constexpr bool OK = LPB >= 8 && LDS <= 160 * 1024;
 };
