@@ -200,7 +200,7 @@ int launch_tinymat_f64(int n, int shape, bool stage, const TinyArgs &a, hipStrea
 bool pow2_real_supported(int F);
 void pow2_real_build_twiddles(int F, HostTable &out);
 template <typename T> int launch_pow2_real(int gen_op, const RealArgs<T> &a, bool col, hipStream_t s);
-template <typename T> int pow2_real_col_lanes(int F);   // adjacent lanes per column tile (0: none)
+template <typename T> int pow2_real_col_lanes(int F, int kind);   // adjacent lanes per column tile (0: none); kind: 0 = C2C, 1 = R2C, 2 = C2R, 3 = DCT
 template <typename T> int pow2_real_narrow_lanes(int F);   // lanes per XCD-aware narrow column tile (0: none)
 void pow2_real_build_narrow_twiddles(int dtype, int F, HostTable &out);
 template <typename T> int launch_pow2_real_narrow(int gen_op, const RealArgs<T> &a, hipStream_t s);

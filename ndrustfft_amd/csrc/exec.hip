@@ -622,7 +622,7 @@ static int big_fft(const FftConfig &c, const DevConfig &d, const cpx<T> *zin, in
     //   (3) one transpose into natural order
     {
         const bool row2 = c.sub2->cfg[CFG_MAIN].pow2;
-        const int col_lanes = std::is_same<T, float>::value ? pow2_real_col_lanes<float>(F1) : pow2_real_col_lanes<double>(F1);
+        const int col_lanes = std::is_same<T, float>::value ? pow2_real_col_lanes<float>(F1, 0) : pow2_real_col_lanes<double>(F1, 0);
         const int nar_lanes = std::is_same<T, float>::value ? pow2_real_narrow_lanes<float>(F1) : pow2_real_narrow_lanes<double>(F1);
         const bool col1 = !c.sub1->cfg[CFG_MAIN].twp_col.re.empty() && F2 >= 8 && col_lanes > 0;
         const bool nar1 = !c.sub1->cfg[CFG_MAIN].twp_narrow.re.empty() && F2 >= 64 && nar_lanes > 0 && narrow_enabled();
@@ -1035,10 +1035,11 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
         const bool have_tw = use_jit || use_blue || (is_c2c ? !c.twp_col.re.empty() : c.pow2);
         const bool row = (!is_c2c || use_blue) && P.xs == 1 && P.ys == 1 && P.b.size() <= 1;
         bool col = false, narrow = false;
+        const int col_kind = is_c2c ? 0 : (P.op == NDFFT_OP_R2C ? 1 : (P.op == NDFFT_OP_C2R ? 2 : 3));   // which sides of a column tile are real lanes (kernels_pow2_real.hip: ColGeom)
         if (!row && (!odd_variant || use_blue || use_plain) && P.xlen > 1 && !P.b.empty() && P.b.size() <= 2 && P.b.back().sin == 1 && P.b.back().sout == 1) {
             if (have_tw && P.b.back().shape >= 8) {
                 const int lanes = (use_jit || use_blue) ? std::max((use_jit || c.bluereg) ? jit_col_lanes(plan->dtype, c.jitcfg) : 0, use_rader ? rader_col_lanes(plan->dtype, c.radercfg) : 0)
-                                          : plan->dtype == NDFFT_F32 ? pow2_real_col_lanes<float>(c.F) : pow2_real_col_lanes<double>(c.F);
+                                          : plan->dtype == NDFFT_F32 ? pow2_real_col_lanes<float>(c.F, col_kind) : pow2_real_col_lanes<double>(c.F, col_kind);
                 col = lanes > 0;
             }
             // long lanes: XCD-aware narrow tiles (one HBM pass) instead of the three-pass transpose route

@@ -89,26 +89,25 @@ static constexpr int col_threads(int tpl, int lanes) { return tpl * lanes > 1024
 // rows are 2 MiB apart -- the column four-step's first stage on cfg3-A -- at 0.56-0.62 of 8 TB/s with 128-byte rows, 0.71-0.74
 // with 256-byte rows, 0.68-0.71 with 512.  f32 REAL data (4 bytes per lane) therefore takes 64 lanes per tile where the
 // tile still fits (REAL = the op reads or writes real lanes); everything else keeps 32 lanes (256 B for c64 / f64, 512 B for c128).
-template <typename T, int F, bool REAL = false> struct ColGeom {
+// KIND: 0 = C2C (complex rows on both sides), 1 = R2C (real in, complex out), 2 = C2R (complex in, real out), 3 = DCT (both sides real)
+template <typename T, int F, int KIND = 0> struct ColGeom {
     static constexpr int TPL = RealCfg<F>::TPL;
-    static constexpr int WANT = (sizeof(T) == 4 && REAL) ? 2 * NDFFT_COL_LANES_F32 : (sizeof(T) == 4 ? NDFFT_COL_LANES_F32 : NDFFT_COL_LANES_F64);
+    static constexpr int WANT = (sizeof(T) == 4 && KIND > 0) ? 2 * NDFFT_COL_LANES_F32 : (sizeof(T) == 4 ? NDFFT_COL_LANES_F32 : NDFFT_COL_LANES_F64);
     static constexpr int LPB0 = col_threads(TPL, WANT) / TPL;
     static constexpr size_t LANE_BYTES = (size_t)(((F + (F >> 4) + 2) | 1)) * 2 * sizeof(T);
-    // A tile above 80 KiB is ONE 1024-thread workgroup per CU: nothing runs while it loads or stores.  f64 tiles are halved down to 8 lanes:
+    // A tile above 80 KiB is ONE 1024-thread workgroup per CU: nothing runs while it loads or stores.  f64 tiles are halved:
     //   F = 256 (32 -> 16 lanes): the strided axes of cfg4 89.5 / 91.8 -> 87.1 us, the last pass of the inverse real four-step -15 % (profiles/r06/r06s_*, r06t_*)
     //   F = 512 (16 -> 8 lanes):  ndfft axis 0 of 512 x 32768 c128 117 -> 87 us (0.57 -> 0.77), nddct2 / ndfft_r2c axis 0 of 1024 x 16384 f64 71 / 64 -> 57 / 50 us
     //                             although their real rows are 64 bytes then (profiles/r06/r06v_*)
+    //   F = 1024 (8 -> 4 lanes) and F = 2048 (4 lanes, no column tile before): only where the OUTPUT rows are complex (64 bytes): ndfft axis 0 of 1024 x 16384 c128
+    //                             128 -> 120 us, of 2048 x 8192 c128 216 (narrow XCD tiles) -> 157 us, ndfft_r2c f64 n = 2048 / 4096 68 / 132 -> 61 / 83 us;
+    //                             32-byte output rows are ruinous (ndifft_r2c n = 2048 74 -> 241 us, nddct2 82 -> 200 us): not for KIND >= 2   (profiles/r06/r06w_*)
     // f32 tiles (F = 256 real ops: 64 lanes, 140 KiB) measured the same halved or not and stay.
-#ifndef NDFFT_COL_HALVE_MIN_LANES_F64
-#define NDFFT_COL_HALVE_MIN_LANES_F64 16
-#endif
-#ifndef NDFFT_COL_HALVE_MIN_LANES_F32
-#define NDFFT_COL_HALVE_MIN_LANES_F32 1000
-#endif
-    static constexpr int HALVE_FROM = sizeof(T) == 8 ? NDFFT_COL_HALVE_MIN_LANES_F64 : NDFFT_COL_HALVE_MIN_LANES_F32;
+    static constexpr int HALVE_FROM = sizeof(T) == 8 ? (KIND >= 2 ? 16 : 8) : 1000;
     static constexpr int LPB = (LPB0 >= HALVE_FROM && LPB0 * LANE_BYTES > 80 * 1024) ? LPB0 / 2 : LPB0;
     static constexpr size_t LDS = (size_t)LPB * LANE_BYTES;
-    static constexpr bool OK = LPB >= 8 && LDS <= 160 * 1024;
+    static constexpr int MIN_LANES = (sizeof(T) == 8 && KIND <= 1) ? 4 : 8;
+    static constexpr bool OK = LPB >= MIN_LANES && LDS <= 160 * 1024;
 };
 
 // narrow (XCD-aware) column tiles for long lanes: 1024 threads, LPB = 2 or 4 lanes
@@ -196,9 +195,9 @@ template <typename T, int F, int OP> static int launch_real_one(const RealArgs<T
             return launch_k<RealPow2Kernel<T, F, TPL, LPB, typename RealCfg<F>::RL, OP, false>, T>(a, LPB, s);
         }
     }
-    constexpr bool REAL = !(OP == G_C2C_FWD || OP == G_C2C_INV);   // the op reads or writes real lanes (cfg3-A 210 -> 202 us, cfg3-A' 259 -> 235 us)
-    if constexpr (ColGeom<T, F, REAL>::OK) {
-        constexpr int LPB = ColGeom<T, F, REAL>::LPB;
+    constexpr int KIND = (OP == G_C2C_FWD || OP == G_C2C_INV) ? 0 : (OP == G_R2C_EVEN ? 1 : (OP == G_C2R_EVEN ? 2 : 3));   // which sides are real lanes (cfg3-A 210 -> 202 us, cfg3-A' 259 -> 235 us)
+    if constexpr (ColGeom<T, F, KIND>::OK) {
+        constexpr int LPB = ColGeom<T, F, KIND>::LPB;
         return launch_k<RealPow2Kernel<T, F, TPL, LPB, typename RealCfg<F>::RL, OP, true>, T>(a, LPB, s);
     } else {
         return fail(NDFFT_ERR_UNSUPPORTED, "pow2 real kernel: no column tile for this F");
@@ -219,17 +218,18 @@ template <typename T, int F> static int launch_real_F(int op, const RealArgs<T> 
     }
 }
 
-// lanes per column tile for inner FFT length F (0 = no column kernel)
-template <typename T> int pow2_real_col_lanes(int F) {
+// lanes per column tile for inner FFT length F (0 = no column kernel); kind: 0 = C2C, 1 = R2C, 2 = C2R, 3 = DCT
+template <typename T> int pow2_real_col_lanes(int F, int kind) {
     switch (F) {
-#define NDFFT_CASE(F_, TPL_, ...) case F_: return ColGeom<T, F_>::OK ? ColGeom<T, F_>::LPB : 0;
+#define NDFFT_CASE(F_, TPL_, ...) case F_: return kind == 0 ? (ColGeom<T, F_, 0>::OK ? ColGeom<T, F_, 0>::LPB : 0) : kind == 1 ? (ColGeom<T, F_, 1>::OK ? ColGeom<T, F_, 1>::LPB : 0) \
+                                                       : kind == 2 ? (ColGeom<T, F_, 2>::OK ? ColGeom<T, F_, 2>::LPB : 0) : (ColGeom<T, F_, 3>::OK ? ColGeom<T, F_, 3>::LPB : 0);
         NDFFT_REAL_CONFIGS(NDFFT_CASE)
 #undef NDFFT_CASE
         default: return 0;
     }
 }
-template int pow2_real_col_lanes<float>(int);
-template int pow2_real_col_lanes<double>(int);
+template int pow2_real_col_lanes<float>(int, int);
+template int pow2_real_col_lanes<double>(int, int);
 
 template <typename T> int launch_pow2_real(int op, const RealArgs<T> &a, bool col, hipStream_t s) {
     switch (a.F) {

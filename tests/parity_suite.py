@@ -863,7 +863,7 @@ def narrow_xcd_tiles(L):
     """Long strided lanes (inner FFT 2048..8192) with >= 64 adjacent lanes: XCD-aware narrow column tiles,
     incl. ragged tails, 3-D outer dims and every op family."""
     cases = (("ndfft_r2c", (8192, 128), 0, np.float32), ("ndifft_r2c", (8192, 64), 0, np.float32), ("ndfft", (4096, 72), 0, np.float32),
-             ("ndfft", (4096, 64), 0, np.float64), ("nddct2", (2, 4096, 130), 1, np.float64), ("ndifft", (2048, 200), 0, np.float64),
+             ("ndfft", (4096, 64), 0, np.float64), ("nddct2", (2, 4096, 130), 1, np.float64), ("ndifft", (2048, 200), 0, np.float32),
              ("nddct1", (4097, 64), 0, np.float32), ("ndfft", (8192, 64), 0, np.float32), ("ndfft_r2c", (16384, 66), 0, np.float32),
              ("nddct3", (4096, 1000), 0, np.float64), ("nddct4", (8192, 96), 0, np.float32))
     os.environ["NDFFT_COLSPLIT"] = "0"          # the column four-step would take the C2C / R2C / C2R cases
@@ -872,6 +872,12 @@ def narrow_xcd_tiles(L):
             assert run_case(L, name, shape, axis, rdt) == "pow2_col_xcd", (name, shape)
     finally:
         del os.environ["NDFFT_COLSPLIT"]
+    # round 3: f64 lanes whose OUTPUT rows are complex take ordinary column tiles of 4 lanes (64-byte rows) at inner lengths 1024 / 2048 instead
+    # (c128 n = 2048: narrow tiles 216 us -> 157 us; f64 R2C n = 4096: 132 -> 83 us); real output rows keep the 8-lane minimum
+    for name, shape, axis, rdt, want in (("ndifft", (2048, 200), 0, np.float64, "pow2_col"), ("ndfft", (3, 2048, 10), 1, np.float64, "pow2_col"), ("ndfft", (1024, 21), 0, np.float64, "pow2_col"),
+                                         ("ndfft_r2c", (4096, 70), 0, np.float64, "pow2_col"), ("ndfft_r2c", (2048, 21), 0, np.float64, "pow2_col"),
+                                         ("ndifft_r2c", (4096, 64), 0, np.float64, "pow2_col_xcd"), ("nddct2", (4096, 64), 0, np.float64, "pow2_col_xcd")):
+        assert run_case(L, name, shape, axis, rdt) == want, (name, shape)
 
 
 def column_four_step(L):

@@ -3,7 +3,7 @@ import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
-from ndrustfft_amd import DctHandler, R2cFftHandler, FftHandler, _lib, nddct2, ndfft_r2c, ndfft
+from ndrustfft_amd import DctHandler, R2cFftHandler, FftHandler, _lib, nddct2, ndfft_r2c, ndifft_r2c, ndfft
 dev = torch.device("cuda:0")
 def t(fn, *a, steps=20):
     for _ in range(5): fn(*a)
@@ -15,12 +15,12 @@ def t(fn, *a, steps=20):
     return e0.elapsed_time(e1) * 1e3 / steps
 for rdt, cdt in ((np.float64, np.complex128), (np.float32, np.complex64)):
     tr = torch.from_numpy(np.zeros(1, rdt)).dtype; tc = torch.from_numpy(np.zeros(1, cdt)).dtype
-    for n in (512, 1024, 2048):
+    for n in [int(v) for v in os.environ.get("COL_MID_N", "512,1024,2048").split(",")]:
         cols = (1 << 24) // n
         xc = torch.randn((n, cols), dtype=tc, device=dev); yc = torch.empty_like(xc)
         xr = torch.randn((n, cols), dtype=tr, device=dev); yr = torch.empty_like(xr)
-        xh = torch.empty((n // 2 + 1, cols), dtype=tc, device=dev)
-        for name, fn, a, b, h in (("ndfft", ndfft, xc, yc, FftHandler(n, rdt)), ("nddct2", nddct2, xr, yr, DctHandler(n, rdt)), ("ndfft_r2c", ndfft_r2c, xr, xh, R2cFftHandler(n, rdt))):
+        xh = torch.randn((n // 2 + 1, cols), dtype=tc, device=dev)
+        for name, fn, a, b, h in (("ndfft", ndfft, xc, yc, FftHandler(n, rdt)), ("nddct2", nddct2, xr, yr, DctHandler(n, rdt)), ("ndfft_r2c", ndfft_r2c, xr, xh, R2cFftHandler(n, rdt)), ("ndifft_r2c", ndifft_r2c, xh, yr, R2cFftHandler(n, rdt))):
             us = t(fn, a, b, h, 0)
             nb = a.numel() * a.element_size() + b.numel() * b.element_size()
             print(f"{name:10s} axis=0 {n}x{cols} {np.dtype(rdt).name}: {us:7.1f} us  {nb / us / 1e3 / 8000:.3f}  {_lib.default().last_path()}", flush=True)
