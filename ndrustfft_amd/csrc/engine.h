@@ -89,6 +89,7 @@ struct FftConfig {                 // one complex-FFT-of-length-F recipe + op ta
     // long STRIDED lanes (pow2 n, C2C and R2C/C2R slots): column four-step n = cs_F1 * cs_F2 in two passes of
     // wide column tiles (exec.hip col_split); cs_sub1 has the kind of the owning plan, cs_sub2 is C2C
     bool cs = false; int cs_F1 = 0, cs_F2 = 0, cs_logB = 0;
+    int cs_ops = 0;                // ops that take it (measured against the one-pass column tiles): 1 = C2C, 2 = R2C, 4 = C2R
     ndfft_plan *cs_sub1 = nullptr, *cs_sub2 = nullptr;
     HostTable cs_twlo, cs_twhi;    // W_n^m for m < n, split like twlo / twhi
     // long CONTIGUOUS real-data lanes (MAIN slot of R2C and DCT plans, big, n a power of two): REAL four-step n = rfs_N1 * rfs_N2

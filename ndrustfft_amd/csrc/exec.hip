@@ -1051,7 +1051,7 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
         // long strided power-of-two lanes on a dense C-layout block: column four-step (two wide-tile passes)
         if (c.cs && slot == CFG_MAIN && colsplit_enabled() && !row && !P.b.empty() && P.b.size() <= 2 && P.b.back().sin == 1 &&
             P.b.back().sout == 1 && P.xs == P.b.back().shape && P.ys == P.b.back().shape && P.b.back().shape >= 16 &&
-            (P.op == NDFFT_OP_C2C_FWD || P.op == NDFFT_OP_C2C_INV || P.op == NDFFT_OP_R2C || P.op == NDFFT_OP_C2R)) {
+            (((P.op == NDFFT_OP_C2C_FWD || P.op == NDFFT_OP_C2C_INV) && (c.cs_ops & 1)) || (P.op == NDFFT_OP_R2C && (c.cs_ops & 2)) || (P.op == NDFFT_OP_C2R && (c.cs_ops & 4)))) {
             return plan->dtype == NDFFT_F32 ? col_split<float>(P, d_in, d_out, c, d, stream) : col_split<double>(P, d_in, d_out, c, d, stream);
         }
         if (narrow) {

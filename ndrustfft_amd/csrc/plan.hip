@@ -374,9 +374,16 @@ static void add_colsplit(ndfft_plan *p) {
     const int F2 = colsplit_inner_len();
     if (n % F2) return;
     const size_t F1 = n / F2;
-    const size_t lo = p->kind == NDFFT_KIND_C2C ? 64 : 128, hi = p->kind == NDFFT_KIND_C2C ? 1024 : 2048;
+    // shortest F1 per op, measured against the one-pass column tiles on 2^24-point arrays (profiles/r06/r06x_*):
+    //   f64: C2C from n = 4096, R2C / C2R from n = 8192 (below: 4-lane / narrow column tiles win or tie)
+    //   f32: C2C from n = 2048 (narrow tiles 135 us -> 110 us), R2C from n = 4096 (137 -> 57 us), C2R from n = 2048 (95 -> 55 us; n = 4096: 98 -> 58 us)
+    const bool f32 = p->dtype == NDFFT_F32, c2c = p->kind == NDFFT_KIND_C2C;
+    size_t lo_fwd = c2c ? (f32 ? 32 : 64) : (f32 ? 64 : 128), lo_inv = c2c ? lo_fwd : (f32 ? 32 : 128);
+    if (const char *e = getenv(c2c ? "NDFFT_CS_LO_C2C" : "NDFFT_CS_LO_R2C")) lo_fwd = lo_inv = (size_t)atoi(e);   // developer knob
+    const size_t lo = std::min(lo_fwd, lo_inv), hi = c2c ? 1024 : 2048;
     if (F1 < lo || F1 > hi) return;
     FftConfig &c = p->cfg[CFG_MAIN];
+    c.cs_ops = c2c ? (F1 >= lo_fwd ? 1 : 0) : ((F1 >= lo_fwd ? 2 : 0) | (F1 >= lo_inv ? 4 : 0));
     c.cs = true; c.cs_F1 = (int)F1; c.cs_F2 = F2;
     c.cs_sub1 = make_plan(p->kind, p->dtype, F1);
     c.cs_sub2 = make_plan(NDFFT_KIND_C2C, p->dtype, (size_t)F2);

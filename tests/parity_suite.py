@@ -893,6 +893,13 @@ def column_four_step(L):
              ("ndfft", (16384, 19), 0, np.float32, "Default"))
     for name, shape, axis, rdt, norm in cases:
         assert run_case(L, name, shape, axis, rdt, norm=norm) == "col_split", (name, shape)
+    # round 3: per-op, per-dtype lower ends -- f32 C2C and C2R from n = 2048 (first factor 32), f32 R2C from 4096; f64 keeps 4096 / 8192
+    for name, shape, axis, rdt, want in (("ndfft", (2048, 40), 0, np.float32, "col_split"), ("ndifft", (2048, 33), 0, np.float32, "col_split"), ("ndfft", (2, 2048, 24), 1, np.float32, "col_split"),
+                                         ("ndfft_r2c", (4096, 48), 0, np.float32, "col_split"), ("ndifft_r2c", (4096, 40), 0, np.float32, "col_split"),
+                                         ("ndifft_r2c", (2048, 24), 0, np.float32, "col_split"), ("ndifft_r2c", (3, 2048, 17), 1, np.float32, "col_split"),
+                                         ("ndfft_r2c", (2048, 24), 0, np.float32, "pow2_col"), ("ndfft", (2048, 40), 0, np.float64, "pow2_col"), ("ndfft_r2c", (4096, 48), 0, np.float64, "pow2_col")):
+        for norm in ("Default", "None"):
+            assert run_case(L, name, shape, axis, rdt, norm=norm) == want, (name, shape)
     # too few adjacent lanes for a wide tile: narrow tiles / transpose route as before
     assert run_case(L, "ndfft", (4096, 8), 0, np.float64) != "col_split"
     # column chunks (Infinity-Cache-resident intermediate): force small chunks so that these shapes split
