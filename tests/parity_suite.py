@@ -833,7 +833,13 @@ def pow2_col_sizes(L, sizes=(64, 128, 256, 512, 1024), dtypes=(np.float64, np.fl
             for name in OPS:
                 n = F if name in ("ndfft", "ndifft") else (F + 1 if name == "nddct1" else 2 * F)
                 for shape, axis in (((n, 40), 0), ((3, n, 17), 1), ((n, 9), 0)):
-                    assert run_case(L, name, shape, axis, rdt, offset=F) == "pow2_col", (name, shape)
+                    # (round 3: f32 C2R lanes of 2048 points take the column four-step when the tile can be >= 16 lanes wide; the one-pass tile stays covered)
+                    split = name == "ndifft_r2c" and np.dtype(rdt) == np.float32 and n == 2048 and shape[-1] >= 16
+                    assert run_case(L, name, shape, axis, rdt, offset=F) == ("col_split" if split else "pow2_col"), (name, shape)
+                    if split:
+                        os.environ["NDFFT_COLSPLIT"] = "0"
+                        try: assert run_case(L, name, shape, axis, rdt, offset=F) == "pow2_col", (name, shape)
+                        finally: del os.environ["NDFFT_COLSPLIT"]
 
 
 def shared_handler_across_threads(L, nthreads=8):
