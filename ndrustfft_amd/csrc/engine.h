@@ -247,7 +247,7 @@ size_t generic_max_len(size_t csize);   // longest complex FFT the single-launch
 bool jit_choose(int dtype, int n, JitCfg &cfg, bool allow_partial = false);
 void jit_build_twiddles(const JitCfg &cfg, HostTable &out);
 int launch_jit_c2c(int dtype, const JitCfg &cfg, int nt, const Pow2Args &a, hipStream_t s);
-int jit_col_lanes(int dtype, const JitCfg &cfg);
+int jit_col_lanes(int dtype, const JitCfg &cfg, bool c2c = false);   // c2c: a 4-lane tile is acceptable (complex output rows)
 // thread-per-lane two-factor kernels (reg_kernel.h), specialised with hiprtc
 bool regfft_factor(int n, int *n1, int *n2);
 int regfft_max_n(int dtype);

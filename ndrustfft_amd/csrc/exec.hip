@@ -1038,7 +1038,7 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
         const int col_kind = is_c2c ? 0 : (P.op == NDFFT_OP_R2C ? 1 : (P.op == NDFFT_OP_C2R ? 2 : 3));   // which sides of a column tile are real lanes (kernels_pow2_real.hip: ColGeom)
         if (!row && (!odd_variant || use_blue || use_plain) && P.xlen > 1 && !P.b.empty() && P.b.size() <= 2 && P.b.back().sin == 1 && P.b.back().sout == 1) {
             if (have_tw && P.b.back().shape >= 8) {
-                const int lanes = (use_jit || use_blue) ? std::max((use_jit || c.bluereg) ? jit_col_lanes(plan->dtype, c.jitcfg) : 0, use_rader ? rader_col_lanes(plan->dtype, c.radercfg) : 0)
+                const int lanes = (use_jit || use_blue) ? std::max((use_jit || c.bluereg) ? jit_col_lanes(plan->dtype, c.jitcfg, is_c2c && use_jit && !use_blue) : 0, use_rader ? rader_col_lanes(plan->dtype, c.radercfg) : 0)
                                           : plan->dtype == NDFFT_F32 ? pow2_real_col_lanes<float>(c.F, col_kind) : pow2_real_col_lanes<double>(c.F, col_kind);
                 col = lanes > 0;
             }

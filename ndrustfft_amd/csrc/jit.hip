@@ -473,7 +473,7 @@ int launch_jit_regreal(int dtype, int gop, int n, int f1, int f2, bool stage, co
 }
 
 // lanes per column tile of the specialised real-op / column kernel (0: no useful tile)
-int jit_col_lanes(int dtype, const JitCfg &cfg) {
+int jit_col_lanes(int dtype, const JitCfg &cfg, bool c2c) {
     if (const char *e = getenv("NDFFT_JIT_COL_LPB")) { const int l = atoi(e); return l * cfg.tpl <= 1024 ? l : 0; }   // developer knob
     // 8 adjacent lanes (f32: 16 where they fit): rows of 64-128 bytes that start on a 64-byte boundary.  Measured on 2^24 points (profiles/r04/
     // r04i_jit_col_lanes.txt): the former "as many as fit" gave 9 lanes for 1000x16384 c128 (144-byte rows) = 257 us, 8 lanes 137 us;
@@ -481,6 +481,9 @@ int jit_col_lanes(int dtype, const JitCfg &cfg) {
     const size_t lane = (size_t)((cfg.n + (cfg.n >> 4) + 2) | 1) * 2 * (dtype == NDFFT_F32 ? 4 : 8);
     for (int l : {dtype == NDFFT_F32 ? 16 : 8, 8})
         if (l * cfg.tpl <= 1024 && (size_t)l * lane <= jit_lds_limit()) return l;
+    // C2C lanes too long for an 8-lane tile: 4 lanes (64-byte rows for c128, 32 for c64) still beat the transpose route -- ndfft axis 0 of 1500 x 11184 / 2000 x 8384 c128
+    // 326 / 309 -> 209 / 203 us, 2000 x 8384 c64 188 -> 149 us; real OUTPUT rows of 4 lanes are ruinous (nddct2 / ndifft_r2c 2-4 x slower): C2C only (profiles/r06/r06y_*)
+    if (c2c && 4 * cfg.tpl <= 1024 && (size_t)4 * lane <= jit_lds_limit()) return 4;
     return 0;
 }
 
@@ -492,7 +495,7 @@ template <typename T> int launch_jit_real(int gop, const JitCfg &cfg, bool col, 
     // rows: one-wave workgroups where a lane needs <= 64 threads (alternating A-B-A-B runs, profiles/r04/r04s_abab_jit_row.txt: nddct2 f64 n = 100..2000 +5-19 %,
     // ndfft_r2c f32 +2-6 % against 256-thread workgroups)
     static const int row_thr = [] { const char *e = getenv("NDFFT_JIT_ROW_THREADS"); return e ? atoi(e) : 64; }();   // developer knob
-    const int lpb = col ? jit_col_lanes(dtype, cfg) : cfg.row_lpb > 0 ? cfg.row_lpb : (cfg.tpl >= row_thr ? 1 : std::max(1, row_thr / cfg.tpl));
+    const int lpb = col ? jit_col_lanes(dtype, cfg, gop == G_C2C_FWD || gop == G_C2C_INV) : cfg.row_lpb > 0 ? cfg.row_lpb : (cfg.tpl >= row_thr ? 1 : std::max(1, row_thr / cfg.tpl));
     if (lpb <= 0) return NDFFT_ERR_UNSUPPORTED;
     int dev = 0;
     NDFFT_HIP(hipGetDevice(&dev));

@@ -43,7 +43,7 @@ int launch_jit_c2c(int dtype, const JitCfg &cfg, int, const Pow2Args &a, hipStre
     if (cfg.n == 210) return dtype == NDFFT_F32 ? c2c_one<float, 210, 14, 18, PRL210>(a, s) : c2c_one<double, 210, 14, 18, PRL210>(a, s);
     return NDFFT_ERR_UNSUPPORTED;
 }
-int jit_col_lanes(int, const JitCfg &cfg) { return (cfg.n == 64 || cfg.n == 256 || cfg.n == 264 || cfg.n == 210 || cfg.n == 45 || cfg.n == 550 || cfg.n == 90) ? 8 : 0; }
+int jit_col_lanes(int, const JitCfg &cfg, bool) { return (cfg.n == 64 || cfg.n == 256 || cfg.n == 264 || cfg.n == 210 || cfg.n == 45 || cfg.n == 550 || cfg.n == 90) ? 8 : 0; }
 // the same two partial-round configurations on the real-op / column kernel (pow2_real.h)
 template <typename K, typename T> __global__ void k_real_emul(const RealArgs<T> a) { K::run(a); }
 template <typename T, int F, int TPL, int LPBR, typename RL, int OP> static int real_one(bool col, const RealArgs<T> &a, hipStream_t s) {

@@ -460,3 +460,14 @@ def test_pinned_host_pipeline(L):
         assert np.abs(y - y2).max() <= 50 * np.finfo(rdt).eps * np.abs(y2).max(), (name, shape)
         yo = np.zeros(sout, odt); ps.OPS[name][1](src, yo, o, axis)
         assert_close(y, yo, axis, TOL[np.dtype(rdt)], f"pinned {name} {shape}")
+
+
+def test_jit_column_tiles_of_four_lanes(L):
+    """Smooth non-power-of-two C2C lanes too long for an 8-lane column tile (n = 1500, 2000) take 4-lane tiles instead of the transpose route (round 3); real-output ops keep
+    the 8-lane rule (their 4-lane rows measured 2-4 x slower) and fall to the transpose route as before."""
+    for name, shape, rdt, want in (("ndfft", (1500, 48), np.float64, "jit_col"), ("ndifft", (2000, 40), np.float64, "jit_col"), ("ndfft", (2000, 37), np.float32, "jit_col"),
+                                   ("ndfft", (3, 1500, 17), np.float64, "jit_col")):
+        axis = len(shape) - 2
+        for norm in ("Default", "None"):
+            assert ps.run_case(L, name, shape, axis, rdt, norm=norm) == want, (name, shape)
+    assert ps.run_case(L, "nddct2", (4000, 40), 0, np.float64) != "jit_col"
