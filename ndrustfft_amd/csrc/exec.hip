@@ -409,6 +409,12 @@ static bool narrow_enabled() {
     return on;
 }
 
+// test switch: NDFFT_NARROW_DCT=1 sends long strided DCT lanes through the narrow tiles again (read per call)
+static bool narrow_dct_enabled() {
+    const char *e = getenv("NDFFT_NARROW_DCT");
+    return e && e[0] == '1';
+}
+
 // developer / test switch: NDFFT_WAVE=0 keeps short dense C2C lanes on the older kernels (read per call)
 static bool wave_enabled() {
     const char *e = getenv("NDFFT_WAVE");
@@ -1043,7 +1049,9 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
                 col = lanes > 0;
             }
             // long lanes: XCD-aware narrow tiles (one HBM pass) instead of the three-pass transpose route
-            if (!col && !c.twp_narrow.re.empty() && P.b.back().shape >= 64 && narrow_enabled()) {
+            // (not for the DCTs since round 3: transpose -> row kernel -> transpose measured faster -- nddct2 axis 0 of 4096 x 4096 / 8192 x 2048 f32 166 / 172 -> 100 / 103 us,
+            //  f64 174 / 283 -> 164 / 190 us, profiles/r06/r06z_*; C2R f64 n = 4096 stays: 126 vs 174 us)
+            if (!col && (col_kind != 3 || narrow_dct_enabled()) && !c.twp_narrow.re.empty() && P.b.back().shape >= 64 && narrow_enabled()) {
                 const int lanes = plan->dtype == NDFFT_F32 ? pow2_real_narrow_lanes<float>(c.F) : pow2_real_narrow_lanes<double>(c.F);
                 narrow = lanes > 0;
             }
