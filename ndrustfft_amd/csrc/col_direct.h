@@ -165,4 +165,10 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, int MODE> st
     }
 };
 
+// Entry point with a floor on waves per SIMD (= a cap on VGPRs): without it these kernels take 126-159 VGPRs -- ONE 512-thread workgroup per CU.
+#ifndef NDFFT_COLDIRECT_MIN_WAVES
+#define NDFFT_COLDIRECT_MIN_WAVES 4
+#endif
+template <typename K, typename T> __global__ __launch_bounds__(K::THREADS, NDFFT_COLDIRECT_MIN_WAVES) void k_col_direct(const RealArgs<T> a) { K::run(a); }
+
 }  // namespace ndfft

@@ -69,7 +69,7 @@ template <typename T, int F, int OP, int MODE> static int launch_fsd(const RealA
     const int64_t nblk = (a.nlanes + LPB - 1) / LPB;
     if (nblk <= 0) return NDFFT_OK;
     if (nblk > 0x7fffffffLL) return fail(NDFFT_ERR_UNSUPPORTED, "too many lanes for one launch");
-    hipLaunchKernelGGL((k_pow2_real<K, T>), dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((k_col_direct<K, T>), dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, a);
     NDFFT_HIP(hipGetLastError());
     return NDFFT_OK;
 }
