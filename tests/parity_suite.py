@@ -765,6 +765,8 @@ def long_lanes_four_step(L, full=True):
             assert with_env({"NDFFT_FS_DIRECT": direct}, lambda: run_case(L, name, shape, 1, rdt)) == want, (name, shape, direct)
     for name, rdt in (("ndfft_r2c", np.float64), ("nddct2", np.float64), ("nddct2", np.float32), ("ndifft_r2c", np.float64), ("nddct3", np.float32)):   # the packed route stays covered
         assert with_env({"NDFFT_REAL_FOURSTEP": "0"}, lambda: run_case(L, name, (2, 1 << 16 if rdt is np.float64 else 1 << 17), 1, rdt)) == "four_step"
+    for name, rdt in (("ndifft_r2c", np.float64), ("nddct3", np.float32)):   # last pass of the inverse direction through dispatch() (general column kernel / column four-step)
+        assert with_env({"NDFFT_RFS_C2R_TILE": "0"}, lambda: run_case(L, name, (3, 1 << 16 if rdt is np.float64 else 1 << 17), 1, rdt)) == "real_four_step"
     # a lane count that leaves a partial tile in every pass, an output pitch larger than the lane, DCT types without a real four-step (I, IV) on the same length
     for name in ("ndfft_r2c", "ndifft_r2c", "nddct2", "nddct3"):
         assert run_case(L, name, (5, 1 << 16), 1, np.float64, offset=3) == "real_four_step", name
