@@ -57,11 +57,12 @@ template <typename T, int F, int OP, int CS, bool ROWOUT> static int launch_fs(c
     return NDFFT_OK;
 }
 
-// the lane-fastest register kernels of col_direct.h for the same two passes: measured SLOWER here (32 x 2^20 c64 388 -> 526 us, c128 560 -> 580 us:
-// profiles/r06), so they run only when NDFFT_FS_DIRECT=1 asks for them (parity tests do); the real four-step's second pass uses them for f64
-static bool fs_direct() {
-    const char *e = getenv("NDFFT_FS_DIRECT");   // (read per call: the parity tests switch it)
-    return e && e[0] == '1';
+// the lane-fastest register kernels of col_direct.h for the same two passes.  c128: faster since their VGPR cap (two workgroups per CU) -- 256 x 65536 218 -> 204 us,
+// 16 x 2^20 282 -> 261 us (profiles/r06/r06zv_*); c64: slower (32 x 2^20 372 -> 542 us: a wavefront of 8-16 lanes writes 32-64-byte runs in the transposing pass) and stays on
+// the staged kernels.  NDFFT_FS_DIRECT=0 / 1 forces one form (read per call: the parity tests switch it).
+template <typename T> static bool fs_direct() {
+    const char *e = getenv("NDFFT_FS_DIRECT");
+    return e ? e[0] == '1' : sizeof(T) == 8;
 }
 template <typename T, int F, int OP, int MODE> static int launch_fsd(const RealArgs<T> &a, hipStream_t s) {
     constexpr int LPB = FsGeom<T, F>::LPB;
@@ -80,7 +81,7 @@ bool fourstep_supported(int F) { return F == 64 || F == 128 || F == 256 || F == 
 template <typename T> int launch_fourstep(int pass, int F, bool inverse, const RealArgs<T> &a, hipStream_t s) {
 #define NDFFT_FS_CASE(F_)                                                                                              \
     case F_:                                                                                                           \
-        if (fs_direct() && !a.makhoul) {   /* (the fused DCT-IV first pass exists in the staged form only) */                \
+        if (fs_direct<T>() && !a.makhoul) {   /* (the fused DCT-IV first pass exists in the staged form only) */                \
             if (pass == 1) return inverse ? launch_fsd<T, F_, G_C2C_INV, 0>(a, s) : launch_fsd<T, F_, G_C2C_FWD, 0>(a, s); \
             return inverse ? launch_fsd<T, F_, G_C2C_INV, 4>(a, s) : launch_fsd<T, F_, G_C2C_FWD, 4>(a, s);            \
         }                                                                                                              \
