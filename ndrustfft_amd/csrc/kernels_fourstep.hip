@@ -44,15 +44,24 @@ template <typename T, int F> struct FsGeom {
     static_assert(TPL * LPB <= 1024, "workgroup too large");
 };
 
+// Entry point with a floor on waves per SIMD (= a cap on VGPRs).  c64: 8 waves = 64 VGPRs, which these kernels fit (at most 28 bytes of scratch in the forward
+// transposing pass); without it they take ~80 and a 1024-thread tile is ONE workgroup per CU: 32 x 2^20 c64 375 -> 302 us (0.18 -> 0.22; profiles/r06/r06zu_*).
+// c128 runs on the lane-fastest kernels below, which have their own floor (col_direct.h).
+#ifndef NDFFT_FS_STAGED_MIN_WAVES_F32
+#define NDFFT_FS_STAGED_MIN_WAVES_F32 8
+#endif
+template <typename K, typename T, int MW> __global__ __launch_bounds__(K::THREADS, MW) void k_fs_staged(const RealArgs<T> a) { K::run(a); }
+template <typename T> struct FsStagedWaves { static constexpr int value = sizeof(T) == 4 ? NDFFT_FS_STAGED_MIN_WAVES_F32 : 1; };
+
 template <typename T, int F, int OP, int CS, bool ROWOUT> static int launch_fs(const RealArgs<T> &a, hipStream_t s) {
     constexpr int LPB = FsGeom<T, F>::LPB;
     using K = RealPow2Kernel<T, F, FsCfg<F>::TPL, LPB, typename FsCfg<F>::RL, OP, true, false, CS, ROWOUT>;
     static_assert(K::LDS_BYTES <= 160 * 1024, "tile does not fit LDS");
-    NDFFT_ENSURE_LDS_ATTR((k_pow2_real<K, T>));
+    NDFFT_ENSURE_LDS_ATTR((k_fs_staged<K, T, FsStagedWaves<T>::value>));
     const int64_t nblk = (a.nlanes + LPB - 1) / LPB;
     if (nblk <= 0) return NDFFT_OK;
     if (nblk > 0x7fffffffLL) return fail(NDFFT_ERR_UNSUPPORTED, "too many lanes for one launch");
-    hipLaunchKernelGGL((k_pow2_real<K, T>), dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((k_fs_staged<K, T, FsStagedWaves<T>::value>), dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, a);
     NDFFT_HIP(hipGetLastError());
     return NDFFT_OK;
 }

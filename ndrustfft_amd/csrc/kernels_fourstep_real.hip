@@ -52,17 +52,23 @@ template <typename T, int F, int STAGE> struct RfsGeom {
     static_assert(TPL * LPB <= 1024, "workgroup too large");
 };
 
+// Entry point of the staged kernels of this file with a floor on waves per SIMD (= a cap on VGPRs).  f32: 8 waves = 64 VGPRs, which these kernels fit without
+// scratch (they take 80-92 otherwise: ONE 1024-thread workgroup per CU) -- 64 x 262144 f32 nddct2 100 -> 85 us, ndfft_r2c 91 -> 78 us; f64 spills 20-224 bytes per lane
+// under the same floor (ndifft_r2c 118 -> 205 us) and keeps the compiler's choice (profiles/r06/r06zu_*)
+template <typename K, typename T, int MW> __global__ __launch_bounds__(K::THREADS, MW) void k_rfs_staged(const RealArgs<T> a) { K::run(a); }
+template <typename T> struct RfsStagedWaves { static constexpr int value = sizeof(T) == 4 ? 8 : 1; };
+
 template <typename T, int F, int STAGE> static int launch_rfs(const RealArgs<T> &a, hipStream_t s) {
     constexpr int LPB = RfsGeom<T, F, STAGE>::LPB;
     using K = typename cond_type<STAGE == 1,
                                  RealPow2Kernel<T, F, RfsCfg<F>::TPL, LPB, typename RfsCfg<F>::RL, G_R2C_EVEN, true, false, 0, true>,
                                  RealPow2Kernel<T, F, RfsCfg<F>::TPL, LPB, typename RfsCfg<F>::RL, G_C2C_FWD, true, false, STAGE == 2 ? 5 : 6, false>>::type;
     static_assert(K::LDS_BYTES <= 160 * 1024, "tile does not fit LDS");
-    NDFFT_ENSURE_LDS_ATTR((k_pow2_real<K, T>));
+    NDFFT_ENSURE_LDS_ATTR((k_rfs_staged<K, T, RfsStagedWaves<T>::value>));
     const int64_t nblk = (a.nlanes + LPB - 1) / LPB;
     if (nblk <= 0) return NDFFT_OK;
     if (nblk > 0x7fffffffLL) return fail(NDFFT_ERR_UNSUPPORTED, "too many lanes for one launch");
-    hipLaunchKernelGGL((k_pow2_real<K, T>), dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((k_rfs_staged<K, T, RfsStagedWaves<T>::value>), dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, a);
     NDFFT_HIP(hipGetLastError());
     return NDFFT_OK;
 }
@@ -90,11 +96,11 @@ template <typename T, int F> static int launch_rfs_c2r(const RealArgs<T> &a, hip
     constexpr int LPB = RfsGeom<T, F, 1>::LPB;
     using K = RealPow2Kernel<T, F, RfsCfg<F>::TPL, LPB, typename RfsCfg<F>::RL, G_C2R_EVEN, true, false, 0, false>;
     static_assert(K::LDS_BYTES <= 160 * 1024, "tile does not fit LDS");
-    NDFFT_ENSURE_LDS_ATTR((k_pow2_real<K, T>));
+    NDFFT_ENSURE_LDS_ATTR((k_rfs_staged<K, T, RfsStagedWaves<T>::value>));
     const int64_t nblk = (a.nlanes + LPB - 1) / LPB;
     if (nblk <= 0) return NDFFT_OK;
     if (nblk > 0x7fffffffLL) return fail(NDFFT_ERR_UNSUPPORTED, "too many lanes for one launch");
-    hipLaunchKernelGGL((k_pow2_real<K, T>), dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((k_rfs_staged<K, T, RfsStagedWaves<T>::value>), dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, a);
     NDFFT_HIP(hipGetLastError());
     return NDFFT_OK;
 }

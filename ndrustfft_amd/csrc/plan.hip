@@ -406,7 +406,7 @@ static void add_real_fourstep(ndfft_plan *p) {
     int e = 0; while (((size_t)1 << e) < n) ++e;
     // The split and the ops that take this route, from the sweep over n = 2^16..2^21 at 2^24 points per array (profiles/r06/r06l_*, r06m_*):
     //   f64: N1 = 2^ceil(e/2), but N1 = 2048 rather than N2 = 1024 at e = 20; faster than the packed route for every op and length (1.02-1.7 x)
-    //   f32: N1 = 1024 from e = 17 up (2048 at e = 21); R2C only up to e = 18, C2R and DCT-II up to e = 20, DCT-III always (the packed route's
+    //   f32: N1 = 1024 from e = 17 up (2048 at e = 21); R2C only up to e = 19 (re-swept after the f32 wave floors, r06zu_*), C2R and DCT-II up to e = 20, DCT-III always (the packed route's
     //        complex passes run at twice f64's element rate, so its extra pass costs less)
     const bool f32 = p->dtype == NDFFT_F32;
     int a = f32 ? std::min(10, (e + 1) / 2 + 1) : (e + 1) / 2;
@@ -414,7 +414,7 @@ static void add_real_fourstep(ndfft_plan *p) {
     a = std::min(11, std::max(7, a));
     if (e - a > 10) a = e - 10;
     if (e - a < 6) a = e - 6;
-    c.rfs_ops = f32 ? ((e <= 18 ? 1 : 0) | (e <= 20 ? 2 | 4 : 0) | 8) : 15;
+    c.rfs_ops = f32 ? ((e <= 19 ? 1 : 0) | (e <= 20 ? 2 | 4 : 0) | 8) : 15;
     if (const char *k = getenv("NDFFT_RFS_LOGN1")) { const int v = atoi(k); if (v >= 7 && v <= 11) a = v; }   // developer knob (A/B of the split)
     const int b = e - a;
     if (b < 6 || b > 10 || !fourstep_real_supported(1 << a, 1 << b)) return;

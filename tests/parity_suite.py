@@ -786,7 +786,7 @@ def long_lanes_four_step(L, full=True):
         # f32 at 2^21: the plan's table keeps DCT-II / R2C / C2R on the packed route (measured faster), DCT-III on the real four-step; 2 forces it
         assert run_case(L, "nddct2", (2, 1 << 21), 1, np.float32) == "four_step"
         assert run_case(L, "nddct3", (2, 1 << 21), 1, np.float32) == "real_four_step"
-        assert run_case(L, "ndfft_r2c", (2, 1 << 19), 1, np.float32) == "four_step"
+        assert run_case(L, "ndfft_r2c", (2, 1 << 20), 1, np.float32) == "four_step"
         for name in ("nddct2", "ndfft_r2c", "ndifft_r2c"):
             assert with_env({"NDFFT_REAL_FOURSTEP": "2"}, lambda: run_case(L, name, (2, 1 << 21), 1, np.float32)) == "real_four_step", name
         assert run_case(L, "nddct3", (2, 1 << 19), 1, np.float64) == "real_four_step"

@@ -31,7 +31,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print("RESULT " + json.dumps(out))
     sys.exit(0)
 res = {}
-routes = [("packed", {"NDFFT_REAL_FOURSTEP": "0"}), ("real", {})] + [(f"N1=2^{a}", {"NDFFT_RFS_LOGN1": a}) for a in os.environ.get("SWEEP_LOGN1", "").split(",") if a]
+routes = [("packed", {"NDFFT_REAL_FOURSTEP": "0"}), ("real", {"NDFFT_REAL_FOURSTEP": os.environ.get("SWEEP_REAL_MODE", "1")})] + [(f"N1=2^{a}", {"NDFFT_RFS_LOGN1": a}) for a in os.environ.get("SWEEP_LOGN1", "").split(",") if a]
 for label, env in routes:
     p = subprocess.run([sys.executable, __file__, "child"], env={**os.environ, **env}, capture_output=True, text=True)
     line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
