@@ -55,8 +55,17 @@ void pow2_real_build_twiddles(int F, HostTable &out) {
     }
 }
 
+// Entry point with a floor on waves per SIMD (= a cap on VGPRs) for the f32 WIDE COLUMN kernels whose workgroup is 1024 threads (F >= 256, and 64-lane real tiles): left alone
+// they take 80-92 VGPRs = ONE workgroup per CU; a floor of 8 waves caps them at 64, which they fit without scratch.  Transform along axis 0 of 2^24-point f32 arrays
+// (profiles/r06/r06zt_*): nddct2 n = 512 / 1024 45.5 / 49 -> 37.3 / 39.5 us, ndfft_r2c n = 512 / 1024 / 2048 42.5 / 44.4 / 49.7 -> 32.9 / 33.7 / 41 us; C2C and C2R unchanged.
+// Not for: f64 (spills under any floor), the narrow XCD tiles and the 1024-thread row kernels (12-220 bytes of scratch at 64 VGPRs), DCT-III (its V[k] registers: 12 bytes).
+template <typename K, typename T, int MW> __global__ __launch_bounds__(K::THREADS, MW) void k_real_aot(const RealArgs<T> a) { K::run(a); }
+template <typename K> struct IsWideCol { static constexpr bool value = false; };
+template <typename T, int F, int TPL, int LPB, typename RL, int OP> struct IsWideCol<RealPow2Kernel<T, F, TPL, LPB, RL, OP, true, false, 0, false>> { static constexpr bool value = OP != G_DCT3_EVEN; };
+template <typename K, typename T> struct RealAotWaves { static constexpr int value = (sizeof(T) == 4 && K::THREADS >= 1024 && IsWideCol<K>::value) ? 8 : 1; };
+
 template <typename K, typename T> static int launch_k(const RealArgs<T> &a, int lpb, hipStream_t s) {
-    NDFFT_ENSURE_LDS_ATTR((k_pow2_real<K, T>));
+    NDFFT_ENSURE_LDS_ATTR((k_real_aot<K, T, RealAotWaves<K, T>::value>));
     const int64_t nblk = (a.nlanes + lpb - 1) / lpb;
     if (nblk <= 0) return NDFFT_OK;
     if (nblk > 0x7fffffffLL) return fail(NDFFT_ERR_UNSUPPORTED, "too many lanes for one launch");
@@ -72,7 +81,7 @@ template <typename K, typename T> static int launch_k(const RealArgs<T> &a, int 
             b.xcd_chunk = xcd_chunk_for((size_t)lpb * (size_t)a.n_in * esz, nblk);
         }
     }
-    hipLaunchKernelGGL((k_pow2_real<K, T>), dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, b);
+    hipLaunchKernelGGL((k_real_aot<K, T, RealAotWaves<K, T>::value>), dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, b);
     NDFFT_HIP(hipGetLastError());
     return NDFFT_OK;
 }
