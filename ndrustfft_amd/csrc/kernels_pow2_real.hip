@@ -55,14 +55,18 @@ void pow2_real_build_twiddles(int F, HostTable &out) {
     }
 }
 
-// Entry point with a floor on waves per SIMD (= a cap on VGPRs) for the f32 WIDE COLUMN kernels whose workgroup is 1024 threads (F >= 256, and 64-lane real tiles): left alone
+// Entry point with a floor on waves per SIMD (= a cap on VGPRs) for the f32 WIDE COLUMN kernels whose workgroup is 512 or 1024 threads (from 512: nddct2 n = 128 31.5 -> 28.3 us, the rest
+// unchanged, no scratch either): left alone
 // they take 80-92 VGPRs = ONE workgroup per CU; a floor of 8 waves caps them at 64, which they fit without scratch.  Transform along axis 0 of 2^24-point f32 arrays
 // (profiles/r06/r06zt_*): nddct2 n = 512 / 1024 45.5 / 49 -> 37.3 / 39.5 us, ndfft_r2c n = 512 / 1024 / 2048 42.5 / 44.4 / 49.7 -> 32.9 / 33.7 / 41 us; C2C and C2R unchanged.
 // Not for: f64 (spills under any floor), the narrow XCD tiles and the 1024-thread row kernels (12-220 bytes of scratch at 64 VGPRs), DCT-III (its V[k] registers: 12 bytes).
+#ifndef NDFFT_REAL_F32_FLOOR_THREADS
+#define NDFFT_REAL_F32_FLOOR_THREADS 512
+#endif
 template <typename K, typename T, int MW> __global__ __launch_bounds__(K::THREADS, MW) void k_real_aot(const RealArgs<T> a) { K::run(a); }
 template <typename K> struct IsWideCol { static constexpr bool value = false; };
 template <typename T, int F, int TPL, int LPB, typename RL, int OP> struct IsWideCol<RealPow2Kernel<T, F, TPL, LPB, RL, OP, true, false, 0, false>> { static constexpr bool value = OP != G_DCT3_EVEN; };
-template <typename K, typename T> struct RealAotWaves { static constexpr int value = (sizeof(T) == 4 && K::THREADS >= 1024 && IsWideCol<K>::value) ? 8 : 1; };
+template <typename K, typename T> struct RealAotWaves { static constexpr int value = (sizeof(T) == 4 && K::THREADS >= NDFFT_REAL_F32_FLOOR_THREADS && IsWideCol<K>::value) ? 8 : 1; };
 
 template <typename K, typename T> static int launch_k(const RealArgs<T> &a, int lpb, hipStream_t s) {
     NDFFT_ENSURE_LDS_ATTR((k_real_aot<K, T, RealAotWaves<K, T>::value>));
