@@ -59,14 +59,24 @@ void pow2_real_build_twiddles(int F, HostTable &out) {
 // unchanged, no scratch either): left alone
 // they take 80-92 VGPRs = ONE workgroup per CU; a floor of 8 waves caps them at 64, which they fit without scratch.  Transform along axis 0 of 2^24-point f32 arrays
 // (profiles/r06/r06zt_*): nddct2 n = 512 / 1024 45.5 / 49 -> 37.3 / 39.5 us, ndfft_r2c n = 512 / 1024 / 2048 42.5 / 44.4 / 49.7 -> 32.9 / 33.7 / 41 us; C2C and C2R unchanged.
-// Not for: f64 (spills under any floor), the narrow XCD tiles and the 1024-thread row kernels (12-220 bytes of scratch at 64 VGPRs), DCT-III (its V[k] registers: 12 bytes).
+// Not for: f64 (spills under any floor), the narrow XCD tiles (12-220 bytes of scratch at 64 VGPRs), DCT-III column tiles (its V[k] registers: 12 bytes).
 #ifndef NDFFT_REAL_F32_FLOOR_THREADS
 #define NDFFT_REAL_F32_FLOOR_THREADS 512
 #endif
 template <typename K, typename T, int MW> __global__ __launch_bounds__(K::THREADS, MW) void k_real_aot(const RealArgs<T> a) { K::run(a); }
 template <typename K> struct IsWideCol { static constexpr bool value = false; };
 template <typename T, int F, int TPL, int LPB, typename RL, int OP> struct IsWideCol<RealPow2Kernel<T, F, TPL, LPB, RL, OP, true, false, 0, false>> { static constexpr bool value = OP != G_DCT3_EVEN; };
-template <typename K, typename T> struct RealAotWaves { static constexpr int value = (sizeof(T) == 4 && K::THREADS >= NDFFT_REAL_F32_FLOOR_THREADS && IsWideCol<K>::value) ? 8 : 1; };
+// ... and for the f32 ROW kernels of 512 / 1024 threads (F = 4096 / 8192: 66 VGPRs left alone = 7 waves per SIMD, i.e. three 512-thread or ONE 1024-thread workgroup per CU
+// where the LDS allows four / two): ndfft_r2c rows n = 16384 46.5 -> 34 us (0.36 -> 0.49) although that kernel keeps 12 bytes of scratch at 64 VGPRs, 8192 x 8192 f32 108.7 -> 101.9 us,
+// n = 8192 30.5 -> 29.2 us (profiles/r06/r06zs_*)
+#ifndef NDFFT_REAL_F32_ROW_FLOOR_THREADS
+#define NDFFT_REAL_F32_ROW_FLOOR_THREADS 512
+#endif
+template <typename K> struct IsRowKernel { static constexpr bool value = false; };
+template <typename T, int F, int TPL, int LPB, typename RL, int OP> struct IsRowKernel<RealPow2Kernel<T, F, TPL, LPB, RL, OP, false, false, 0, false>> { static constexpr bool value = true; };
+template <typename K, typename T> struct RealAotWaves {
+    static constexpr int value = (sizeof(T) == 4 && ((K::THREADS >= NDFFT_REAL_F32_FLOOR_THREADS && IsWideCol<K>::value) || (K::THREADS >= NDFFT_REAL_F32_ROW_FLOOR_THREADS && IsRowKernel<K>::value))) ? 8 : 1;
+};
 
 template <typename K, typename T> static int launch_k(const RealArgs<T> &a, int lpb, hipStream_t s) {
     NDFFT_ENSURE_LDS_ATTR((k_real_aot<K, T, RealAotWaves<K, T>::value>));
