@@ -503,9 +503,13 @@ template <typename T> int launch_jit_real(int gop, const JitCfg &cfg, bool col, 
     const int threads = cfg.tpl * lpb;
     const std::string inst = std::string("RealPow2Kernel<") + tn + ", " + std::to_string(cfg.n) + ", " + std::to_string(cfg.tpl) + ", " +
                              std::to_string(lpb) + ", RadixList<" + radix_list(cfg) + ">, " + std::to_string(gop) + ", " + (col ? "true" : "false") + ", false>";
+    // f32 kernels of >= 512 threads: floor on waves per SIMD (kernels_pow2_real.hip: RealAotWaves); NDFFT_JIT_F32_MIN_WAVES (developer knob, read once)
+    static const int f32_floor = [] { const char *e = getenv("NDFFT_JIT_F32_MIN_WAVES"); return e ? atoi(e) : 1; }();
+    const int floor_w = (sizeof(T) == 4 && threads >= 512 && f32_floor > 1 && gop != G_DCT3_EVEN) ? f32_floor : 1;
+    const std::string bounds = std::to_string(threads) + (floor_w > 1 ? ", " + std::to_string(floor_w) : std::string());
     const std::string src = std::string("#include \"pow2_real.h\"\nusing namespace ndfft;\nextern \"C\" __global__ __launch_bounds__(") +
-                            std::to_string(threads) + ") void k_jit(const RealArgs<" + tn + "> a) { " + inst + "::run(a); }\n";
-    const Entry e = get_or_compile("dev" + std::to_string(dev) + ":" + inst, src, inst);
+                            bounds + ") void k_jit(const RealArgs<" + tn + "> a) { " + inst + "::run(a); }\n";
+    const Entry e = get_or_compile("dev" + std::to_string(dev) + ":" + inst + (floor_w > 1 ? "/w" + std::to_string(floor_w) : std::string()), src, inst);
     if (e.failed) return NDFFT_ERR_UNSUPPORTED;
     const int F = cfg.n;
     const size_t lane_lds = col ? (size_t)((F + (F >> 4) + 2) | 1) : (size_t)((F + (F >> 4) + 3) & ~1);
