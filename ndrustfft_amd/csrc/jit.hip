@@ -349,6 +349,22 @@ Entry get_or_compile(const std::string &key, const std::string &src, const std::
     g_cv.notify_all();
     return ne;
 }
+// bytes of scratch (register spill) per work-item of a compiled kernel; -1 if the runtime cannot tell.  Cached per function handle.
+int entry_scratch_bytes(const Entry &e) {
+    static std::mutex mu;
+    static std::map<hipFunction_t, int> cache;
+    if (e.failed || !e.fn) return -1;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = cache.find(e.fn);
+        if (it != cache.end()) return it->second;
+    }
+    int v = -1;
+    if (hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, e.fn) != hipSuccess) { (void)hipGetLastError(); v = -1; }
+    std::lock_guard<std::mutex> g(mu);
+    cache[e.fn] = v;
+    return v;
+}
 std::string radix_list(const JitCfg &cfg) {
     std::string rl;
     for (size_t i = 0; i < cfg.radix.size(); ++i) rl += (i ? ", " : "") + std::to_string(cfg.radix[i]);
@@ -503,13 +519,22 @@ template <typename T> int launch_jit_real(int gop, const JitCfg &cfg, bool col, 
     const int threads = cfg.tpl * lpb;
     const std::string inst = std::string("RealPow2Kernel<") + tn + ", " + std::to_string(cfg.n) + ", " + std::to_string(cfg.tpl) + ", " +
                              std::to_string(lpb) + ", RadixList<" + radix_list(cfg) + ">, " + std::to_string(gop) + ", " + (col ? "true" : "false") + ", false>";
-    // f32 kernels of >= 512 threads: floor on waves per SIMD (kernels_pow2_real.hip: RealAotWaves); NDFFT_JIT_F32_MIN_WAVES (developer knob, read once)
-    static const int f32_floor = [] { const char *e = getenv("NDFFT_JIT_F32_MIN_WAVES"); return e ? atoi(e) : 1; }();
+    // f32 kernels of >= 512 threads: floor of 8 waves per SIMD = 64 VGPRs (kernels_pow2_real.hip: RealAotWaves) -- but only where the specialised kernel FITS 64 registers:
+    // the compiled code object is asked for its scratch size, and a recipe that spills falls back to the plain form (n = 1500: 2-3 x slower with the floor, n = 1000 / 2000:
+    // 10-20 % faster, profiles/r06/r06zr_*).  NDFFT_JIT_F32_MIN_WAVES overrides the floor (1 = none; read once).
+    static const int f32_floor = [] { const char *e = getenv("NDFFT_JIT_F32_MIN_WAVES"); return e ? atoi(e) : 8; }();
     const int floor_w = (sizeof(T) == 4 && threads >= 512 && f32_floor > 1 && gop != G_DCT3_EVEN) ? f32_floor : 1;
-    const std::string bounds = std::to_string(threads) + (floor_w > 1 ? ", " + std::to_string(floor_w) : std::string());
-    const std::string src = std::string("#include \"pow2_real.h\"\nusing namespace ndfft;\nextern \"C\" __global__ __launch_bounds__(") +
-                            bounds + ") void k_jit(const RealArgs<" + tn + "> a) { " + inst + "::run(a); }\n";
-    const Entry e = get_or_compile("dev" + std::to_string(dev) + ":" + inst + (floor_w > 1 ? "/w" + std::to_string(floor_w) : std::string()), src, inst);
+    auto make_src = [&](int w) {
+        return std::string("#include \"pow2_real.h\"\nusing namespace ndfft;\nextern \"C\" __global__ __launch_bounds__(") + std::to_string(threads) +
+               (w > 1 ? ", " + std::to_string(w) : std::string()) + ") void k_jit(const RealArgs<" + tn + "> a) { " + inst + "::run(a); }\n";
+    };
+    Entry e;
+    bool plain = floor_w <= 1;
+    if (!plain) {
+        e = get_or_compile("dev" + std::to_string(dev) + ":" + inst + "/w" + std::to_string(floor_w), make_src(floor_w), inst);
+        if (e.failed || entry_scratch_bytes(e) != 0) plain = true;
+    }
+    if (plain) e = get_or_compile("dev" + std::to_string(dev) + ":" + inst, make_src(1), inst);
     if (e.failed) return NDFFT_ERR_UNSUPPORTED;
     const int F = cfg.n;
     const size_t lane_lds = col ? (size_t)((F + (F >> 4) + 2) | 1) : (size_t)((F + (F >> 4) + 3) & ~1);
