@@ -10,16 +10,20 @@ N > 1 runs N ranks, one per GPU, over torch.distributed (RCCL):
   * started plainly (`python bench.py --gpus N`, no WORLD_SIZE in the environment) this process only spawns the N
     ranks as children -- before anything here touches the GPU or imports torch -- and exits with their status.
 
-Primary line (the contract's `value`): the configuration BASELINE.json's metric is quoted on -- ndfft axis=1 on a
-4096x4096 Complex<f64> array, device resident -- PER GPU at every N ("scaling": "weak": N ranks hold the N
+Primary line (the contract's `value`, `ms_per_step`, `roofline.frac`): the configuration BASELINE.json's metric is quoted on --
+ndfft axis=1 on 4096x4096 Complex<f64> arrays, device resident -- PER GPU at every N ("scaling": "weak": N ranks hold the N
 contiguous 4096-row blocks of a (4096 N) x 4096 array; lanes are independent, src/lib.rs:120-124 / 187-194, so
-there is no data-path collective).  One "step" = one ndfft call over the whole resident array through the C ABI
-(ndfft_exec_device).  EXACTLY K steps are timed between barrier + synchronize on both sides, max over ranks.
+there is no data-path collective).  One "step" = one ndfft call over one whole resident array through the C ABI
+(ndfft_exec_device).  The steps walk over ROTATING (in, out) pairs whose footprint (6 pairs = 3 GiB) exceeds the 256 MiB
+Infinity Cache, so every step's input really comes from HBM: this is the HBM-sourced number (round 4; until round 3 the
+headline re-read one 256 MiB input that the Infinity Cache partly holds -- that loop is now `roofline.frac_warm`).
 
-Two more measurements ride in the same JSON line (each its own timed region, after the primary one):
-  * roofline.frac_cold -- the same kernel on ROTATING (in, out) pairs whose footprint (>= 2.5 GiB) exceeds the
-    256 MiB Infinity Cache, so every step's input really comes from HBM (`frac` re-reads one 256 MiB input, which
-    the Infinity Cache can hold);
+Every region is timed as --blocks (7) blocks of EXACTLY K steps each, every block between barrier + synchronize on both sides,
+max over ranks per block; the line reports the MEDIAN block (`steps` = K, `ms_per_step`, `value`) and min / median / max over the
+blocks under `blocks`, so that one ~2 ms sample does not decide the record.
+
+More measurements ride in the same JSON line (each its own timed region, after the primary one):
+  * roofline.frac_warm / roofline.warm -- the same call on ONE (in, out) pair re-used every step (Infinity-Cache assisted);
   * strong_cfg5 -- BASELINE configs[4]: the 65536x4096 array split in N contiguous row blocks, one per rank
     (N = 1: the whole 4 GiB + 4 GiB array on one GPU), i.e. STRONG scaling of the north star's multi-GPU target.
 """
@@ -193,12 +197,14 @@ def main():
     ap.add_argument("--ramp-ms", type=float, default=400.0, help="untimed busy period before the warm-up steps (clock ramp)")
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--rows", type=int, default=4096, help="lanes per GPU of the primary line (4096 = the metric's shape)")
-    ap.add_argument("--cold-pairs", type=int, default=6, help="distinct (in, out) pairs rotated by the cache-cold measurement (0 = skip)")
+    ap.add_argument("--cold-pairs", type=int, default=6, help="distinct (in, out) pairs the primary (HBM-sourced) region rotates over (>= 2; 6 pairs = 3 GiB)")
+    ap.add_argument("--blocks", type=int, default=7, help="timed blocks of K steps per region (the line reports the median block and min / median / max)")
+    ap.add_argument("--no-warm", action="store_true", help="skip the Infinity-Cache-assisted side measurement (one pair re-used every step)")
     ap.add_argument("--strong-steps", type=int, default=20, help="timed steps of the cfg5 strong-scaling block (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-api", action="store_true", help="skip the PCIe-inclusive ndfft_exec (host arrays) side measurement")
     ap.add_argument("--no-xgmi", action="store_true", help="N > 1: skip the scatter / gather / all-to-all measurements over xGMI")
-    ap.add_argument("--profile-phase", default="", choices=["", "primary", "cold", "strong"],
+    ap.add_argument("--profile-phase", default="", choices=["", "primary", "warm", "strong"],
                     help="profiling aid (tools/prof_bench.sh): run ONLY this timed region at full length so that rocprofv3's per-kernel "
                          "averages belong to it (the others shrink to one step / are skipped); the printed line is then not a bench result")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only with --dry (CPU rendezvous check)")
@@ -206,12 +212,14 @@ def main():
     ap.add_argument("--dist", action="store_true", help="initialise torch.distributed (RCCL) even at world size 1 (path check)")
     args = ap.parse_args()
     primary_steps = args.steps
+    primary_blocks = warm_blocks = max(1, args.blocks)
+    args.cold_pairs = max(2, args.cold_pairs)
     if args.profile_phase:
         args.no_cpu_baseline = args.no_host_api = args.no_xgmi = True
         if args.profile_phase != "primary":
-            primary_steps = 1; args.warmup = 1; args.ramp_ms = 0.0
-        if args.profile_phase != "cold":
-            args.cold_pairs = 0
+            primary_steps = 1; primary_blocks = 1; args.warmup = 1; args.ramp_ms = 0.0
+        if args.profile_phase != "warm":
+            args.no_warm = True
         if args.profile_phase != "strong":
             args.strong_steps = 0
         elif args.strong_steps < args.steps:
@@ -310,13 +318,37 @@ def main():
             el, dev_ms = float(t[0]), float(t[1])
         return el, dev_ms
 
-    # ------------------------------------------------------------------ primary: cfg2 per GPU, resident array
-    # device-resident shard: rank r holds global rows [r*rows, (r+1)*rows) of the (ngpu*rows) x n array
+    def timed_blocks(fn, steps, nblocks):
+        """nblocks blocks of EXACTLY `steps` calls each; returns (median block (wall s, device ms), summary dict)."""
+        res = [timed(fn, steps) for _ in range(nblocks)]
+        by_wall = sorted(res, key=lambda r: r[0])
+        med = by_wall[len(by_wall) // 2]
+        devs = sorted(r[1] for r in res)
+
+        def mmm(vals, scale):
+            return {"min": round(vals[0] * scale, 5), "median": round(vals[len(vals) // 2] * scale, 5), "max": round(vals[-1] * scale, 5)}
+        return med, {"n": nblocks, "steps_each": steps,
+                     "ms_per_step": mmm([r[0] for r in by_wall], 1e3 / steps),
+                     "avg_launch_us": mmm(devs, 1e3 / steps)}
+
+    # ------------------------------------------------------------------ primary: cfg2 per GPU, HBM-sourced (rotating pairs)
+    # device-resident shard: rank r holds global rows [r*rows, (r+1)*rows) of the (ngpu*rows) x n array; pair p > 0 holds other
+    # synthetic arrays of the same shape (the stream continued)
     x = synth.complex_array((rows, n), offset=rank * rows * n)
     xd = torch.from_numpy(x).to(dev)
     yd = torch.empty_like(xd)
+    pairs = [(xd, yd)]
+    for p in range(1, args.cold_pairs):
+        xi = synth.complex_array_torch((rows, n), dev, offset=(rank + p * ngpu) * rows * n)
+        pairs.append((xi, torch.empty_like(xi)))
+    counter = [0]
 
     def step(_i=0):
+        a, b = pairs[counter[0] % len(pairs)]
+        counter[0] += 1
+        ndfft(a, b, h, 1)
+
+    def warm_step(_i=0):
         ndfft(xd, yd, h, 1)
 
     # Untimed preamble: the GPU's clocks need ~30-40 ms of sustained work to reach their steady state
@@ -328,46 +360,38 @@ def main():
         for _ in range(50):
             step()
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 2 * len(pairs) if not args.profile_phase or args.profile_phase == "primary" else 1)):
         step()
-    el, dev_ms = timed(step, primary_steps)
+    (el, dev_ms), blocks = timed_blocks(step, primary_steps, primary_blocks)
     path = lib.last_path()
+    policy = lib.last_input_policy()
 
-    # quick self-check of the timed output on a few lanes against numpy's FFT (not timed; the oracle is only used by
-    # the cpu_baseline leg below and by the tests)
+    # quick self-check of the timed outputs on a few lanes against numpy's FFT (not timed; the oracle is only used by
+    # the cpu_baseline leg below and by the tests): pair 0 and the last pair
     if rank == 0:
-        yo = np.fft.fft(x[:4], axis=1)
-        err = np.abs(yd[:4].cpu().numpy() - yo).max() / np.abs(yo).max()
-        assert err < 1e-10, f"bench output differs from numpy.fft: {err}"
+        torch.cuda.synchronize()
+        for a, b in (pairs[0], pairs[-1]) if primary_steps * primary_blocks + args.warmup >= len(pairs) else (pairs[0],):
+            yo = np.fft.fft(a[:4].cpu().numpy(), axis=1)
+            err = np.abs(b[:4].cpu().numpy() - yo).max() / np.abs(yo).max()
+            assert err < 1e-10, f"bench output differs from numpy.fft: {err}"
 
     bytes_per_launch = 2 * rows * n * 16               # 32 B/point = one read + one write of c128
-    kern_s = dev_ms / 1e3 / primary_steps              # average launch duration on the launch stream (HIP events)
+    kern_s = dev_ms / 1e3 / primary_steps              # average launch duration on the launch stream (HIP events), median block
 
-    # ------------------------------------------------------------------ cache-cold: rotating pairs (> Infinity Cache)
-    cold = None
-    if args.cold_pairs > 0:
-        pairs = [(xd, yd)]
-        for p in range(1, args.cold_pairs):
-            xi = synth.complex_array_torch((rows, n), dev, offset=(rank + p * ngpu) * rows * n)
-            pairs.append((xi, torch.empty_like(xi)))
-
-        def cold_step(i):
-            a, b = pairs[i % len(pairs)]
-            ndfft(a, b, h, 1)
-        for i in range(2 * len(pairs)):
-            cold_step(i)
-        c_el, c_ms = timed(cold_step, args.steps)
-        c_kern = c_ms / 1e3 / args.steps
-        cold = {"pairs": len(pairs), "footprint_bytes": len(pairs) * bytes_per_launch,
-                "avg_launch_us": round(c_kern * 1e6, 2), "achieved": round(bytes_per_launch / c_kern / 1e9, 1),
-                "ms_per_step": round(c_el / args.steps * 1e3, 5),
-                "value": round(ngpu * rows * n * args.steps / c_el / 1e9, 3)}
-        if rank == 0:                                  # the rotated outputs are real transforms too
-            a, b = pairs[-1]
-            yo = np.fft.fft(a[:2].cpu().numpy(), axis=1)
-            err = np.abs(b[:2].cpu().numpy() - yo).max() / np.abs(yo).max()
-            assert err < 1e-10, f"cold-rotation output differs from numpy.fft: {err}"
-        del pairs[1:]
+    # ------------------------------------------------------------------ warm: ONE pair re-used every step (Infinity-Cache assisted)
+    warm = None
+    if not args.no_warm:
+        for _ in range(5):
+            warm_step()
+        (w_el, w_ms), w_blocks = timed_blocks(warm_step, args.steps, warm_blocks)
+        w_kern = w_ms / 1e3 / args.steps
+        warm = {"what": "the same call on ONE (in, out) pair re-used every step: the 256 MiB Infinity Cache serves part of the re-read input "
+                        "(FETCH_SIZE counts those hits) -- not an HBM-sourced number",
+                "avg_launch_us": round(w_kern * 1e6, 2), "achieved": round(bytes_per_launch / w_kern / 1e9, 1),
+                "ms_per_step": round(w_el / args.steps * 1e3, 5),
+                "value": round(ngpu * rows * n * args.steps / w_el / 1e9, 3), "blocks": w_blocks,
+                "input_policy": lib.last_input_policy()}
+    del pairs[1:]
 
     # ------------------------------------------------------------------ strong scaling: cfg5 = 65536 x 4096 split in N
     strong = None
@@ -457,19 +481,23 @@ def main():
                                                   "--pmc passes of this bench command, x2 gfx950 read correction)")
             except Exception:
                 traffic = None
+        cold_traffic = tdata.get("4096x4096_cold_rotating") if (traffic is not None and rows == 4096 and n == 4096) else None
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": traffic_src if traffic is not None else "no PMC run on record for the current kernel sources (profiles/pmc_traffic.json is for older kernel text)",
-                "traffic_note": "PMC bytes from an EARLIER profiling run of this command (not measured by this process); "
-                                "FETCH_SIZE counts Infinity-Cache hits too" if traffic is not None else None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": cold_traffic,
+                "traffic_source": traffic_src if cold_traffic is not None else "no PMC run on record for the current kernel sources (profiles/pmc_traffic.json is for older kernel text)",
+                "traffic_note": "PMC bytes from an EARLIER profiling run of this command (not measured by this process)" if cold_traffic is not None else None,
                 "kernel": "k_pow2<double,4096>", "algorithmic_bytes_per_launch": bytes_per_launch,
                 "avg_launch_us": round(kern_s * 1e6, 2),
-                "frac_note": "one 256 MiB input re-read every step: the 256 MiB Infinity Cache can serve part of it; see frac_cold"}
-        if cold:
-            roof["frac_cold"] = round(cold["achieved"] / HBM_PEAK_GBS, 4)
-            if traffic is not None and rows == 4096 and n == 4096:
-                cold["traffic"] = tdata.get("4096x4096_cold_rotating"); cold["traffic_source"] = traffic_src
-            roof["cold"] = cold
+                "source": f"HBM: {args.cold_pairs} rotating (in, out) pairs, footprint {args.cold_pairs * bytes_per_launch} B >> the 256 MiB Infinity Cache; "
+                          "median of `blocks`",
+                "pairs": args.cold_pairs, "footprint_bytes": args.cold_pairs * bytes_per_launch, "input_policy": policy,
+                "blocks": blocks}
+        roof["frac_cold"] = roof["frac"]               # the name rounds 2-3 used for this same region
+        if warm:
+            roof["frac_warm"] = round(warm["achieved"] / HBM_PEAK_GBS, 4)
+            if traffic is not None:
+                warm["traffic"] = traffic; warm["traffic_note"] = "FETCH_SIZE counts Infinity-Cache hits too"
+            roof["warm"] = warm
         if strong and traffic is not None and ngpu == 1 and n == 4096:
             strong["traffic"] = tdata.get("65536x4096"); strong["traffic_source"] = traffic_src
         out = {
@@ -480,9 +508,10 @@ def main():
             "ms_per_step": round(el / primary_steps * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            "blocks": blocks["n"],
             "config": {"workload": f"ndfft axis=1 on {ngpu * rows}x{n} Complex<f64> "
                                    f"({'BASELINE configs[1] per GPU' if rows == 4096 else str(rows) + ' rows per GPU'}), "
-                                   f"device-resident, splitmix64 U[-1,1) seed 20241008",
+                                   f"device-resident in HBM ({args.cold_pairs} rotating array pairs), splitmix64 U[-1,1) seed 20241008",
                        "lanes_per_gpu": rows, "lane_len": n, "kernel_path": path,
                        "sharding": "none" if ngpu == 1 else f"lanes split in {ngpu} contiguous blocks, one per GPU, no collective in the timed region"},
             "roofline": roof,

@@ -172,6 +172,15 @@ const char *ndfft_last_path(void);
  * Returns the number of bytes the full text needs (excluding the NUL), or a negative status.  Used by tests/test_plan_recipes.py. */
 int ndfft_explain_plan(int kind, int dtype, size_t n, char *buf, size_t buflen);
 
+/* Environment switches (no reference counterpart).  The library reads its NDFFT_* environment switches ONCE, on first use, into one
+ * struct (csrc/switches.h); nothing on the call path reads the environment.  INTEGRATION.md section 6 documents every switch.
+ * ndfft_documented_switches writes their names, one per line, into buf (NUL-terminated, truncated to buflen) and returns the bytes the
+ * full text needs.  ndfft_reload_switches re-reads the environment -- a TEST hook (the parity tests close a kernel route, reload, run a
+ * case, restore): it must not run while another thread is inside ndfft_exec* / ndfft_plan_create, and plans keep the recipes they were
+ * created with. */
+int ndfft_documented_switches(char *buf, size_t buflen);
+int ndfft_reload_switches(void);
+
 /* ---- device memory helpers for shims that keep arrays resident between nd* calls ----------- */
 int ndfft_dev_alloc(void **d_ptr, size_t bytes);
 int ndfft_dev_free(void *d_ptr);

@@ -25,7 +25,11 @@ SYMBOLS = [
     "ndfft_exec", "ndfft_exec_device", "ndfft_exec_sharded", "ndfft_exec_sharded_device", "ndfft_last_path", "ndfft_explain_plan",
     "ndfft_dev_alloc", "ndfft_dev_free", "ndfft_dev_upload", "ndfft_dev_download", "ndfft_dev_sync",
     "ndfft_release_workspace", "ndfft_host_alloc", "ndfft_host_free", "ndfft_set_input_hint", "ndfft_host_forget", "ndfft_host_reg_cache", "ndfft_last_input_policy",
+    "ndfft_documented_switches", "ndfft_reload_switches",
 ]
+
+
+_loaded = []          # every Library this process has opened (tests/conftest.py reloads their switches between tests)
 
 
 class NdfftError(RuntimeError):
@@ -46,6 +50,7 @@ class Library:
                 "ndrustfft_amd has no CPU fallback.")
         self.path = path
         L = self.c = ctypes.CDLL(path)
+        _loaded.append(self)
         vp, i32, sz, i64p, dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_double
         L.ndfft_abi_version.restype = i32
         L.ndfft_last_error.restype = ctypes.c_char_p
@@ -80,6 +85,8 @@ class Library:
         L.ndfft_host_forget.argtypes = [vp]; L.ndfft_host_forget.restype = i32
         L.ndfft_host_reg_cache.argtypes = [sz]; L.ndfft_host_reg_cache.restype = i32
         L.ndfft_last_input_policy.argtypes = []; L.ndfft_last_input_policy.restype = i32
+        L.ndfft_documented_switches.argtypes = [ctypes.c_char_p, sz]; L.ndfft_documented_switches.restype = i32
+        L.ndfft_reload_switches.argtypes = []; L.ndfft_reload_switches.restype = i32
 
     def check(self, status):
         if status == OK:
@@ -91,6 +98,19 @@ class Library:
 
     def last_path(self):
         return self.c.ndfft_last_path().decode()
+
+    def reload_switches(self):
+        """Re-read the NDFFT_* environment switches (test hook: the library parses them once; see include/ndfft_mi355x.h)."""
+        self.check(self.c.ndfft_reload_switches())
+
+    def documented_switches(self):
+        buf = ctypes.create_string_buffer(4096)
+        self.c.ndfft_documented_switches(buf, len(buf))
+        return buf.value.decode().split()
+
+    def last_input_policy(self):
+        """Load policy of the last device exec on this thread: 0 default, 1 streaming loads, -1 fixed by the kernel (diagnostic)."""
+        return int(self.c.ndfft_last_input_policy())
 
     def explain_plan(self, kind, dtype, n):
         """Text description of the recipes a handler of (kind, dtype, n) would use (diagnostic; needs no GPU)."""

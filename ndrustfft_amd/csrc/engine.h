@@ -12,6 +12,7 @@
 
 #include "../../include/ndfft_mi355x.h"
 #include "device_common.h"
+#include "switches.h"
 
 namespace ndfft {
 

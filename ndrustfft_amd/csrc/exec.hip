@@ -363,7 +363,7 @@ static bool F_nt_ok(int F) { return F >= 64; }   // (short lanes: the staging lo
 static int row_load_policy(const void *in, size_t bytes, const void *out, size_t out_bytes);
 static int c2c_row_load_policy(const void *in, const void *out, size_t bytes) { return row_load_policy(in, bytes, out, bytes); }
 static int row_load_policy(const void *in, size_t bytes, const void *out, size_t out_bytes) {
-    static const int force = [] { const char *e = getenv("NDFFT_STREAM_LOADS"); return e ? atoi(e) : -1; }();   // developer switch: 0 / 1 forces a policy
+    const int force = sw().stream_loads;            // NDFFT_STREAM_LOADS: 0 / 1 forces a policy
     DeviceWs *ws;
     if (current_ws(&ws)) return -1;
     int pol = force >= 0 ? (force != 0) : g_input_hint == NDFFT_INPUT_CACHED ? 0 : g_input_hint == NDFFT_INPUT_COLD ? 1 : ws->mall.decide(in, bytes);
@@ -403,72 +403,25 @@ static int transpose_batched(const void *in, void *out, int64_t batch, int64_t r
 }
 
 
-// developer switch: NDFFT_NARROW=0 sends long strided lanes through the transpose route instead
-static bool narrow_enabled() {
-    static const bool on = [] { const char *e = getenv("NDFFT_NARROW"); return !(e && e[0] == '0'); }();
-    return on;
-}
-
-// test switch: NDFFT_NARROW_DCT=1 sends long strided DCT lanes through the narrow tiles again (read per call)
-static bool narrow_dct_enabled() {
-    const char *e = getenv("NDFFT_NARROW_DCT");
-    return e && e[0] == '1';
-}
-
-// developer / test switch: NDFFT_WAVE=0 keeps short dense C2C lanes on the older kernels (read per call)
-static bool wave_enabled() {
-    const char *e = getenv("NDFFT_WAVE");
-    return !(e && e[0] == '0');
-}
-
-// developer / test switch: NDFFT_FOURSTEP2=0 keeps long power-of-two lanes on the three-pass form (read per call)
-static bool fourstep2_enabled() {
-    const char *e = getenv("NDFFT_FOURSTEP2");
-    return !(e && e[0] == '0');
-}
-
-// developer / test switch: NDFFT_REAL_FOURSTEP=0 keeps long real-data lanes on the packed complex four-step with separate PRE / POST passes
+// Route switches (switches.h; parsed once, never read from the environment on the call path).  Each closes one route so that the kernel
+// behind it runs: the parity tests reach every fallback kernel that way.
+static bool narrow_enabled() { return true; }                              // (long strided lanes on narrow column tiles; the transpose route is the fallback)
+static bool narrow_dct_enabled() { return sw().narrow_dct; }               // NDFFT_NARROW_DCT=1: long strided DCT lanes on the narrow tiles again
+static bool wave_enabled() { return sw().wave; }                           // NDFFT_WAVE=0: short dense C2C lanes on the older kernels
+static bool fourstep2_enabled() { return sw().fourstep2; }                 // NDFFT_FOURSTEP2=0: long power-of-two lanes on the three-pass form
+// NDFFT_REAL_FOURSTEP=0 keeps long real-data lanes on the packed complex four-step with separate PRE / POST passes
 // (2 = for every eligible op, also where the plan's table says the packed route is faster: parity tests)
-static int real_fourstep_enabled() {
-    const char *e = getenv("NDFFT_REAL_FOURSTEP");
-    return e ? atoi(e) : 1;
-}
-
+static int real_fourstep_enabled() { return sw().real_fourstep; }
 // largest handler length the thread-per-lane real-op register kernels take (raw lane + Z + outputs in registers)
 static int regreal_max_n(int f64) {
-    static const int m32 = [] { const char *e = getenv("NDFFT_REGREAL_MAX_F32"); return e ? atoi(e) : 72; }();   // f32 n = 64: 0.66 vs 0.50; n = 96 / 100: 0.39 / 0.37 vs 0.41 / 0.49
-    static const int m64 = [] { const char *e = getenv("NDFFT_REGREAL_MAX_F64"); return e ? atoi(e) : 48; }();   // f64 n = 48: 0.66 vs 0.30
-    return f64 ? m64 : m32;
+    return f64 ? (int)NDFFT_DEV_INT("NDFFT_REGREAL_MAX_F64", 48)           // f64 n = 48: 0.66 vs 0.30
+               : (int)NDFFT_DEV_INT("NDFFT_REGREAL_MAX_F32", 72);          // f32 n = 64: 0.66 vs 0.50; n = 96 / 100: 0.39 / 0.37 vs 0.41 / 0.49
 }
-
-// developer / test switch: NDFFT_CHUNK_OUT=0 keeps R2C rows on the per-lane stores
-static bool chunk_out_enabled() {
-    const char *e = getenv("NDFFT_CHUNK_OUT");
-    return !(e && e[0] == '0');
-}
-
-// developer / test switch: NDFFT_TINY=0 keeps very short lanes on the LDS kernel (read per call)
-static bool tiny_enabled() {
-    const char *e = getenv("NDFFT_TINY");
-    return !(e && e[0] == '0');
-}
-
-// developer / test switch: NDFFT_PLAIN=0 keeps the odd-n real ops with a smooth inner FFT on the LDS kernel (read per call)
-static bool plain_enabled() {
-    const char *e = getenv("NDFFT_PLAIN");
-    return !(e && e[0] == '0');
-}
-// developer switch: NDFFT_BLUE=0 keeps Bluestein lengths on the LDS kernel
-static bool blue_enabled() {
-    const char *e = getenv("NDFFT_BLUE");
-    return !(e && e[0] == '0');
-}
-
-// developer switch: NDFFT_COLSPLIT=0 keeps long strided lanes on the narrow-tile / transpose routes
-static bool colsplit_enabled() {   // read per call: the parity tests toggle it to reach the narrow-tile kernels
-    const char *e = getenv("NDFFT_COLSPLIT");
-    return !(e && e[0] == '0');
-}
+static bool chunk_out_enabled() { return true; }                           // (R2C rows store whole chunks; settled in round 2)
+static bool tiny_enabled() { return sw().tiny; }                           // NDFFT_TINY=0: very short lanes on the LDS kernel
+static bool plain_enabled() { return sw().plain; }                         // NDFFT_PLAIN=0: odd-n real ops with a smooth inner FFT on the LDS kernel
+static bool blue_enabled() { return sw().blue; }                           // NDFFT_BLUE=0: Bluestein lengths on the LDS kernel
+static bool colsplit_enabled() { return sw().colsplit; }                   // NDFFT_COLSPLIT=0: long strided lanes on the narrow-tile / transpose routes
 
 // Column four-step (pow2_real.h, CS kernels): a long STRIDED power-of-two lane, n = F1 * F2, as two passes
 // of wide column tiles over a dense C-layout block [O][n][I] -- no transpose, no narrow tiles:
@@ -492,8 +445,7 @@ static int col_split(const Problem &P, const void *d_in, void *d_out, const FftC
     // small chunks LOSE (32 MiB: 293 us, 8 MiB: 628 us): every chunk costs two launches of a few microseconds.
     int64_t C = I;
     {
-        const char *e = getenv("NDFFT_CS_CHUNK_MB");   // developer / test switch (0 = one chunk)
-        const int64_t target = (int64_t)(e ? atoi(e) : 144) << 20;
+        const int64_t target = (int64_t)sw().cs_chunk_mb << 20;   // NDFFT_CS_CHUNK_MB (0 = one chunk)
         const int64_t per_col = (int64_t)K1 * F2 * (int64_t)sizeof(cpx<T>);
         if (target > 0 && O == 1 && per_col * I > target) {   // equal chunks, a multiple of 64 columns each
             const int64_t nchunk = (per_col * I + target - 1) / target;
@@ -509,7 +461,7 @@ static int col_split(const Problem &P, const void *d_in, void *d_out, const FftC
     // layout needs the (b, i) batch dimensions unmerged, and the column kernels take two).
     int64_t pad = 0;
     if (O == 1) {
-        static const int pad_bytes = [] { const char *e = getenv("NDFFT_CS_PAD"); return e ? atoi(e) : 0; }();   // measured on cfg3-A / cfg3-A' (profiles/r05/r05a_cs_pad_abab.txt): 0 / 256 / 512 / 1024 B all within 200-207 us: no effect, off
+        constexpr int pad_bytes = 0;   // measured on cfg3-A / cfg3-A' (profiles/r05/r05a_cs_pad_abab.txt): 0 / 256 / 512 / 1024 B all within 200-207 us: no effect, off
         pad = pad_bytes / (int64_t)sizeof(cpx<T>);
     }
     const int64_t Cp = C + pad;              // pitch of one (k1, b) row of the intermediate, in complex elements
@@ -536,7 +488,7 @@ static int col_split(const Problem &P, const void *d_in, void *d_out, const FftC
         if (!c2r) {
             // A: column transform of length F1 over a = row / F2; lanes (b, i)
             Q.op = P.op; Q.xlen = F1; Q.ylen = K1; Q.xs = (int64_t)F2 * I; Q.ys = (int64_t)F2 * Cp;
-            { const char *e1 = getenv("NDFFT_CS_KEEP"); Q.keep_out = e1 ? atoi(e1) : chunked; const char *e2 = getenv("NDFFT_CS_NT_IN"); Q.stream_in = e2 ? atoi(e2) : 0; }
+            Q.keep_out = chunked; Q.stream_in = 0;
             if (split_bi) { Q.b.push_back({(int64_t)F2, I, Cp}); Q.b.push_back({Cc, 1, 1}); }
             else {
                 if (O > 1) Q.b.push_back({O, sin_o, (int64_t)K1 * F2 * I});
@@ -609,7 +561,7 @@ static int big_fft(const FftConfig &c, const DevConfig &d, const cpx<T> *zin, in
         a.cs_twlo = (const cpx<T> *)d.twlo; a.cs_twhi = (const cpx<T> *)d.twhi; a.cs_logB = c.logB;
         a.cs_k1n = 1; a.cs_f1 = F1; a.cs_n = (int)F; a.cs_outer_in = 0; a.cs_outer_out = 0; a.cs_pitch = 0;
         // (used by the half-line tiles only, F = 1024 f32 -- pow2_real.h; 32 x 2^20 c64: 403 -> 354 us, profiles/r06)
-        { static const int xc = [] { const char *e = getenv("NDFFT_FS_XCD_CHUNK"); return e ? atoi(e) : 32; }(); a.xcd_chunk = xc; }
+        a.xcd_chunk = (int)NDFFT_DEV_INT("NDFFT_FS_XCD_CHUNK", 32);
         // pass 1: lanes (l, n2)
         a.in = zin; a.out = s1; a.nlanes = L * F2; a.n = F1; a.F = F1; a.n_in = F1; a.n_out = F1; a.scale = (T)1;
         a.inner = F2; a.outer_in = pitch_in; a.outer_out = 0; a.elem_in = F2; a.elem_out = 0; a.pitch_out = F1;
@@ -711,8 +663,8 @@ static int real_fourstep(const Problem &P, int gop, const FftConfig &c, const De
     if ((rc = launch_fourstep_real<T>(1, N1 / 2, a, stream))) return rc;
     // pass 2: lanes (l, k1)
     a.makhoul = 0;
-    { static const int mp = [] { const char *e = getenv("NDFFT_RFS_MIRROR_PLAIN"); return e ? atoi(e) : 1; }(); a.keep_out = mp; }
-    { static const int xc = [] { const char *e = getenv("NDFFT_RFS_XCD_CHUNK"); return e ? atoi(e) : 8; }(); a.xcd_chunk = xc; }
+    a.keep_out = 1;                                  // plain stores at the lines the mirrored rows share
+    a.xcd_chunk = (int)NDFFT_DEV_INT("NDFFT_RFS_XCD_CHUNK", 8);
     a.in = s1; a.out = d_out; a.nlanes = B * K; a.n = N2; a.F = N2; a.n_in = N2; a.n_out = N2; a.scale = (T)P.scale;
     a.inner = K; a.outer_in = (int64_t)N2 * K; a.outer_out = pout; a.elem_in = K; a.elem_out = 0; a.pitch_out = 0;
     a.aux1 = nullptr; a.aux2 = (const cpx<T> *)d.aux2; a.twp = (const cpx<T> *)dt2->cfg[CFG_MAIN].twp_col;
@@ -744,9 +696,9 @@ static int real_fourstep_inv(const Problem &P, int gop, const FftConfig &c, cons
     a.twp = (const cpx<T> *)dt2->cfg[CFG_MAIN].twp_col;
     // runs of consecutive tiles per XCD: the mirrored index N1 - k1 is shifted by one element against the tile grid (and DCT-III's real rows are
     // half lines), so neighbouring tiles share every line
-    { static const int xc = [] { const char *e = getenv("NDFFT_RFS_XCD_CHUNK"); return e ? atoi(e) : 8; }(); a.xcd_chunk = xc; }
+    a.xcd_chunk = (int)NDFFT_DEV_INT("NDFFT_RFS_XCD_CHUNK", 8);
     if ((rc = launch_fourstep_real<T>(gop == G_DCT3_EVEN ? 5 : 4, N2, a, stream))) return rc;
-    if (const char *e = getenv("NDFFT_RFS_C2R_TILE"); !(e && e[0] == '0')) {   // the column C2R kernel on 128-byte tiles (0: the general column kernel through dispatch())
+    if (sw().rfs_c2r_tile) {   // the column C2R kernel on 128-byte tiles (0: the general column kernel through dispatch())
         const DevTables *dt1;
         if ((rc = get_dev_tables(c.rfs_sub1, &dt1))) return rc;
         a.xcd_chunk = 0; a.keep_out = 0;
@@ -1016,7 +968,7 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
         const int rcj = launch_jit_c2c(plan->dtype, plan->cfg[CFG_MAIN].jitcfg, nt, a, stream);
         if (rcj == NDFFT_OK) { set_last_path("jit_reg"); return NDFFT_OK; }
         if (rcj != NDFFT_ERR_UNSUPPORTED) return rcj;   // a real HIP error; UNSUPPORTED = no hiprtc / compile failed -> LDS kernel
-        if (getenv("NDFFT_JIT_VERBOSE")) fprintf(stderr, "ndfft: jit_reg declined n = %zu\n", plan->n);
+        if (sw().jit_verbose) fprintf(stderr, "ndfft: jit_reg declined n = %zu\n", plan->n);
     }
     // tuned paths on the register-resident real-op engine (pow2_real.h), power-of-two inner FFT:
     //   row: R2C / C2R / DCT on contiguous lanes;  col: the same ops AND C2C on a strided axis whose
@@ -1066,7 +1018,7 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
             auto fill = [&](auto &a) {
                 a.in = d_in; a.out = d_out; a.nlanes = P.nlanes;
                 a.pitch_in = 0; a.pitch_out = 0; a.vec_in = 0; a.vec_out = 0;
-                { const char *e = getenv("NDFFT_XCD_REMAP"); a.xcd_remap = !(e && e[0] == '0'); }
+                a.xcd_remap = 1;
                 a.keep_out = 0;
                 a.n = n; a.F = c.F; a.n_in = (int)P.xlen; a.n_out = (int)P.ylen;
                 a.inner = P.b.back().shape;
@@ -1305,19 +1257,22 @@ bool is_pinned(const void *p) {
 class HostRegCache {
   public:
     static HostRegCache &get() { static HostRegCache *c = new HostRegCache; return *c; }
-    // true: [p, p + bytes) is registered now (and held until release())
+    // true: [p, p + bytes) lies inside a registration THIS CACHE owns, and is held until release(): its LRU stamp is fresh and neither
+    // eviction, forget() nor set_limit(0) will unregister it while the call's copies are in flight.  Asked BEFORE is_pinned() (round 4: a
+    // registered array looks like any pinned one to hipPointerGetAttributes, and the steady-state calls used to bypass the cache -- the
+    // hottest arrays were evicted first, nothing held them during the DMA, and a stale registration was not retried).
     bool acquire(const void *p, size_t bytes) {
-        if (bytes < ((size_t)8 << 20)) return false;
-        const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+        const uintptr_t lo = (uintptr_t)p, hi = lo + std::max<size_t>(bytes, 1);
         std::lock_guard<std::mutex> g(mu_);
-        if (!limit_) return false;
         ++tick_;
+        for (R &r : v_) if (r.registered && r.lo <= lo && hi <= r.hi) { r.last = tick_; ++r.inuse; return true; }   // any size: sub-views of a registered array too
+        if (!limit_ || bytes < ((size_t)8 << 20)) return false;
         R *hit = nullptr;
         for (size_t i = 0; i < v_.size();) {
             R &r = v_[i];
-            if (r.lo <= lo && hi <= r.hi) { hit = &r; ++i; continue; }
-            if (lo < r.hi && r.lo < hi) {                 // overlaps without containing: the caller's allocation changed
-                if (r.inuse) return false;                //   (another thread is moving data through it: leave everything alone)
+            if (r.lo == lo && r.hi == hi) { hit = &r; ++i; continue; }
+            if (lo < r.hi && r.lo < hi) {                 // overlaps another range: the caller's allocation changed (an unregistered sighting of a
+                if (r.inuse) return false;                //   larger, older array must not be what gets pinned -- only the range of THIS call is)
                 drop(i);
                 continue;
             }
@@ -1325,12 +1280,10 @@ class HostRegCache {
         }
         if (hit) {
             hit->last = tick_;
-            if (hit->registered) { ++hit->inuse; return true; }
-            if (++hit->seen < 2) return false;
-            if (hipHostRegister((void *)hit->lo, hit->hi - hit->lo, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); hit->seen = -1000000; return false; }
-            hit->registered = true; hit->inuse = 1; reg_bytes_ += hit->hi - hit->lo;
-            const uintptr_t keep = hit->lo;               // (evict() may move entries)
-            evict(keep);
+            if (++hit->seen < 2) return false;            // (after a failed registration `seen` restarts at -8: a bounded back-off, not a ban)
+            if (hipHostRegister((void *)lo, hi - lo, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); hit->seen = -8; return false; }
+            hit->registered = true; hit->inuse = 1; reg_bytes_ += hi - lo;
+            evict(lo);                                    // (evict() may move entries: `hit` is dead from here)
             return true;
         }
         if (v_.size() >= 256) {                           // forget the oldest unregistered sighting
@@ -1358,7 +1311,7 @@ class HostRegCache {
     }
   private:
     struct R { uintptr_t lo, hi; uint64_t last; int seen; bool registered; int inuse; };
-    HostRegCache() { const char *e = getenv("NDFFT_HOST_REG_CACHE_MB"); limit_ = (size_t)(e ? std::max(0L, atol(e)) : 0L) << 20; }
+    HostRegCache() { limit_ = (size_t)std::max(0L, sw().host_reg_cache_mb) << 20; }
   public:
     void set_limit(size_t bytes) {
         std::lock_guard<std::mutex> g(mu_);
@@ -1479,7 +1432,7 @@ __attribute__((target("avx2"))) void copy_nt_avx2(char *d, const char *s, size_t
     if (n) memcpy(d, s, n);
 }
 void bulk_copy(char *d, const char *s, size_t n) {
-    static const bool nt = [] { const char *e = getenv("NDFFT_COPY_NT"); return !(e && e[0] == '0') && __builtin_cpu_supports("avx2"); }();
+    static const bool nt = __builtin_cpu_supports("avx2");
     if (nt && n >= ((size_t)256 << 10)) copy_nt_avx2(d, s, n); else memcpy(d, s, n);
 }
 #else
@@ -1512,14 +1465,14 @@ class CopyPool {
         // threads: three quarters of the CPUs this process may use (affinity / hardware count capped by the cgroup quota:
         // the MI355X boxes show 256 CPUs and grant 16), between 2 and 12.  Measured on 4096 x 4096 c128 (2 x 256 MiB,
         // plain path 9.8 ms): 4 threads 9.5-10.6 ms, 8 threads 8.8 ms, 12 threads 7.9-8.4 ms -- the host copies, not PCIe, bound it
-        const char *e = getenv("NDFFT_COPY_THREADS");
+        const int forced = sw().copy_threads;            // NDFFT_COPY_THREADS
         long hw = (long)std::thread::hardware_concurrency();
         if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
             char q[32] = {0}; long per = 0;
             if (fscanf(f, "%31s %ld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) hw = std::min(hw, std::max(1L, (atol(q) + per - 1) / per));
             fclose(f);
         }
-        nthreads_ = e ? atoi(e) : (int)std::max(2L, std::min(12L, hw * 3 / 4));
+        nthreads_ = forced > 0 ? forced : (int)std::max(2L, std::min(12L, hw * 3 / 4));
         if (nthreads_ < 1) nthreads_ = 1;
         for (int i = 0; i < nthreads_; ++i) std::thread([this] { loop(); }).detach();
     }
@@ -1656,17 +1609,17 @@ int ndfft_exec(const ndfft_plan *plan, int op, const void *in, void *out, int nd
         out_dense && ibytes + obytes >= ((size_t)8 << 20)) {
         const int64_t isp = inner_span(ndim, shape_in, stride_in), osp = inner_span(ndim, shape_out, stride_out);
         if (isp > 0 && osp > 0 && stride_in[0] >= isp && stride_out[0] >= osp) {
-            const char *e = getenv("NDFFT_PIPE_CHUNKS");
             // a chunk must stay a real problem: kernel choice depends on the size of a call (hiprtc specialisation from 2^16-2^17
             // points), so never cut below 2^18 points per chunk
             const int64_t max_chunks = std::max<int64_t>(1, (P.nlanes * std::max(P.xlen, P.ylen)) >> 18);
-            // the caller's own arrays, seen before: registered once, DMA straight from / to them from then on
-            const bool own_in = is_pinned(in), own_out = is_pinned(out);
+            // the caller's own arrays, seen before: registered once, DMA straight from / to them from then on.  The cache is asked FIRST
+            // (held = a registration it owns, kept alive for this call); only an array it does not own can be the caller's pinned memory
             bool retry_unpinned = false;
             {
-                HostPin pin_in(hin, own_in ? 0 : ibytes), pin_out(hout, own_out ? 0 : obytes);
+                HostPin pin_in(hin, ibytes), pin_out(hout, obytes);
+                const bool own_in = !pin_in.held && is_pinned(in), own_out = !pin_out.held && is_pinned(out);
                 if ((own_in || pin_in.held) && (own_out || pin_out.held)) {
-                    const int chunks = (int)std::min<int64_t>(std::min<int64_t>(shape_in[0], max_chunks), e ? std::max(1, atoi(e)) : 8);
+                    const int chunks = (int)std::min<int64_t>(std::min<int64_t>(shape_in[0], max_chunks), 8);
                     const int rcp = exec_pinned_pipeline(ws, plan, op, hin, hout, ndim, shape_in, stride_in, shape_out, stride_out, axis, norm, scale, ein, eout, chunks);
                     // A registration made by the cache can be stale: the caller freed the array and the allocator handed the same addresses out
                     // again (seen on the MI355X with numpy arrays: hipMemcpyAsync then fails with "invalid argument" -- before anything has been
@@ -1680,12 +1633,12 @@ int ndfft_exec(const ndfft_plan *plan, int op, const void *in, void *out, int nd
                 HostRegCache::get().forget(hin); HostRegCache::get().forget(hout);
                 clear_err();
             }
-            const char *hp = getenv("NDFFT_HOST_PIPE");
-            const bool force = hp && hp[0] == '1';            // tests: pipeline small calls too
-            if (force || (!(hp && hp[0] == '0') && max_chunks >= 4 && ibytes + obytes >= ((size_t)32 << 20))) {   // small calls: the plain path
+            const int hp = sw().host_pipe;                    // NDFFT_HOST_PIPE
+            const bool force = hp == 1;                       // tests: pipeline small calls too
+            if (force || (hp != 0 && max_chunks >= 4 && ibytes + obytes >= ((size_t)32 << 20))) {   // small calls: the plain path
                 // chunks of ~32 MiB per direction (at least 4, at most 64)
                 const int64_t want = std::max<int64_t>(4, std::min<int64_t>(64, (int64_t)(std::max(ibytes, obytes) >> 25)));
-                const int chunks = (int)std::min<int64_t>(std::min<int64_t>(shape_in[0], force ? 64 : max_chunks), e ? std::max(1, atoi(e)) : want);
+                const int chunks = (int)std::min<int64_t>(std::min<int64_t>(shape_in[0], force ? 64 : max_chunks), want);
                 return exec_bounce_pipeline(ws, plan, op, hin, hout, ndim, shape_in, stride_in, shape_out, stride_out, axis, norm, scale, ein, eout, chunks);
             }
         }

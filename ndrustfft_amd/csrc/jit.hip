@@ -41,7 +41,7 @@ struct Rtc {
 Rtc &rtc() {
     static Rtc r = [] {
         Rtc x;
-        { const char *e = getenv("NDFFT_JIT"); if (e && e[0] == '0') return x; }   // NDFFT_JIT=0: behave like a host without libhiprtc
+        if (sw().jit == 0) return x;   // NDFFT_JIT=0: behave like a host without libhiprtc
         const char *names[] = {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"};
         for (const char *n : names) if ((x.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
         if (!x.lib) return x;
@@ -67,8 +67,7 @@ std::condition_variable g_cv;
 std::map<std::string, Slot> g_cache;
 
 bool jit_disabled() {
-    static const bool off = [] { const char *e = getenv("NDFFT_JIT"); return e && e[0] == '0'; }();
-    return off;
+    return sw().jit == 0;
 }
 }  // namespace
 
@@ -77,7 +76,7 @@ bool jit_disabled() {
 // Partial-round configurations (pow2_kernel.h: slots / full): any radix list whose product is n, any TPL.
 // Cost ~ passes x (work incl. idle threads of partial rounds): minimise NP / utilisation; ties -> E nearest 16.
 static size_t jit_lds_limit();
-static int jit_full_min() { static const int v = [] { const char *e = getenv("NDFFT_JIT_FULL_MIN"); return e ? atoi(e) : 256; }(); return v; }
+static int jit_full_min() { return 256; }
 static bool jit_choose_partial(int dtype, int n, JitCfg &cfg, int emax_arg = 0) {
     const int emax = emax_arg > 0 ? emax_arg : dtype == NDFFT_F32 ? 32 : 30;
     const int cand[] = {16, 13, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
@@ -124,10 +123,10 @@ static bool jit_choose_default(int dtype, int n, JitCfg &cfg, bool allow_partial
 // (profiles/r04/r04j_realplan_ab.txt: nddct2 / ndfft_r2c n = 96, 120, 300, 360, 1200, 3000, 6000 gain 1.3-2.9x; recipes with e <= 12 were as good
 // or better than the model's pick) -- and are replaced by the pick of the cost model fitted for the Rader kernel (plan_fft_by_cost).
 bool jit_choose(int dtype, int n, JitCfg &cfg, bool allow_partial) {
-    static const bool on = [] { const char *e = getenv("NDFFT_JIT_REALPLAN"); return !(e && e[0] == '0'); }();
-    static const int nmax = [] { const char *e = getenv("NDFFT_JIT_REALPLAN_MAX"); return e ? atoi(e) : 8192; }();
+    constexpr bool on = true;
+    constexpr int nmax = 8192;
     if (!jit_choose_default(dtype, n, cfg, allow_partial)) return false;
-    if (const char *e = getenv("NDFFT_JIT_CFG")) {       // developer knob: "n:tpl:r0.r1.r2[:lanes]" replaces the recipe of length n (read per plan)
+    if (const char *e = NDFFT_DEV_STR("NDFFT_JIT_CFG")) {       // developer knob: "n:tpl:r0.r1.r2[:lanes]" replaces the recipe of length n (read per plan)
         if (atoi(e) == n && allow_partial) {
             const char *q = strchr(e, ':');
             JitCfg c; c.n = n; c.tpl = q ? atoi(q + 1) : 0; c.vec = 1;
@@ -145,7 +144,7 @@ bool jit_choose(int dtype, int n, JitCfg &cfg, bool allow_partial) {
     }
     // f32 lanes below 256 points are re-planned from e > 8 (A-B-A-B, profiles/r04/r04zg_abab_shortplan.txt: c64 n = 80 / 96 / 160 51.5 / 50.5 / 49.7 -> 39.6 / 38.9 / 38.2 us,
     // ndfft_r2c f32 n = 160 / 192 / 320 +10 %, the rest within 3 %; in f64 the same rule was a wash: c128 n = 96 -6 %, nddct2 n = 192 +5 %)
-    static const bool short_too = [] { const char *e = getenv("NDFFT_JIT_REALPLAN_SHORT"); return !(e && e[0] == '0'); }();
+    constexpr bool short_too = true;
     const bool bad_e = cfg.e > (dtype == NDFFT_F32 ? 24 : 18) || (short_too && dtype == NDFFT_F32 && n < 256 && cfg.e > 8);
     if (!on || !allow_partial || n > nmax || !bad_e) return true;
     const size_t lane = (size_t)((n + (n >> 4) + 3) & ~1) * 2 * (dtype == NDFFT_F32 ? 4 : 8);
@@ -192,8 +191,7 @@ static bool jit_choose_default(int dtype, int n, JitCfg &cfg, bool allow_partial
 // dynamic LDS a module (hiprtc) function may be launched with: the full 160 KiB of a gfx950 CU -- no
 // opt-in attribute is needed for module functions (checked on the MI355X: a 136 KiB launch runs and is correct)
 static size_t jit_lds_limit() {
-    static const size_t v = [] { const char *e = getenv("NDFFT_JIT_LDS_KB"); return (size_t)(e ? atoi(e) : 160) * 1024; }();
-    return v;
+    return (size_t)160 * 1024;
 }
 
 void jit_build_twiddles(const JitCfg &cfg, HostTable &out) {
@@ -220,11 +218,11 @@ namespace {
 // library with different kernel text never picks up a stale object.  Written to a temp file and renamed.
 const char *const kJitOpts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast"};
 std::string cache_dir() {
-    const char *e = getenv("NDFFT_JIT_CACHE");
+    const Switches &S = sw();                       // NDFFT_JIT_CACHE
     std::string d;
-    if (e) { if (!e[0] || !strcmp(e, "0")) return ""; d = e; }
-    else if (const char *x = getenv("XDG_CACHE_HOME")) d = std::string(x) + "/ndfft_mi355x";
-    else if (const char *h = getenv("HOME")) { const std::string c = std::string(h) + "/.cache"; (void)mkdir(c.c_str(), 0755); d = c + "/ndfft_mi355x"; }
+    if (S.jit_cache_set) { if (S.jit_cache.empty() || S.jit_cache == "0") return ""; d = S.jit_cache; }
+    else if (!S.xdg_cache_home.empty()) d = S.xdg_cache_home + "/ndfft_mi355x";
+    else if (!S.home.empty()) { const std::string c = S.home + "/.cache"; (void)mkdir(c.c_str(), 0755); d = c + "/ndfft_mi355x"; }
     else return "";
     if (mkdir(d.c_str(), 0755) != 0 && errno != EEXIST) return "";
     return d;
@@ -250,8 +248,8 @@ std::string cache_name(const std::string &src, const char *const *hs, int nh) {
 // 1025 -- tools/prebuild_jit.py writes it on an MI355X), so that a first nd* call on those never waits ~0.5 s for hiprtc.  Same file
 // names (hash of source + headers + options): an object built from other kernel text is simply not found.
 std::string prebuilt_path(const std::string &cache_file_path_or_name) {
-    static const std::string dir = [] {
-        if (const char *e = getenv("NDFFT_JIT_PREBUILT")) return (!e[0] || !strcmp(e, "0")) ? std::string() : std::string(e);
+    const std::string dir = [] {
+        if (sw().jit_prebuilt_set) return (sw().jit_prebuilt.empty() || sw().jit_prebuilt == "0") ? std::string() : sw().jit_prebuilt;   // NDFFT_JIT_PREBUILT
         Dl_info info;
         if (!dladdr((const void *)&fnv1a, &info) || !info.dli_fname) return std::string();
         std::string p = info.dli_fname;
@@ -298,9 +296,7 @@ static Entry compile_entry(const std::string &src, const std::string &what) {
             return ne;
         (void)hipGetLastError();
         ne = Entry();
-        if (const char *e = getenv("NDFFT_JIT_NOCOMPILE")) {      // test switch: cached code objects only
-            if (e[0] == '1') { ne.failed = true; return ne; }
-        }
+        if (sw().jit == 2) { ne.failed = true; return ne; }      // NDFFT_JIT=cached: cached / prebuilt code objects only
     }
     const char *hn[] = {"device_common.h", "butterflies.h", "pow2_kernel.h", "realops.h", "pow2_real.h", "blue_kernel.h", "reg_kernel.h", "rader_kernel.h", "plain_kernel.h"};
     const char *hs[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h, jit_src_realops_h, jit_src_pow2_real_h, jit_src_blue_kernel_h, jit_src_reg_kernel_h, jit_src_rader_kernel_h, jit_src_plain_kernel_h};
@@ -308,7 +304,7 @@ static Entry compile_entry(const std::string &src, const std::string &what) {
     bool ok = r.ok && r.create(&prog, src.c_str(), "k_jit.hip", 9, hs, hn) == 0;
     if (ok) {
         ok = r.compile(prog, 4, (const char **)kJitOpts) == 0;
-        if (!ok && getenv("NDFFT_JIT_VERBOSE")) {
+        if (!ok && sw().jit_verbose) {
             size_t ls = 0; r.log_size(prog, &ls);
             std::string log(ls, '\0'); r.log(prog, &log[0]);
             fprintf(stderr, "ndfft jit: compile of %s failed:\n%s\n", what.c_str(), log.c_str());
@@ -321,8 +317,8 @@ static Entry compile_entry(const std::string &src, const std::string &what) {
         const hipError_t e1 = hipModuleLoadData(&ne.mod, code.data());
         const hipError_t e2 = e1 == hipSuccess ? hipModuleGetFunction(&ne.fn, ne.mod, "k_jit") : e1;
         ok = e2 == hipSuccess;
-        if (!ok && getenv("NDFFT_JIT_VERBOSE")) fprintf(stderr, "ndfft jit: loading %s failed: %s\n", what.c_str(), hipGetErrorString(e2));
-    } else if (getenv("NDFFT_JIT_VERBOSE")) {
+        if (!ok && sw().jit_verbose) fprintf(stderr, "ndfft jit: loading %s failed: %s\n", what.c_str(), hipGetErrorString(e2));
+    } else if (sw().jit_verbose) {
         fprintf(stderr, "ndfft jit: no code object for %s (hiprtc %s)\n", what.c_str(), r.ok ? "present" : "missing");
     }
     if (ok) { const std::string path = cache_path(src, hs, 9); if (!path.empty()) write_file_atomic(path, code); }
@@ -382,7 +378,7 @@ int launch_jit_c2c(int dtype, const JitCfg &cfg_in, int nt, const Pow2Args &a, h
     const char *tn = dtype == NDFFT_F32 ? "float" : "double";
     // one-wave workgroups where a lane needs <= 64 threads: +1-4 % in alternating A-B-A-B runs (profiles/r04/r04s_abab_c2c_row.txt: 1000 / 264 / 1331 / 96 c128,
     // 1000 c64); 0 = the recipe's own lanes (256 threads)
-    static const int c2c_thr = [] { const char *e = getenv("NDFFT_JIT_C2C_ROW_THREADS"); return e ? atoi(e) : 64; }();
+    const int c2c_thr = (int)NDFFT_DEV_INT("NDFFT_JIT_C2C_ROW_THREADS", 64);
     JitCfg cfg = cfg_in;
     if (c2c_thr > 0 && cfg.row_lpb == 0) cfg.lpb = cfg.tpl >= c2c_thr ? 1 : std::max(1, c2c_thr / cfg.tpl);
     const int threads = cfg.tpl * cfg.lpb;
@@ -397,10 +393,10 @@ int launch_jit_c2c(int dtype, const JitCfg &cfg_in, int nt, const Pow2Args &a, h
     const std::string src = "#include \"pow2_kernel.h\"\nusing namespace ndfft;\nextern \"C\" __global__ __launch_bounds__(" +
                             std::to_string(threads) + ") void k_jit(const Pow2Args a) { " + inst + "::run(a); }\n";
     const Entry e = get_or_compile("dev" + std::to_string(dev) + ":" + inst, src, inst);
-    if (e.failed) { if (getenv("NDFFT_JIT_VERBOSE")) fprintf(stderr, "ndfft jit: %s unavailable\n", inst.c_str()); return NDFFT_ERR_UNSUPPORTED; }
+    if (e.failed) { if (sw().jit_verbose) fprintf(stderr, "ndfft jit: %s unavailable\n", inst.c_str()); return NDFFT_ERR_UNSUPPORTED; }
     const size_t esz = dtype == NDFFT_F32 ? 4 : 8;
     const size_t lds = (size_t)cfg.lpb * (size_t)(cfg.n + (cfg.n >> 4) + 1) * esz * (half ? 1 : 2);   // Pow2Kernel::LDS_BYTES
-    if (lds > jit_lds_limit()) { if (getenv("NDFFT_JIT_VERBOSE")) fprintf(stderr, "ndfft jit: %s needs %zu B of LDS\n", inst.c_str(), lds); return NDFFT_ERR_UNSUPPORTED; }
+    if (lds > jit_lds_limit()) { if (sw().jit_verbose) fprintf(stderr, "ndfft jit: %s needs %zu B of LDS\n", inst.c_str(), lds); return NDFFT_ERR_UNSUPPORTED; }
     const int64_t nblk = (a.nlanes + cfg.lpb - 1) / cfg.lpb;
     if (nblk <= 0) return NDFFT_OK;
     if (nblk > 0x7fffffffLL) return NDFFT_ERR_UNSUPPORTED;
@@ -428,8 +424,7 @@ int regfft_max_n(int dtype) {
     // measured (profiles/r03c_reg_kernel_sweep.txt): dense rows win up to n = 63 in both precisions (0.80 -> 0.50 of 8 TB/s; the
     // general register kernel takes over from n = 72: 0.65-0.86); strided axes up to 63 (f64: 0.73-0.86, n = 64 has its tile
     // kernel) and 96 (f32: 0.70-0.85 against 0.49-0.75)
-    static const int f32 = [] { const char *e = getenv("NDFFT_REG_MAX_F32"); return e ? atoi(e) : 96; }();
-    static const int f64 = [] { const char *e = getenv("NDFFT_REG_MAX_F64"); return e ? atoi(e) : 63; }();
+    const int f32 = (int)NDFFT_DEV_INT("NDFFT_REG_MAX_F32", 96), f64 = (int)NDFFT_DEV_INT("NDFFT_REG_MAX_F64", 63);
     return dtype == NDFFT_F32 ? f32 : f64;
 }
 int launch_jit_regfft(int dtype, int n1, int n2, bool stage, const TinyArgs &a, hipStream_t s) {
@@ -472,8 +467,7 @@ int launch_jit_regreal(int dtype, int gop, int n, int f1, int f2, bool stage, co
     const std::string inst = std::string("RegReal<") + tn + ", " + std::to_string(gop) + ", " + std::to_string(n) + ", " + std::to_string(f1) + ", " +
                              std::to_string(f2) + ", " + std::to_string(lanes) + ", " + (stage ? "true" : "false") + ">";
     // developer switch (read per call): NDFFT_REPRO_MASKED_TAIL=1 builds the predicated-tail form of the staging loads -- see reg_kernel.h
-    const char *rp = getenv("NDFFT_REPRO_MASKED_TAIL");
-    const bool repro = rp && rp[0] == '1';
+    const bool repro = NDFFT_DEV_INT("NDFFT_REPRO_MASKED_TAIL", 0) == 1;   // (developer build only: tools/repro_masked_tail.py)
     const std::string src = std::string(repro ? "#define NDFFT_REPRO_MASKED_TAIL 1\n" : "") + "#include \"reg_kernel.h\"\nusing namespace ndfft;\nextern \"C\" __global__ __launch_bounds__(" +
                             std::to_string(lanes) + ") void k_jit(const RegRealArgs a) { " + inst + "::run(a); }\n";
     const Entry e = get_or_compile("dev" + std::to_string(dev) + ":" + inst + (repro ? ":masked-tail" : ""), src, inst);
@@ -490,7 +484,7 @@ int launch_jit_regreal(int dtype, int gop, int n, int f1, int f2, bool stage, co
 
 // lanes per column tile of the specialised real-op / column kernel (0: no useful tile)
 int jit_col_lanes(int dtype, const JitCfg &cfg, bool c2c) {
-    if (const char *e = getenv("NDFFT_JIT_COL_LPB")) { const int l = atoi(e); return l * cfg.tpl <= 1024 ? l : 0; }   // developer knob
+    if (const char *e = NDFFT_DEV_STR("NDFFT_JIT_COL_LPB")) { const int l = atoi(e); return l * cfg.tpl <= 1024 ? l : 0; }   // developer knob
     // 8 adjacent lanes (f32: 16 where they fit): rows of 64-128 bytes that start on a 64-byte boundary.  Measured on 2^24 points (profiles/r04/
     // r04i_jit_col_lanes.txt): the former "as many as fit" gave 9 lanes for 1000x16384 c128 (144-byte rows) = 257 us, 8 lanes 137 us;
     // nddct2 1000x16384 f64 150 -> 80 us; 264x65536 c128 143 -> 127 us; n = 96 unchanged.
@@ -510,7 +504,7 @@ template <typename T> int launch_jit_real(int gop, const JitCfg &cfg, bool col, 
     const int dtype = sizeof(T) == 4 ? NDFFT_F32 : NDFFT_F64;
     // rows: one-wave workgroups where a lane needs <= 64 threads (alternating A-B-A-B runs, profiles/r04/r04s_abab_jit_row.txt: nddct2 f64 n = 100..2000 +5-19 %,
     // ndfft_r2c f32 +2-6 % against 256-thread workgroups)
-    static const int row_thr = [] { const char *e = getenv("NDFFT_JIT_ROW_THREADS"); return e ? atoi(e) : 64; }();   // developer knob
+    const int row_thr = (int)NDFFT_DEV_INT("NDFFT_JIT_ROW_THREADS", 64);
     const int lpb = col ? jit_col_lanes(dtype, cfg, gop == G_C2C_FWD || gop == G_C2C_INV) : cfg.row_lpb > 0 ? cfg.row_lpb : (cfg.tpl >= row_thr ? 1 : std::max(1, row_thr / cfg.tpl));
     if (lpb <= 0) return NDFFT_ERR_UNSUPPORTED;
     int dev = 0;
@@ -522,7 +516,7 @@ template <typename T> int launch_jit_real(int gop, const JitCfg &cfg, bool col, 
     // f32 kernels of >= 512 threads: floor of 8 waves per SIMD = 64 VGPRs (kernels_pow2_real.hip: RealAotWaves) -- but only where the specialised kernel FITS 64 registers:
     // the compiled code object is asked for its scratch size, and a recipe that spills falls back to the plain form (n = 1500: 2-3 x slower with the floor, n = 1000 / 2000:
     // 10-20 % faster, profiles/r06/r06zr_*).  NDFFT_JIT_F32_MIN_WAVES overrides the floor (1 = none; read once).
-    static const int f32_floor = [] { const char *e = getenv("NDFFT_JIT_F32_MIN_WAVES"); return e ? atoi(e) : 8; }();
+    const int f32_floor = (int)NDFFT_DEV_INT("NDFFT_JIT_F32_MIN_WAVES", 8);
     const int floor_w = (sizeof(T) == 4 && threads >= 512 && f32_floor > 1 && gop != G_DCT3_EVEN) ? f32_floor : 1;
     auto make_src = [&](int w) {
         return std::string("#include \"pow2_real.h\"\nusing namespace ndfft;\nextern \"C\" __global__ __launch_bounds__(") + std::to_string(threads) +
@@ -583,7 +577,7 @@ template int launch_jit_plain<double>(int, const JitCfg &, bool, const RealArgs<
 template <typename T> int launch_jit_blue(int gop, const JitCfg &cfg, bool col, const RealArgs<T> &a, hipStream_t s) {
     if (!rtc().ok) return NDFFT_ERR_UNSUPPORTED;
     const int dtype = sizeof(T) == 4 ? NDFFT_F32 : NDFFT_F64;
-    static const int row_thr = [] { const char *e = getenv("NDFFT_BLUE_ROW_THREADS"); return e ? atoi(e) : 256; }();   // developer knob
+    const int row_thr = (int)NDFFT_DEV_INT("NDFFT_BLUE_ROW_THREADS", 256);
     const int lpb = col ? jit_col_lanes(dtype, cfg) : cfg.row_lpb > 0 ? cfg.row_lpb : (cfg.tpl >= row_thr ? 1 : std::max(1, row_thr / cfg.tpl));
     if (lpb <= 0) return NDFFT_ERR_UNSUPPORTED;
     int dev = 0;
@@ -609,10 +603,7 @@ template <typename T> int launch_jit_blue(int gop, const JitCfg &cfg, bool col, 
     return NDFFT_OK;
 }
 // ---- Rader / Good-Thomas kernel (rader_kernel.h) ---------------------------------------------------------------------
-static bool rader_enabled() {   // developer / test switch: NDFFT_RADER=0 keeps every such length on Bluestein (read per call)
-    const char *e = getenv("NDFFT_RADER");
-    return !(e && e[0] == '0');
-}
+static bool rader_enabled() { return sw().rader; }   // NDFFT_RADER=0 keeps every such length on Bluestein
 static size_t rader_lane_lds(const RaderCfg &rc, bool col) {   // complex elements per lane = RaderKernel::LANE_LDS
     const size_t M = (size_t)rc.p - 1, F = (size_t)rc.p * rc.mc;
     const size_t sub = M + (M >> 4) + 2, lane = std::max((size_t)rc.mc * sub, F + (F >> 4) + 3);
@@ -623,7 +614,7 @@ static size_t rader_lane_lds(const RaderCfg &rc, bool col) {   // complex elemen
 // <= 64 threads (no real barriers: 127 c128 150 -> 121 us, 511 c128 125 -> 110 us), otherwise the fullest waves with the fewest of them.
 static int row_lanes_by_fill(int lt, size_t lane, int forced, double *util_out);
 static int rader_row_lanes_for(int dtype, const RaderCfg &rc, double *util_out) {
-    const int forced = [] { const char *e = getenv("NDFFT_RADER_LPB"); return e ? atoi(e) : 0; }();
+    const int forced = (int)NDFFT_DEV_INT("NDFFT_RADER_LPB", 0);
     return row_lanes_by_fill(rc.fft.tpl * rc.mc, rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8), forced, util_out);
 }
 static int rader_row_lanes(int dtype, const RaderCfg &rc) { return rader_row_lanes_for(dtype, rc, nullptr); }
@@ -730,8 +721,7 @@ static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg
 // profiles/r04/r04zg_abab_shortplan.txt)
 bool jit_choose_real(int dtype, int F, JitCfg &cfg) {
     if (!jit_choose(dtype, F, cfg, true)) return false;
-    static const bool on = [] { const char *e = getenv("NDFFT_JIT_REALPLAN"); return !(e && e[0] == '0'); }();
-    if (on && !getenv("NDFFT_JIT_CFG") && F < 128 && cfg.e > 8 && cfg.row_lpb == 0) {
+    if (!NDFFT_DEV_STR("NDFFT_JIT_CFG") && F < 128 && cfg.e > 8 && cfg.row_lpb == 0) {
         const size_t lane = (size_t)((F + (F >> 4) + 3) & ~1) * 2 * (dtype == NDFFT_F32 ? 4 : 8);
         JitCfg alt;
         if (plan_fft_by_cost(dtype, F, 1, lane, alt)) { alt.vec = 1; alt.row_lpb = alt.lpb; cfg = alt; }
@@ -749,8 +739,7 @@ static int min_passes(int m) {
     return best;
 }
 int blue_pick_len(int dtype, int F, int m_pow2) {
-    static const bool on = [] { const char *e = getenv("NDFFT_BLUE_SMOOTH"); return !(e && e[0] == '0'); }();
-    if (!on || jit_disabled()) return m_pow2;
+    if (jit_disabled()) return m_pow2;
     // shortlist by passes x length, then the register planner's own cost (passes x work / wave fill + penalties) x length decides; the power of two
     // competes with its E = 8 recipe: passes x length (+ 5 %: a smooth length must win clearly)
     // Measured (profiles/r04/r04y_abab_blue_smooth.txt): per point the mixed-radix passes cost about 1.3x the power-of-two E = 8 recipe, so a smooth length only
@@ -809,7 +798,7 @@ bool rader_choose(int dtype, int F, RaderCfg &rc) {
       if (wide && mc * ((p - 1) / wide) < 6) return false; }
     rc.p = p; rc.mc = mc;
     if (rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8) > jit_lds_limit()) return false;
-    if (const char *e = getenv("NDFFT_RADER_CFG")) {     // developer knob (tools/probes/rader_tune.py): "tpl:r0.r1.r2" for FFT_(p-1), read per plan
+    if (const char *e = NDFFT_DEV_STR("NDFFT_RADER_CFG")) {     // developer knob (tools/probes/rader_tune.py): "tpl:r0.r1.r2" for FFT_(p-1), read per plan
         JitCfg &c = rc.fft;
         c = JitCfg(); c.n = p - 1; c.tpl = atoi(e);
         const char *q = strchr(e, ':');
@@ -823,7 +812,7 @@ bool rader_choose(int dtype, int F, RaderCfg &rc) {
 }
 int rader_col_lanes(int dtype, const RaderCfg &rc) {
     const int lt = rc.fft.tpl * rc.mc;
-    if (const char *e = getenv("NDFFT_RADER_COL_LPB")) { const int l = atoi(e); return l * lt <= 1024 ? l : 0; }   // developer knob
+    if (const char *e = NDFFT_DEV_STR("NDFFT_RADER_COL_LPB")) { const int l = atoi(e); return l * lt <= 1024 ? l : 0; }   // developer knob
     // whole multiples of 8 adjacent lanes (64-byte rows in f64): measured 512x65536 f64 DCT-I 16 lanes 260 us (8: 284, 12: 375), 1009x16384 c128
     // 8 lanes 207 us (9: 321), 127x131072 c64 24 lanes 87 us (8: 93, 16: 100, 32: 96)
     const size_t lane = rader_lane_lds(rc, true) * 2 * (dtype == NDFFT_F32 ? 4 : 8);

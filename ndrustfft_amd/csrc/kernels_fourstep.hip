@@ -70,8 +70,8 @@ template <typename T, int F, int OP, int CS, bool ROWOUT> static int launch_fs(c
 // 16 x 2^20 282 -> 261 us (profiles/r06/r06zv_*); c64: slower (32 x 2^20 372 -> 542 us: a wavefront of 8-16 lanes writes 32-64-byte runs in the transposing pass) and stays on
 // the staged kernels.  NDFFT_FS_DIRECT=0 / 1 forces one form (read per call: the parity tests switch it).
 template <typename T> static bool fs_direct() {
-    const char *e = getenv("NDFFT_FS_DIRECT");
-    return e ? e[0] == '1' : sizeof(T) == 8;
+    const int f = sw().fs_direct;                    // NDFFT_FS_DIRECT
+    return f >= 0 ? f == 1 : sizeof(T) == 8;
 }
 template <typename T, int F, int OP, int MODE> static int launch_fsd(const RealArgs<T> &a, hipStream_t s) {
     constexpr int LPB = FsGeom<T, F>::LPB;

@@ -76,8 +76,8 @@ template <typename T, int F, int STAGE> static int launch_rfs(const RealArgs<T> 
 // stages 2 / 3 on the lane-fastest register kernels of col_direct.h: f64 by default (64 x 262144 nddct2 187 -> 155 us with runs of tiles per XCD
 // and plain stores at shared lines), f32 stays on the staged column kernels above (120 vs 127 us); NDFFT_FS_DIRECT=0 / 1 forces one form
 template <typename T> static bool rfs_direct() {
-    const char *e = getenv("NDFFT_FS_DIRECT");   // (read per call: the parity tests switch it)
-    return e ? e[0] == '1' : sizeof(T) == 8;
+    const int f = sw().fs_direct;                    // NDFFT_FS_DIRECT
+    return f >= 0 ? f == 1 : sizeof(T) == 8;
 }
 template <typename T, int F, int STAGE> static int launch_rfsd(const RealArgs<T> &a, hipStream_t s) {
     constexpr int LPB = RfsGeom<T, F, 2>::LPB;

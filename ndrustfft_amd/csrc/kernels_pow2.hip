@@ -102,7 +102,7 @@ void pow2_build_twiddles(int dtype, int n, HostTable &out) {
 // 4096 x 4096 6.58 -> 6.85 TB/s; runs of 128 KiB .. 8 MiB are within 2 % of each other, one eighth of the array per
 // XCD is worse when cold.  NDFFT_XCD_CHUNK_KB overrides the run length (0 = identity map).
 int xcd_chunk_for(size_t block_bytes, int64_t nblk) {
-    static const long kb = [] { const char *e = getenv("NDFFT_XCD_CHUNK_KB"); return e ? atol(e) : 512L; }();
+    const long kb = NDFFT_DEV_INT("NDFFT_XCD_CHUNK_KB", 512);
     if (kb <= 0 || block_bytes == 0) return 0;
     if (block_bytes >= ((size_t)256 << 10)) return 0;   // one workgroup already streams >= 256 KiB (n = 16384): the map only cost there (0.54 -> 0.50)
     int64_t c = (int64_t)((size_t)kb * 1024 / block_bytes);
@@ -116,7 +116,7 @@ int xcd_chunk_for(size_t block_bytes, int64_t nblk) {
 // 0.86 vs 0.74 of the roofline), if not they cost 6 % (0.70 vs 0.74) -- the asymmetric bet; a 268 MB input that the bench loop
 // re-reads (cfg3-B) still ran 88 us with plain loads vs 99 us streaming, hence the margin above 256 MiB.  NDFFT_STREAM_LOADS=0/1 forces it.
 bool stream_loads_for(size_t in_bytes) {
-    static const int force = [] { const char *e = getenv("NDFFT_STREAM_LOADS"); return e ? atoi(e) : -1; }();
+    const int force = sw().stream_loads;             // NDFFT_STREAM_LOADS
     if (force >= 0) return force != 0;
     return in_bytes > ((size_t)384 << 20);
 }
@@ -126,7 +126,7 @@ bool stream_loads_for(size_t in_bytes) {
 // Measured A-B-A-B on 2^24 points (profiles/r05/r05d_psplit_abab.txt): c64 n = 16384 65.5 -> 56.5 us (0.51 -> 0.59 of 8 TB/s), c64 n = 8192 51.8 -> 48.0 us
 // (0.65 -> 0.70); c128 n = 16384 unchanged (126 VGPRs x 1024 threads: registers, not LDS, keep it at one workgroup per CU), c128 n = 8192 -2 %.
 template <typename T, int N> struct Pow2PSplit { static constexpr int value = (sizeof(T) == 4 && N >= 8192) ? 2 : 1; };
-static int psplit_override() { static const int v = [] { const char *e = getenv("NDFFT_PSPLIT"); return e ? atoi(e) : 0; }(); return v; }
+static int psplit_override() { return (int)NDFFT_DEV_INT("NDFFT_PSPLIT", 0); }
 
 template <typename T, int N, int NT, int VEC, int FL, int PS> static int launch_inst_ps(const Pow2Args &a0, hipStream_t s) {
     constexpr int TPL = Pow2Cfg<T, N>::TPL, LPB = lpb_for(TPL);
@@ -140,7 +140,7 @@ template <typename T, int N, int NT, int VEC, int FL, int PS> static int launch_
     Pow2Args a = a0;
     a.xcd_chunk = xcd_chunk_for((size_t)LPB * N * sizeof(cpx<T>), nblk);
     // developer knob (A/B only): extra dynamic LDS per workgroup = fewer resident workgroups per CU
-    static const size_t pad = [] { const char *e = getenv("NDFFT_POW2_LDS_PAD_KB"); return e ? (size_t)atoi(e) << 10 : (size_t)0; }();
+    const size_t pad = (size_t)NDFFT_DEV_INT("NDFFT_POW2_LDS_PAD_KB", 0) << 10;
     hipLaunchKernelGGL(k_pow2<K>, dim3((unsigned)nblk), dim3(K::THREADS), std::min(K::LDS_BYTES + pad, (size_t)160 * 1024), s, a);
     NDFFT_HIP(hipGetLastError());
     return NDFFT_OK;

@@ -88,7 +88,7 @@ template <typename K, typename T> static int launch_k(const RealArgs<T> &a, int 
         if (a.inner > 1) {
             // column tiles: consecutive tiles are adjacent pieces of the SAME rows; 4 per XCD run (1 KiB of every row) measured
             // +3 % on cfg4' warm, +1 % cold, 16 / 64 nothing (profiles/r02n_xcd_map_real_kernels.txt); row kernels: neutral at n = 512
-            static const int col = [] { const char *e = getenv("NDFFT_XCD_CHUNK_COL"); return e ? atoi(e) : 4; }();
+            const int col = (int)NDFFT_DEV_INT("NDFFT_XCD_CHUNK_COL", 4);
             b.xcd_chunk = nblk >= 16 * (int64_t)std::max(col, 1) ? col : 0;
         } else {
             const size_t esz = sizeof(T) * (K::IN_CPLX ? 2 : 1);

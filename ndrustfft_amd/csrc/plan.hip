@@ -379,7 +379,7 @@ static void add_colsplit(ndfft_plan *p) {
     //   f32: C2C from n = 2048 (narrow tiles 135 us -> 110 us), R2C from n = 4096 (137 -> 57 us), C2R from n = 2048 (95 -> 55 us; n = 4096: 98 -> 58 us)
     const bool f32 = p->dtype == NDFFT_F32, c2c = p->kind == NDFFT_KIND_C2C;
     size_t lo_fwd = c2c ? (f32 ? 32 : 64) : (f32 ? 64 : 128), lo_inv = c2c ? lo_fwd : (f32 ? 32 : 128);
-    if (const char *e = getenv(c2c ? "NDFFT_CS_LO_C2C" : "NDFFT_CS_LO_R2C")) lo_fwd = lo_inv = (size_t)atoi(e);   // developer knob
+    if (const char *e = c2c ? NDFFT_DEV_STR("NDFFT_CS_LO_C2C") : NDFFT_DEV_STR("NDFFT_CS_LO_R2C")) lo_fwd = lo_inv = (size_t)atoi(e);   // developer knob
     const size_t lo = std::min(lo_fwd, lo_inv), hi = c2c ? 1024 : 2048;
     if (F1 < lo || F1 > hi) return;
     FftConfig &c = p->cfg[CFG_MAIN];
@@ -415,7 +415,7 @@ static void add_real_fourstep(ndfft_plan *p) {
     if (e - a > 10) a = e - 10;
     if (e - a < 6) a = e - 6;
     c.rfs_ops = f32 ? ((e <= 19 ? 1 : 0) | (e <= 20 ? 2 | 4 : 0) | 8) : 15;
-    if (const char *k = getenv("NDFFT_RFS_LOGN1")) { const int v = atoi(k); if (v >= 7 && v <= 11) a = v; }   // developer knob (A/B of the split)
+    if (const int v = sw().rfs_logn1; v >= 7 && v <= 11) a = v;   // NDFFT_RFS_LOGN1 (parity tests of every split)
     const int b = e - a;
     if (b < 6 || b > 10 || !fourstep_real_supported(1 << a, 1 << b)) return;
     c.rfs = true; c.rfs_N1 = 1 << a; c.rfs_N2 = 1 << b;
@@ -516,9 +516,65 @@ int get_dev_tables(const ndfft_plan *cplan, const DevTables **out) {
 
 using namespace ndfft;
 
+// ---- environment switches (switches.h): parsed once -----------------------------------------------------------------
+namespace ndfft {
+namespace {
+std::atomic<const Switches *> g_sw{nullptr};
+std::mutex g_sw_mu;
+const Switches *parse_switches() {
+    Switches *S = new Switches();
+    auto str = [](const char *name, bool &set, std::string &v) { const char *e = getenv(name); set = e != nullptr; v = e ? e : ""; };
+    auto on = [](const char *name, bool def) { const char *e = getenv(name); return e ? e[0] != '0' : def; };       // "0" closes, anything else opens
+    auto one = [](const char *name) { const char *e = getenv(name); return e && e[0] == '1'; };                      // only "1" enables
+    auto num = [](const char *name, long def) { const char *e = getenv(name); return e ? atol(e) : def; };
+    if (const char *e = getenv("NDFFT_JIT")) S->jit = e[0] == '0' ? 0 : !strcmp(e, "cached") ? 2 : 1;
+    str("NDFFT_JIT_CACHE", S->jit_cache_set, S->jit_cache);
+    str("NDFFT_JIT_PREBUILT", S->jit_prebuilt_set, S->jit_prebuilt);
+    S->jit_verbose = getenv("NDFFT_JIT_VERBOSE") != nullptr;
+    if (const char *e = getenv("XDG_CACHE_HOME")) S->xdg_cache_home = e;
+    if (const char *e = getenv("HOME")) S->home = e;
+    S->wave = on("NDFFT_WAVE", true); S->tiny = on("NDFFT_TINY", true); S->plain = on("NDFFT_PLAIN", true); S->blue = on("NDFFT_BLUE", true);
+    S->rader = on("NDFFT_RADER", true); S->colsplit = on("NDFFT_COLSPLIT", true); S->fourstep2 = on("NDFFT_FOURSTEP2", true);
+    S->real_fourstep = (int)num("NDFFT_REAL_FOURSTEP", 1);
+    if (const char *e = getenv("NDFFT_FS_DIRECT")) S->fs_direct = e[0] == '1' ? 1 : 0;
+    S->narrow_dct = one("NDFFT_NARROW_DCT");
+    S->rfs_c2r_tile = on("NDFFT_RFS_C2R_TILE", true);
+    S->rfs_logn1 = (int)num("NDFFT_RFS_LOGN1", 0);
+    S->cs_chunk_mb = (int)num("NDFFT_CS_CHUNK_MB", 144);
+    S->stream_loads = (int)num("NDFFT_STREAM_LOADS", -1);
+    if (const char *e = getenv("NDFFT_HOST_PIPE")) S->host_pipe = e[0] == '1' ? 1 : e[0] == '0' ? 0 : -1;
+    S->host_reg_cache_mb = num("NDFFT_HOST_REG_CACHE_MB", 0);
+    S->copy_threads = (int)num("NDFFT_COPY_THREADS", 0);
+    if (const char *e = getenv("NDFFT_SHARD_CHUNK_KB")) S->shard_chunk_kb = std::max(1L, atol(e));
+    S->shard_force_remote = one("NDFFT_SHARD_FORCE_REMOTE");
+    return S;
+}
+}  // namespace
+const Switches &sw() {
+    const Switches *p = g_sw.load(std::memory_order_acquire);
+    if (__builtin_expect(p != nullptr, 1)) return *p;
+    std::lock_guard<std::mutex> g(g_sw_mu);
+    p = g_sw.load(std::memory_order_relaxed);
+    if (!p) { p = parse_switches(); g_sw.store(p, std::memory_order_release); }
+    return *p;
+}
+void reload_switches() {
+    std::lock_guard<std::mutex> g(g_sw_mu);
+    g_sw.store(parse_switches(), std::memory_order_release);     // (the previous struct is leaked on purpose: another thread may still hold a reference)
+}
+}  // namespace ndfft
+
 extern "C" {
 
 int ndfft_abi_version(void) { return NDFFT_ABI_VERSION; }
+int ndfft_reload_switches(void) { ndfft::reload_switches(); return NDFFT_OK; }
+int ndfft_documented_switches(char *buf, size_t cap) {
+    static const char *const names[] = {NDFFT_DOCUMENTED_SWITCHES};
+    std::string s;
+    for (const char *n : names) { s += n; s += '\n'; }
+    if (buf && cap) { const size_t k = std::min(cap - 1, s.size()); memcpy(buf, s.data(), k); buf[k] = 0; }
+    return (int)s.size();
+}
 const char *ndfft_last_error(void) { return last_err().c_str(); }
 const char *ndfft_last_path(void) { return last_path(); }
 

@@ -235,8 +235,8 @@ int ensure_peer_access(int a, int b) {
 }
 
 size_t shard_chunk_bytes() {   // developer / test switch: bytes of input per pipelined chunk of a block (default 64 MiB)
-    const char *e = getenv("NDFFT_SHARD_CHUNK_KB");
-    return e ? (size_t)std::max(1, atoi(e)) << 10 : (size_t)64 << 20;
+    const long kb = sw().shard_chunk_kb;             // NDFFT_SHARD_CHUNK_KB
+    return kb > 0 ? (size_t)kb << 10 : (size_t)64 << 20;
 }
 
 struct RemoteBlock {
@@ -442,8 +442,7 @@ int ndfft_exec_sharded_device(const ndfft_plan *plan, int op, const void *d_in, 
         }
         // developer / test switch: NDFFT_SHARD_FORCE_REMOTE=1 sends the root's own blocks through the scatter / gather pipeline too, so that a
         // one-GPU box exercises the pack / unpack kernels, the streams and the events (a peer copy to the same device is a device copy)
-        const char *fr = getenv("NDFFT_SHARD_FORCE_REMOTE");
-        const bool remote = rb.dev != rb.root || (fr && fr[0] == '1');
+        const bool remote = rb.dev != rb.root || sw().shard_force_remote;
         fs.push_back(worker_for(b.device).submit([rb, remote]() { return remote ? run_remote_block(rb) : run_root_block(rb); }));
     }
     return collect(fs);

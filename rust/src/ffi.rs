@@ -60,6 +60,8 @@ extern "C" {
     pub fn ndfft_release_workspace() -> c_int;
     /// Diagnostic: text description of the recipes a handler of (kind, dtype, n) would use; needs no GPU.
     pub fn ndfft_explain_plan(kind: c_int, dtype: c_int, n: usize, buf: *mut c_char, buflen: usize) -> c_int;
+    pub fn ndfft_documented_switches(buf: *mut c_char, buflen: usize) -> c_int;
+    pub fn ndfft_reload_switches() -> c_int;
     // device-resident arrays (no reference counterpart)
     pub fn ndfft_exec_device(
         plan: *const ndfft_plan, op: c_int, d_input: *const c_void, d_output: *mut c_void, ndim: c_int,

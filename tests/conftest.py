@@ -33,3 +33,18 @@ def blvec():
     """Independent truths at the BASELINE lane lengths 4096 / 8192 / 16384 / 512 (tests/golden/make_golden_baseline.py):
     numpy / scipy on every lane, long-double O(n^2) definitions on lane 0, mpmath on 12 bins of lane 0."""
     return np.load(os.path.join(ROOT, "tests", "golden", "baseline_lengths.npz"))
+
+
+@pytest.fixture(autouse=True)
+def _reload_library_switches():
+    """The library parses its NDFFT_* switches once (csrc/switches.h); a test that changed the environment (monkeypatch.setenv + reload_switches)
+    must not leak its setting into the next test: reload after every test, for whichever builds of the library this process has loaded."""
+    yield
+    lib_mod = sys.modules.get("ndrustfft_amd._lib")
+    if lib_mod is None:
+        return
+    for lib in list(getattr(lib_mod, "_loaded", [])):
+        try:
+            lib.c.ndfft_reload_switches()
+        except Exception:
+            pass

@@ -1,6 +1,8 @@
 // TEST INFRASTRUCTURE ONLY -- fiber scheduler behind tests/emul/hip/hip_runtime.h.
 #include <ucontext.h>
 
+#include <atomic>
+
 #include <cstdio>
 #include <map>
 #include <mutex>
@@ -135,11 +137,21 @@ hipError_t hipHostUnregister(void *p) {
     std::lock_guard<std::mutex> g(g_reg_mu);
     return g_reg.erase((char *)p) ? 0 : 713;
 }
+// test hook: the next n hipMemcpyAsync calls that touch a registered host range fail with "invalid argument" -- what the MI355X runtime does when a
+// registration has outlived its array (tests of the registration cache's retry through the bounce buffers)
+namespace { std::atomic<int> g_fail_reg_copies{0}; }
+extern "C" void emul_fail_registered_copies(int n) { g_fail_reg_copies = n; }
+bool emul_copy_should_fail(const void *a, const void *b) {
+    if (g_fail_reg_copies.load() <= 0) return false;
+    if (!emul_host_registered(a) && !emul_host_registered(b)) return false;
+    return g_fail_reg_copies.fetch_sub(1) > 0;
+}
 bool emul_host_registered(const void *p) {
     std::lock_guard<std::mutex> g(g_reg_mu);
     for (auto &kv : g_reg) if ((const char *)p >= kv.first && (const char *)p < kv.first + kv.second) return true;
     return false;
 }
+extern "C" int emul_is_registered(const void *p) { return emul_host_registered(p) ? 1 : 0; }
 extern "C" size_t emul_host_registered_bytes() {
     std::lock_guard<std::mutex> g(g_reg_mu);
     size_t b = 0;

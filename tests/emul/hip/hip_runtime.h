@@ -87,7 +87,8 @@ enum { hipErrorPeerAccessAlreadyEnabled = 704 };
 hipError_t hipDeviceCanAccessPeer(int *can, int dev, int peer);
 hipError_t hipDeviceEnablePeerAccess(int peer, unsigned flags);
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
-inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t) { return hipMemcpy(d, s, n, k); }
+bool emul_copy_should_fail(const void *a, const void *b);   // emul_runtime.cpp: injected failures of copies on registered host ranges
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t) { if (emul_copy_should_fail(d, s)) return 1; return hipMemcpy(d, s, n, k); }
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
 inline hipError_t hipHostFree(void *p) { free(p); return 0; }
 enum { hipHostRegisterDefault = 0 };

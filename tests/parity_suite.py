@@ -2,6 +2,7 @@
 through the C ABI) and tests/test_emul_parity.py (the same sources compiled for the host through
 tests/emul, CPU container).  Every case compares against the CPU oracle on the same seeded inputs
 and/or the committed golden vectors.  Tolerances are BASELINE.json's: 1e-10 (f64), 1e-4 (f32)."""
+import contextlib
 import os
 
 import numpy as np
@@ -25,6 +26,25 @@ OPS = {
     "nddct3": (api.nddct3, orc.nddct3, "DctHandler", False, False),
     "nddct4": (api.nddct4, orc.nddct4, "DctHandler", False, False),
 }
+
+
+
+@contextlib.contextmanager
+def switches(L, **env):
+    """Environment switches of the library for the duration of a block.  The library parses its switches ONCE (csrc/switches.h), so a
+    change only takes effect through ndfft_reload_switches() -- a test hook, never called while another thread transforms."""
+    old = {k: os.environ.get(k) for k in env}
+    for k, v in env.items():
+        if v is None: os.environ.pop(k, None)
+        else: os.environ[k] = str(v)
+    L.reload_switches()
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+        L.reload_switches()
 
 
 def handlers_for(name, n, rdt, L, norm="Default"):
@@ -286,16 +306,10 @@ def host_pipeline_pageable(L, shapes=None):
         odt = cdt_of(rdt) if OPS[name][4] else np.dtype(rdt)
         h, o = handlers_for(name, shape[axis], rdt, L)
         y1 = np.zeros(sout, odt); y2 = np.zeros(sout, odt); yo = np.zeros(sout, odt)
-        os.environ["NDFFT_HOST_PIPE"] = "1"                      # force the pipeline whatever the size
-        try:
+        with switches(L, NDFFT_HOST_PIPE="1"):                   # force the pipeline whatever the size
             OPS[name][0](x, y1, h, axis)
-        finally:
-            del os.environ["NDFFT_HOST_PIPE"]
-        os.environ["NDFFT_HOST_PIPE"] = "0"
-        try:
+        with switches(L, NDFFT_HOST_PIPE="0"):
             OPS[name][0](x, y2, h, axis)
-        finally:
-            del os.environ["NDFFT_HOST_PIPE"]
         assert np.abs(y1 - y2).max() <= 50 * np.finfo(rdt).eps * np.abs(y2).max(), (name, shape)
         OPS[name][1](x, yo, o, axis)
         assert_close(y1, yo, axis, TOL[np.dtype(rdt)], f"host pipeline {name} {shape}")
@@ -303,11 +317,8 @@ def host_pipeline_pageable(L, shapes=None):
     xb = synth.complex_array((600, 1100)); x = xb[:, :1024]
     yb = np.full((600, 1030), 9.0 + 0j); y = yb[:, :1024]
     h = handlers.FftHandler(1024, _library=L)
-    os.environ["NDFFT_HOST_PIPE"] = "1"
-    try:
+    with switches(L, NDFFT_HOST_PIPE="1"):
         api.ndfft(x, y, h, 1)
-    finally:
-        del os.environ["NDFFT_HOST_PIPE"]
     yo = np.zeros((600, 1024), np.complex128); orc.ndfft(np.ascontiguousarray(x), yo, orc.FftHandler(1024), 1)
     assert_close(y, yo, 1, 1e-10, "host path, padded rows"); assert np.all(yb[:, 1024:] == 9.0)
 
@@ -411,20 +422,12 @@ def wave_short_lanes(L):
     x = synth.complex_array((9, 80))[:, :64]; y = np.zeros((9, 64), np.complex128); yo = np.zeros_like(y)
     api.ndfft(x, y, handlers.FftHandler(64, _library=L), 1); orc.ndfft(np.ascontiguousarray(x), yo, orc.FftHandler(64), 1)
     assert_close(y, yo, 1, 1e-10, "padded rows n=64")
-    old = os.environ.get("NDFFT_WAVE")
-    os.environ["NDFFT_WAVE"] = "0"
-    try:
+    with switches(L, NDFFT_WAVE="0"):
         for rdt in (np.float64, np.float32):
             assert run_case(L, "ndfft", (37, 64), 1, rdt) == "pow2_reg"
             assert run_case(L, "ndifft", (37, 16), 1, rdt) == "tiny_row"
-            os.environ["NDFFT_TINY"] = "0"
-            try:
+            with switches(L, NDFFT_TINY="0"):
                 assert run_case(L, "ndifft", (37, 16), 1, rdt) == "generic_row"
-            finally:
-                del os.environ["NDFFT_TINY"]
-    finally:
-        if old is None: del os.environ["NDFFT_WAVE"]
-        else: os.environ["NDFFT_WAVE"] = old
 
 
 def sharded_exec(L, device_ids, torch_device=None):
@@ -677,12 +680,9 @@ def long_strided_lanes(L):
              ("ndfft_r2c", (8192, 40), 0, np.float32, "transpose+pow2_real"), ("ndifft_r2c", (8192, 20), 0, np.float32, "transpose+pow2_real"),
              ("nddct2", (3, 4096, 17), 1, np.float64, "transpose+pow2_real"), ("ndfft", (3000, 33), 0, np.float64, "transpose+generic_row"),
              ("nddct3", (2, 4000, 16), 1, np.float32, "transpose+generic_row"))
-    os.environ["NDFFT_COLSPLIT"] = "0"          # (the column four-step would take the first four)
-    try:
+    with switches(L, NDFFT_COLSPLIT="0"):       # (the column four-step would take the first four)
         for name, shape, axis, rdt, want in cases:
             assert run_case(L, name, shape, axis, rdt) == want, (name, shape)
-    finally:
-        del os.environ["NDFFT_COLSPLIT"]
 
 
 def pow2_real_sizes(L, sizes=(64, 128, 256, 512, 1024, 2048, 4096, 8192), dtypes=(np.float64, np.float32)):
@@ -747,13 +747,8 @@ def long_lanes_four_step(L, full=True):
     # half spectrum, then twiddled complex FFTs of length N2 writing X[k] / conj at the mirrored index (DCT-II: y[k], y[n-k]); staged and lane-fastest
     # kernels for pass 2, the packed route it replaces, and f32 R2C forced through it
     def with_env(env, fn):
-        old = {k: os.environ.get(k) for k in env}
-        os.environ.update(env)
-        try: return fn()
-        finally:
-            for k, v in old.items():
-                if v is None: del os.environ[k]
-                else: os.environ[k] = v
+        with switches(L, **env):
+            return fn()
     for norm in ("Default", "None"):
         for name in ("ndfft_r2c", "ndifft_r2c", "nddct2", "nddct3"):
             assert run_case(L, name, (2, 1 << 16), 1, np.float64, norm=norm) == "real_four_step", name
@@ -801,14 +796,9 @@ def long_lanes_four_step(L, full=True):
         for norm in ("Default", "None"):
             assert run_case(L, name, (3, 32768), 1, np.float64, norm=norm) == "four_step"
             assert run_case(L, name, (5, 65536), 1, np.float32, norm=norm) == "four_step"
-    old = os.environ.get("NDFFT_FOURSTEP2")
-    os.environ["NDFFT_FOURSTEP2"] = "0"
-    try:
+    with switches(L, NDFFT_FOURSTEP2="0"):
         assert run_case(L, "ndfft", (2, 32768), 1, np.float64) == "four_step"
         assert run_case(L, "ndifft", (2, 65536), 1, np.float32) == "four_step"
-    finally:
-        if old is None: del os.environ["NDFFT_FOURSTEP2"]
-        else: os.environ["NDFFT_FOURSTEP2"] = old
     # long lanes in an arbitrary strided layout (stepped + reversed input view, padded output view): pack -> rows -> unpack
     n = 1 << 15
     big = synth.complex_array((3, 2 * n)); x = big[::-1, ::2]
@@ -839,9 +829,8 @@ def pow2_col_sizes(L, sizes=(64, 128, 256, 512, 1024), dtypes=(np.float64, np.fl
                     split = name == "ndifft_r2c" and np.dtype(rdt) == np.float32 and n == 2048 and shape[-1] >= 16
                     assert run_case(L, name, shape, axis, rdt, offset=F) == ("col_split" if split else "pow2_col"), (name, shape)
                     if split:
-                        os.environ["NDFFT_COLSPLIT"] = "0"
-                        try: assert run_case(L, name, shape, axis, rdt, offset=F) == "pow2_col", (name, shape)
-                        finally: del os.environ["NDFFT_COLSPLIT"]
+                        with switches(L, NDFFT_COLSPLIT="0"):
+                            assert run_case(L, name, shape, axis, rdt, offset=F) == "pow2_col", (name, shape)
 
 
 def shared_handler_across_threads(L, nthreads=8):
@@ -877,18 +866,12 @@ def narrow_xcd_tiles(L):
     dct_cases = (("nddct2", (2, 4096, 130), 1, np.float64), ("nddct1", (4097, 64), 0, np.float32), ("nddct3", (4096, 1000), 0, np.float64), ("nddct4", (8192, 96), 0, np.float32))
     for name, shape, axis, rdt in dct_cases:
         assert run_case(L, name, shape, axis, rdt).startswith("transpose+"), (name, shape)
-    os.environ["NDFFT_NARROW_DCT"] = "1"
-    try:
+    with switches(L, NDFFT_NARROW_DCT="1"):
         for name, shape, axis, rdt in dct_cases:
             assert run_case(L, name, shape, axis, rdt) == "pow2_col_xcd", (name, shape)
-    finally:
-        del os.environ["NDFFT_NARROW_DCT"]
-    os.environ["NDFFT_COLSPLIT"] = "0"          # the column four-step would take the C2C / R2C / C2R cases
-    try:
+    with switches(L, NDFFT_COLSPLIT="0"):       # the column four-step would take the C2C / R2C / C2R cases
         for name, shape, axis, rdt in cases:
             assert run_case(L, name, shape, axis, rdt) == "pow2_col_xcd", (name, shape)
-    finally:
-        del os.environ["NDFFT_COLSPLIT"]
     # round 3: f64 lanes whose OUTPUT rows are complex take ordinary column tiles of 4 lanes (64-byte rows) at inner lengths 1024 / 2048 instead
     # (c128 n = 2048: narrow tiles 216 us -> 157 us; f64 R2C n = 4096: 132 -> 83 us); real output rows keep the 8-lane minimum
     for name, shape, axis, rdt, want in (("ndifft", (2048, 200), 0, np.float64, "pow2_col"), ("ndfft", (3, 2048, 10), 1, np.float64, "pow2_col"), ("ndfft", (1024, 21), 0, np.float64, "pow2_col"),
@@ -920,24 +903,18 @@ def column_four_step(L):
     # too few adjacent lanes for a wide tile: narrow tiles / transpose route as before
     assert run_case(L, "ndfft", (4096, 8), 0, np.float64) != "col_split"
     # column chunks (Infinity-Cache-resident intermediate): force small chunks so that these shapes split
-    os.environ["NDFFT_CS_CHUNK_MB"] = "1"
-    try:
+    with switches(L, NDFFT_CS_CHUNK_MB="1"):
         for name, shape, rdt in (("ndfft_r2c", (8192, 200), np.float32), ("ndifft_r2c", (8192, 136), np.float32),
                                  ("ndfft", (4096, 100), np.float64), ("ndifft", (8192, 150), np.float32)):
             assert run_case(L, name, shape, 0, rdt) == "col_split", (name, shape)
-    finally:
-        del os.environ["NDFFT_CS_CHUNK_MB"]
 
 
 def bluestein_register_kernel(L, sizes=((17, 64), (31, 64), (97, 256), (127, 256)), col_max_M=256):
     """Lengths with a prime factor > 13 on the register-resident Bluestein kernel (blue_kernel.h): every op
     family incl. the odd-n variants, rows and column tiles.  `sizes` = (F, M): inner FFT length F, M = 2^k >= 2F-1.
     (NDFFT_RADER=0: lengths that have a Rader recipe would otherwise go to rader_kernel.h -- see rader_kernel below.)"""
-    os.environ["NDFFT_RADER"] = "0"
-    try:
+    with switches(L, NDFFT_RADER="0"):
         _bluestein_register_kernel(L, sizes, col_max_M)
-    finally:
-        del os.environ["NDFFT_RADER"]
 
 
 def odd_real_lengths(L, sizes=(45,), dct4=False):

@@ -66,7 +66,7 @@ def test_sharded_device_resident_views_with_holes(L):
 
 def test_sharded_device_resident_chunk_pipeline(L, monkeypatch):
     """Blocks cut into many pipelined chunks (scatter of chunk c+1 beside the transform of chunk c and the gather of chunk c-1; two buffer slots)."""
-    monkeypatch.setenv("NDFFT_SHARD_CHUNK_KB", "4")
+    monkeypatch.setenv("NDFFT_SHARD_CHUNK_KB", "4"); L.reload_switches()                  # (conftest reloads again after the test)
     ps.dev_sharded_case(L, "ndfft", (61, 64), 1, root=1, ids=[0, 1, 2], repeats=2)          # contiguous spans, uneven chunks
     ps.dev_sharded_case(L, "ndfft", (64, 90), 0, root=0, ids=[1, 2], repeats=2)             # packed, many chunks
     ps.dev_sharded_case(L, "nddct2", (40, 32, 3), 1, root=2, ids=[0, 1], out_view=((40, 32, 6), np.s_[:, :, ::2]), repeats=2)
@@ -83,11 +83,8 @@ def test_infinity_cache_residency_model(L):
     def dev_buf(rows):
         p = ctypes.c_void_p(); L.check(L.c.ndfft_dev_alloc(ctypes.byref(p), rows * n * 16)); return p
     def fft(src, dst, rows, op=_lib.OP_C2C_FWD):
-        os.environ["NDFFT_WAVE"] = "0"          # n = 64 on the register row kernel (pow2_reg), the one the model serves
-        try:
+        with ps.switches(L, NDFFT_WAVE="0"):    # n = 64 on the register row kernel (pow2_reg), the one the model serves
             L.check(L.c.ndfft_exec_device(h._plan, op, src, dst, 2, api_mod._i64((rows, n)), api_mod._i64((n, 1)), api_mod._i64((rows, n)), api_mod._i64((n, 1)), 1, _lib.NORM_DEFAULT, 0.0, None))
-        finally:
-            del os.environ["NDFFT_WAVE"]
         assert L.last_path() == "pow2_reg", L.last_path()
         return L.c.ndfft_last_input_policy()
     big = (72 << 20) // (n * 16)                 # 72 MiB arrays: outputs above the 64 MiB line
@@ -153,6 +150,49 @@ def test_host_registration_cache_lru(L):
     finally:
         L.check(L.c.ndfft_host_reg_cache(0))
     assert reg() == 0
+
+
+def test_host_registration_cache_keeps_hot_arrays_and_retries_stale_ones(L):
+    """Round 4 (advisor): steady-state calls go through the cache BEFORE is_pinned, so (1) a hot pair's LRU stamp stays fresh -- with room for two
+    pairs, pair A used again and again survives the registration of pair C, the idle pair B is the one evicted; (2) a copy that fails on a
+    cache-owned registration (injected: what a stale registration does on the MI355X) makes the call forget the ranges and finish through the
+    bounce buffers, with the right answer."""
+    import ctypes
+    import synth
+    from ndrustfft_amd import api, handlers
+    from oracle import oracle_ctypes as orc
+    L.c.emul_host_registered_bytes.restype = ctypes.c_size_t
+    isreg = lambda a: bool(L.c.emul_is_registered(ctypes.c_void_p(a.ctypes.data)))
+    n = 1024; h = handlers.FftHandler(n, _library=L); o = orc.FftHandler(n)
+    def pair(k):
+        x = synth.complex_array((520, n), offset=1000 * k); y = np.zeros_like(x); yo = np.zeros_like(x); orc.ndfft(x, yo, o, 1)
+        return x, y, yo
+    (xa, ya, yoa), (xb, yb, yob), (xc, yc, yoc) = pair(0), pair(1), pair(2)
+    L.check(L.c.ndfft_host_reg_cache(4 * xa.nbytes + 4096))                # room for two pairs
+    try:
+        for _ in range(2): api.ndfft(xa, ya, h, 1)
+        for _ in range(2): api.ndfft(xb, yb, h, 1)
+        assert isreg(xa) and isreg(ya) and isreg(xb) and isreg(yb)
+        for _ in range(10):                                                # A is hot: every call must refresh its stamp
+            ya[...] = 0; api.ndfft(xa, ya, h, 1)
+            assert np.abs(ya - yoa).max() <= 1e-10 * np.abs(yoa).max()
+        for _ in range(2): api.ndfft(xc, yc, h, 1)                         # registering C needs room: the idle pair B goes
+        assert isreg(xc) and isreg(yc)
+        assert isreg(xa) and isreg(ya), "the hot pair was evicted"
+        assert not isreg(xb) and not isreg(yb)
+        assert L.c.emul_host_registered_bytes() <= 4 * xa.nbytes + 4096
+        # a stale registration: the first async copy on a registered range fails; the call recovers through the bounce buffers
+        L.c.emul_fail_registered_copies(1)
+        ya[...] = 0; api.ndfft(xa, ya, h, 1)
+        L.c.emul_fail_registered_copies(0)
+        assert np.abs(ya - yoa).max() <= 1e-10 * np.abs(yoa).max()
+        assert not isreg(xa) and not isreg(ya), "the failing ranges were not forgotten"
+        ya[...] = 0; api.ndfft(xa, ya, h, 1)                               # and the pair is usable (and registrable) again
+        assert np.abs(ya - yoa).max() <= 1e-10 * np.abs(yoa).max()
+    finally:
+        L.c.emul_fail_registered_copies(0)
+        L.check(L.c.ndfft_host_reg_cache(0))
+    assert L.c.emul_host_registered_bytes() == 0
 
 
 def test_interleaved_mut_views(L): ps.interleaved_mut_views_two_threads(L, rounds=1)

@@ -59,7 +59,7 @@ ndfft(xb, yb, FftHandler(n), 1); p3 = _lib.default().last_path()
 torch.cuda.synchronize()
 print("PATHS", p1, p2, p3)
 """ % (ROOT, os.path.join(ROOT, "tests"))
-    env = dict(os.environ, NDFFT_JIT_CACHE="0", NDFFT_JIT_NOCOMPILE="1")
+    env = dict(os.environ, NDFFT_JIT_CACHE="0", NDFFT_JIT="cached")
     env.pop("NDFFT_JIT_PREBUILT", None)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -67,31 +67,18 @@ print("PATHS", p1, p2, p3)
     assert line[1:] == ["jit_col", "jit_col", "jit_reg"], f"prebuilt code objects missing or stale (paths {line[1:]}): run tools/prebuild_jit.py on an MI355X"
 
 
-def test_masked_tail_loads_reproducer(L):
-    """RegReal's tail workgroup clamps its staging addresses because predicated loads into AGPR-spilled registers lost values on the
-    MI355X (n = 40, 48 in f64).  The product form must be right; the predicated form (tools/repro_masked_tail.py, NDFFT_REPRO_MASKED_TAIL=1) is built
-    too and its outcome recorded: the day it is right as well, the compiler has been fixed and the clamp can go (a warning, not a failure)."""
+def test_regreal_tail_workgroup(L):
+    """RegReal's tail workgroup clamps its staging addresses (predicated loads into AGPR-spilled registers once lost values on the
+    MI355X, n = 40, 48 in f64): the product form on a partial last workgroup.  The predicated form is no longer in the product library
+    (round 4: it is compiled only in a developer build, `make DEV=1`; tools/repro_masked_tail.py)."""
     import sys
-    import warnings
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import repro_masked_tail as rp
-    old = os.environ.get("NDFFT_REPRO_MASKED_TAIL")
-    try:
-        outcome = {}
-        for n in (40, 48):
-            lanes = 65536 // n * 2 + 37
-            path, err = rp.run_case(n, lanes, masked=False)
-            assert path == "regreal_row", path
-            assert err.max() <= 1e-10, f"product (clamped) form wrong for n={n}: {err.max()}"
-            path, err = rp.run_case(n, lanes, masked=True)
-            outcome[n] = int((err > 1e-10).sum())
-        if all(v == 0 for v in outcome.values()):
-            warnings.warn("predicated tail loads into AGPR-spilled registers are now CORRECT on this toolchain: reg_kernel.h's address clamp is no longer needed")
-        else:
-            print("masked-tail reproducer: wrong lanes per n:", outcome)
-    finally:
-        if old is None: os.environ.pop("NDFFT_REPRO_MASKED_TAIL", None)
-        else: os.environ["NDFFT_REPRO_MASKED_TAIL"] = old
+    for n in (40, 48):
+        lanes = 65536 // n * 2 + 37
+        path, err = rp.run_case(n, lanes, masked=False)
+        assert path == "regreal_row", path
+        assert err.max() <= 1e-10, f"product (clamped) form wrong for n={n}: {err.max()}"
 
 
 def test_host_registration_cache(L):
@@ -135,7 +122,7 @@ def test_sharded_device_resident_pipeline_on_one_gpu(L, monkeypatch):
     """ndfft_exec_sharded_device's scatter -> transform -> gather pipeline (pack / unpack kernels on the root, per-device streams, events, two buffer
     slots) on real hardware: with one GPU per lease every block lives on the root, so NDFFT_SHARD_FORCE_REMOTE sends them through the pipeline anyway.
     Blocks interleaved in memory (axis 0 of a C-contiguous array), output views with holes (sentinels must survive), many small chunks."""
-    monkeypatch.setenv("NDFFT_SHARD_FORCE_REMOTE", "1")
+    monkeypatch.setenv("NDFFT_SHARD_FORCE_REMOTE", "1"); L.reload_switches()     # (conftest reloads again after the test)
     n = L.c.ndfft_device_count()
     ids = list(range(n)) if n > 1 else [0, 0, 0]
     ps.dev_sharded_case(L, "ndfft", (64, 300), 0, root=0, ids=ids, repeats=5)
@@ -144,7 +131,7 @@ def test_sharded_device_resident_pipeline_on_one_gpu(L, monkeypatch):
     ps.dev_sharded_case(L, "ndfft", (9, 16, 6), 1, root=0, ids=ids, out_view=((9, 16, 12), np.s_[::-1, :, 1::2]), in_view=((18, 16, 6), np.s_[::2]), repeats=3)
     ps.dev_sharded_case(L, "ndfft", (4096, 512), 1, root=0, ids=ids, repeats=2)                     # contiguous spans, 16 MiB
     ps.dev_sharded_case(L, "ndfft", (512, 4096), 0, root=0, ids=ids, repeats=2)                     # packed images, 16 MiB
-    monkeypatch.setenv("NDFFT_SHARD_CHUNK_KB", "256")
+    monkeypatch.setenv("NDFFT_SHARD_CHUNK_KB", "256"); L.reload_switches()
     ps.dev_sharded_case(L, "ndfft", (4096, 512), 1, root=0, ids=ids, repeats=2)                     # ~22 chunks per block through two slots
     ps.dev_sharded_case(L, "nddct2", (300, 64, 40), 1, root=0, ids=ids, out_view=((300, 64, 80), np.s_[:, :, ::2]), repeats=2)
 
@@ -403,15 +390,15 @@ assert np.abs(y - np.fft.fft(x, axis=1)).max() / np.abs(y).max() < 1e-12
 print("CALL_S", dt)
 ''' % (ROOT, ROOT)
     env = dict(os.environ, NDFFT_JIT_CACHE=str(tmp_path))
-    # second process: compiling is forbidden (NDFFT_JIT_NOCOMPILE=1), so "jit_reg" can only come from the cached code object
-    for extra in ({}, {"NDFFT_JIT_NOCOMPILE": "1"}):
+    # second process: compiling is forbidden (NDFFT_JIT=cached), so "jit_reg" can only come from the cached code object
+    for extra in ({}, {"NDFFT_JIT": "cached"}):
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, **extra), timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         files = [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]
         assert len(files) == 1, files
     # and without a cache the same switch sends the call to the LDS kernel (the assert inside the child fails)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
-                       env=dict(os.environ, NDFFT_JIT_CACHE="0", NDFFT_JIT_NOCOMPILE="1"), timeout=600)
+                       env=dict(os.environ, NDFFT_JIT_CACHE="0", NDFFT_JIT="cached"), timeout=600)
     assert r.returncode != 0 and "AssertionError" in r.stderr, r.stdout[-500:] + r.stderr[-1500:]
 
 

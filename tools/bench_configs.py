@@ -42,6 +42,59 @@ def timeit(fn, steps, warmup=5, ramp_ms=None):
 
 
 PAIRS = 1   # --pairs K: rotate K distinct (in, out) pairs so that every launch finds its input in HBM, not in the Infinity Cache
+ROWS = []   # every row printed by this process (for --compare)
+REP = 0
+
+
+def gpu_state():
+    """Best-effort snapshot of the GPU's clocks and power from sysfs (readable without privileges): a compute-bound row measured at a lower
+    core clock is a different measurement, and the table should say so (round 3's 154 vs 124 us for the same Rader row in one run)."""
+    import glob
+    out = {}
+    try:
+        for h in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            def rd(name):
+                try:
+                    return int(open(os.path.join(h, name)).read().strip())
+                except Exception:
+                    return None
+            f = [rd(f"freq{i}_input") for i in range(1, 11)]
+            lab = []
+            for i in range(1, 11):
+                try:
+                    lab.append(open(os.path.join(h, f"freq{i}_label")).read().strip())
+                except Exception:
+                    lab.append(None)
+            sclk = [v for v, l in zip(f, lab) if v and l and l.startswith("sclk")]
+            mclk = [v for v, l in zip(f, lab) if v and l and l.startswith("mclk")]
+            if sclk:
+                out["sclk_mhz"] = round(sum(sclk) / len(sclk) / 1e6); out["sclk_min_mhz"] = round(min(sclk) / 1e6)
+            if mclk:
+                out["mclk_mhz"] = round(mclk[0] / 1e6)
+            pw = rd("power1_average") or rd("power1_input")
+            if pw:
+                out["power_w"] = round(pw / 1e6)
+            if out:
+                break
+    except Exception:
+        pass
+    return out
+
+
+def emit(row):
+    row["rep"] = REP
+    row.update(gpu_state())
+    ROWS.append(row)
+    print(json.dumps(row), flush=True)
+
+
+def set_switch(name, value):
+    """The library parses its environment switches once: change + ndfft_reload_switches (csrc/switches.h)."""
+    if value is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = value
+    _lib.default().reload_switches()
 
 
 def run(name, fn, x, y, h, axis, points, steps):
@@ -57,14 +110,71 @@ def run(name, fn, x, y, h, axis, points, steps):
         t = timeit(lambda: fn(x, y, h, axis), steps)
     nbytes = x.numel() * x.element_size() + y.numel() * y.element_size()
     gbs = nbytes / t / 1e9
-    print(json.dumps({"workload": name, "us": round(t * 1e6, 2), "GFFT-points/s": round(points / t / 1e9, 2),
-                      "algorithmic_bytes": nbytes, "GB/s": round(gbs, 1), "frac_of_8TBs": round(gbs / PEAK, 4),
-                      "path": _lib.default().last_path()}), flush=True)
+    L = _lib.default()
+    emit({"workload": name, "us": round(t * 1e6, 2), "GFFT-points/s": round(points / t / 1e9, 2),
+          "algorithmic_bytes": nbytes, "GB/s": round(gbs, 1), "frac_of_8TBs": round(gbs / PEAK, 4),
+          "path": L.last_path(), "policy": L.last_input_policy()})
+
+
+def compare(rows, prev_path, tol):
+    """--compare: every row of this run against the same workload in an earlier table.  Prints the table's own noise first (each row is
+    timed --repeat times, far apart: the spread between the repeats is what a difference must exceed to mean anything), then fails (exit 1)
+    on any row whose BEST time is more than `tol` slower than the earlier table's best."""
+    prev = {}
+    for line in open(prev_path):
+        line = line.strip()
+        if line.startswith("{"):
+            r = json.loads(line)
+            if "workload" in r and "us" in r:
+                prev[r["workload"]] = min(prev.get(r["workload"], 1e30), r["us"])
+    cur = {}
+    for r in rows:
+        cur.setdefault(r["workload"], []).append(r)
+    noise = []
+    for w, rs in cur.items():
+        if len(rs) > 1:
+            us = [r["us"] for r in rs]
+            noise.append((max(us) / min(us) - 1, w, us))
+    if noise:
+        noise.sort(reverse=True)
+        med = sorted(n[0] for n in noise)[len(noise) // 2]
+        print(f"# noise of this table (max/min - 1 over {len(next(iter(cur.values())))} repeats): median {med * 100:.1f} %, worst:", file=sys.stderr)
+        for n, w, us in noise[:8]:
+            print(f"#   {n * 100:5.1f} %  {w}  {us}", file=sys.stderr)
+    bad = []; matched = 0
+    for w, rs in cur.items():
+        if w not in prev:
+            continue
+        matched += 1
+        best = min(r["us"] for r in rs)
+        if best > prev[w] * (1 + tol):
+            bad.append((best / prev[w] - 1, w, prev[w], best, rs[0].get("path"), [r.get("sclk_mhz") for r in rs]))
+    print(f"# compared {matched} rows with {prev_path}: {len(bad)} slower by more than {tol * 100:.0f} %", file=sys.stderr)
+    for d, w, a, b, path, clk in sorted(bad, reverse=True):
+        print(f"#   +{d * 100:5.1f} %  {w}: {a} -> {b} us  path={path} sclk={clk}", file=sys.stderr)
+    return 1 if bad else 0
 
 
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=50); ap.add_argument("--only", default=""); ap.add_argument("--ramp-ms", type=float, default=150.0); ap.add_argument("--pairs", type=int, default=1); ap.add_argument("--preheat-s", type=float, default=0.0)
+    ap.add_argument("--repeat", type=int, default=1, help="run the whole selected table this many times, one after the other (rows carry `rep`): the spread between repeats is the table's noise")
+    ap.add_argument("--compare", default="", help="an earlier table (jsonl): exit 1 if any row's best time is more than --tolerance slower than there")
+    ap.add_argument("--tolerance", type=float, default=0.06)
+    ap.add_argument("--rows-from", default="", help="with --compare: do not measure, compare this table (jsonl) instead (runs anywhere, no GPU)")
     a = ap.parse_args()
+    if a.rows_from:
+        rows = [json.loads(l) for l in open(a.rows_from) if l.strip().startswith("{")]
+        sys.exit(compare([r for r in rows if "workload" in r and "us" in r], a.compare, a.tolerance))
+    global REP
+    rc = 0
+    for REP in range(max(1, a.repeat)):
+        table(a)
+    if a.compare:
+        rc = compare(ROWS, a.compare, a.tolerance)
+    sys.exit(rc)
+
+
+def table(a):
     if a.preheat_s > 0:
         # The FIRST process on a fresh box runs LDS- / latency-bound kernels 15-25 % slower for its first tens of seconds (core clock; HBM-bound kernels are
         # unaffected): `nddct1` cfg4 234 us in the first process, 184 us in every later one (profiles/r04/r04s_abab_pow2real_cfg4.txt).  Keep the GPU busy first.
@@ -164,13 +274,13 @@ def main():
         return
     if a.only == "rader2":
         for rad in ("1", "0"):
-            os.environ["NDFFT_RADER"] = rad
+            set_switch("NDFFT_RADER", rad)
             for n, cdt, rdt in ((306, np.complex128, np.float64), (513, np.complex128, np.float64), (532, np.complex128, np.float64), (2336, np.complex128, np.float64),
                                 (103, np.complex128, np.float64), (137, np.complex128, np.float64), (2466, np.complex128, np.float64), (513, np.complex64, np.float32), (103, np.complex64, np.float32)):
                 rows = (1 << 24) // n
                 x = torch.from_numpy(synth.complex_array((rows, n), cdt)).to(dev); y = torch.empty_like(x)
                 run(f"rader2[NDFFT_RADER={rad}] ndfft axis=1 {rows}x{n} {np.dtype(cdt).name}", ndfft, x, y, FftHandler(n, rdt), 1, x.numel(), a.steps)
-        del os.environ["NDFFT_RADER"]
+        set_switch("NDFFT_RADER", None)
         return
     if a.only == "r2crows":
         for n in (256, 1024, 8192):
@@ -192,7 +302,7 @@ def main():
         return
     if a.only == "oddreal":
         for v in ("1", "0"):
-            os.environ["NDFFT_PLAIN"] = v
+            set_switch("NDFFT_PLAIN", v)
             for n in (63, 125, 243, 625, 1001, 3003):
                 rows = (1 << 24) // n
                 x = torch.from_numpy(synth.real_array((rows, n))).to(dev); y = torch.empty_like(x)
@@ -201,7 +311,7 @@ def main():
                 run(f"oddreal[NDFFT_PLAIN={v}] ndfft_r2c axis=1 {rows}x{n} f32", ndfft_r2c, xf, w, R2cFftHandler(n, np.float32), 1, xf.numel(), a.steps)
             x = torch.from_numpy(synth.real_array((625, 16384))).to(dev); y = torch.empty_like(x)
             run(f"oddreal[NDFFT_PLAIN={v}] nddct2 axis=0 625x16384 f64", nddct2, x, y, DctHandler(625), 0, x.numel(), a.steps)
-        del os.environ["NDFFT_PLAIN"]
+        set_switch("NDFFT_PLAIN", None)
         return
     if a.only == "shortplan":
         for n in (72, 80, 96, 100, 120, 144, 160, 200, 250):
@@ -255,12 +365,12 @@ def main():
         return
     if a.only == "raderbig":
         for rad in ("1", "0"):
-            os.environ["NDFFT_RADER"] = rad
+            set_switch("NDFFT_RADER", rad)
             for n, cdt, rdt in ((8191, np.complex128, np.float64), (7001, np.complex128, np.float64), (8191, np.complex64, np.float32), (16001, np.complex64, np.float32)):
                 rows = (1 << 24) // n
                 x = torch.from_numpy(synth.complex_array((rows, n), cdt)).to(dev); y = torch.empty_like(x)
                 run(f"raderbig[NDFFT_RADER={rad}] ndfft axis=1 {rows}x{n} {np.dtype(cdt).name}", ndfft, x, y, FftHandler(n, rdt), 1, x.numel(), max(a.steps // 4, 3))
-        del os.environ["NDFFT_RADER"]
+        set_switch("NDFFT_RADER", None)
         return
     if a.only == "radersweep":
         for n, cdt, rdt in ((1009, np.complex128, np.float64), (127, np.complex128, np.float64), (511, np.complex128, np.float64), (2017, np.complex128, np.float64),
@@ -274,7 +384,7 @@ def main():
     if want("primes"):
         # lengths with a prime factor > 13: Rader / Good-Thomas (rader_kernel.h) against Bluestein (NDFFT_RADER=0)
         for rad in ("1", "0"):
-            os.environ["NDFFT_RADER"] = rad
+            set_switch("NDFFT_RADER", rad)
             tag = "rader" if rad == "1" else "bluestein"
             for n, cdt, rdt in ((1009, np.complex128, np.float64), (97, np.complex128, np.float64), (127, np.complex128, np.float64), (257, np.complex128, np.float64),
                                 (511, np.complex128, np.float64), (2017, np.complex128, np.float64), (4001, np.complex128, np.float64), (3027, np.complex128, np.float64),
@@ -288,7 +398,7 @@ def main():
             run(f"primes[{tag}] nddct1 axis=0 512x65536 f64", nddct1, x, y, DctHandler(512), 0, x.numel(), a.steps)
             x = torch.from_numpy(synth.real_array((16384, 2018))).to(dev); y = torch.empty((16384, 1010), dtype=torch.complex128, device=dev)
             run(f"primes[{tag}] ndfft_r2c axis=1 16384x2018 f64", ndfft_r2c, x, y, R2cFftHandler(2018), 1, x.numel(), a.steps)
-        del os.environ["NDFFT_RADER"]
+        set_switch("NDFFT_RADER", None)
     if want("generic"):
         for n in (1000, 264, 1331, 1009, 3000, 96):
             rows = (1 << 24) // n
@@ -309,9 +419,9 @@ def main():
                 ndfft(_x, w, _h, 1); ndfft(w, _y, _h, 0)
             t = timeit(lambda: fft2(x, y, h, 0), a.steps)
             nbytes = 4 * x.numel() * x.element_size()
-            print(json.dumps({"workload": f"fft2 {n}x{n} {np.dtype(cdt).name} (axis 1 then axis 0, work array in HBM)", "us": round(t * 1e6, 1),
-                              "GFFT-points/s": round(2 * x.numel() / t / 1e9, 1), "algorithmic_bytes(2 passes)": nbytes,
-                              "GB/s": round(nbytes / t / 1e9, 1), "frac_of_8TBs": round(nbytes / t / 1e9 / PEAK, 4)}), flush=True)
+            emit({"workload": f"fft2 {n}x{n} {np.dtype(cdt).name} (axis 1 then axis 0, work array in HBM)", "us": round(t * 1e6, 1),
+                  "GFFT-points/s": round(2 * x.numel() / t / 1e9, 1), "algorithmic_bytes(2 passes)": nbytes,
+                  "GB/s": round(nbytes / t / 1e9, 1), "frac_of_8TBs": round(nbytes / t / 1e9 / PEAK, 4), "path": _lib.default().last_path()})
     if want("refbench"):
         for n in (128, 264, 512, 1024):
             x = torch.from_numpy(synth.bench_fill_complex((n, n))).to(dev); y = torch.empty_like(x)

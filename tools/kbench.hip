@@ -1,7 +1,7 @@
 // tools/kbench.hip -- developer microbenchmark (not part of the product library).
 // Times variants of the register-resident pow2 kernel and copy kernels with the same access
 // pattern on one MI355X, interleaved rounds in ONE process (guide rule 24), HIP events.
-//   build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -I ndrustfft_amd/csrc tools/kbench.hip -o tools/kbench
+//   build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=fast -I ndrustfft_amd/csrc -I tools tools/kbench.hip -o tools/kbench
 #include <hip/hip_runtime.h>
 #include <unistd.h>
 
@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "pow2_kernel.h"
+#include "pow2_persist.h"
 
 using namespace ndfft;
 
@@ -73,6 +74,65 @@ template <typename K, typename T, typename RL> static Variant fft_variant(const 
     return v;
 }
 
+// persistent, software-pipelined form (pow2_persist.h): grid = wg_per_cu x CUs workgroups (0 = what the occupancy query allows)
+template <typename K, typename T, typename RL> static Variant persist_variant(const char *name, const void *in, void *out, int64_t lanes, int n, int wg_per_cu, int xcd_chunk, int rot) {
+    using P = Pow2Persist<K>;
+    HostTable t; build_tw<RL>(t);
+    void *tw = upload_tw<T>(t);
+    CK(hipFuncSetAttribute((const void *)k_pow2_persist<P>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    int occ = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_pow2_persist<P>, P::THREADS, P::LDS_BYTES));
+    hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0));
+    const int per = wg_per_cu > 0 ? wg_per_cu : occ;
+    Pow2Args a; a.in = in; a.out = out; a.nlanes = lanes; a.pitch_in = n; a.pitch_out = n; a.inverse = 0; a.scale = 1.0; a.twp = tw; a.xcd_chunk = xcd_chunk;
+    const int per_blk = K::THREADS / (n / K::E);
+    const unsigned nblk = (unsigned)((lanes + per_blk - 1) / per_blk);
+    const unsigned grid = std::min<unsigned>(nblk, (unsigned)(per * pr.multiProcessorCount));
+    static char nm[64][96]; static int ni = 0;
+    snprintf(nm[ni], 96, "%s [occ %d, grid %u]", name, occ, grid);
+    Variant v; v.name = nm[ni++];
+    static size_t counter = 0;
+    const size_t pair_bytes = (size_t)lanes * n * 2 * sizeof(T);
+    v.launch = [=]() {
+        Pow2Args b = a;
+        const size_t k = rot > 1 ? (counter++ % (size_t)rot) : 0;
+        b.in = (const char *)a.in + k * pair_bytes; b.out = (char *)a.out + k * pair_bytes;
+        hipLaunchKernelGGL(k_pow2_persist<P>, dim3(grid), dim3(P::THREADS), P::LDS_BYTES, 0, b);
+    };
+    v.bytes = 2.0 * lanes * n * 2 * sizeof(T);
+    v.check = true;
+    return v;
+}
+
+// dynamic persistent grid (pow2_persist.h: Pow2Dyn): wg_per_cu x CUs workgroups take lane blocks from per-XCD counters
+template <typename K, typename T, typename RL> static Variant dyn_variant(const char *name, const void *in, void *out, int64_t lanes, int n, int wg_per_cu, int xcd_chunk, int rot) {
+    using D = Pow2Dyn<K>;
+    HostTable t; build_tw<RL>(t);
+    void *tw = upload_tw<T>(t);
+    CK(hipFuncSetAttribute((const void *)k_pow2_dyn<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    int occ = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_pow2_dyn<D>, D::THREADS, D::LDS_BYTES));
+    hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0));
+    const int per = wg_per_cu > 0 ? wg_per_cu : occ;
+    static unsigned *ctr = nullptr;
+    if (!ctr) { CK(hipMalloc(&ctr, 4096)); CK(hipMemset(ctr, 0, 4096)); }
+    Pow2Args a; a.in = in; a.out = out; a.nlanes = lanes; a.pitch_in = n; a.pitch_out = n; a.inverse = 0; a.scale = 1.0; a.twp = tw; a.xcd_chunk = xcd_chunk;
+    const unsigned grid = std::min<unsigned>((unsigned)lanes, (unsigned)(per * pr.multiProcessorCount)) & ~7u;
+    static char nm[64][96]; static int ni = 0;
+    snprintf(nm[ni], 96, "%s [occ %d, grid %u]", name, occ, grid);
+    Variant v; v.name = nm[ni++];
+    static size_t counter = 0;
+    const size_t pair_bytes = (size_t)lanes * n * 2 * sizeof(T);
+    unsigned *c = ctr;
+    v.launch = [=]() {
+        Pow2Args b = a;
+        const size_t k = rot > 1 ? (counter++ % (size_t)rot) : 0;
+        b.in = (const char *)a.in + k * pair_bytes; b.out = (char *)a.out + k * pair_bytes;
+        hipLaunchKernelGGL(k_pow2_dyn<D>, dim3(grid), dim3(D::THREADS), D::LDS_BYTES, 0, b, c);
+    };
+    v.bytes = 2.0 * lanes * n * 2 * sizeof(T);
+    v.check = true;
+    return v;
+}
+
 template <typename T> struct Bench {
     int n; int64_t lanes; int rounds; int rot = 1;
     cpx<T> *din, *dout, *dref;
@@ -89,6 +149,8 @@ template <typename T> struct Bench {
         CK(hipMemcpy(din, h.data(), elems * sizeof(cpx<T>), hipMemcpyHostToDevice));
     }
     template <typename K, typename RL> void add(const char *name, int xcd_chunk = 0) { vs.push_back(fft_variant<K, T, RL>(name, din, dout, lanes, n, 0, xcd_chunk, rot)); }
+    template <typename K, typename RL> void addp(const char *name, int wg_per_cu, int xcd_chunk) { vs.push_back(persist_variant<K, T, RL>(name, din, dout, lanes, n, wg_per_cu, xcd_chunk, rot)); }
+    template <typename K, typename RL> void addd(const char *name, int wg_per_cu, int xcd_chunk) { vs.push_back(dyn_variant<K, T, RL>(name, din, dout, lanes, n, wg_per_cu, xcd_chunk, rot)); }
     void run(double tol) {
         const size_t elems = (size_t)lanes * n;
         vs[0].launch(); CK(hipDeviceSynchronize());
@@ -212,6 +274,25 @@ int main(int argc, char **argv) {
         VC("1024x4 4.4.4.4.4.4 nt1", 1024, 1, 0, 1, 1, 4, 4, 4, 4, 4, 4);
         VC("ABLATE load+store only", 512, 1, 7, 1, 1, 8, 8, 8, 8);
         VC("ABLATE no LDS exchange", 512, 1, 2, 1, 1, 8, 8, 8, 8);
+        b.run(1e-12);
+    } else if (what == "f64_persist") {
+        // persistent software-pipelined grid (pow2_persist.h) against the product kernel; lanes = 4096 with rot = 6 is bench.py's cache-cold region
+        const int64_t lanes = argc > 3 ? atoll(argv[3]) : 4096;
+        Bench<double> b{4096, lanes, rounds}; b.rot = argc > 4 ? atoi(argv[4]) : 6; b.init();
+        using RL8 = RadixList<8, 8, 8, 8>;
+        using K1 = Pow2Kernel<double, 4096, 512, 1, true, RL8, 16, 1, 1, 1>;
+        using K3 = Pow2Kernel<double, 4096, 512, 1, true, RL8, 16, 1, 3, 1>;
+        using K1w4 = Pow2Kernel<double, 4096, 512, 1, true, RL8, 16, 4, 1, 1>;
+        using K3w4 = Pow2Kernel<double, 4096, 512, 1, true, RL8, 16, 4, 3, 1>;
+        b.template add<K1, RL8>("product nt1 chunk 8", 8);
+        b.template add<K3, RL8>("product nt3 chunk 8", 8);
+        b.template addd<K3, RL8>("dyn nt3 c8 4/CU", 0, 8);
+        b.template addd<K1, RL8>("dyn nt1 c8 4/CU", 0, 8);
+        b.template addd<K3, RL8>("dyn nt3 c8 3/CU", 3, 8);
+        b.template addd<K3, RL8>("dyn nt3 c32 4/CU", 0, 32);
+        b.template addp<K3w4, RL8>("persist nt3 c8", 0, 8);
+        b.template addp<K3w4, RL8>("persist nt3 c32", 0, 32);
+        b.template add<K3, RL8>("product nt3 chunk 8 (again)", 8);
         b.run(1e-12);
     } else if (what == "f64_map") {
         // XCD-aware lane-block maps (device_common.h: xcd_block) x lanes per workgroup x load policy; lanes = 4096 is the

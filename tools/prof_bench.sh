@@ -5,7 +5,7 @@
 TAG=${1:-prof}; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-for PH in primary cold strong; do
+for PH in primary warm strong; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$PH -- python3 $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --profile-phase $PH > $OUT/stats_$PH.log 2>&1
   echo "stats $PH exit $?"
   find $OUT/stats_$PH -name "*kernel_stats.csv" | head -1 | xargs -r -I{} cp {} $OUT/${PH}_kernel_stats.csv
@@ -23,7 +23,7 @@ python3 - "$OUT" <<'PY'
 import csv, glob, json, sys, collections, re
 out = sys.argv[1]
 res = {}
-for ph in ("primary", "cold", "strong"):
+for ph in ("primary", "warm", "strong"):
     vals = collections.defaultdict(lambda: collections.defaultdict(list))
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for f in glob.glob(f"{out}/pmc_{ph}_{c}/**/*counter_collection.csv", recursive=True):
@@ -49,9 +49,9 @@ def pick(ph, grid_lanes):
             best = v["hbm_traffic_bytes_per_launch"]
     return best
 tag = os.path.basename(out)
-tj = {"4096x4096": pick("primary", 4096), "4096x4096_cold_rotating": pick("cold", 4096), "65536x4096": pick("strong", 65536),
+tj = {"4096x4096": pick("warm", 4096), "4096x4096_cold_rotating": pick("primary", 4096), "65536x4096": pick("strong", 65536),
       "kernel_source_sha": subprocess.check_output(["python3", os.path.join(root, "tools", "pmc_source_sha.py")], text=True).strip(),
-      "source": f"profiles/r05/{tag}_pmc_bench_summary.json (tools/prof_bench.sh {tag} pmc: separate FETCH_SIZE / WRITE_SIZE --pmc passes of `bench.py --profile-phase ...`, "
+      "source": f"profiles/r07/{tag}_pmc_bench_summary.json (tools/prof_bench.sh {tag} pmc: separate FETCH_SIZE / WRITE_SIZE --pmc passes of `bench.py --profile-phase ...`, "
                 "x2 gfx950 read correction on FETCH_SIZE; kernel k_pow2<Pow2Kernel<double,4096,512,...>>)"}
 json.dump(tj, open(f"{out}/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(tj, indent=1))
