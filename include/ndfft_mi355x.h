@@ -210,6 +210,7 @@ int ndfft_host_forget(const void *h_ptr);
 /* Frees the CALLING THREAD's device workspace on EVERY device it has used: the scratch arrays of the multi-pass paths (transpose route,
  * four-step, column four-step, global Bluestein) and the staging buffers of ndfft_exec.  They are otherwise
  * kept per thread and per stream for reuse (HIP-graph capture needs them stable).  Synchronises the device.
+ * Also frees the chunk buffers of the multi-device workers behind ndfft_exec_sharded* (every worker, after its streams drained).
  * No reference counterpart: rustfft allocates its scratch inside every process() call (src/lib.rs:317). */
 int ndfft_release_workspace(void);
 

@@ -107,12 +107,15 @@ struct FftConfig {                 // one complex-FFT-of-length-F recipe + op ta
     // rader_twp = per-pass twiddles of FFT_(p-1), rader_tab = g^i mod p (i < p - 1) followed by g^-i mod p
     bool rader = false; RaderCfg radercfg; HostTable rader_bhat, rader_twp, rader_twp2, rader_ctw; std::vector<int32_t> rader_tab;   // twp2: the passes in reverse order
     bool jit = false; JitCfg jitcfg;   // C2C slot: smooth non-power-of-two n -> specialised register kernel (jit.hip); twiddles in twp
+    // C2C slot: the recipe of the COLUMN tiles where it differs from the rows' (f32 lanes below 256 points: the rows' re-planned recipe -- more
+    // threads per lane, fewer elements each -- measured 29 % slower on column tiles, 81 x 100 x 2048 c64 56.9 vs 44.2 us, profiles/r07/r07e_*)
+    bool jit_col_alt = false; JitCfg jitcfg_col; HostTable twp_jcol;
     bool unsupported = false;      // no single-kernel fit and no usable factorisation (large prime factor)
 };
 
 struct DevConfig {                 // device copies (typed by dtype) of one FftConfig
     void *tw = nullptr, *twM = nullptr, *chirp = nullptr, *bhat = nullptr, *aux1 = nullptr, *aux2 = nullptr, *twp = nullptr;
-    void *twlo = nullptr, *twhi = nullptr, *twp_col = nullptr, *twp_narrow = nullptr;
+    void *twlo = nullptr, *twhi = nullptr, *twp_col = nullptr, *twp_narrow = nullptr, *twp_jcol = nullptr;
     void *cs_twlo = nullptr, *cs_twhi = nullptr;
     void *rfs_twlo = nullptr, *rfs_twhi = nullptr;
     void *wave_tw = nullptr;
@@ -246,6 +249,8 @@ size_t generic_max_len(size_t csize);   // longest complex FFT the single-launch
 
 // jit.hip : hiprtc specialisation of the register-resident kernel for smooth non-power-of-two lengths
 bool jit_choose(int dtype, int n, JitCfg &cfg, bool allow_partial = false);
+void shard_release_all();   // shard.hip: every shard worker frees its chunk buffers (ndfft_release_workspace)
+bool jit_choose_col(int dtype, int n, const JitCfg &row_cfg, JitCfg &col_cfg);   // true: column tiles of a C2C plan should use col_cfg instead of row_cfg
 void jit_build_twiddles(const JitCfg &cfg, HostTable &out);
 int launch_jit_c2c(int dtype, const JitCfg &cfg, int nt, const Pow2Args &a, hipStream_t s);
 int jit_col_lanes(int dtype, const JitCfg &cfg, bool c2c = false);   // c2c: a 4-lane tile is acceptable (complex output rows)

@@ -991,12 +991,15 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
         const bool use_blue = use_rader || (c.bluereg && ((P.nlanes * (int64_t)c.M >= (1 << 16) && blue_enabled()) || c.blue_reg_only));
         const bool use_plain = odd_variant && use_jit && !use_blue && plain_enabled();         // odd-n real ops with a smooth inner FFT: plain_kernel.h
         const bool have_tw = use_jit || use_blue || (is_c2c ? !c.twp_col.re.empty() : c.pow2);
+        // column tiles of a C2C plan may have their own recipe (FftConfig::jit_col_alt)
+        const bool col_alt = use_jit && !use_blue && !use_plain && is_c2c && c.jit_col_alt;
+        const JitCfg &jcol = col_alt ? c.jitcfg_col : c.jitcfg;
         const bool row = (!is_c2c || use_blue) && P.xs == 1 && P.ys == 1 && P.b.size() <= 1;
         bool col = false, narrow = false;
         const int col_kind = is_c2c ? 0 : (P.op == NDFFT_OP_R2C ? 1 : (P.op == NDFFT_OP_C2R ? 2 : 3));   // which sides of a column tile are real lanes (kernels_pow2_real.hip: ColGeom)
         if (!row && (!odd_variant || use_blue || use_plain) && P.xlen > 1 && !P.b.empty() && P.b.size() <= 2 && P.b.back().sin == 1 && P.b.back().sout == 1) {
             if (have_tw && P.b.back().shape >= 8) {
-                const int lanes = (use_jit || use_blue) ? std::max((use_jit || c.bluereg) ? jit_col_lanes(plan->dtype, c.jitcfg, is_c2c && use_jit && !use_blue) : 0, use_rader ? rader_col_lanes(plan->dtype, c.radercfg) : 0)
+                const int lanes = (use_jit || use_blue) ? std::max((use_jit || c.bluereg) ? jit_col_lanes(plan->dtype, use_blue ? c.jitcfg : jcol, is_c2c && use_jit && !use_blue) : 0, use_rader ? rader_col_lanes(plan->dtype, c.radercfg) : 0)
                                           : plan->dtype == NDFFT_F32 ? pow2_real_col_lanes<float>(c.F, col_kind) : pow2_real_col_lanes<double>(c.F, col_kind);
                 col = lanes > 0;
             }
@@ -1081,7 +1084,8 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
                 }
                 rc2 = use_blue ? (c.bluereg ? launch_jit_blue<float>(gop, c.jitcfg, col, a, stream) : NDFFT_ERR_UNSUPPORTED)
                       : use_plain ? launch_jit_plain<float>(gop, c.jitcfg, col, a, stream)
-                      : use_jit ? launch_jit_real<float>(gop, c.jitcfg, col, a, stream) : launch_pow2_real<float>(gop, a, col, stream);
+                      : use_jit ? ((col && col_alt) ? (a.twp = (const cpx<float> *)d.twp_jcol, launch_jit_real<float>(gop, jcol, col, a, stream)) : launch_jit_real<float>(gop, c.jitcfg, col, a, stream))
+                      : launch_pow2_real<float>(gop, a, col, stream);
             } else {
                 RealArgs<double> a; fill(a); a.scale = P.scale;
                 a.aux1 = (const double2 *)d.aux1; a.aux2 = (const double2 *)d.aux2; a.twp = (const double2 *)((is_c2c && !use_jit && !use_blue) ? d.twp_col : d.twp);
@@ -1094,7 +1098,8 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
                 }
                 rc2 = use_blue ? (c.bluereg ? launch_jit_blue<double>(gop, c.jitcfg, col, a, stream) : NDFFT_ERR_UNSUPPORTED)
                       : use_plain ? launch_jit_plain<double>(gop, c.jitcfg, col, a, stream)
-                      : use_jit ? launch_jit_real<double>(gop, c.jitcfg, col, a, stream) : launch_pow2_real<double>(gop, a, col, stream);
+                      : use_jit ? ((col && col_alt) ? (a.twp = (const double2 *)d.twp_jcol, launch_jit_real<double>(gop, jcol, col, a, stream)) : launch_jit_real<double>(gop, c.jitcfg, col, a, stream))
+                      : launch_pow2_real<double>(gop, a, col, stream);
             }
             if (!((use_jit || use_blue) && rc2 == NDFFT_ERR_UNSUPPORTED)) {   // UNSUPPORTED from the JIT = no hiprtc / compile failed: fall through to the LDS kernel
                 set_last_path(use_blue ? (col ? "blue_col" : "blue_reg") : use_plain ? (col ? "plain_col" : "plain_real") : use_jit ? (col ? "jit_col" : "jit_real") : (col ? "pow2_col" : "pow2_real"));
@@ -1598,11 +1603,28 @@ int ndfft_exec(const ndfft_plan *plan, int op, const void *in, void *out, int nd
     view_range(ndim, shape_in, stride_in, ilo, ihi, icnt);
     view_range(ndim, shape_out, stride_out, olo, ohi, ocnt);
     const size_t ibytes = (size_t)(ihi - ilo + 1) * ein, obytes = (size_t)(ohi - olo + 1) * eout;
-    if ((rc = ws.stage_in.reserve(ibytes))) return rc;
-    if ((rc = ws.stage_out.reserve(obytes))) return rc;
     const char *hin = (const char *)in + ilo * (int64_t)ein;
     char *hout = (char *)out + olo * (int64_t)eout;
     const bool out_dense = (int64_t)(ohi - olo + 1) == ocnt;
+    // Small calls (the reference's own bench shapes: benches/ndrustfft.rs:6-7, n x n with n = 128 ... 264): no DMA at all.  The kernels read the
+    // input straight from a pinned, device-mapped bounce buffer over PCIe and write the output into another one: two host memcpys and ONE stream
+    // synchronisation are the whole call (the plain path below pays two synchronous hipMemcpy of pageable memory, ~15-20 us each whatever the size).
+    const size_t small_limit = (size_t)NDFFT_DEV_INT("NDFFT_HOST_SMALL_KB", 2048) << 10;
+    if (ibytes + obytes <= small_limit) {
+        if ((rc = ws.bounce_in[0].reserve(std::max(ibytes, small_limit))) || (rc = ws.bounce_out[0].reserve(std::max(obytes, small_limit)))) return rc;
+        memcpy(ws.bounce_in[0].p, hin, ibytes);
+        const char *din = (const char *)ws.bounce_in[0].p - ilo * (int64_t)ein;
+        char *dout = (char *)ws.bounce_out[0].p - olo * (int64_t)eout;
+        rc = dispatch_peeled(P, din, dout, ein, eout, (hipStream_t) nullptr);
+        const hipError_t se = hipStreamSynchronize(nullptr);
+        if (rc) return rc;
+        if (se != hipSuccess) return fail(NDFFT_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(se));
+        if (out_dense) memcpy(hout, ws.bounce_out[0].p, obytes);
+        else copy_view_elements((char *)out, (const char *)ws.bounce_out[0].p - olo * (int64_t)eout, ndim, shape_out, stride_out, eout);   // holes belong to the caller
+        return NDFFT_OK;
+    }
+    if ((rc = ws.stage_in.reserve(ibytes))) return rc;
+    if ((rc = ws.stage_out.reserve(obytes))) return rc;
     // dense, C-ordered in dimension 0, transform along another axis: pipelined row chunks -- straight DMA for pinned arrays
     // (ndfft_host_alloc), through pinned bounce buffers filled by the copy pool for pageable ones.  NDFFT_HOST_PIPE=0: plain path.
     if (ndim >= 2 && axis != 0 && ilo == 0 && olo == 0 && shape_in[0] == shape_out[0] && shape_in[0] >= 16 &&
@@ -1693,6 +1715,7 @@ int ndfft_set_input_hint(int hint) {
 int ndfft_release_workspace(void) {
     clear_err();
     g_tws.release_all();   // every device this thread has used; each synchronised under its own hipSetDevice
+    shard_release_all();   // and the chunk buffers of the multi-device workers (up to 4 x 64 MiB per worker)
     return NDFFT_OK;
 }
 

@@ -122,7 +122,22 @@ static bool jit_choose_default(int dtype, int n, JitCfg &cfg, bool allow_partial
 // (F = 48: 8.6 on 2 threads, e = 24; 3000 = 10.10.10.3, e = 30).  Those measure badly -- f64 from e > 18, f32 from e > 24
 // (profiles/r04/r04j_realplan_ab.txt: nddct2 / ndfft_r2c n = 96, 120, 300, 360, 1200, 3000, 6000 gain 1.3-2.9x; recipes with e <= 12 were as good
 // or better than the model's pick) -- and are replaced by the pick of the cost model fitted for the Rader kernel (plan_fft_by_cost).
-bool jit_choose(int dtype, int n, JitCfg &cfg, bool allow_partial) {
+static bool jit_choose_impl(int dtype, int n, JitCfg &cfg, bool allow_partial, bool short_too);
+bool jit_choose(int dtype, int n, JitCfg &cfg, bool allow_partial) { return jit_choose_impl(dtype, n, cfg, allow_partial, true); }
+// The short-lane f32 re-plan below was measured on ROWS (+30 % at n = 80 / 96 / 160); on column tiles the default recipe is the faster one
+// (round 4, A-B-A-B against the round-2 library and with the recipe forced: 81 x 100 x 2048 c64 axis 1 56.9 -> 44.2 us; rows of n = 100 the same
+// either way).  A C2C plan therefore keeps a second recipe for its column tiles where the two differ.
+bool jit_choose_col(int dtype, int n, const JitCfg &row_cfg, JitCfg &col_cfg) {
+    if (dtype != NDFFT_F32 || n >= 256 || !NDFFT_DEV_INT("NDFFT_JIT_COL_ALT", 1)) return false;
+    if (!jit_choose_impl(dtype, n, col_cfg, true, false)) return false;
+    if (col_cfg.tpl == row_cfg.tpl && col_cfg.radix == row_cfg.radix) return false;
+    // Sweep of all 23 lengths in 97..255 where the two recipes differ, column tiles of (k, n, 2048) and (k, n, 64) c64 arrays, two alternating processes per
+    // setting (tools/sweep_col_recipes.py, profiles/r07/r07f_col_recipe_sweep_c64.jsonl): the default recipe wins 13-41 % on all ten lengths where it
+    // keeps <= 18 elements per thread in no more passes than the rows' recipe (98, 99, 100, 110, 121, 143, 144, 156, 162, 220) and loses 3-32 % on nine
+    // of the other thirteen (126, 132, 135, 160, 176, 189, 192, 225, 242; 140 / 147 / 154 within 2 %; only 231 would have gained, 12 %).
+    return col_cfg.e <= 18 && col_cfg.radix.size() <= row_cfg.radix.size();
+}
+static bool jit_choose_impl(int dtype, int n, JitCfg &cfg, bool allow_partial, bool short_too) {
     constexpr bool on = true;
     constexpr int nmax = 8192;
     if (!jit_choose_default(dtype, n, cfg, allow_partial)) return false;
@@ -144,7 +159,6 @@ bool jit_choose(int dtype, int n, JitCfg &cfg, bool allow_partial) {
     }
     // f32 lanes below 256 points are re-planned from e > 8 (A-B-A-B, profiles/r04/r04zg_abab_shortplan.txt: c64 n = 80 / 96 / 160 51.5 / 50.5 / 49.7 -> 39.6 / 38.9 / 38.2 us,
     // ndfft_r2c f32 n = 160 / 192 / 320 +10 %, the rest within 3 %; in f64 the same rule was a wash: c128 n = 96 -6 %, nddct2 n = 192 +5 %)
-    constexpr bool short_too = true;
     const bool bad_e = cfg.e > (dtype == NDFFT_F32 ? 24 : 18) || (short_too && dtype == NDFFT_F32 && n < 256 && cfg.e > 8);
     if (!on || !allow_partial || n > nmax || !bad_e) return true;
     const size_t lane = (size_t)((n + (n >> 4) + 3) & ~1) * 2 * (dtype == NDFFT_F32 ? 4 : 8);

@@ -76,6 +76,8 @@ template <typename T> static bool fs_direct() {
 template <typename T, int F, int OP, int MODE> static int launch_fsd(const RealArgs<T> &a, hipStream_t s) {
     constexpr int LPB = FsGeom<T, F>::LPB;
     using K = ColDirectKernel<T, F, FsCfg<F>::TPL, LPB, typename FsCfg<F>::RL, OP, MODE>;
+    static_assert(K::LDS_BYTES <= 160 * 1024, "a workgroup's LDS");
+    NDFFT_ENSURE_LDS_ATTR((k_col_direct<K, T>));
     const int64_t nblk = (a.nlanes + LPB - 1) / LPB;
     if (nblk <= 0) return NDFFT_OK;
     if (nblk > 0x7fffffffLL) return fail(NDFFT_ERR_UNSUPPORTED, "too many lanes for one launch");

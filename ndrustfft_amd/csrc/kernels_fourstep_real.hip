@@ -82,6 +82,8 @@ template <typename T> static bool rfs_direct() {
 template <typename T, int F, int STAGE> static int launch_rfsd(const RealArgs<T> &a, hipStream_t s) {
     constexpr int LPB = RfsGeom<T, F, 2>::LPB;
     using K = ColDirectKernel<T, F, RfsCfg<F>::TPL, LPB, typename RfsCfg<F>::RL, G_C2C_FWD, STAGE + 3>;   // stages 2..6 = modes 5..9
+    static_assert(K::LDS_BYTES <= 160 * 1024, "a workgroup's LDS");
+    NDFFT_ENSURE_LDS_ATTR((k_col_direct<K, T>));          // RfsGeom<double, 1024, 2>: 69,696 B, above the 64 KiB a launch may ask for without the opt-in
     const int64_t nblk = (a.nlanes + LPB - 1) / LPB;
     if (nblk <= 0) return NDFFT_OK;
     if (nblk > 0x7fffffffLL) return fail(NDFFT_ERR_UNSUPPORTED, "too many lanes for one launch");

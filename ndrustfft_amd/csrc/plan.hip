@@ -259,7 +259,10 @@ static void build_plan_tables(ndfft_plan *p) {
         if (pow2_supported(p->dtype, n)) { m.pow2 = true; pow2_build_twiddles(p->dtype, n, m.twp); }
         if (pow2_real_supported(n)) pow2_real_build_twiddles(n, m.twp_col);
         if (wave_supported(n) || n <= 128) for (int k = 0; k < n; ++k) unit(m.wave_tw, k, n);   // W_n^k: wavefront and thread-per-lane kernels
-        if (!m.pow2 && !m.blue && jit_choose(p->dtype, n, m.jitcfg, true)) { m.jit = true; jit_build_twiddles(m.jitcfg, m.twp); }
+        if (!m.pow2 && !m.blue && jit_choose(p->dtype, n, m.jitcfg, true)) {
+            m.jit = true; jit_build_twiddles(m.jitcfg, m.twp);
+            if (jit_choose_col(p->dtype, n, m.jitcfg, m.jitcfg_col)) { m.jit_col_alt = true; jit_build_twiddles(m.jitcfg_col, m.twp_jcol); }
+        }
         p->has_cfg[CFG_MAIN] = true;
     } else if (p->kind == NDFFT_KIND_R2C) {
         if (n % 2 == 0) {
@@ -494,6 +497,7 @@ int get_dev_tables(const ndfft_plan *cplan, const DevTables **out) {
         if ((rc = upload_any(plan->dtype, c.rfs_twlo, &d.rfs_twlo))) return rc;
         if ((rc = upload_any(plan->dtype, c.rfs_twhi, &d.rfs_twhi))) return rc;
         if ((rc = upload_any(plan->dtype, c.twp_col, &d.twp_col))) return rc;
+        if ((rc = upload_any(plan->dtype, c.twp_jcol, &d.twp_jcol))) return rc;
         if ((rc = upload_any(plan->dtype, c.twp_narrow, &d.twp_narrow))) return rc;
         if ((rc = upload_any(plan->dtype, c.wave_tw, &d.wave_tw))) return rc;
         for (int q = 0; q < 4; ++q) if ((rc = upload_any(plan->dtype, c.tinymat[q], &d.tinymat[q]))) return rc;
@@ -626,7 +630,7 @@ int ndfft_plan_destroy(ndfft_plan *plan) {
         (void)hipSetDevice(kv.first);
         for (int i = 0; i < CFG_COUNT; ++i) {
             DevConfig &d = kv.second.cfg[i];
-            void *ptrs[] = {d.tw, d.twM, d.chirp, d.bhat, d.aux1, d.aux2, d.twp, d.twlo, d.twhi, d.twp_col, d.twp_narrow, d.cs_twlo, d.cs_twhi, d.rfs_twlo, d.rfs_twhi, d.wave_tw, d.tinymat[0], d.tinymat[1], d.tinymat[2], d.tinymat[3], d.rader_bhat, d.rader_twp, d.rader_twp2, d.rader_tab, d.twp_rev, d.rader_ctw};
+            void *ptrs[] = {d.tw, d.twM, d.chirp, d.bhat, d.aux1, d.aux2, d.twp, d.twlo, d.twhi, d.twp_col, d.twp_jcol, d.twp_narrow, d.cs_twlo, d.cs_twhi, d.rfs_twlo, d.rfs_twhi, d.wave_tw, d.tinymat[0], d.tinymat[1], d.tinymat[2], d.tinymat[3], d.rader_bhat, d.rader_twp, d.rader_twp2, d.rader_tab, d.twp_rev, d.rader_ctw};
             for (void *q : ptrs) if (q) (void)hipFree(q);
         }
     }
@@ -655,7 +659,10 @@ int ndfft_explain_plan(int kind, int dtype, size_t n, char *buf, size_t buflen) 
         else if (c.rader) l += " route=rader p=" + std::to_string(c.radercfg.p) + " mc=" + std::to_string(c.radercfg.mc1) + "x" + std::to_string(c.radercfg.mc2) + " M=" + std::to_string(c.radercfg.fft.n) +
                                " tpl=" + std::to_string(c.radercfg.fft.tpl) + " e=" + std::to_string(c.radercfg.fft.e) + " radix=" + radix(c.radercfg.fft.radix) + " lanes=" + std::to_string(c.radercfg.fft.lpb);
         else if (c.pow2) l += " route=pow2";
-        else if (c.jit) l += " route=jit tpl=" + std::to_string(c.jitcfg.tpl) + " e=" + std::to_string(c.jitcfg.e) + " radix=" + radix(c.jitcfg.radix) + " lanes=" + std::to_string(c.jitcfg.row_lpb);
+        else if (c.jit) {
+            l += " route=jit tpl=" + std::to_string(c.jitcfg.tpl) + " e=" + std::to_string(c.jitcfg.e) + " radix=" + radix(c.jitcfg.radix) + " lanes=" + std::to_string(c.jitcfg.row_lpb);
+            if (c.jit_col_alt) l += " col_tpl=" + std::to_string(c.jitcfg_col.tpl) + " col_e=" + std::to_string(c.jitcfg_col.e) + " col_radix=" + radix(c.jitcfg_col.radix);
+        }
         else if (c.big && !c.bigblue) l += " route=four_step F1=" + std::to_string(c.F1) + " F2=" + std::to_string(c.F2) +
                                            (c.rfs ? " real_four_step=" + std::to_string(c.rfs_N1) + "x" + std::to_string(c.rfs_N2) + " ops=" + std::to_string(c.rfs_ops) : std::string());
         else if (c.F <= 1) l += " route=trivial";

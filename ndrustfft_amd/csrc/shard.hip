@@ -68,8 +68,9 @@ class Worker {
 
 // never destroyed: the workers are detached and outlive static destruction
 std::mutex &pool_mu() { static std::mutex *m = new std::mutex; return *m; }
+std::map<int, Worker *> &pool_ref() { static std::map<int, Worker *> *pool = new std::map<int, Worker *>; return *pool; }
 Worker &worker_for(int device) {
-    static std::map<int, Worker *> *pool = new std::map<int, Worker *>;
+    std::map<int, Worker *> *pool = &pool_ref();
     std::lock_guard<std::mutex> g(pool_mu());
     auto it = pool->find(device);
     if (it == pool->end()) it = pool->emplace(device, new Worker(device)).first;
@@ -177,6 +178,29 @@ struct ShardWs {
     }
 };
 thread_local ShardWs t_sws;
+
+// ndfft_release_workspace: every worker gives back its chunk buffers (its own device's and the root-side images it reserved), after its streams drained
+void release_this_threads_shard_buffers() {
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); return; }
+    for (auto &kv : t_sws.streams) if (kv.second.ok && hipSetDevice(kv.first) == hipSuccess) for (auto &x : kv.second.s) (void)hipStreamSynchronize(x);
+    for (int k = 0; k < kSlots; ++k) {
+        for (auto *m : {&t_sws.rin[k], &t_sws.rout[k]}) for (auto &kv : *m) if (hipSetDevice(kv.first) == hipSuccess) kv.second.release();
+    }
+    (void)hipSetDevice(cur);
+    for (int k = 0; k < kSlots; ++k) { t_sws.din[k].release(); t_sws.dout[k].release(); }
+    (void)hipGetLastError();
+}
+}  // namespace
+void shard_release_all() {
+    std::vector<Worker *> ws;
+    { std::lock_guard<std::mutex> g(pool_mu()); for (auto &kv : pool_ref()) ws.push_back(kv.second); }
+    std::vector<std::future<TaskResult>> fs;
+    for (Worker *w : ws) fs.push_back(w->submit([]() { release_this_threads_shard_buffers(); return TaskResult(); }));
+    for (auto &f : fs) (void)f.get();
+    release_this_threads_shard_buffers();          // a caller thread that ran a root block itself
+}
+namespace {
 
 // a view as the device copy kernel sees it: extent-1 dimensions dropped, C order (last dimension fastest)
 struct ViewDesc { int32_t nd; int32_t pad_; int64_t shape[NDFFT_MAX_DIMS]; int64_t stride[NDFFT_MAX_DIMS]; };
@@ -293,9 +317,9 @@ TaskResult run_remote_block(const RemoteBlock &b) {
     {   // every buffer is sized once for the largest chunk, in whichever form (span or dense image) is larger
         const Side i = side_of(b.si, b.sti, emax), o = side_of(b.so, b.sto, emax);
         const size_t ib = (size_t)std::max(i.span, i.count) * b.ein, ob = (size_t)std::max(o.span, o.count) * b.eout;
-        for (int k = 0; k < kSlots && !rc0; ++k) {   // root is current
-            if ((rc0 = t_sws.rin[k][root].reserve(ib))) break;
-            rc0 = t_sws.rout[k][root].reserve(ob);
+        for (int k = 0; k < kSlots && !rc0; ++k) {   // root is current; root-side images only for the sides that travel packed (a span is copied directly)
+            if (i.packed && (rc0 = t_sws.rin[k][root].reserve(ib))) break;
+            if (o.packed) rc0 = t_sws.rout[k][root].reserve(ob);
         }
         if (hipSetDevice(dev) != hipSuccess) { r.rc = NDFFT_ERR_HIP; r.err = "hipSetDevice(dev)"; return r; }
         if (rc0) return bad(rc0);

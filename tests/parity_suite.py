@@ -1057,6 +1057,11 @@ def jit_specialised_sizes(L):
                 m = n if name in ("ndfft", "ndifft") else (n + 1 if name == "nddct1" else 2 * n)
                 assert run_case(L, name, (m, 1500), 0, rdt, offset=n) == "jit_col", (name, m)
                 assert run_case(L, name, (3, m, 700), 1, rdt, offset=n + 1) == "jit_col", (name, m)
+    # round 4: column tiles of short f32 C2C lanes run their own recipe where the rows' re-planned one measured slower (jit.hip: jit_choose_col)
+    for n in (98, 99, 156, 220):
+        for name in ("ndfft", "ndifft"):
+            assert run_case(L, name, (n, 1400), 0, np.float32, offset=n) == "jit_col", (name, n)
+            assert run_case(L, name, (900, n), 1, np.float32, offset=n) == "jit_reg", (name, n)
 
 
 def handler_clone_shares_plan(L):

@@ -106,3 +106,10 @@ def test_known_recipes(lib):
     assert d["route"] == "blue_reg" and d["blueM"] == "4096"
     dct = lib.explain_plan(_lib.KIND_DCT, _lib.F64, 512).splitlines()
     assert any("slot=DCT1 F=511 route=rader" in l for l in dct), dct
+    # round 4 (profiles/r07/r07f_col_recipe_sweep_c64.jsonl): column tiles of short f32 C2C lanes keep the default recipe where it holds <= 18
+    # elements per thread in no more passes than the rows' re-planned one -- exactly these ten lengths below 256
+    alt = [n for n in range(97, 256) if "col_tpl" in lib.explain_plan(_lib.KIND_C2C, _lib.F32, n)]
+    assert alt == [98, 99, 100, 110, 121, 143, 144, 156, 162, 220], alt
+    d = _fields(lib.explain_plan(_lib.KIND_C2C, _lib.F32, 100).splitlines()[0])
+    assert d["radix"] == "5.5.4" and d["col_radix"] == "10.10" and d["col_tpl"] == "10"
+    assert not any("col_tpl" in lib.explain_plan(_lib.KIND_C2C, _lib.F64, n) for n in (100, 144, 220))
