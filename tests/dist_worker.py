@@ -24,9 +24,32 @@ def wrap(ofn):
     return fn
 
 
+def xgmi_block_at_bench_shapes(rank, world):
+    """bench.py's N > 1 side measurement with the EXACT argument shapes the real run uses (n = 4096, 2048 rows per rank = 128 MiB per link, the
+    (1024 N)^2 all-to-all, the 1024^2 sharded fft2), at the world size of the driver's scaling run, on gloo with the oracle as the executor: the first
+    8-GPU run must not execute an argument shape for the first time (round-3 review item 8)."""
+    import bench
+    hs = {}
+    class H:
+        def __init__(self, n): self.h = hs.setdefault(n, orc.FftHandler(n))
+    def ndfft_o(x, y, handler, axis):
+        wrap(orc.ndfft_par)(x, y, handler.h, axis)
+    xg = bench.xgmi_block(dist, torch, torch.device("cpu"), rank, world, 4096, ndfft_o, H, dist.barrier)
+    if rank == 0:
+        print("xgmi block at bench shapes:", {k: v for k, v in xg.items()})
+    return bool(xg["gather"]["scatter_transform_gather_matches_numpy"] and xg["all_to_all_reshard"]["round_trip_exact"] and xg["sharded_fft2_rel_err"] < 1e-10
+                and xg["scatter"]["links"] == world - 1 and xg["all_to_all_reshard"]["array"] == f"{1024 * world}x{1024 * world} c128")
+
+
 def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
+    if os.environ.get("DIST_WORKER_MODE") == "xgmi_bench_shapes":
+        ok = xgmi_block_at_bench_shapes(rank, world)
+        if rank == 0:
+            print("DIST_OK" if ok else "DIST_FAIL")
+        dist.destroy_process_group()
+        return
     cases = [
         ("ndfft", (6, 16), 1, np.complex128, np.complex128, orc.FftHandler(16), orc.ndfft),
         ("ndfft", (5, 16), 1, np.complex128, np.complex128, orc.FftHandler(16), orc.ndfft),        # uneven split

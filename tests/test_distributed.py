@@ -20,6 +20,15 @@ def test_lane_sharding_world2_gloo():
     assert r.returncode == 0 and "DIST_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+def test_xgmi_block_at_bench_shapes_world8_gloo():
+    """bench.py's xGMI block (scatter / gather of 128 MiB slices, (1024 N)^2 all-to-all, sharded fft2) with the real run's argument shapes at N = 8."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", DIST_WORKER_MODE="xgmi_bench_shapes")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(ROOT, "tests", "dist_worker.py")], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and "DIST_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 def test_shard_helpers():
     from ndrustfft_amd import distributed as d
     assert d.shard_dim((4096, 4096), 1) == 0

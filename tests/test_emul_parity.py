@@ -20,6 +20,8 @@ os.environ.setdefault("EMUL_DEVICES", "3")     # three fake devices: the multi-d
 
 @pytest.fixture(scope="module")
 def L():
+    if os.environ.get("NDFFT_EMUL_LIB"):                    # a side build of the emulation (make -C tests/emul SAN=1: UBSan)
+        return _lib.Library(os.path.abspath(os.environ["NDFFT_EMUL_LIB"]))
     subprocess.check_call(["make", "-C", EMUL_DIR, "-s", "-j4"])
     return _lib.Library(os.path.join(EMUL_DIR, "_build", "libndfft_emul.so"))
 
@@ -70,6 +72,15 @@ def test_sharded_device_resident_chunk_pipeline(L, monkeypatch):
     ps.dev_sharded_case(L, "ndfft", (61, 64), 1, root=1, ids=[0, 1, 2], repeats=2)          # contiguous spans, uneven chunks
     ps.dev_sharded_case(L, "ndfft", (64, 90), 0, root=0, ids=[1, 2], repeats=2)             # packed, many chunks
     ps.dev_sharded_case(L, "nddct2", (40, 32, 3), 1, root=2, ids=[0, 1], out_view=((40, 32, 6), np.s_[:, :, ::2]), repeats=2)
+
+
+def test_sharded_fft2_on_three_devices(L, monkeypatch):
+    """fft2 / rfft2 with every array resident on one device and both passes split over three (the second pass = the re-shard), also in many small chunks."""
+    ps.dev_sharded_fft2(L, (96, 128), root=1, ids=[0, 1, 2])
+    ps.dev_sharded_fft2(L, (90, 64), root=0, ids=[2, 1], real=True)
+    monkeypatch.setenv("NDFFT_SHARD_CHUNK_KB", "8"); L.reload_switches()
+    ps.dev_sharded_fft2(L, (128, 256), root=2, ids=[0, 1, 2])
+    ps.dev_sharded_fft2(L, (64, 100), root=0, ids=[0, 1, 2], real=True)
 
 
 def test_baseline_length_fixtures(L, blvec): ps.baseline_length_fixtures(L, blvec)

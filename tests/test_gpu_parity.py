@@ -118,6 +118,15 @@ def test_host_registration_cache(L):
     L.check(L.c.ndfft_host_reg_cache(0))
 
 
+def test_sharded_fft2_pipeline_on_one_gpu(L, monkeypatch):
+    """fft2 / rfft2 at bench.py's sharded-fft2 size (1024 x 1024) through ndfft_exec_sharded_device, every block forced through the remote pipeline."""
+    monkeypatch.setenv("NDFFT_SHARD_FORCE_REMOTE", "1"); L.reload_switches()
+    n = L.c.ndfft_device_count()
+    ids = list(range(n)) if n > 1 else [0, 0, 0]
+    ps.dev_sharded_fft2(L, (1024, 1024), root=0, ids=ids)
+    ps.dev_sharded_fft2(L, (768, 1000), root=0, ids=ids, real=True)
+
+
 def test_sharded_device_resident_pipeline_on_one_gpu(L, monkeypatch):
     """ndfft_exec_sharded_device's scatter -> transform -> gather pipeline (pack / unpack kernels on the root, per-device streams, events, two buffer
     slots) on real hardware: with one GPU per lease every block lives on the root, so NDFFT_SHARD_FORCE_REMOTE sends them through the pipeline anyway.

@@ -52,6 +52,7 @@ def med(f, batches=7, reps=None, budget=0.15):
 
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--md", action="store_true"); ap.add_argument("--no-gpu", action="store_true")
+    ap.add_argument("--host-only", action="store_true", help="only the gpu_host column (A/B runs of the host path)")
     a = ap.parse_args()
     os.environ.setdefault("OMP_NUM_THREADS", str(usable_cpus()))
     # libgomp's spinning waiters and a container CPU quota do not mix: with the default policy every small `_par` call here took 32 / 64 ms
@@ -78,6 +79,15 @@ def main():
                 x = i.copy(); y = np.zeros((n, n)); oh = orc.DctHandler(n)
                 alg = 2 * n * n * 8
             r = {"group": grp, "op": op, "n": n, "algorithmic_bytes": alg, "cpu_threads": orc.num_threads()}
+            if a.host_only:
+                getattr(orc, op + "_par")(x, y, oh, 0); yo = y.copy()
+                h = {"ndfft": FftHandler, "ndfft_r2c": R2cFftHandler, "nddct1": DctHandler}[op](n)
+                fn = {"ndfft": ndfft, "ndfft_r2c": ndfft_r2c, "nddct1": nddct1}[op]
+                yh = np.zeros_like(y)
+                r["gpu_host_us"] = med(lambda: fn(x, yh, h, 0), budget=0.1) * 1e6
+                assert np.abs(yh - yo).max() / max(np.abs(yo).max(), 1e-300) < 1e-10
+                print(json.dumps({k: (round(v, 2) if isinstance(v, float) else v) for k, v in r.items()}), flush=True)
+                continue
             r["cpu_serial_us"] = med(lambda: getattr(orc, op)(x, y, oh, 0)) * 1e6
             yo = y.copy()
             r["cpu_par_us"] = med(lambda: getattr(orc, op + "_par")(x, y, oh, 0)) * 1e6
@@ -127,7 +137,7 @@ def main():
                 assert np.abs(yh - yo).max() / max(np.abs(yo).max(), 1e-300) < 1e-10
             rows.append(r)
             print(json.dumps({k: (round(v, 2) if isinstance(v, float) else v) for k, v in r.items()}), flush=True)
-    if a.md:
+    if a.md and rows:
         print("\n| bench (reference) | n | CPU serial | CPU `_par` (%d threads) | GPU eager (Python) | GPU graph replay | of 8 TB/s | GPU host arrays | kernel |" % rows[0]["cpu_threads"])
         print("|---|---|---|---|---|---|---|---|---|")
         for r in rows:
