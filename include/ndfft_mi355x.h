@@ -107,7 +107,10 @@ size_t ndfft_plan_lane_len_out(const ndfft_plan *plan, int op);
  * norm, scale  : see ndfft_norm; `scale` is read only for NDFFT_NORM_SCALE
  *
  * ndfft_exec        : host arrays.  Synchronous: `out` is fully written on return; nothing is
- *                     retained.  Staging through HBM is internal.
+ *                     retained.  Staging is internal: calls of up to 2 MiB (input + output) run the kernels
+ *                     straight from / into pinned, device-mapped bounce buffers (no DMA: two host copies
+ *                     and one stream synchronisation -- 30-40 us for the reference's 128 x 128 bench
+ *                     shapes); larger ones are staged through HBM, from 8 MiB as a pipeline of row chunks.
  * ndfft_exec_device : device-resident arrays (hipMalloc'd).  Asynchronous on `stream`
  *                     (a hipStream_t, NULL = default stream).  This is what the roofline numbers
  *                     are measured on and what multi-axis / multi-GPU callers chain.
