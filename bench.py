@@ -355,11 +355,19 @@ def main():
     # (tools/kbench creep: 95-107 us per launch for the first ~400 launches, 85 us afterwards), far
     # longer than W launches of a ~90 us kernel.  Keep the device busy for --ramp-ms first, then do
     # the W warm-up steps the contract asks for.  Nothing in here is timed.
-    t_ramp = time.perf_counter()
-    while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
+    # On a fresh box the settling can take longer than a fixed time: keep going (at most 3 s) until three consecutive 50-step batches
+    # agree within 1 %.
+    t_ramp = time.perf_counter(); hist = []
+    while args.ramp_ms > 0:
+        tb = time.perf_counter()
         for _ in range(50):
             step()
         torch.cuda.synchronize()
+        hist.append(time.perf_counter() - tb)
+        ramped_ms = (time.perf_counter() - t_ramp) * 1e3
+        settled = len(hist) >= 3 and max(hist[-3:]) <= 1.01 * min(hist[-3:])
+        if (ramped_ms >= args.ramp_ms and settled) or ramped_ms >= max(3000.0, args.ramp_ms):
+            break
     for _ in range(max(args.warmup, 2 * len(pairs) if not args.profile_phase or args.profile_phase == "primary" else 1)):
         step()
     (el, dev_ms), blocks = timed_blocks(step, primary_steps, primary_blocks)
