@@ -1272,17 +1272,17 @@ class HostRegCache {
         ++tick_;
         for (R &r : v_) if (r.registered && r.lo <= lo && hi <= r.hi) { r.last = tick_; ++r.inuse; return true; }   // any size: sub-views of a registered array too
         if (!limit_ || bytes < ((size_t)8 << 20)) return false;
-        R *hit = nullptr;
         for (size_t i = 0; i < v_.size();) {
             R &r = v_[i];
-            if (r.lo == lo && r.hi == hi) { hit = &r; ++i; continue; }
-            if (lo < r.hi && r.lo < hi) {                 // overlaps another range: the caller's allocation changed (an unregistered sighting of a
-                if (r.inuse) return false;                //   larger, older array must not be what gets pinned -- only the range of THIS call is)
+            if (!(r.lo == lo && r.hi == hi) && lo < r.hi && r.lo < hi) {   // overlaps another range: the caller's allocation changed (an unregistered sighting
+                if (r.inuse) return false;                                //   of a larger, older array must not be what gets pinned -- only the range of THIS call is)
                 drop(i);
                 continue;
             }
             ++i;
         }
+        R *hit = nullptr;                                 // (looked up after the erasures above: they move entries)
+        for (R &r : v_) if (r.lo == lo && r.hi == hi) { hit = &r; break; }
         if (hit) {
             hit->last = tick_;
             if (++hit->seen < 2) return false;            // (after a failed registration `seen` restarts at -8: a bounded back-off, not a ban)
