@@ -412,7 +412,7 @@ def main():
             ndfft(xs, ys, h, 1)
         for _ in range(3):
             strong_step()
-        s_el, s_ms = timed(strong_step, args.strong_steps)
+        (s_el, s_ms), s_blocks = timed_blocks(strong_step, args.strong_steps, 1 if args.profile_phase else min(3, max(1, args.blocks)))
         s_bytes = 2 * srows * n * 16
         s_kern = s_ms / 1e3 / args.strong_steps
         if rank == 0:
@@ -425,7 +425,7 @@ def main():
                   "ms_per_step": round(s_el / args.strong_steps * 1e3, 5),
                   "avg_launch_us": round(s_kern * 1e6, 2),
                   "per_gpu_achieved_GBs": round(s_bytes / s_kern / 1e9, 1),
-                  "per_gpu_frac": round(s_bytes / s_kern / 1e9 / HBM_PEAK_GBS, 4)}
+                  "per_gpu_frac": round(s_bytes / s_kern / 1e9 / HBM_PEAK_GBS, 4), "blocks": s_blocks}
         del xs, ys
 
     # ------------------------------------------------------------------ N > 1: the data movement of SURVEY 8e / 8f rank 3 over xGMI
