@@ -457,7 +457,7 @@ static int col_split(const Problem &P, const void *d_in, void *d_out, const FftC
     // Row pitch of the intermediate.  It is OUR array, so its rows need not sit a power of two apart: tools/colprobe.hip
     // (profiles/r05/r05a_colprobe.txt) reads 256-byte segments 8192 rows deep at 0.55 of 8 TB/s when the rows are 32 KiB apart and
     // at 0.85 when they are 32 KiB + 512 B apart (writes 0.33 -> 0.70): a power-of-two pitch keeps every row of a column tile on
-    // the same few HBM channels.  NDFFT_CS_PAD = padding in BYTES (0 keeps dense rows); only for one outer block (the padded
+    // the same few HBM channels.  pad_bytes = padding in BYTES (0 keeps dense rows); only for one outer block (the padded
     // layout needs the (b, i) batch dimensions unmerged, and the column kernels take two).
     int64_t pad = 0;
     if (O == 1) {
@@ -1421,7 +1421,7 @@ static int exec_pinned_pipeline(DeviceWs &ws, const ndfft_plan *plan, int op, co
 namespace {
 // Bulk host copy with streaming (non-temporal) stores: the pieces the pool moves (a few MiB each) are below glibc's own non-temporal threshold, so plain
 // memcpy reads the destination lines before overwriting them (three memory transfers per byte instead of two).  AVX2 only where the CPU has it;
-// NDFFT_COPY_NT=0 keeps memcpy.  Host code only.
+// (-DNDFFT_NO_NT_COPY keeps memcpy).  Host code only.
 #if defined(__x86_64__) && !defined(NDFFT_NO_NT_COPY)
 __attribute__((target("avx2"))) void copy_nt_avx2(char *d, const char *s, size_t n) {
     while (n && ((uintptr_t)d & 31)) { *d++ = *s++; --n; }

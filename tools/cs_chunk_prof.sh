@@ -5,7 +5,7 @@ TAG=${1:-cschunk}; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 for CH in 144 64 32 16; do
-  NDFFT_CS_CHUNK_MB=$CH NDFFT_CS_NT_IN=1 NDFFT_CS_KEEP=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ch$CH -- python3 $GRAFT_REPO_ROOT/tools/bench_configs.py --only cfg3A_only --steps 20 > $OUT/ch$CH.log 2>&1
+  NDFFT_CS_CHUNK_MB=$CH timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ch$CH -- python3 $GRAFT_REPO_ROOT/tools/bench_configs.py --only cfg3A_only --steps 20 > $OUT/ch$CH.log 2>&1
   f=$(find $OUT/ch$CH -name "*kernel_stats.csv" | head -1)
   echo "== chunk $CH MiB"; grep -h "cfg3A" $OUT/ch$CH.log | cut -c1-160
   python3 - "$f" <<'PY'
