@@ -361,6 +361,38 @@ def test_device_resident_path_matches_host_path(L):
     assert_close(yt.cpu().numpy(), y.T, 0, 1e-10, "transposed device view")
 
 
+def test_perf_canary_never_fails(L):
+    """NOT a pass / fail gate (box-to-box spread is several per cent and a slow lease must not turn the suite red): times the BASELINE row kernels for a
+    few milliseconds and WARNS when one is more than 15 % slower than the best value on record (profiles/r07/r07d, r07j), so that a regression shows up
+    in the warnings summary of whoever runs the GPU tests.  tools/bench_configs.py --compare is the real guard."""
+    import time
+    import warnings
+    torch = pytest.importorskip("torch")
+    from ndrustfft_amd import DctHandler, FftHandler, nddct2, ndfft
+    dev = torch.device("cuda:0")
+    rows = []
+    x = torch.from_numpy(synth.complex_array((4096, 4096))).to(dev); y = torch.empty_like(x); h = FftHandler(4096)
+    rows.append(("cfg2 ndfft axis=1 4096x4096 c128 (re-read loop)", lambda: ndfft(x, y, h, 1), 77.9))
+    xr = torch.from_numpy(synth.real_array((256, 256, 512))).to(dev); yr = torch.empty_like(xr); hd = DctHandler(512)
+    rows.append(("cfg4 nddct2 axis=2 256x256x512 f64 (re-read loop)", lambda: nddct2(xr, yr, hd, 2), 79.0))
+    for name, fn, best_us in rows:
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.4:                     # clocks
+            for _ in range(50): fn()
+            torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50): fn()
+            e1.record(); torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3 / 50)
+        us = min(ts)
+        print(f"perf canary: {name}: {us:.1f} us (best on record {best_us} us)")
+        if us > 1.15 * best_us:
+            warnings.warn(f"perf canary: {name} took {us:.1f} us, more than 15 % over its best recorded {best_us} us")
+
+
 def test_hip_graph_capture_and_replay(L):
     """exec_device issues only kernel launches on the caller's stream (no allocation, no sync) on the row
     kernels, so a multi-axis transform can be captured once into a HIP graph and replayed."""
