@@ -5,6 +5,8 @@ import socket
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -53,17 +55,21 @@ def test_bench_spawns_n_ranks_dry_gloo():
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2
 
 
-def test_bench_under_launcher_dry_gloo():
-    """The driver's N > 1 shape: torch.distributed.run provides the rank environment; bench.py must not spawn again."""
+@pytest.mark.parametrize("nranks", [2, 8])
+def test_bench_under_launcher_dry_gloo(nranks):
+    """The driver's N > 1 shape: torch.distributed.run provides the rank environment; bench.py must not spawn again.
+    nranks = 8 is the exact command line of the driver's SCALE run (8 ranks of one node), so that spawn path has run once."""
     import json
     env = dict(os.environ, OMP_NUM_THREADS="1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
                         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry"],
-                       capture_output=True, text=True, env=env, timeout=600)
+                        os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--steps", "20", "--warmup", "5", "--backend", "gloo", "--dry"],
+                       capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1 and json.loads(lines[0])["ranks_seen"] == 2, r.stdout
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["ranks_seen"] == nranks and out["n_gpus"] == nranks, r.stdout
 
 
 def test_synth_torch_generator_matches_numpy():
