@@ -27,6 +27,9 @@ extern "C" {
 #endif
 
 #define NDFFT_ABI_VERSION 1
+/* Minor revision: bumped when entry points are ADDED (existing ones keep their meaning).  1 = round-4 exports (ndfft_reload_switches,
+ * ndfft_documented_switches, ndfft_set_input_hint ...); 2 = ndfft_abi_minor itself. */
+#define NDFFT_ABI_MINOR 2
 
 typedef enum {
     NDFFT_OK = 0,
@@ -76,6 +79,7 @@ typedef struct ndfft_plan ndfft_plan;
 
 /* ---- library / device ------------------------------------------------------------------- */
 int ndfft_abi_version(void);
+int ndfft_abi_minor(void);   /* NDFFT_ABI_MINOR of the loaded library */
 /* Message of the last failing call on THIS thread ("" if none). */
 const char *ndfft_last_error(void);
 /* Number of visible gfx950 devices (0 if none; never an error). */
@@ -107,10 +111,13 @@ size_t ndfft_plan_lane_len_out(const ndfft_plan *plan, int op);
  * norm, scale  : see ndfft_norm; `scale` is read only for NDFFT_NORM_SCALE
  *
  * ndfft_exec        : host arrays.  Synchronous: `out` is fully written on return; nothing is
- *                     retained.  Staging is internal: calls of up to 2 MiB (input + output) run the kernels
- *                     straight from / into pinned, device-mapped bounce buffers (no DMA: two host copies
- *                     and one stream synchronisation -- 30-40 us for the reference's 128 x 128 bench
- *                     shapes); larger ones are staged through HBM, from 8 MiB as a pipeline of row chunks.
+ *                     retained.  Staging is internal: calls whose input + output span at most 2 MiB run the
+ *                     kernels straight from / into pinned, device-mapped bounce buffers (no DMA: two host copies
+ *                     and one stream synchronisation -- 30-40 us for the reference's n = 128 / 129 bench
+ *                     shapes; 264 x 264 c128 is 2.2 MiB and already takes the next path); larger ones are staged
+ *                     through HBM with two synchronous copies; dense C-ordered calls are cut into a pipeline of row
+ *                     chunks from 8 MiB when both arrays are pinned (ndfft_host_alloc) or cache-registered, and from
+ *                     32 MiB (and at least 2^20 points) through pinned bounce buffers when they are pageable.
  * ndfft_exec_device : device-resident arrays (hipMalloc'd).  Asynchronous on `stream`
  *                     (a hipStream_t, NULL = default stream).  This is what the roofline numbers
  *                     are measured on and what multi-axis / multi-GPU callers chain.
@@ -210,7 +217,8 @@ int ndfft_host_free(void *h_ptr);
 int ndfft_host_reg_cache(size_t max_bytes);
 int ndfft_host_forget(const void *h_ptr);
 
-/* Frees the CALLING THREAD's device workspace on EVERY device it has used: the scratch arrays of the multi-pass paths (transpose route,
+/* BLOCKS until every multi-device worker (ndfft_exec_sharded*) has drained its streams, then frees their chunk buffers and the CALLING
+ * THREAD's device workspace on EVERY device it has used: the scratch arrays of the multi-pass paths (transpose route,
  * four-step, column four-step, global Bluestein) and the staging buffers of ndfft_exec.  They are otherwise
  * kept per thread and per stream for reuse (HIP-graph capture needs them stable).  Synchronises the device.
  * Also frees the chunk buffers of the multi-device workers behind ndfft_exec_sharded* (every worker, after its streams drained).

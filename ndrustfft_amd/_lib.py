@@ -19,7 +19,7 @@ INPUT_AUTO, INPUT_CACHED, INPUT_COLD = 0, 1, 2
 
 # every symbol include/ndfft_mi355x.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "ndfft_abi_version", "ndfft_last_error", "ndfft_device_count", "ndfft_set_device",
+    "ndfft_abi_version", "ndfft_abi_minor", "ndfft_last_error", "ndfft_device_count", "ndfft_set_device",
     "ndfft_plan_create", "ndfft_plan_retain", "ndfft_plan_destroy", "ndfft_plan_n", "ndfft_plan_kind",
     "ndfft_plan_dtype", "ndfft_plan_lane_len_in", "ndfft_plan_lane_len_out",
     "ndfft_exec", "ndfft_exec_device", "ndfft_exec_sharded", "ndfft_exec_sharded_device", "ndfft_last_path", "ndfft_explain_plan",
@@ -53,6 +53,7 @@ class Library:
         _loaded.append(self)
         vp, i32, sz, i64p, dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_double
         L.ndfft_abi_version.restype = i32
+        L.ndfft_abi_minor.restype = i32
         L.ndfft_last_error.restype = ctypes.c_char_p
         L.ndfft_last_path.restype = ctypes.c_char_p
         L.ndfft_explain_plan.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]

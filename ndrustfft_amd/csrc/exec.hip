@@ -1266,11 +1266,22 @@ class HostRegCache {
     // eviction, forget() nor set_limit(0) will unregister it while the call's copies are in flight.  Asked BEFORE is_pinned() (round 4: a
     // registered array looks like any pinned one to hipPointerGetAttributes, and the steady-state calls used to bypass the cache -- the
     // hottest arrays were evicted first, nothing held them during the DMA, and a stale registration was not retried).
-    bool acquire(const void *p, size_t bytes) {
+    // Two steps (round 5, advisor): lookup() only consults the registrations this cache owns; sight() records a sighting of a range and registers it
+    // on the second one.  HostPin calls sight() only for memory that is NOT pinned already: an ndfft_host_alloc / hipHostMalloc array that missed the
+    // lookup is the caller's own pinned memory -- registering it again would either fail every time or leave the cache owning (and later
+    // unregistering) a registration over memory the caller frees with hipHostFree.
+    bool lookup(const void *p, size_t bytes) {
         const uintptr_t lo = (uintptr_t)p, hi = lo + std::max<size_t>(bytes, 1);
         std::lock_guard<std::mutex> g(mu_);
         ++tick_;
         for (R &r : v_) if (r.registered && r.lo <= lo && hi <= r.hi) { r.last = tick_; ++r.inuse; return true; }   // any size: sub-views of a registered array too
+        return false;
+    }
+    bool wants(size_t bytes) { std::lock_guard<std::mutex> g(mu_); return limit_ && bytes >= ((size_t)8 << 20); }
+    bool sight(const void *p, size_t bytes) {
+        const uintptr_t lo = (uintptr_t)p, hi = lo + std::max<size_t>(bytes, 1);
+        std::lock_guard<std::mutex> g(mu_);
+        ++tick_;
         if (!limit_ || bytes < ((size_t)8 << 20)) return false;
         for (size_t i = 0; i < v_.size();) {
             R &r = v_[i];
@@ -1345,7 +1356,11 @@ class HostRegCache {
 };
 struct HostPin {       // one side of a call: registered for the duration of the call if the cache says so
     const void *p = nullptr; bool held = false;
-    HostPin(const void *ptr, size_t bytes) : p(ptr) { held = HostRegCache::get().acquire(ptr, bytes); }
+    HostPin(const void *ptr, size_t bytes) : p(ptr) {
+        HostRegCache &c = HostRegCache::get();
+        held = c.lookup(ptr, bytes);
+        if (!held && c.wants(bytes) && !is_pinned(ptr)) held = c.sight(ptr, bytes);
+    }
     ~HostPin() { if (held) HostRegCache::get().release(p); }
 };
 int pipe_init(Pipe &p, int chunks) {

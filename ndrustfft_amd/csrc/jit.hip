@@ -529,7 +529,7 @@ template <typename T> int launch_jit_real(int gop, const JitCfg &cfg, bool col, 
                              std::to_string(lpb) + ", RadixList<" + radix_list(cfg) + ">, " + std::to_string(gop) + ", " + (col ? "true" : "false") + ", false>";
     // f32 kernels of >= 512 threads: floor of 8 waves per SIMD = 64 VGPRs (kernels_pow2_real.hip: RealAotWaves) -- but only where the specialised kernel FITS 64 registers:
     // the compiled code object is asked for its scratch size, and a recipe that spills falls back to the plain form (n = 1500: 2-3 x slower with the floor, n = 1000 / 2000:
-    // 10-20 % faster, profiles/r06/r06zr_*).  NDFFT_JIT_F32_MIN_WAVES overrides the floor (1 = none; read once).
+    // 10-20 % faster, profiles/r06/r06zr_*).  NDFFT_JIT_F32_MIN_WAVES overrides the floor in the developer build (1 = none).
     const int f32_floor = (int)NDFFT_DEV_INT("NDFFT_JIT_F32_MIN_WAVES", 8);
     const int floor_w = (sizeof(T) == 4 && threads >= 512 && f32_floor > 1 && gop != G_DCT3_EVEN) ? f32_floor : 1;
     auto make_src = [&](int w) {

@@ -530,7 +530,15 @@ const Switches *parse_switches() {
     auto str = [](const char *name, bool &set, std::string &v) { const char *e = getenv(name); set = e != nullptr; v = e ? e : ""; };
     auto on = [](const char *name, bool def) { const char *e = getenv(name); return e ? e[0] != '0' : def; };       // "0" closes, anything else opens
     auto one = [](const char *name) { const char *e = getenv(name); return e && e[0] == '1'; };                      // only "1" enables
-    auto num = [](const char *name, long def) { const char *e = getenv(name); return e ? atol(e) : def; };
+    // numeric switches are clamped to [lo, hi]; text that is not a number keeps the default
+    auto num = [](const char *name, long def, long lo, long hi) {
+        const char *e = getenv(name);
+        if (!e) return def;
+        char *end = nullptr;
+        const long v = strtol(e, &end, 10);
+        if (end == e) return def;
+        return std::min(hi, std::max(lo, v));
+    };
     if (const char *e = getenv("NDFFT_JIT")) S->jit = e[0] == '0' ? 0 : !strcmp(e, "cached") ? 2 : 1;
     str("NDFFT_JIT_CACHE", S->jit_cache_set, S->jit_cache);
     str("NDFFT_JIT_PREBUILT", S->jit_prebuilt_set, S->jit_prebuilt);
@@ -539,17 +547,17 @@ const Switches *parse_switches() {
     if (const char *e = getenv("HOME")) S->home = e;
     S->wave = on("NDFFT_WAVE", true); S->tiny = on("NDFFT_TINY", true); S->plain = on("NDFFT_PLAIN", true); S->blue = on("NDFFT_BLUE", true);
     S->rader = on("NDFFT_RADER", true); S->colsplit = on("NDFFT_COLSPLIT", true); S->fourstep2 = on("NDFFT_FOURSTEP2", true);
-    S->real_fourstep = (int)num("NDFFT_REAL_FOURSTEP", 1);
+    S->real_fourstep = (int)num("NDFFT_REAL_FOURSTEP", 1, 0, 2);
     if (const char *e = getenv("NDFFT_FS_DIRECT")) S->fs_direct = e[0] == '1' ? 1 : 0;
     S->narrow_dct = one("NDFFT_NARROW_DCT");
     S->rfs_c2r_tile = on("NDFFT_RFS_C2R_TILE", true);
-    S->rfs_logn1 = (int)num("NDFFT_RFS_LOGN1", 0);
-    S->cs_chunk_mb = (int)num("NDFFT_CS_CHUNK_MB", 144);
-    S->stream_loads = (int)num("NDFFT_STREAM_LOADS", -1);
+    S->rfs_logn1 = (int)num("NDFFT_RFS_LOGN1", 0, 0, 11);
+    S->cs_chunk_mb = (int)num("NDFFT_CS_CHUNK_MB", 144, 0, 1 << 20);
+    S->stream_loads = (int)num("NDFFT_STREAM_LOADS", -1, -1, 1);
     if (const char *e = getenv("NDFFT_HOST_PIPE")) S->host_pipe = e[0] == '1' ? 1 : e[0] == '0' ? 0 : -1;
-    S->host_reg_cache_mb = num("NDFFT_HOST_REG_CACHE_MB", 0);
-    S->copy_threads = (int)num("NDFFT_COPY_THREADS", 0);
-    if (const char *e = getenv("NDFFT_SHARD_CHUNK_KB")) S->shard_chunk_kb = std::max(1L, atol(e));
+    S->host_reg_cache_mb = num("NDFFT_HOST_REG_CACHE_MB", 0, 0, 1L << 22);
+    S->copy_threads = (int)num("NDFFT_COPY_THREADS", 0, 0, 64);
+    S->shard_chunk_kb = num("NDFFT_SHARD_CHUNK_KB", 0, 1, 1L << 24);
     S->shard_force_remote = one("NDFFT_SHARD_FORCE_REMOTE");
     return S;
 }
@@ -571,6 +579,7 @@ void reload_switches() {
 extern "C" {
 
 int ndfft_abi_version(void) { return NDFFT_ABI_VERSION; }
+int ndfft_abi_minor(void) { return NDFFT_ABI_MINOR; }
 int ndfft_reload_switches(void) { ndfft::reload_switches(); return NDFFT_OK; }
 int ndfft_documented_switches(char *buf, size_t cap) {
     static const char *const names[] = {NDFFT_DOCUMENTED_SWITCHES};

@@ -4,13 +4,19 @@
 // The struct is filled on first use and again only by ndfft_reload_switches() (a test hook: the parity tests flip a route switch,
 // reload, run a case, flip it back -- never concurrently with transforms on other threads).
 //
+// START-UP ONLY (captured once in a static the first time they are used; ndfft_reload_switches() does not reach them): NDFFT_JIT=0 against
+// an already loaded hiprtc (a process started with NDFFT_JIT=0 never loads it, and a reload to 1 does not either), NDFFT_HOST_REG_CACHE_MB
+// (the initial budget; ndfft_host_reg_cache() changes it at run time) and NDFFT_COPY_THREADS (the copy pool is created once).  Numeric
+// switches are clamped to their valid range by the parser; text that is not a number keeps the default.
+//
 // Two classes:
 //  * DOCUMENTED switches (the fields below; INTEGRATION.md section "Environment switches" lists every one, tests/test_switches.py
 //    keeps the two lists identical): where code objects are cached, which kernel routes are allowed (so that every fallback kernel
 //    can be reached by a test), host-path and multi-GPU chunking.
 //  * developer knobs (NDFFT_DEV_INT / NDFFT_DEV_STR at their point of use): tuning parameters whose A/B is recorded in DESIGN.md.
-//    They are compile-time constants in the product build; `make DEV=1` (-DNDFFT_DEV_KNOBS) turns each into a read-once
-//    environment value for sweeps with tools/.
+//    They are compile-time constants in the product build; `make DEV=1` (-DNDFFT_DEV_KNOBS) turns each into an environment value
+//    that is read AT EVERY USE (per plan / per call, no caching), so that a sweep may change a knob between plans inside one
+//    process (tools/probes/rader_tune.py, jit_col_lanes.py).
 #pragma once
 #include <cstdlib>
 #include <string>
@@ -60,10 +66,11 @@ struct Switches {
 const Switches &sw();            // plan.hip
 void reload_switches();          // plan.hip (ndfft_reload_switches)
 
-// developer knobs: constants in the product build, read-once environment values under -DNDFFT_DEV_KNOBS
+// developer knobs: constants in the product build; under -DNDFFT_DEV_KNOBS environment values read at every use (the developer build
+// is the only one that calls getenv outside parse_switches)
 #ifdef NDFFT_DEV_KNOBS
-#define NDFFT_DEV_INT(NAME, DEF) ([]() -> long { static const long v_ = [] { const char *e_ = getenv(NAME); return e_ ? atol(e_) : (long)(DEF); }(); return v_; }())
-#define NDFFT_DEV_STR(NAME) ([]() -> const char * { static const char *const v_ = getenv(NAME); return v_; }())
+#define NDFFT_DEV_INT(NAME, DEF) ([]() -> long { const char *e_ = getenv(NAME); return e_ ? atol(e_) : (long)(DEF); }())
+#define NDFFT_DEV_STR(NAME) ((const char *)getenv(NAME))
 #else
 #define NDFFT_DEV_INT(NAME, DEF) ((long)(DEF))
 #define NDFFT_DEV_STR(NAME) ((const char *)nullptr)

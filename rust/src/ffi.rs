@@ -35,6 +35,9 @@ pub const NDFFT_NORM_DEFAULT: c_int = 1;
 
 extern "C" {
     pub fn ndfft_last_error() -> *const c_char;
+    /// NDFFT_ABI_VERSION / NDFFT_ABI_MINOR of the loaded library (minor grows when entry points are added)
+    pub fn ndfft_abi_version() -> c_int;
+    pub fn ndfft_abi_minor() -> c_int;
     pub fn ndfft_plan_create(kind: c_int, dtype: c_int, n: usize, out_plan: *mut *mut ndfft_plan) -> c_int;
     pub fn ndfft_plan_retain(plan: *mut ndfft_plan) -> c_int;
     pub fn ndfft_plan_destroy(plan: *mut ndfft_plan) -> c_int;

@@ -15,7 +15,7 @@ int main(void) {
     int i, st;
     /* every entry point must at least link (address taken) */
     typedef void (*anyfn)(void);
-    anyfn syms[] = {(anyfn)ndfft_abi_version, (anyfn)ndfft_last_error, (anyfn)ndfft_device_count, (anyfn)ndfft_set_device, (anyfn)ndfft_plan_create,
+    anyfn syms[] = {(anyfn)ndfft_abi_version, (anyfn)ndfft_abi_minor, (anyfn)ndfft_last_error, (anyfn)ndfft_device_count, (anyfn)ndfft_set_device, (anyfn)ndfft_plan_create,
                     (anyfn)ndfft_plan_retain, (anyfn)ndfft_plan_destroy, (anyfn)ndfft_plan_n, (anyfn)ndfft_plan_kind, (anyfn)ndfft_plan_dtype,
                     (anyfn)ndfft_plan_lane_len_in, (anyfn)ndfft_plan_lane_len_out, (anyfn)ndfft_exec, (anyfn)ndfft_exec_device, (anyfn)ndfft_exec_sharded,
                     (anyfn)ndfft_exec_sharded_device, (anyfn)ndfft_last_path, (anyfn)ndfft_explain_plan, (anyfn)ndfft_dev_alloc, (anyfn)ndfft_dev_free,
@@ -23,7 +23,7 @@ int main(void) {
                     (anyfn)ndfft_host_free, (anyfn)ndfft_set_input_hint, (anyfn)ndfft_last_input_policy, (anyfn)ndfft_host_reg_cache, (anyfn)ndfft_host_forget,
                     (anyfn)ndfft_documented_switches, (anyfn)ndfft_reload_switches};
     for (i = 0; i < (int)(sizeof syms / sizeof syms[0]); ++i) if (!syms[i]) return 2;
-    if (ndfft_abi_version() != 1) { printf("abi version\n"); return 1; }
+    if (ndfft_abi_version() != 1 || ndfft_abi_minor() != NDFFT_ABI_MINOR) { printf("abi version\n"); return 1; }
     for (i = 0; i < 24; ++i) data[i] = (double)i;
     st = ndfft_plan_create(NDFFT_KIND_R2C, NDFFT_F64, 6, &plan);
     if (ndfft_device_count() == 0) {

@@ -30,7 +30,7 @@ def test_header_symbols_exported(lib):
     assert declared == sorted(_lib.SYMBOLS), "binding's symbol list drifted from the header"
     for s in declared:
         assert hasattr(lib.c, s), f"{s} declared in include/ndfft_mi355x.h but not exported"
-    assert lib.c.ndfft_abi_version() == 1
+    assert lib.c.ndfft_abi_version() == 1 and lib.c.ndfft_abi_minor() >= 2
 
 
 def test_library_is_gfx950_code_object():

@@ -36,7 +36,7 @@ def test_no_getenv_outside_the_parser():
             a, b = src.index("const Switches *parse_switches()"), src.index("const Switches &sw()")
             src = src[:a] + src[b:]
         if f.endswith("switches.h"):
-            src = re.sub(r"#ifdef NDFFT_DEV_KNOBS.*?#else", "", src, flags=re.S)      # the developer build's read-once macros
+            src = re.sub(r"#ifdef NDFFT_DEV_KNOBS.*?#else", "", src, flags=re.S)      # the developer build's read-at-every-use macros
         for m in re.finditer(r"\bgetenv\s*\(", src):
             offenders.append((os.path.basename(f), src.count("\n", 0, m.start()) + 1))
     assert not offenders, offenders

@@ -1,4 +1,5 @@
-"""Specialised f32 C2C kernels: half vs whole-complex LDS exchange (NDFFT_JIT_FULL_MIN)."""
+"""Specialised f32 C2C row kernels at eight smooth lengths: time, fraction of 8 TB/s and the kernel path (the half vs whole-complex
+LDS exchange A/B this script was written for is settled: the knob is gone, the measured setting is the code)."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))

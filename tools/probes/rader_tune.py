@@ -79,7 +79,6 @@ def main():
         M = p - 1
         rows = (1 << 24) // F
         if dct:
-            os.environ["NDFFT_RADER_SHORT"] = "1"
             from ndrustfft_amd import nddct2
             x = torch.from_numpy(synth.real_array((rows // 2, 2 * F))).to(dev)
         else:
