@@ -63,7 +63,13 @@ template <typename T> struct GenArgs {
 struct HostTable { std::vector<long double> re, im; };
 struct JitCfg { int n = 0, tpl = 0, e = 0, lpb = 1, vec = 1; bool partial = false; std::vector<int> radix; int row_lpb = 0; };   // row_lpb: planned lanes per row workgroup (0 = default rule)   // partial: some pass has an incomplete last round
 // Rader / Good-Thomas recipe of rader_kernel.h: F = mc * p, p prime with p - 1 smooth; fft = register configuration of FFT_(p-1)
-struct RaderCfg { int p = 0, mc = 1, mc1 = 1, mc2 = 1; JitCfg fft; };   // mc = mc1 * mc2: cofactor as one butterfly (mc2 = 1) or a two-factor transform in registers
+struct RaderCfg {
+    int p = 0, mc = 1, mc1 = 1, mc2 = 1; JitCfg fft;   // mc = mc1 * mc2: cofactor as one butterfly (mc2 = 1) or a two-factor transform in registers
+    // sym (DCT-I slot, odd cofactor > 1; round 5): the inner FFT input is built EVEN-SYMMETRIC, z[-i] = z[i] (rader_kernel.h), so the Good-Thomas rows n1 and
+    // mc - n1 have mirrored spectra and only rows 0 .. (mc - 1) / 2 run Rader's convolution
+    bool sym = false;
+    int rows() const { return sym ? (mc + 1) / 2 : mc; }
+};
 }  // namespace ndfft
 struct ndfft_plan;
 namespace ndfft {   // built once in long double
@@ -216,7 +222,7 @@ template <typename T> int launch_jit_blue(int gen_op, const JitCfg &cfgM, bool c
 // Bluestein (jit.hip): convolution length for inner FFT length F -- the cheapest 13-smooth M in [2F - 1, m_pow2] by passes x M -- and the register recipe for it
 int blue_pick_len(int dtype, int F, int m_pow2);
 bool blue_plan_cfg(int dtype, int M, JitCfg &cfg);
-bool rader_choose(int dtype, int F, RaderCfg &rc);
+bool rader_choose(int dtype, int F, RaderCfg &rc, bool dct1_slot = false);
 template <typename T> int launch_jit_plain(int gen_op, const JitCfg &cfg, bool col, const RealArgs<T> &a, hipStream_t s);   // plain_kernel.h: odd-n real ops, smooth F
 bool jit_choose_real(int dtype, int F, JitCfg &cfg);   // jit_choose for the real-op slots (rows of RealPow2Kernel): cost-model recipe
 int rader_col_lanes(int dtype, const RaderCfg &rc);

@@ -307,10 +307,13 @@ struct MallModel {
     }
     // 1: streaming loads, 0: plain loads, -1: unknown buffer (the launcher decides by size)
     int decide(const void *in, size_t bytes) {
-        if (bytes > kCap) return -1;
         const Entry *x = find(in, bytes);
         if (!x) return -1;
         if (x->state == OUT_COLD) return 1;
+        // a buffer larger than the cache (BASELINE configs[2]'s 4097 x 8192 c64 is 64 KiB over): only an IMMEDIATE re-read still finds most of it
+        // there (the size rule decides, as for an unknown buffer); anything else this thread has read since has pushed it out -- round 5: the
+        // rotating-pairs table ran this shape with plain loads (policy 0), 95.9 us against 92 us with streaming loads
+        if (bytes > kCap) return clock == x->stamp ? -1 : 1;
         return clock - x->stamp + bytes <= kCap ? 0 : 1;
     }
     void put(const void *p, size_t bytes, int state, bool through_cache) {

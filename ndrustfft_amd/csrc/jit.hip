@@ -620,7 +620,9 @@ template <typename T> int launch_jit_blue(int gop, const JitCfg &cfg, bool col, 
 static bool rader_enabled() { return sw().rader; }   // NDFFT_RADER=0 keeps every such length on Bluestein
 static size_t rader_lane_lds(const RaderCfg &rc, bool col) {   // complex elements per lane = RaderKernel::LANE_LDS
     const size_t M = (size_t)rc.p - 1, F = (size_t)rc.p * rc.mc;
-    const size_t sub = M + (M >> 4) + 2, lane = std::max((size_t)rc.mc * sub, F + (F >> 4) + 3);
+    const size_t zlen = rc.sym ? (size_t)((rc.p + 1) / 2) * rc.mc : F;                  // RaderKernel::ZLEN / ZRAW
+    const size_t zraw = std::max(zlen + (zlen >> 4) + 3, rc.sym ? (F + 2) / 2 : (size_t)0);
+    const size_t sub = M + (M >> 4) + 2, lane = std::max((size_t)rc.rows() * sub, zraw);
     (void)col;
     return lane | 1;
 }
@@ -629,7 +631,7 @@ static size_t rader_lane_lds(const RaderCfg &rc, bool col) {   // complex elemen
 static int row_lanes_by_fill(int lt, size_t lane, int forced, double *util_out);
 static int rader_row_lanes_for(int dtype, const RaderCfg &rc, double *util_out) {
     const int forced = (int)NDFFT_DEV_INT("NDFFT_RADER_LPB", 0);
-    return row_lanes_by_fill(rc.fft.tpl * rc.mc, rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8), forced, util_out);
+    return row_lanes_by_fill(rc.fft.tpl * rc.rows(), rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8), forced, util_out);
 }
 static int rader_row_lanes(int dtype, const RaderCfg &rc) { return rader_row_lanes_for(dtype, rc, nullptr); }
 
@@ -639,10 +641,20 @@ static int rader_row_lanes(int dtype, const RaderCfg &rc) { return rader_row_lan
 // under profiles/r04/r04c_rader_tune.txt and r04d_rader_tune_lpb.txt (tools/probes/rader_tune.py).
 static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg &out, int wide, double *cost_out);
 static thread_local bool g_rader_planning = false;      // plan_fft_by_cost is called for the Rader kernel (f64 cap 21 instead of 18)
+static thread_local bool g_rader_sym = false;           // ... for its symmetric DCT-I form: f64 cap 16 (nddct1 n = 512, FFT_72 on 4 rows: 9.8 on 5 threads, e = 18,
+                                                        //     222 us; on 8 threads, e = 16, two lanes per wave, 142 us -- profiles/r08/r08e_dct1_sym_tune_512.txt)
+static thread_local bool g_rader_sym_full_waves = false;   // ... and only recipes whose lane is a divisor or a multiple of one wave (the cost model's own picks, 9.8 on 5 threads and
+                                                           //     12.6 on 6, measured 222 and > 190 us)
 static bool rader_plan_fft(int dtype, int M, RaderCfg &rc, int wide) {
-    g_rader_planning = true;
-    const bool ok = plan_fft_by_cost(dtype, M, rc.mc, rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8), rc.fft, wide, nullptr);
-    g_rader_planning = false;
+    g_rader_planning = true; g_rader_sym = rc.sym;
+    bool ok = false;
+    if (rc.sym) {
+        g_rader_sym_full_waves = true;
+        ok = plan_fft_by_cost(dtype, M, rc.rows(), rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8), rc.fft, wide, nullptr);
+        g_rader_sym_full_waves = false;
+    }
+    if (!ok) ok = plan_fft_by_cost(dtype, M, rc.rows(), rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8), rc.fft, wide, nullptr);
+    g_rader_planning = false; g_rader_sym = false;
     return ok;
 }
 // lanes per workgroup for `lt` threads per lane and `lane` bytes of LDS per lane: one wave where a lane needs <= 64 threads, else the
@@ -680,7 +692,7 @@ static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg
     // f64 cap: 18 for the row kernels (1500 = 10.6.5.5 at e = 20 lost 10 %), 21 for the Rader kernel (mc > 0 marks it: 2016 = 16.9.7.2 on 126 threads, e = 21, 146 us
     // against 185 us for 12.12.7.2 on 168 threads, e = 14 -- two full waves against three at 7/8)
     const bool rader_call = g_rader_planning;
-    const int emax = dtype == NDFFT_F32 ? 32 : (wide ? std::max(wide, rader_call ? 21 : 18) : (rader_call ? 21 : 18)), esoft = dtype == NDFFT_F32 ? 21 : 18;
+    const int emax = dtype == NDFFT_F32 ? 32 : (wide ? std::max(wide, rader_call ? 21 : 18) : (g_rader_sym ? 16 : rader_call ? 21 : 18)), esoft = dtype == NDFFT_F32 ? 21 : 18;
     const double eslope = dtype == NDFFT_F32 ? 0.05 : 0.1;
     // wide: M has one factor 17 or 19 (f32 also 23, 29, 31; Rader for primes like 103, 137, 191, 47, 59): that radix joins the list
     std::vector<int> cand = {16, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
@@ -694,6 +706,7 @@ static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg
         std::sort(tpls.begin(), tpls.end()); tpls.erase(std::unique(tpls.begin(), tpls.end()), tpls.end());
         for (int tpl : tpls) {
             if (tpl < 1 || tpl * mc > 1024) continue;
+            if (g_rader_sym_full_waves && (tpl * mc) % 64 != 0 && 64 % (tpl * mc) != 0) continue;
             int e = 0; double work = 0; bool partial = false;
             for (int r : cur) { const int nb = M / r, sl = (nb + tpl - 1) / tpl; e = std::max(e, sl * r); work += (double)sl * tpl * r; if (nb % tpl) partial = true; }
             if (e > emax) continue;
@@ -788,7 +801,7 @@ bool blue_plan_cfg(int dtype, int M, JitCfg &cfg) {
     return true;
 }
 
-bool rader_choose(int dtype, int F, RaderCfg &rc) {
+bool rader_choose(int dtype, int F, RaderCfg &rc, bool dct1_slot) {
     if (jit_disabled() || F < 17) return false;
     int p = 1, m = F;
     for (int f = 2; (int64_t)f * f <= m; ++f) while (m % f == 0) { p = f; m /= f; }
@@ -811,6 +824,9 @@ bool rader_choose(int dtype, int F, RaderCfg &rc) {
       //  profiles/r04/r04za_rader_f32_wide.txt)
       if (wide && mc * ((p - 1) / wide) < 6) return false; }
     rc.p = p; rc.mc = mc;
+    // DCT-I with an odd cofactor > 1 (nddct1 n = 512: F = 511 = 7 x 73): even-symmetric inner FFT input, (mc + 1) / 2 of the mc Rader transforms
+    // (developer build: NDFFT_RADER_SYM=0 keeps the full form for A/B runs)
+    rc.sym = dct1_slot && mc > 1 && (mc & 1) && NDFFT_DEV_INT("NDFFT_RADER_SYM", 1) != 0;
     if (rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8) > jit_lds_limit()) return false;
     if (const char *e = NDFFT_DEV_STR("NDFFT_RADER_CFG")) {     // developer knob (tools/probes/rader_tune.py): "tpl:r0.r1.r2" for FFT_(p-1), read per plan
         JitCfg &c = rc.fft;
@@ -818,14 +834,14 @@ bool rader_choose(int dtype, int F, RaderCfg &rc) {
         const char *q = strchr(e, ':');
         int prod = 1;
         while (q && *q) { const int r = atoi(q + 1); if (r < 2) break; c.radix.push_back(r); prod *= r; q = strchr(q + 1, '.'); }
-        if (c.tpl < 1 || prod != p - 1 || c.tpl * mc > 1024) return false;
+        if (c.tpl < 1 || prod != p - 1 || c.tpl * rc.rows() > 1024) return false;
         for (int r : c.radix) { const int nb = c.n / r, sl = (nb + c.tpl - 1) / c.tpl; c.e = std::max(c.e, sl * r); if (nb % c.tpl) c.partial = true; }
         return true;
     }
     return rader_plan_fft(dtype, p - 1, rc, wide);
 }
 int rader_col_lanes(int dtype, const RaderCfg &rc) {
-    const int lt = rc.fft.tpl * rc.mc;
+    const int lt = rc.fft.tpl * rc.rows();
     if (const char *e = NDFFT_DEV_STR("NDFFT_RADER_COL_LPB")) { const int l = atoi(e); return l * lt <= 1024 ? l : 0; }   // developer knob
     // whole multiples of 8 adjacent lanes (64-byte rows in f64): measured 512x65536 f64 DCT-I 16 lanes 260 us (8: 284, 12: 375), 1009x16384 c128
     // 8 lanes 207 us (9: 321), 127x131072 c64 24 lanes 87 us (8: 93, 16: 100, 32: 96)
@@ -837,7 +853,8 @@ int rader_col_lanes(int dtype, const RaderCfg &rc) {
 template <typename T> int launch_jit_rader(int gop, const RaderCfg &rc, bool col, const RealArgs<T> &a, hipStream_t s) {
     if (!rtc().ok || !rader_enabled()) return NDFFT_ERR_UNSUPPORTED;
     const int dtype = sizeof(T) == 4 ? NDFFT_F32 : NDFFT_F64;
-    const int lt = rc.fft.tpl * rc.mc;
+    const int lt = rc.fft.tpl * rc.rows();
+    if (rc.sym && gop != G_DCT1) return NDFFT_ERR_UNSUPPORTED;       // (the symmetric recipe exists in the DCT-I slot only)
     const int lpb = col ? rader_col_lanes(dtype, rc) : rader_row_lanes(dtype, rc);
     if (lpb <= 0) return NDFFT_ERR_UNSUPPORTED;
     int dev = 0;
@@ -845,7 +862,7 @@ template <typename T> int launch_jit_rader(int gop, const RaderCfg &rc, bool col
     const char *tn = sizeof(T) == 4 ? "float" : "double";
     const int threads = lt * lpb;
     const std::string inst = std::string("RaderKernel<") + tn + ", " + std::to_string(rc.p) + ", " + std::to_string(rc.mc1) + ", " + std::to_string(rc.mc2) + ", " + std::to_string(rc.fft.tpl) + ", " +
-                             std::to_string(lpb) + ", RadixList<" + radix_list(rc.fft) + ">, " + std::to_string(gop) + ", " + (col ? "true" : "false") + ">";
+                             std::to_string(lpb) + ", RadixList<" + radix_list(rc.fft) + ">, " + std::to_string(gop) + ", " + (col ? "true" : "false") + ", " + (rc.sym ? "true" : "false") + ">";
     const std::string src = std::string("#include \"rader_kernel.h\"\nusing namespace ndfft;\nextern \"C\" __global__ __launch_bounds__(") +
                             std::to_string(threads) + ") void k_jit(const RealArgs<" + tn + "> a) { " + inst + "::run(a); }\n";
     const Entry e = get_or_compile("dev" + std::to_string(dev) + ":" + inst, src, inst);

@@ -442,7 +442,7 @@ static void add_narrow_tables(ndfft_plan *p) {
         }
         // ... and, where F = (small cofactor) x (prime p with p - 1 smooth), Rader's convolution of length p - 1 instead (rader_kernel.h)
         //     (also beyond Bluestein's single-launch reach: lanes of up to ~9600 (f64) / ~19000 (f32) elements that otherwise take the multi-pass routes)
-        if (p->has_cfg[i] && (c.blue || c.big) && c.F >= 17 && rader_choose(p->dtype, c.F, c.radercfg)) { c.rader = true; build_rader_tables(c); }
+        if (p->has_cfg[i] && (c.blue || c.big) && c.F >= 17 && rader_choose(p->dtype, c.F, c.radercfg, p->kind == NDFFT_KIND_DCT && i == CFG_DCT1)) { c.rader = true; build_rader_tables(c); }
     }
     // specialised (hiprtc) register kernels for the real-data ops with a smooth non-power-of-two inner FFT
     if (p->kind != NDFFT_KIND_C2C)
@@ -666,7 +666,7 @@ int ndfft_explain_plan(int kind, int dtype, size_t n, char *buf, size_t buflen) 
         std::string l = std::string("slot=") + slot_name[i] + " F=" + std::to_string(c.F);
         if (c.unsupported) l += " route=unsupported";
         else if (c.rader) l += " route=rader p=" + std::to_string(c.radercfg.p) + " mc=" + std::to_string(c.radercfg.mc1) + "x" + std::to_string(c.radercfg.mc2) + " M=" + std::to_string(c.radercfg.fft.n) +
-                               " tpl=" + std::to_string(c.radercfg.fft.tpl) + " e=" + std::to_string(c.radercfg.fft.e) + " radix=" + radix(c.radercfg.fft.radix) + " lanes=" + std::to_string(c.radercfg.fft.lpb);
+                               " tpl=" + std::to_string(c.radercfg.fft.tpl) + " e=" + std::to_string(c.radercfg.fft.e) + " radix=" + radix(c.radercfg.fft.radix) + " lanes=" + std::to_string(c.radercfg.fft.lpb) + (c.radercfg.sym ? " sym_rows=" + std::to_string(c.radercfg.rows()) : std::string());
         else if (c.pow2) l += " route=pow2";
         else if (c.jit) {
             l += " route=jit tpl=" + std::to_string(c.jitcfg.tpl) + " e=" + std::to_string(c.jitcfg.e) + " radix=" + radix(c.jitcfg.radix) + " lanes=" + std::to_string(c.jitcfg.row_lpb);

@@ -33,19 +33,37 @@ constexpr int rader_inv_mod(int a, int m) {   // a^-1 mod m for coprime a, m (0 
 
 // MC = MC1 * MC2: the cofactor transform is one butterfly (MC2 = 1: MC = 2..16) or a two-factor Cooley-Tukey in registers (reg_kernel.h: RegFft2::fft,
 // e.g. 18 = 6 x 3, 27 = 9 x 3, 28 = 7 x 4; its twiddles W_MC^k come through a.chirp)
-template <typename T, int P, int MC1, int MC2, int TPL, int LPB, typename RL, int OP, bool COL = false> struct RaderKernel {
+//
+// SYM (round 5; DCT-I with an ODD cofactor MC > 1, e.g. nddct1 n = 512: F = 511 = 7 x 73): the even extension e of length 2F is split by Good-Thomas
+// over 2 x F (F odd) instead of being packed two reals per complex: u_a[b] = e[m], m = b (mod F), m = a (mod 2), are two REAL EVEN sequences of
+// length F, and with z = u_0 + i u_1, i.e.
+//       z[b] = (x[b], x[F - b]) s  for even b,   (x[F - b], x[b]) s  for odd b          (s = the pre-scale, src/lib.rs:692-696)
+// Z = FFT_F(z) = U_0 + i U_1 with U_0, U_1 real, and DFT_2F(e)[q] = U_0[q h] + (-1)^q U_1[q h], h = (F + 1) / 2 = 2^-1 mod F:
+//       y[q] = (Re Z[j] + Im Z[j]) / 2,  j = q / 2              for even q,
+//       y[q] = (Re Z[j] - Im Z[j]) / 2,  j = ((q + F) / 2) mod F for odd q             (no split twiddle at all)
+// z is EVEN, z[-b] = z[b]: in the Good-Thomas grid x[n1, n2] = x[MC - n1, P - n2], so the length-P spectra of rows n1 and MC - n1 are mirror images,
+// Y[MC - n1][k2] = Y[n1][-k2].  Only rows 0 .. (MC - 1) / 2 run Rader's convolution -- 4 of 7 for F = 511 -- on (MC + 1) / 2 x TPL threads per lane;
+// each result goes to its own place of the [k2][n1] grid or to the mirrored one, and because Z is even too only the columns k2 <= (P - 1) / 2 get
+// their cofactor transform (POST reads Z[F - j] for the others).
+template <typename T, int P, int MC1, int MC2, int TPL, int LPB, typename RL, int OP, bool COL = false, bool SYM = false> struct RaderKernel {
     static constexpr int MC = MC1 * MC2;
+    static_assert(!SYM || (OP == G_DCT1 && MC > 1 && (MC & 1)), "SYM: DCT-I with an odd cofactor");
+    static constexpr int ROWS = SYM ? (MC + 1) / 2 : MC;            // sub-transforms that run the convolution
     using COF = RegFft2<T, MC1, MC2, 1, false>;
     static constexpr int M = P - 1, F = P * MC;
     using RLR = RadixReversed<RL>;
-    using FFT = Pow2Kernel<T, M, TPL, LPB * MC, false, RL, 0, 1, 0>;
-    using FFT2 = Pow2Kernel<T, M, TPL, LPB * MC, false, RLR, 0, 1, 0>;
+    using FFT = Pow2Kernel<T, M, TPL, LPB * ROWS, false, RL, 0, 1, 0>;
+    using FFT2 = Pow2Kernel<T, M, TPL, LPB * ROWS, false, RLR, 0, 1, 0>;
     static_assert(FFT2::E == FFT::E, "same radices, same registers");
     static constexpr int E = FFT::E;
-    static constexpr int LTHREADS = TPL * MC;                       // threads of one lane
+    static constexpr int LTHREADS = TPL * ROWS;                     // threads of one lane
     static constexpr int THREADS = LTHREADS * LPB;
     static constexpr int SUB_LDS = M + (M >> 4) + 2;                // complex elements of one sub-transform's exchange region
-    static constexpr int LANE_MIN = (MC * SUB_LDS > F + (F >> 4) + 3) ? MC * SUB_LDS : F + (F >> 4) + 3;   // ... and the raw lane / Z
+    // ... and the raw lane / Z.  SYM keeps only the bins it computes, Z[k1, k2] with k2 <= (P - 1) / 2, at k2 * MC + k1: about half the LDS per lane,
+    // i.e. twice the lanes per CU (nddct1 n = 512: 545 -> 313 complex elements)
+    static constexpr int ZLEN = SYM ? ((P + 1) / 2) * MC : F;
+    static constexpr int ZRAW = (SYM && (F + 2) / 2 > ZLEN + (ZLEN >> 4) + 3) ? (F + 2) / 2 : ZLEN + (ZLEN >> 4) + 3;
+    static constexpr int LANE_MIN = (ROWS * SUB_LDS > ZRAW) ? ROWS * SUB_LDS : ZRAW;
     // odd pitch: with few threads per lane the threads of a wave sit in DIFFERENT lanes at the same offset -- an even pitch (in 16-byte elements) puts them on the same
     // LDS banks (F = 34, 2 threads per lane, pitch 40: 16-way conflicts, nddct2 n = 68 179 us; odd pitch: see profiles/r04/r04zd_rader_pitch.txt)
     static constexpr int LANE_LDS = LANE_MIN | 1;
@@ -70,10 +88,29 @@ template <typename T, int P, int MC1, int MC2, int TPL, int LPB, typename RL, in
 
     // inner-FFT input element i (natural order) from the raw lane
     static __device__ __forceinline__ cpx<T> pre(const RealArgs<T> &a, const void *raw, int i) {
+        if constexpr (SYM) {
+            const T u = ((const T *)raw)[i] * a.scale, w = ((const T *)raw)[F - i] * a.scale;
+            return (i & 1) ? mk<T>(w, u) : mk<T>(u, w);
+        } else
         if constexpr (OP == G_C2C_FWD || OP == G_R2C_EVEN) return ((const cpx<T> *)raw)[i];   // R2C even: z[i] = (x[2i], x[2i+1])
         else if constexpr (OP == G_C2C_INV) return cconj(((const cpx<T> *)raw)[i]);
         else if constexpr (OP == G_R2C_ODD) return mk<T>(((const T *)raw)[i], (T)0);
         else return pre_elem<T, OP, ZiNone>(a, raw, i);
+    }
+
+    // real output element q from the natural-order Z
+    static __device__ __forceinline__ T post_r(const RealArgs<T> &a, const cpx<T> *res, int q) {
+        if constexpr (SYM) {
+            int j = (q & 1) ? (q + F) >> 1 : q >> 1;
+            if (j >= F) j -= F;
+            // bin j = (k1, k2) = (j mod MC, j mod P) of the Good-Thomas output map; Z[-j] = Z[j] and only k2 <= (P - 1) / 2 was computed
+            int k2 = j % P, k1 = j % MC;
+            if (k2 > (P - 1) / 2) { k2 = P - k2; k1 = k1 ? MC - k1 : 0; }
+            const cpx<T> c = res[ZiPhi::map(k2 * MC + k1)];
+            return (T)0.5 * ((q & 1) ? c.x - c.y : c.x + c.y);
+        } else {
+            return post_real<T, OP, ZiPhi>(a, res, q);
+        }
     }
 
     static __device__ __forceinline__ void run(const RealArgs<T> &a) {
@@ -166,16 +203,31 @@ template <typename T, int P, int MC1, int MC2, int TPL, int LPB, typename RL, in
             for (int q = 0; q < NBF0; ++q)
                 if (FULL0 || t + q * TPL < NB0) {
 #pragma unroll
-                    for (int r = 0; r < R0; ++r) zz[ginv[t + q * TPL + r * NB0] * MC + n1] = cconj(v[q * R0 + r]);
+                    for (int r = 0; r < R0; ++r) {
+                        const int k2 = ginv[t + q * TPL + r * NB0];
+                        const cpx<T> y = cconj(v[q * R0 + r]);
+                        if constexpr (SYM) {
+                            // only the columns k2 <= (P - 1) / 2 of the grid are transformed (Z is even as well): a value lands in its own place, or -- from the
+                            // upper half -- in the mirrored place of row MC - n1, Y[MC - n1][-k2] = Y[n1][k2]; row 0 is its own mirror
+                            if (k2 <= (P - 1) / 2) zz[k2 * MC + n1] = y;
+                            else if (n1 > 0) zz[(P - k2) * MC + (MC - n1)] = y;
+                        } else {
+                            zz[k2 * MC + n1] = y;
+                        }
+                    }
                 }
-            if (t == 0) zz[n1] = X0;
+            if (t == 0) {
+                zz[n1] = X0;
+                if constexpr (SYM) { if (n1 > 0) zz[MC - n1] = X0; }
+            }
             __syncthreads();
-            constexpr int NS = (P + LTHREADS - 1) / LTHREADS;
+            constexpr int PK = SYM ? (P + 1) / 2 : P;                       // columns k2 that get a cofactor transform
+            constexpr int NS = (PK + LTHREADS - 1) / LTHREADS;
             cpx<T> w[NS][MC];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int k2 = tl + s * LTHREADS;
-                if (k2 < P) {
+                if (k2 < PK) {
 #pragma unroll
                     for (int j = 0; j < MC; ++j) w[s][j] = zz[k2 * MC + j];
                 }
@@ -184,14 +236,18 @@ template <typename T, int P, int MC1, int MC2, int TPL, int LPB, typename RL, in
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int k2 = tl + s * LTHREADS;
-                if (k2 < P) {
+                if (k2 < PK) {
                     COF::fft(w[s], a.chirp);                              // register slot j holds output k1 = COF::out_index(j)
-                    const int kb = MC * ((k2 * MINV) % P);              // k2 C2 mod F
+                    [[maybe_unused]] const int kb = MC * ((k2 * MINV) % P);              // k2 C2 mod F
 #pragma unroll
                     for (int j = 0; j < MC; ++j) {
-                        int k = kb + P * ((COF::out_index(j) * PINV) % MC);   // + k1 C1 mod F
-                        if (k >= F) k -= F;
-                        zz[ZiPhi::map(k)] = w[s][j];
+                        if constexpr (SYM) {
+                            zz[ZiPhi::map(k2 * MC + COF::out_index(j))] = w[s][j];       // compact: bin (k1, k2) at k2 MC + k1 (post_r)
+                        } else {
+                            int k = kb + P * ((COF::out_index(j) * PINV) % MC);   // + k1 C1 mod F
+                            if (k >= F) k -= F;
+                            zz[ZiPhi::map(k)] = w[s][j];
+                        }
                     }
                 }
             }
@@ -209,7 +265,7 @@ template <typename T, int P, int MC1, int MC2, int TPL, int LPB, typename RL, in
                 for (int q = j0; q < a.n_out; q += THREADS / LPB) gstore<T, true>(out + (int64_t)q * a.elem_out, post_cplx<T, OP, ZiPhi>(a, res, q));
             } else {
                 T *out = (T *)a.out + base;
-                for (int q = j0; q < a.n_out; q += THREADS / LPB) __builtin_nontemporal_store(post_real<T, OP, ZiPhi>(a, res, q), out + (int64_t)q * a.elem_out);
+                for (int q = j0; q < a.n_out; q += THREADS / LPB) __builtin_nontemporal_store(post_r(a, res, q), out + (int64_t)q * a.elem_out);
             }
         } else {
             if (!live) return;
@@ -219,7 +275,7 @@ template <typename T, int P, int MC1, int MC2, int TPL, int LPB, typename RL, in
                 for (int q = tl; q < a.n_out; q += LTHREADS) gstore<T, true>(out + q, post_cplx<T, OP, ZiPhi>(a, res, q));
             } else {
                 T *out = (T *)a.out + lane * a.pitch_out;
-                for (int q = tl; q < a.n_out; q += LTHREADS) __builtin_nontemporal_store(post_real<T, OP, ZiPhi>(a, res, q), out + q);
+                for (int q = tl; q < a.n_out; q += LTHREADS) __builtin_nontemporal_store(post_r(a, res, q), out + q);
             }
         }
     }

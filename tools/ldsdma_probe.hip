@@ -8,6 +8,8 @@
 //   reg4 / reg8 / reg16   global_load of 4 / 8 / 16 bytes per thread, 8 in flight per thread, then ds_write (today's stage_loop)
 //   dma / dma-nt          one global_load_lds_dwordx4 per 1 KiB piece (per-lane SOURCE address, so a piece may span rows), all pieces
 //                         of the tile in flight at once, s_waitcnt vmcnt(0) + barrier
+//   pipe1 / pipe1-nt      a PERSISTENT workgroup with ONE LDS image: the tile is read into registers and the next tile's DMA is issued into the same
+//                         image at once (in flight during this tile's compute stand-in and stores); LDS = image + half an image of exchange buffer
 //   pipe / pipe-nt        a PERSISTENT workgroup with two LDS images: the next tile's DMA is issued before this tile's compute / store
 //                         phase, retired by a counted s_waitcnt vmcnt(S) (S = this wave's stores of the previous tile, which are younger)
 //                         and a raw s_barrier
@@ -18,7 +20,7 @@
 //   rfs2     second pass of the real four-step, 64 x 262144 f64: 512 rows x 128 B, 4224 B apart -> 512 rows x 128 B, 8 KiB apart, 512 threads
 // Arrays are walked in `rot` replicas so that every launch reads from HBM (cold) or re-reads one replica (warm: rot = 1).
 //   build: hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/ldsdma_probe.hip -o tools/ldsdma_probe
-//   run  : tools/ldsdma_probe [rounds = 5] [shape filter substring]
+//   run  : tools/ldsdma_probe [rounds = 5] [shape filter substring] [compute stand-in cycles]
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -153,6 +155,47 @@ template <int THREADS, bool NT, int SPT> __global__ __launch_bounds__(THREADS) v
     }
 }
 
+// persistent, ONE LDS image: the tile is read into registers (8 x 16 B per thread at most: tile_bytes <= 128 B x THREADS), and the NEXT tile's DMA
+// is issued into the same image right away -- it is in flight during this tile's compute stand-in and stores.  The compute phase of a real
+// kernel then needs its own exchange buffer (`xlds` bytes, only reserved here so that the occupancy matches).
+template <int THREADS, bool NT, int SPT> __global__ __launch_bounds__(THREADS) void k_pipe1(const char *in, char *out, const Shape s) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int npiece = s.tile_bytes >> 10;
+    const unsigned lds0 = lds_addr(smem);
+    const unsigned G = gridDim.x;
+    unsigned vb = blockIdx.x;
+    if (vb >= (unsigned)s.ntiles) return;
+    auto issue = [&](unsigned tile) {
+        long long bi, bo; tile_base(s, tile, bi, bo);
+        const char *src = in + bi;
+        for (int p = wave; p < npiece; p += THREADS / 64) {
+            const int x = (p << 10) + (lane << 4), row = x >> s.logW, col = x & ((1 << s.logW) - 1);
+            glds16<NT>(src + (long long)row * s.pitch_in + col, lds0 + (unsigned)(p << 10));
+        }
+    };
+    issue(vb);
+    wait_vm<0>();
+    for (; vb < (unsigned)s.ntiles; vb += G) {
+        wait_vm<SPT>();                      // DMA(vb) is older than the previous tile's SPT stores
+        __builtin_amdgcn_s_barrier();
+        v4f v[SPT];
+#pragma unroll
+        for (int k = 0; k < SPT; ++k) v[k] = *(const v4f *)(smem + ((threadIdx.x + k * THREADS) << 4));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();        // every wave holds its part of the image in registers: the image is free
+        if (vb + G < (unsigned)s.ntiles) issue(vb + G);
+        long long bi, bo; tile_base(s, vb, bi, bo);
+        fake_compute(s.cyc);
+        char *o = out + bo;
+#pragma unroll
+        for (int k = 0; k < SPT; ++k) {
+            const int y = (threadIdx.x + k * THREADS) << 4, row = y >> s.logWo, col = y & ((1 << s.logWo) - 1);
+            __builtin_nontemporal_store(v[k], (v4f *)(o + (long long)row * s.pitch_out + col));
+        }
+    }
+}
+
 struct Var { std::string name; int wgcu; size_t lds; int kind; void (*launch)(const Var &, const char *, char *, const Shape &, unsigned cus); int threads; };
 
 template <int THREADS, int LW, bool NT> static void go_reg(const Var &v, const char *i, char *o, const Shape &s, unsigned) {
@@ -168,6 +211,11 @@ template <int THREADS, bool NT, int SPT> static void go_pipe(const Var &v, const
     hipLaunchKernelGGL((k_pipe<THREADS, NT, SPT>), dim3(std::min<unsigned>(s.ntiles, v.wgcu * cus)), dim3(THREADS), v.lds, 0, i, o, s);
 }
 
+template <int THREADS, bool NT, int SPT> static void go_pipe1(const Var &v, const char *i, char *o, const Shape &s, unsigned cus) {
+    static bool once = (hipFuncSetAttribute((const void *)k_pipe1<THREADS, NT, SPT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess); (void)once;
+    hipLaunchKernelGGL((k_pipe1<THREADS, NT, SPT>), dim3(std::min<unsigned>(s.ntiles, v.wgcu * cus)), dim3(THREADS), v.lds, 0, i, o, s);
+}
+
 struct Case { std::string name; Shape s; int threads; size_t bytes_in, bytes_out; int rot; };
 
 template <int THREADS, int SPT> static void add_variants(std::vector<Var> &vs, const Shape &s, size_t extra_lds) {
@@ -180,6 +228,12 @@ template <int THREADS, int SPT> static void add_variants(std::vector<Var> &vs, c
     vs.push_back({"reg16-nt", 0, one, 0, go_reg<THREADS, 16, true>, THREADS});
     vs.push_back({"dma", 0, one, 1, go_dma<THREADS, false>, THREADS});
     vs.push_back({"dma-nt", 0, one, 1, go_dma<THREADS, true>, THREADS});
+    for (int w : {1, 2, 3, 4}) {                                   // one image + a separate exchange buffer of half the image (HALF exchange)
+        const size_t l = (size_t)s.tile_bytes + (size_t)s.tile_bytes / 2 + 4096;
+        if (l * w > 160 * 1024) continue;
+        vs.push_back({"pipe1 " + std::to_string(w) + "wg/cu", w, l, 2, go_pipe1<THREADS, false, SPT>, THREADS});
+        vs.push_back({"pipe1-nt " + std::to_string(w) + "wg/cu", w, l, 2, go_pipe1<THREADS, true, SPT>, THREADS});
+    }
     for (int w : {1, 2, 3, 4}) {
         const size_t l = 2 * (size_t)s.tile_bytes + extra_lds;
         if (l * w > 160 * 1024) continue;
@@ -191,6 +245,7 @@ template <int THREADS, int SPT> static void add_variants(std::vector<Var> &vs, c
 int main(int argc, char **argv) {
     const int rounds = argc > 1 ? atoi(argv[1]) : 5;
     const char *filter = argc > 2 ? argv[2] : "";
+    const int cyc_override = argc > 3 ? atoi(argv[3]) : -1;       // compute stand-in in clocks (default: per shape)
     hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0));
     const unsigned cus = (unsigned)pr.multiProcessorCount;
     const size_t MiB = 1ull << 20;
@@ -220,6 +275,7 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (auto &c : cases) {
         if (filter[0] && c.name.find(filter) == std::string::npos) continue;
+        if (cyc_override >= 0) c.s.cyc = cyc_override;
         std::vector<Var> vs;
         // extra LDS: the exchange buffer of the product kernel where it is not the image itself (rows: HALF exchange lives in the image)
         if (c.threads == 512 && c.s.tile_bytes == 65536) add_variants<512, 8>(vs, c.s, 0);
