@@ -1061,7 +1061,8 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
                 a.makhoul = col ? P.makhoul_out : 0;
                 const size_t es_out = (op_out_cplx(P.op) ? 2 : 1) * real_size(plan->dtype);
                 // dense rows of the ahead-of-time real-op kernels (BASELINE configs[3]): load policy from the Infinity-Cache model, as for the C2C rows
-                if (!col && !use_jit && !use_blue && !use_plain && a.pitch_in == P.xlen && a.pitch_out == P.ylen && F_nt_ok(c.F))
+                // (round 5: also the real-input rows of the Rader kernel)
+                if (!col && ((!use_jit && !use_blue && !use_plain) || (use_rader && !op_in_cplx(P.op))) && a.pitch_in == P.xlen && a.pitch_out == P.ylen && F_nt_ok(c.F))
                     a.stream_in = row_load_policy(d_in, (size_t)P.nlanes * P.xlen * es_in, d_out, (size_t)P.nlanes * P.ylen * es_out) == 1;
                 // column tiles of a caller's array (not the stages of col_split / the four-step, which set their own policy): the same model
                 if (col && !P.no_xcd_map && !P.stream_in && !P.keep_out)

@@ -147,7 +147,17 @@ template <typename T, int P, int MC1, int MC2, int TPL, int LPB, typename RL, in
             } else {
                 const T *in = (const T *)a.in + lsafe * a.pitch_in;
                 T *raw = (T *)lds;
-                stage_loop<LTHREADS>(tl, a.n_in, [&](int j) { return in[j]; }, [&](int j, T v) { raw[j] = v; });
+                // 16-byte staging loads where the lanes are 16-byte aligned in global memory (vec_in) and in LDS (f64: every lane base is), streaming
+                // (nt) when the residency model says the input comes from HBM (stream_in) -- round 5: cfg4 nddct1 from HBM 152 us
+                if ((LANE_LDS * 2 * sizeof(T)) % 16 == 0 && a.vec_in) {
+                    constexpr int W = 16 / sizeof(T);
+                    const int nv = a.n_in / W;
+                    if (a.stream_in) stage_loop<LTHREADS>(tl, nv, [&](int j) { return __builtin_nontemporal_load((const vec4f *)in + j); }, [&](int j, vec4f v) { ((vec4f *)raw)[j] = v; });
+                    else stage_loop<LTHREADS>(tl, nv, [&](int j) { return ((const vec4f *)in)[j]; }, [&](int j, vec4f v) { ((vec4f *)raw)[j] = v; });
+                    for (int j = W * nv + tl; j < a.n_in; j += LTHREADS) raw[j] = in[j];
+                } else {
+                    stage_loop<LTHREADS>(tl, a.n_in, [&](int j) { return in[j]; }, [&](int j, T v) { raw[j] = v; });
+                }
             }
         }
         __syncthreads();
@@ -268,6 +278,29 @@ template <typename T, int P, int MC1, int MC2, int TPL, int LPB, typename RL, in
                 for (int q = j0; q < a.n_out; q += THREADS / LPB) __builtin_nontemporal_store(post_r(a, res, q), out + (int64_t)q * a.elem_out);
             }
         } else {
+            if constexpr (SYM && (LANE_LDS * 2 * sizeof(T)) % 16 == 0) {
+                // DCT-I rows, 16-byte aligned lanes (vec_out): outputs go registers -> LDS (the lane region, natural order) -> 16-byte non-temporal
+                // stores instead of 8-byte stores LTHREADS elements apart (the staged POST of pow2_real.h)
+                if (a.vec_out) {
+                    constexpr int NQ = (F + 1 + LTHREADS - 1) / LTHREADS;
+                    const cpx<T> *res0 = (const cpx<T> *)lds;
+                    T o[NQ];
+#pragma unroll
+                    for (int i = 0; i < NQ; ++i) { const int q = tl + i * LTHREADS; if (q <= F) o[i] = post_r(a, res0, q); }
+                    __syncthreads();                       // every read of Z is done: the lane region becomes the output lane
+                    T *stage = (T *)lds;
+#pragma unroll
+                    for (int i = 0; i < NQ; ++i) { const int q = tl + i * LTHREADS; if (q <= F) stage[q] = o[i]; }
+                    __syncthreads();
+                    if (!live) return;
+                    T *out = (T *)a.out + lane * a.pitch_out;
+                    constexpr int W = 16 / sizeof(T);
+                    constexpr int NV = (F + 1) / W;
+                    for (int j = tl; j < NV; j += LTHREADS) __builtin_nontemporal_store(((const vec4f *)stage)[j], (vec4f *)out + j);
+                    for (int j = W * NV + tl; j <= F; j += LTHREADS) out[j] = stage[j];
+                    return;
+                }
+            }
             if (!live) return;
             const cpx<T> *res = (const cpx<T> *)lds;
             if constexpr (OUT_CPLX) {
