@@ -984,7 +984,9 @@ static int dispatch(const Problem &P, const void *d_in, void *d_out, hipStream_t
         const DevConfig &d = dt->cfg[slot];
         const bool is_c2c = plan->kind == NDFFT_KIND_C2C;
         const bool odd_variant = gop == G_R2C_ODD || gop == G_C2R_ODD || gop == G_DCT2_ODD || gop == G_DCT3_ODD || gop == G_DCT4_ODD;
-        const bool use_jit = c.jit && !c.pow2 && P.nlanes * (int64_t)c.F >= (1 << 16);
+        // (2^15 points since round 5: ndfft_r2c axis 0 of the reference's 264 x 264 bench shape is 264 lanes x 132 points -- generic_col 11.6 us, jit_col 6-7 us in a graph;
+        //  its code object ships in jit_prebuilt/)
+        const bool use_jit = c.jit && !c.pow2 && P.nlanes * (int64_t)c.F >= (1 << 15);
         // Bluestein lengths on the register kernel (blue_kernel.h), every op incl. the odd-n variants and row C2C
         // Rader / Good-Thomas (rader_kernel.h) wherever the plan has a recipe -- also for lanes beyond Bluestein's single-launch reach
         // (F > 4096: M' = 2^k >= 2F - 1 no longer fits, Rader's F complex elements of LDS do); Bluestein stays the fallback where it exists

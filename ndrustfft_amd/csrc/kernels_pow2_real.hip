@@ -129,7 +129,11 @@ template <typename T, int F, int KIND = 0> struct ColGeom {
     static constexpr int HALVE_FROM = sizeof(T) == 8 ? (KIND >= 2 ? 16 : 8) : 1000;
     static constexpr int LPB = (LPB0 >= HALVE_FROM && LPB0 * LANE_BYTES > 80 * 1024) ? LPB0 / 2 : LPB0;
     static constexpr size_t LDS = (size_t)LPB * LANE_BYTES;
+#ifndef NDFFT_COL_MIN_LANES
     static constexpr int MIN_LANES = (sizeof(T) == 8 && KIND <= 1) ? 4 : 8;
+#else
+    static constexpr int MIN_LANES = NDFFT_COL_MIN_LANES;      // side builds only (tools/probes)
+#endif
     static constexpr bool OK = LPB >= MIN_LANES && LDS <= 160 * 1024;
 };
 
@@ -221,6 +225,25 @@ template <typename T, int F, int OP> static int launch_real_one(const RealArgs<T
     constexpr int KIND = (OP == G_C2C_FWD || OP == G_C2C_INV) ? 0 : (OP == G_R2C_EVEN ? 1 : (OP == G_C2R_EVEN ? 2 : 3));   // which sides are real lanes (cfg3-A 210 -> 202 us, cfg3-A' 259 -> 235 us)
     if constexpr (ColGeom<T, F, KIND>::OK) {
         constexpr int LPB = ColGeom<T, F, KIND>::LPB;
+        // Small grids (the reference's own bench shapes, benches/ndrustfft.rs:6-7: n x n arrays with n = 512 ... 1025 along axis 0): with the tile widths above
+        // the whole call is 33 ... 128 workgroups on 256 CUs, and what a call costs is the latency of ONE tile.  Narrower tiles (down to 4 f64 lanes = 32 / 64-byte
+        // rows -- ruinous for arrays that have to come from HBM, irrelevant for a few MiB) spread the lanes over more CUs: replayed from a HIP graph ndfft
+        // n = 512 6.15 -> 4.98 us, ndfft_r2c n = 512 / 1024 7.06 / 7.24 -> 5.43 / 6.44 us, nddct1 n = 513 7.34 -> 6.43 us; nddct1 n = 1025 (F = 1024, real rows)
+        // measured no better (14.2 -> 14.9 us) and keeps its tile (profiles/r08/r08h_small_shapes_col_lanes.txt).  Caller's column tiles only (not the stages of the
+        // four-step routes, which set keep_out / makhoul / stream_in themselves).
+        if constexpr (sizeof(T) == 8 && F >= 256 && !(F >= 1024 && KIND >= 2)) {
+            constexpr int64_t kCus = 256;
+            if (!a.keep_out && !a.makhoul) {
+                if constexpr (LPB / 4 >= 4) {
+                    if ((a.nlanes + LPB / 2 - 1) / (LPB / 2) < kCus)
+                        return launch_k<RealPow2Kernel<T, F, TPL, LPB / 4, typename RealCfg<F>::RL, OP, true>, T>(a, LPB / 4, s);
+                }
+                if constexpr (LPB / 2 >= 4) {
+                    if ((a.nlanes + LPB - 1) / LPB < kCus)
+                        return launch_k<RealPow2Kernel<T, F, TPL, LPB / 2, typename RealCfg<F>::RL, OP, true>, T>(a, LPB / 2, s);
+                }
+            }
+        }
         return launch_k<RealPow2Kernel<T, F, TPL, LPB, typename RealCfg<F>::RL, OP, true>, T>(a, LPB, s);
     } else {
         return fail(NDFFT_ERR_UNSUPPORTED, "pow2 real kernel: no column tile for this F");

@@ -53,6 +53,7 @@ def med(f, batches=7, reps=None, budget=0.15):
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--md", action="store_true"); ap.add_argument("--no-gpu", action="store_true")
     ap.add_argument("--host-only", action="store_true", help="only the gpu_host column (A/B runs of the host path)")
+    ap.add_argument("--gpu-only", action="store_true", help="only the device-resident columns (eager, graph replay): A/B runs of kernel variants")
     a = ap.parse_args()
     os.environ.setdefault("OMP_NUM_THREADS", str(usable_cpus()))
     # libgomp's spinning waiters and a container CPU quota do not mix: with the default policy every small `_par` call here took 32 / 64 ms
@@ -88,9 +89,12 @@ def main():
                 assert np.abs(yh - yo).max() / max(np.abs(yo).max(), 1e-300) < 1e-10
                 print(json.dumps({k: (round(v, 2) if isinstance(v, float) else v) for k, v in r.items()}), flush=True)
                 continue
-            r["cpu_serial_us"] = med(lambda: getattr(orc, op)(x, y, oh, 0)) * 1e6
-            yo = y.copy()
-            r["cpu_par_us"] = med(lambda: getattr(orc, op + "_par")(x, y, oh, 0)) * 1e6
+            if a.gpu_only:
+                getattr(orc, op + "_par")(x, y, oh, 0); yo = y.copy()
+            else:
+                r["cpu_serial_us"] = med(lambda: getattr(orc, op)(x, y, oh, 0)) * 1e6
+                yo = y.copy()
+                r["cpu_par_us"] = med(lambda: getattr(orc, op + "_par")(x, y, oh, 0)) * 1e6
             if gpu:
                 h = {"ndfft": FftHandler, "ndfft_r2c": R2cFftHandler, "nddct1": DctHandler}[op](n)
                 fn = {"ndfft": ndfft, "ndfft_r2c": ndfft_r2c, "nddct1": nddct1}[op]
@@ -132,9 +136,10 @@ def main():
                     del g
                 except Exception as ex:                       # pragma: no cover
                     r["gpu_graph_error"] = repr(ex)[:200]
-                yh = np.zeros_like(y)
-                r["gpu_host_us"] = med(lambda: fn(x, yh, h, 0), budget=0.1) * 1e6
-                assert np.abs(yh - yo).max() / max(np.abs(yo).max(), 1e-300) < 1e-10
+                if not a.gpu_only:
+                    yh = np.zeros_like(y)
+                    r["gpu_host_us"] = med(lambda: fn(x, yh, h, 0), budget=0.1) * 1e6
+                    assert np.abs(yh - yo).max() / max(np.abs(yo).max(), 1e-300) < 1e-10
             rows.append(r)
             print(json.dumps({k: (round(v, 2) if isinstance(v, float) else v) for k, v in r.items()}), flush=True)
     if a.md and rows:
