@@ -521,6 +521,14 @@ static int col_split(const Problem &P, const void *d_in, void *d_out, const FftC
     return NDFFT_OK;
 }
 
+// Pitch padding of the four-step routes' intermediates (round 5).  Pass 2 reads the intermediate as column tiles: 128-byte rows one pitch apart.  With the natural
+// power-of-two pitch (256 x 65536 c128: 4096 B) the rows of a tile fall on few HBM channels; 128 bytes more per row and a copy of that shape runs 6.5 % faster
+// (9 % with streaming LDS-DMA loads; + 512 B: 3.7 %, + 1 KiB: slower -- tools/ldsdma_probe.hip `fs2`, profiles/r08/r08j_fs2_pitch.txt).  The real four-step's
+// forward intermediate always had such a pitch (N1/2 + 1 rounded up to whole lines).  In the product the gain is small: nddct4 64 x 262144 f64 165 -> 157 us,
+// 32 x 2^20 c64 291 -> 281-288 us, 256 x 65536 c128 204 -> 201-204 us (profiles/r08/r08k_longlanes_pad.txt) -- the passes already run at the copy rate of
+// their tile shapes (two passes of 537 MB at 5.3-5.7 TB/s = 195 us for the c128 case).  Elements of type cpx<T>.
+template <typename T> static int fs_pad_elems() { return (int)(NDFFT_DEV_INT("NDFFT_FS_PAD", 128) / (long)sizeof(cpx<T>)); }
+
 // Four-step complex FFT of length F = F1*F2 on L lanes (zin / zout: lane pitches in elements).
 // zin may equal zout.  Sub-FFTs run through dispatch() on the row kernels.
 template <typename T>
@@ -549,7 +557,8 @@ static int big_fft(const FftConfig &c, const DevConfig &d, const cpx<T> *zin, in
     const int esz = (int)sizeof(cpx<T>);
     void *s1, *s2;
     int rc;
-    if ((rc = get_scratch(2, stream, (size_t)(L * F) * esz, &s1))) return rc;
+    const int64_t K1p = F1 + fs_pad_elems<T>();       // pitch of the two-pass intermediate s1[n2][k1]
+    if ((rc = get_scratch(2, stream, (size_t)(L * std::max<int64_t>(F, (int64_t)F2 * K1p)) * esz, &s1))) return rc;
     // Two-pass form, no transpose launch, when both factors have a column kernel (powers of two, 64..1024):
     //   (1) length-F1 FFTs over the strided n1 axis, column load, stored TRANSPOSED as s1[n2][k1] (row store)
     //   (2) length-F2 FFTs over n2 of s1 (stride F1, adjacent k1 contiguous), twiddle W_F^(n2 k1) on load, stored at
@@ -567,12 +576,12 @@ static int big_fft(const FftConfig &c, const DevConfig &d, const cpx<T> *zin, in
         a.xcd_chunk = (int)NDFFT_DEV_INT("NDFFT_FS_XCD_CHUNK", 32);
         // pass 1: lanes (l, n2)
         a.in = zin; a.out = s1; a.nlanes = L * F2; a.n = F1; a.F = F1; a.n_in = F1; a.n_out = F1; a.scale = (T)1;
-        a.inner = F2; a.outer_in = pitch_in; a.outer_out = 0; a.elem_in = F2; a.elem_out = 0; a.pitch_out = F1;
+        a.inner = F2; a.outer_in = pitch_in; a.outer_out = 0; a.elem_in = F2; a.elem_out = 0; a.pitch_out = K1p;
         a.twp = (const cpx<T> *)dt1->cfg[CFG_MAIN].twp_col;
         if ((rc = launch_fourstep<T>(1, F1, inverse, a, stream))) return rc;
         // pass 2: lanes (l, k1)
         a.in = s1; a.out = zout; a.nlanes = L * F1; a.n = F2; a.F = F2; a.n_in = F2; a.n_out = F2; a.scale = scale;
-        a.inner = F1; a.outer_in = F; a.outer_out = pitch_out; a.elem_in = F1; a.elem_out = F1; a.pitch_out = 0;
+        a.inner = F1; a.outer_in = (int64_t)F2 * K1p; a.outer_out = pitch_out; a.elem_in = K1p; a.elem_out = F1; a.pitch_out = 0;
         a.twp = (const cpx<T> *)dt2->cfg[CFG_MAIN].twp_col;
         return launch_fourstep<T>(2, F2, inverse, a, stream);
     }
@@ -688,14 +697,16 @@ static int real_fourstep_inv(const Problem &P, int gop, const FftConfig &c, cons
     int rc;
     if ((rc = get_dev_tables(c.rfs_sub2, &dt2))) return rc;
     void *s1;
-    if ((rc = get_scratch(4, stream, (size_t)(B * Kx * N2) * sizeof(cpx<T>), &s1))) return rc;
+    // (no pitch padding here: with + 128 B per row ndifft_r2c 64 x 262144 f64 measured 112 -> 118 us, nddct3 unchanged -- profiles/r08/r08k_longlanes_pad.txt)
+    const int64_t N2p = N2;                          // pitch of the intermediate s[k1][n2]
+    if ((rc = get_scratch(4, stream, (size_t)(B * Kx * N2p) * sizeof(cpx<T>), &s1))) return rc;
     RealArgs<T> a;
     a.pitch_in = 0; a.vec_in = 0; a.vec_out = 0; a.xcd_remap = 0; a.keep_out = 0; a.stream_in = 0; a.chunk_out = 0; a.xcd_chunk = 0; a.makhoul = 0;
     a.aux1 = nullptr; a.aux2 = (const cpx<T> *)d.aux2; a.chirp = nullptr; a.bhat = nullptr;
     a.cs_twlo = (const cpx<T> *)d.rfs_twlo; a.cs_twhi = (const cpx<T> *)d.rfs_twhi; a.cs_logB = c.rfs_logB;
     a.cs_k1n = Kx; a.cs_f1 = N1; a.cs_n = (int)n; a.cs_outer_in = 0; a.cs_outer_out = 0; a.cs_pitch = 0;
     a.in = d_in; a.out = s1; a.nlanes = B * Kp; a.n = N2; a.F = N2; a.n_in = N2; a.n_out = N2; a.scale = (T)P.scale;
-    a.inner = Kp; a.outer_in = pin; a.outer_out = 0; a.elem_in = N1; a.elem_out = 0; a.pitch_out = N2;
+    a.inner = Kp; a.outer_in = pin; a.outer_out = 0; a.elem_in = N1; a.elem_out = 0; a.pitch_out = N2p;
     a.twp = (const cpx<T> *)dt2->cfg[CFG_MAIN].twp_col;
     // runs of consecutive tiles per XCD: the mirrored index N1 - k1 is shifted by one element against the tile grid (and DCT-III's real rows are
     // half lines), so neighbouring tiles share every line
@@ -706,14 +717,14 @@ static int real_fourstep_inv(const Problem &P, int gop, const FftConfig &c, cons
         if ((rc = get_dev_tables(c.rfs_sub1, &dt1))) return rc;
         a.xcd_chunk = 0; a.keep_out = 0;
         a.in = s1; a.out = d_out; a.nlanes = B * N2; a.n = N1; a.F = N1 / 2; a.n_in = Kx; a.n_out = N1; a.scale = (T)1;
-        a.inner = N2; a.outer_in = (int64_t)Kx * N2; a.outer_out = pout; a.elem_in = N2; a.elem_out = N2; a.pitch_in = 0; a.pitch_out = 0;
+        a.inner = N2; a.outer_in = (int64_t)Kx * N2p; a.outer_out = pout; a.elem_in = N2p; a.elem_out = N2; a.pitch_in = 0; a.pitch_out = 0;
         a.aux1 = (const cpx<T> *)dt1->cfg[CFG_MAIN].aux1; a.twp = (const cpx<T> *)dt1->cfg[CFG_MAIN].twp;
         a.makhoul = gop == G_DCT3_EVEN ? 1 : 0;
         return launch_fourstep_real<T>(7, N1 / 2, a, stream);
     }
     Problem Q;
-    Q.plan = c.rfs_sub1; Q.op = NDFFT_OP_C2R; Q.xlen = Kx; Q.ylen = N1; Q.xs = N2; Q.ys = N2; Q.nlanes = B * N2; Q.scale = 1.0;
-    if (B > 1) Q.b.push_back({B, (int64_t)Kx * N2, pout});
+    Q.plan = c.rfs_sub1; Q.op = NDFFT_OP_C2R; Q.xlen = Kx; Q.ylen = N1; Q.xs = N2p; Q.ys = N2; Q.nlanes = B * N2; Q.scale = 1.0;
+    if (B > 1) Q.b.push_back({B, (int64_t)Kx * N2p, pout});
     Q.b.push_back({(int64_t)N2, 1, 1});
     Q.no_xcd_map = 1; Q.makhoul_out = gop == G_DCT3_EVEN ? 1 : 0;
     return dispatch(Q, s1, d_out, stream);
@@ -729,7 +740,8 @@ static int dct4_fourstep(const Problem &P, const FftConfig &c, const DevConfig &
     int rc;
     if ((rc = get_dev_tables(c.sub1, &dt1)) || (rc = get_dev_tables(c.sub2, &dt2))) return rc;
     void *s1;
-    if ((rc = get_scratch(2, stream, (size_t)(B * F) * sizeof(cpx<T>), &s1))) return rc;
+    const int64_t K1p = F1 + fs_pad_elems<T>();      // pitch of the intermediate s1[n2][k1] (fs_pad_elems)
+    if ((rc = get_scratch(2, stream, (size_t)(B * F2 * K1p) * sizeof(cpx<T>), &s1))) return rc;
     RealArgs<T> a;
     a.pitch_in = 0; a.vec_in = 0; a.vec_out = 0; a.xcd_remap = 0; a.keep_out = 1; a.stream_in = 0; a.chunk_out = 0; a.xcd_chunk = 0;
     a.aux1 = (const cpx<T> *)d.aux1; a.aux2 = (const cpx<T> *)d.aux2; a.chirp = nullptr; a.bhat = nullptr;
@@ -737,13 +749,13 @@ static int dct4_fourstep(const Problem &P, const FftConfig &c, const DevConfig &
     a.cs_k1n = 1; a.cs_f1 = F1; a.cs_n = (int)(2 * F); a.cs_outer_in = 0; a.cs_outer_out = 0; a.cs_pitch = 0;
     // pass 1: lanes (l, n2) of the REAL input
     a.in = d_in; a.out = s1; a.nlanes = B * F2; a.n = F1; a.F = F1; a.n_in = F1; a.n_out = F1; a.scale = (T)P.scale;
-    a.inner = F2; a.outer_in = pin; a.outer_out = 0; a.elem_in = F2; a.elem_out = 0; a.pitch_out = F1;
+    a.inner = F2; a.outer_in = pin; a.outer_out = 0; a.elem_in = F2; a.elem_out = 0; a.pitch_out = K1p;
     a.twp = (const cpx<T> *)dt1->cfg[CFG_MAIN].twp_col; a.makhoul = 2;
     if ((rc = launch_fourstep<T>(1, F1, false, a, stream))) return rc;
     // pass 2: lanes (l, k1), real output
     a.makhoul = 0; a.keep_out = 0;
     a.in = s1; a.out = d_out; a.nlanes = B * F1; a.n = F2; a.F = F2; a.n_in = F2; a.n_out = F2; a.scale = (T)1;
-    a.inner = F1; a.outer_in = F; a.outer_out = pout; a.elem_in = F1; a.elem_out = 0; a.pitch_out = 0;
+    a.inner = F1; a.outer_in = (int64_t)F2 * K1p; a.outer_out = pout; a.elem_in = K1p; a.elem_out = 0; a.pitch_out = 0;
     a.twp = (const cpx<T> *)dt2->cfg[CFG_MAIN].twp_col;
     return launch_fourstep_real<T>(6, F2, a, stream);
 }

@@ -712,7 +712,7 @@ def long_strided_lanes(L):
     cases = (("ndfft", (4096, 24), 0, np.float64, "transpose+pow2_reg"), ("ndifft", (4096, 24), 0, np.float64, "transpose+pow2_reg"),
              ("ndfft_r2c", (8192, 40), 0, np.float32, "transpose+pow2_real"), ("ndifft_r2c", (8192, 20), 0, np.float32, "transpose+pow2_real"),
              ("nddct2", (3, 4096, 17), 1, np.float64, "transpose+pow2_real"), ("ndfft", (3000, 33), 0, np.float64, "transpose+generic_row"),
-             ("nddct3", (2, 4000, 8), 1, np.float32, "transpose+generic_row"))      # (16 lanes x 2000 points: below the 2^15-point threshold of the specialised kernels)
+             ("nddct3", (1, 4000, 16), 1, np.float32, "transpose+generic_row"))      # (16 lanes x 2000 points: below the 2^15-point threshold of the specialised kernels)
     with switches(L, NDFFT_COLSPLIT="0"):       # (the column four-step would take the first four)
         for name, shape, axis, rdt, want in cases:
             assert run_case(L, name, shape, axis, rdt) == want, (name, shape)

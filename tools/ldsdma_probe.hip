@@ -272,6 +272,16 @@ int main(int argc, char **argv) {
         s.ncol = 32; s.nmid = 1; s.col_in = 128; s.col_out = 128; s.outer_in = 512ll * 264 * 16; s.outer_out = 512ll * 512 * 16; s.ntiles = 64 * 32; s.cyc = 6000;
         cases.push_back({"rfs2 (real four-step pass 2: 512 x 128 B rows, out 8 KiB apart)", s, 512, 64 * 512ull * 264 * 16, 64 * 512ull * 512 * 16, 6});
     }
+    // pitch sweep (round 5): the second pass of the complex four-step on 256 x 65536 c128 -- tiles of 256 rows x 128 B (8 adjacent k1);
+    // input = the intermediate s[n2][k1] (its pitch is OURS: 4096 B natural, or padded), output = the caller's array, rows N1 x 16 B = 4096 B apart (fixed).
+    // "pout" variants with a padded OUTPUT pitch are hypothetical (what the store side would gain if the caller's pitch were not a power of two).
+    for (int pin : {4096, 4096 + 128, 4096 + 512, 4096 + 1024})
+        for (int pout : {4096, 4096 + 512}) {
+            Shape s{}; s.logW = 7; s.logWo = 7; s.tile_bytes = 32768; s.pitch_in = pin; s.pitch_out = pout;
+            s.ncol = 32; s.nmid = 1; s.col_in = 128; s.col_out = 128; s.outer_in = 256ll * pin; s.outer_out = 256ll * pout; s.ntiles = 256 * 32 * 2; s.cyc = 3000;
+            cases.push_back({"fs2 pitch_in=" + std::to_string(pin) + " pitch_out=" + std::to_string(pout) + " (four-step pass 2, 256 x 128 B rows)", s, 512,
+                             512ull * 256 * pin, 512ull * 256 * pout, 3});
+        }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (auto &c : cases) {
         if (filter[0] && c.name.find(filter) == std::string::npos) continue;
