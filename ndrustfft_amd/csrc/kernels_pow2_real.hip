@@ -219,6 +219,12 @@ template <typename T, int F, int OP> static int launch_real_one(const RealArgs<T
             // cfg4 nddct2 81.4 -> 78.8 us; ndfft_r2c f32 n = 128 / 256 +3-5 %, n >= 512 no gain: they keep 256 threads)
             constexpr int THR = (NDFFT_REAL_ROW_THREADS == 256 && (sizeof(T) == 8 || F <= 128)) ? 64 : NDFFT_REAL_ROW_THREADS;
             constexpr int LPB = TPL >= THR ? 1 : THR / TPL;
+            // ... but TWO waves when the f64 input comes from HBM (stream_in, set by the residency model): A-B-A-B on cfg4 with three rotating pairs
+            // nddct2 95.6 -> 93.7 us, nddct3 98.2 -> 97.1 us, nddct4 98.5 -> 95.7 us (profiles/r08/r08b_cfg4_row_threads_cold_abab.txt; 256 threads: no gain)
+            if constexpr (sizeof(T) == 8 && THR == 64 && TPL <= 64 && F >= 128 && NDFFT_REAL_ROW_THREADS == 256) {
+                constexpr int LPB2 = 128 / TPL;
+                if (a.stream_in) return launch_k<RealPow2Kernel<T, F, TPL, LPB2, typename RealCfg<F>::RL, OP, false>, T>(a, LPB2, s);
+            }
             return launch_k<RealPow2Kernel<T, F, TPL, LPB, typename RealCfg<F>::RL, OP, false>, T>(a, LPB, s);
         }
     }
