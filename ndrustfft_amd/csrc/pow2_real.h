@@ -115,6 +115,9 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
     static_assert(CS < 5 || OP == G_C2C_FWD, "CS = 5 / 6 are forward kernels");
     // strided staging loop with U independent global loads in flight per thread before the first LDS store
     // (a plain `for (j) dst[j] = in[j * stride]` leaves one or two loads outstanding: latency-bound)
+    // (round 5: loading a one- or two-element remainder -- lanes of 2^k + 1 points, the DCT-I bench sizes -- BEFORE the full batches, so that it costs no round trip
+    //  of its own, gained 2-7 % on the reference's n x n DCT-I bench shapes and cost the register-capped f32 kernels 6-19 %: 32 x 2^20 c64 281 -> 334 us, ndfft_r2c f32
+    //  rows n = 100 .. 512 +6-17 % -- profiles/r08/r08n_configs_compare.txt; not kept)
     template <int STEP, typename LD, typename ST> static __device__ __forceinline__ void stage_loop(int j0, int n, LD ld, ST st) {
         constexpr int U = 8;
         int j = j0;
@@ -151,10 +154,11 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
 
     // every output derived from the spectrum pair (k, F-k), in four fixed slots (q < 0: slot unused)
     template <typename OT> struct PairOut { OT v[4]; int q[4]; };
-    template <typename OT> static __device__ __forceinline__ PairOut<OT> post_pair(const RealArgs<T> &a, const cpx<T> *res, int k) {
+    template <typename OT> static __device__ __forceinline__ PairOut<OT> post_pair(const RealArgs<T> &a, const cpx<T> *res, int k) { return post_pair<OT>(a, res, k, a.aux1[k]); }
+    template <typename OT> static __device__ __forceinline__ PairOut<OT> post_pair(const RealArgs<T> &a, const cpx<T> *res, int k, cpx<T> wk) {
         PairOut<OT> r;
         cpx<T> xk, xf;
-        r2c_split_pair<T, ZiPhi>(res, k, F, a.aux1[k], xk, xf);
+        r2c_split_pair<T, ZiPhi>(res, k, F, wk, xk, xf);
         const int kf = F - k;
         r.q[0] = k; r.q[1] = -1; r.q[2] = kf != k ? kf : -1; r.q[3] = -1;
         if constexpr (OP == G_R2C_EVEN) {
@@ -351,10 +355,19 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
             const int64_t base = (L / a.inner) * a.outer_out + (L % a.inner);
             const cpx<T> *res = (const cpx<T> *)(smem + (size_t)cl * LANE_LDS * 2 * sizeof(T));
             if constexpr (PAIR) {
+                // the split twiddles of this thread's pairs, loaded up front: inside the loops below every iteration would wait for its own table load behind
+                // the previous iteration's stores (F / TPL / 2 + 1 = 5 dependent round trips with E = 8)
+                constexpr int NIT = (F / 2 + TPL) / TPL;
+                cpx<T> w1[NIT];
+#pragma unroll
+                for (int i = 0; i < NIT; ++i) { const int k = j0 + i * TPL; if (k <= F / 2) w1[i] = a.aux1[k]; }
                 if constexpr (OUT_CPLX) {
                     cpx<T> *out = (cpx<T> *)a.out + base;
-                    for (int k = j0; k <= F / 2; k += THREADS / LPB) {
-                        const PairOut<cpx<T>> r = post_pair<cpx<T>>(a, res, k);
+#pragma unroll
+                    for (int i = 0; i < NIT; ++i) {
+                        const int k = j0 + i * TPL;
+                        if (k > F / 2) break;
+                        const PairOut<cpx<T>> r = post_pair<cpx<T>>(a, res, k, w1[i]);
 #pragma unroll
                         for (int z = 0; z < 4; ++z)
                             if (r.q[z] >= 0) {
@@ -363,8 +376,11 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                     }
                 } else {
                     T *out = (T *)a.out + base;
-                    for (int k = j0; k <= F / 2; k += THREADS / LPB) {
-                        const PairOut<T> r = post_pair<T>(a, res, k);
+#pragma unroll
+                    for (int i = 0; i < NIT; ++i) {
+                        const int k = j0 + i * TPL;
+                        if (k > F / 2) break;
+                        const PairOut<T> r = post_pair<T>(a, res, k, w1[i]);
 #pragma unroll
                         for (int z = 0; z < 4; ++z)
                             if (r.q[z] >= 0) {

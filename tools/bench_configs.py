@@ -72,6 +72,7 @@ def timeit3(fn, steps, warmup=5, ramp_ms=None, batches=3):
 
 
 MALL_BYTES = 256 << 20
+NO_REREAD = False
 COLD_FOOTPRINT = 768 << 20   # the inputs an HBM-sourced row rotates over add up to at least this (3 x the 256 MiB Infinity Cache)
 # --pairs K: rotate K distinct (in, out) pairs so that every launch finds its input in HBM, not in the Infinity Cache.
 # 0 (default since round 5) = per row: ceil(768 MiB / input bytes), at least 2, at most 64; 1 for inputs of 768 MiB and more (nothing to rotate: they do not fit the cache)
@@ -163,8 +164,11 @@ def run(name, fn, x, y, h, axis, points, steps):
         t, tmin = timeit3(go, steps)
         row["policy"] = L.last_input_policy()
         del xs, ys
-        tw, twmin = timeit3(lambda: fn(x, y, h, axis), steps)
-        row["policy_reread"] = L.last_input_policy()
+        if NO_REREAD:
+            tw, twmin = t, tmin
+        else:
+            tw, twmin = timeit3(lambda: fn(x, y, h, axis), steps)
+            row["policy_reread"] = L.last_input_policy()
     else:
         t, tmin = timeit3(lambda: fn(x, y, h, axis), steps)
         row["policy"] = L.last_input_policy()
@@ -238,6 +242,7 @@ def compare(rows, prev_path, tol):
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=50); ap.add_argument("--only", default=""); ap.add_argument("--ramp-ms", type=float, default=300.0); ap.add_argument("--pairs", type=int, default=0, help="rotating (in, out) pairs per row; 0 = per row, inputs adding up to >= 768 MiB (HBM-sourced), see pairs_for()"); ap.add_argument("--preheat-s", type=float, default=0.0)
     ap.add_argument("--row", default="", help="only rows whose name contains this text")
+    ap.add_argument("--no-reread", action="store_true", help="skip the re-read measurement of every row (profiling runs: rocprofv3's per-kernel averages then belong to the HBM-sourced launches)")
     ap.add_argument("--repeat", type=int, default=1, help="run the whole selected table this many times, one after the other (rows carry `rep`): the spread between repeats is the table's noise")
     ap.add_argument("--compare", default="", help="an earlier table (jsonl): exit 1 if any row's best time is more than --tolerance slower than there")
     ap.add_argument("--tolerance", type=float, default=0.06)
@@ -268,8 +273,8 @@ def table(a):
                 ndfft(xh, yh, hh, 1)
             torch.cuda.synchronize()
         del xh, yh
-    global RAMP_MS, PAIRS
-    RAMP_MS = a.ramp_ms; PAIRS = a.pairs
+    global RAMP_MS, PAIRS, NO_REREAD
+    RAMP_MS = a.ramp_ms; PAIRS = a.pairs; NO_REREAD = a.no_reread
     dev = torch.device("cuda:0")
     want = lambda k: (not a.only) or a.only in k
     if want("cfg2"):

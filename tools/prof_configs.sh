@@ -5,10 +5,10 @@ TAG=${1:-prof}; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 for W in cfg3 cfg4 cfg5; do
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$W -- python3 $GRAFT_REPO_ROOT/tools/bench_configs.py --only $W --steps 30 > $OUT/stats_$W.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$W -- python3 $GRAFT_REPO_ROOT/tools/bench_configs.py --only $W --steps 30 --no-reread > $OUT/stats_$W.log 2>&1
   find $OUT/stats_$W -name "*kernel_stats.csv" | head -1 | xargs -r -I{} cp {} $OUT/${W}_kernel_stats.csv
   for C in FETCH_SIZE WRITE_SIZE; do
-    timeout 900 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_${W}_$C -- python3 $GRAFT_REPO_ROOT/tools/bench_configs.py --only $W --steps 3 --ramp-ms 0 > $OUT/pmc_${W}_$C.log 2>&1
+    timeout 900 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_${W}_$C -- python3 $GRAFT_REPO_ROOT/tools/bench_configs.py --only $W --steps 3 --ramp-ms 0 --no-reread > $OUT/pmc_${W}_$C.log 2>&1
   done
 done
 cd $GRAFT_REPO_ROOT
