@@ -48,7 +48,7 @@ def pick(ph, grid_lanes):
         if "Pow2Kernel<double, 4096" in k and v["launches"]:
             best = v["hbm_traffic_bytes_per_launch"]
     return best
-tag = os.path.basename(out)
+tag = os.path.basename(os.path.dirname(out)) if os.path.basename(out) == "prof_bench" else os.path.basename(out)
 tj = {"4096x4096": pick("warm", 4096), "4096x4096_cold_rotating": pick("primary", 4096), "65536x4096": pick("strong", 65536),
       "kernel_source_sha": subprocess.check_output(["python3", os.path.join(root, "tools", "pmc_source_sha.py")], text=True).strip(),
       "source": f"profiles/r08/{tag}_pmc_bench_summary.json (tools/prof_bench.sh {tag} pmc: separate FETCH_SIZE / WRITE_SIZE --pmc passes of `bench.py --profile-phase ...`, "
