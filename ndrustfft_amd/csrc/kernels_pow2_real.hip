@@ -103,6 +103,9 @@ template <typename K, typename T> static int launch_k(const RealArgs<T> &a, int 
 #ifndef NDFFT_COL_LANES_F32
 #define NDFFT_COL_LANES_F32 32
 #endif
+#ifndef NDFFT_SMALL_GRID_FLAGS
+#define NDFFT_SMALL_GRID_FLAGS 32
+#endif
 #ifndef NDFFT_COL_LANES_F64
 #define NDFFT_COL_LANES_F64 32
 #endif
@@ -237,16 +240,25 @@ template <typename T, int F, int OP> static int launch_real_one(const RealArgs<T
         // n = 512 6.15 -> 4.98 us, ndfft_r2c n = 512 / 1024 7.06 / 7.24 -> 5.43 / 6.44 us, nddct1 n = 513 7.34 -> 6.43 us; nddct1 n = 1025 (F = 1024, real rows)
         // measured no better (14.2 -> 14.9 us) and keeps its tile (profiles/r08/r08h_small_shapes_col_lanes.txt).  Caller's column tiles only (not the stages of the
         // four-step routes, which set keep_out / makhoul / stream_in themselves).
-        if constexpr (sizeof(T) == 8 && F >= 256 && !(F >= 1024 && KIND >= 2)) {
+        // The small-grid tiles run the LATENCY form of the passes (pow2_kernel.h FLAGS 32: next pass's twiddles loaded before the exchange, LDS-only barriers): SMALL_FLAGS.
+        if constexpr (sizeof(T) == 8 && F >= 256) {
             constexpr int64_t kCus = 256;
+            constexpr int SMALL_FLAGS = NDFFT_SMALL_GRID_FLAGS;
             if (!a.keep_out && !a.makhoul) {
-                if constexpr (LPB / 4 >= 4) {
-                    if ((a.nlanes + LPB / 2 - 1) / (LPB / 2) < kCus)
-                        return launch_k<RealPow2Kernel<T, F, TPL, LPB / 4, typename RealCfg<F>::RL, OP, true>, T>(a, LPB / 4, s);
+                if constexpr (!(F >= 1024 && KIND >= 2)) {
+                    if constexpr (LPB / 4 >= 4) {
+                        if ((a.nlanes + LPB / 2 - 1) / (LPB / 2) < kCus)
+                            return launch_k<RealPow2Kernel<T, F, TPL, LPB / 4, typename RealCfg<F>::RL, OP, true, false, 0, false, SMALL_FLAGS>, T>(a, LPB / 4, s);
+                    }
+                    if constexpr (LPB / 2 >= 4) {
+                        if ((a.nlanes + LPB - 1) / LPB < kCus)
+                            return launch_k<RealPow2Kernel<T, F, TPL, LPB / 2, typename RealCfg<F>::RL, OP, true, false, 0, false, SMALL_FLAGS>, T>(a, LPB / 2, s);
+                    }
                 }
-                if constexpr (LPB / 2 >= 4) {
-                    if ((a.nlanes + LPB - 1) / LPB < kCus)
-                        return launch_k<RealPow2Kernel<T, F, TPL, LPB / 2, typename RealCfg<F>::RL, OP, true>, T>(a, LPB / 2, s);
+                // tiles that cannot shrink (ndfft n = 1024: 4 lanes already; nddct1 n = 1025 keeps 8): the same tile in the latency form when the call is at most two tiles per CU
+                if constexpr (F >= 1024 && SMALL_FLAGS != 0) {
+                    if ((a.nlanes + LPB - 1) / LPB <= 2 * kCus)
+                        return launch_k<RealPow2Kernel<T, F, TPL, LPB, typename RealCfg<F>::RL, OP, true, false, 0, false, SMALL_FLAGS>, T>(a, LPB, s);
                 }
             }
         }

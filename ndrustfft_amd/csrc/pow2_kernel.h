@@ -70,7 +70,10 @@ template <typename T, bool NT> __device__ __forceinline__ void gstore(cpx<T> *p,
 
 // FLAGS is for ablation builds in tools/kbench.hip only (product kernels use 0):
 //   1 = skip twiddle multiplies, 2 = skip the LDS exchange, 4 = skip butterflies
-// product flags: 8 = fused four-step twiddle on load (Pow2Args::twlo), 16 = derive twiddle powers for big late-pass tables
+// product flags: 8 = fused four-step twiddle on load (Pow2Args::twlo), 16 = derive twiddle powers for big late-pass tables,
+//   32 = LATENCY form (round 5): the twiddles of pass p + 1 are loaded BEFORE the exchange that follows pass p and the exchange's barriers wait for the LDS only
+//        (raw s_barrier behind s_waitcnt lgkmcnt(0); __syncthreads() would also drain the table loads), so the table's L2 round trip overlaps the exchange instead of
+//        following it.  Costs up to E - 1 complex registers across the exchange: for calls of few tiles, where one tile's latency is the call's (pow2_real.h: small grids)
 // NT: bit 0 = non-temporal stores, bit 1 = non-temporal loads
 // VEC = 2 (f32 only): global loads/stores move TWO adjacent complex elements (16 B) per lane; the
 //   first and last pass then own adjacent butterfly pairs j = 2t, 2t+1 instead of j = t, t+TPL.
@@ -79,7 +82,17 @@ template <typename T, bool NT> __device__ __forceinline__ void gstore(cpx<T> *p,
 //   position is below N / 2 (written by the butterflies j < N / (2 R), read as r < R' / 2 by every thread), round B the rest.  Twice the
 //   barriers, half the LDS: n = 16384 then takes 70 KiB per lane instead of 139 KiB, i.e. TWO workgroups per CU, so that one lane's load /
 //   store phases overlap the other's exchanges (round 3; needs whole butterfly rounds and power-of-two sizes).
+// barrier of the exchange: LDS traffic only (see FLAGS bit 5)
+template <bool RAW> __device__ __forceinline__ void xbar() {
+#ifdef NDFFT_LDS_BARRIER_OVERRIDE          // (a build for another target supplies its own LDS-only barrier)
+    if constexpr (RAW) NDFFT_LDS_BARRIER_OVERRIDE();
+#else
+    if constexpr (RAW) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+    else __syncthreads();
+}
 template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS = 0, int MINW = 1, int NT = 1, int VEC = 1, int PSPLIT = 1> struct Pow2Kernel {
+    static constexpr bool PREF = (FLAGS & 32) != 0;
     static constexpr int MIN_WAVES = MINW;
     // Pass p has N / R_p butterflies, dealt to the TPL threads of the lane in SLOTS(p) rounds: j = t + q TPL.
     // When TPL does not divide N / R_p the last round is PARTIAL (threads with j >= N / R_p idle): that is what
@@ -100,11 +113,39 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
         else return t + q * TPL;
     }
 
+    // twiddles of pass P for this thread, in the order the multiply loop below consumes them (LATENCY form)
+    template <int P> static __device__ __forceinline__ void load_tw(cpx<T> (&w)[E], const cpx<T> *__restrict__ twp, int t) {
+        constexpr int R = RL::at(P), Ns = RL::ns(P), NBF = slots(P), NB = nbfly(P);
+        const cpx<T> *tw = twp + RL::twoff(P);
+#pragma unroll
+        for (int q = 0; q < NBF; ++q) {
+            const int j = jof<P>(t, q), k = kmod<Ns>(j);
+            if (full(P) || j < NB) {
+#pragma unroll
+                for (int r = 1; r < R; ++r) w[q * R + r] = tw[(r - 1) * Ns + k];
+            }
+        }
+    }
     template <int P>
     static __device__ __forceinline__ void passes(cpx<T> (&v)[E], const cpx<T> *__restrict__ twp, char *lds, int t) {
+        if constexpr (PREF) { cpx<T> w[E]; passes_w<P>(v, twp, lds, t, w); }
+        else { cpx<T> w[1]; passes_w<P>(v, twp, lds, t, w); }
+    }
+    template <int P, int WN>
+    static __device__ __forceinline__ void passes_w(cpx<T> (&v)[E], const cpx<T> *__restrict__ twp, char *lds, int t, cpx<T> (&wpre)[WN]) {
         constexpr int R = RL::at(P), Ns = RL::ns(P), NBF = slots(P), NB = nbfly(P);
         constexpr bool FULL = full(P);
         constexpr bool TW_POWERS = (FLAGS & 16) != 0 && (size_t)(R - 1) * Ns * sizeof(cpx<T>) > 32 * 1024;
+        static_assert(!PREF || !TW_POWERS, "the latency form loads plain tables");
+        if constexpr (P > 0 && !(FLAGS & 1) && PREF) {
+#pragma unroll
+            for (int q = 0; q < NBF; ++q) {
+                if (FULL || jof<P>(t, q) < NB) {
+#pragma unroll
+                    for (int r = 1; r < R; ++r) v[q * R + r] = cmul(v[q * R + r], wpre[q * R + r]);
+                }
+            }
+        } else
         if constexpr (P > 0 && !(FLAGS & 1)) {
             const cpx<T> *tw = twp + RL::twoff(P);
 #pragma unroll
@@ -136,6 +177,7 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
         if constexpr (P + 1 < RL::NP) {
             constexpr int R2 = RL::at(P + 1), NB2 = N / R2, NBF2 = slots(P + 1);
             constexpr bool FULL2 = full(P + 1);
+            if constexpr (PREF && !(FLAGS & 1)) load_tw<P + 1>(wpre, twp, t);     // in flight during the exchange below
             if constexpr (FLAGS & 2) {
             } else if constexpr (HALF) {
                 T *s = (T *)lds;
@@ -145,7 +187,7 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
                     T keep[PSPLIT == 2 ? NBF2 * (R2 / 2) : 1];
 #pragma unroll
                     for (int ps = 0; ps < PSPLIT; ++ps) {
-                        __syncthreads();
+                        xbar<PREF>();
 #pragma unroll
                         for (int q = 0; q < NBF; ++q) {
                             const int j = jof<P>(t, q), k = kmod<Ns>(j), o = (j - k) * R + k - ps * (N / 2), po = phi(o);
@@ -154,7 +196,7 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
                                 for (int r = 0; r < R; ++r) s[phi_at<Ns>(o, po, r)] = half ? v[q * R + r].y : v[q * R + r].x;
                             }
                         }
-                        __syncthreads();
+                        xbar<PREF>();
 #pragma unroll
                         for (int q = 0; q < NBF2; ++q) {
                             const int j = jof<P + 1>(t, q), pj = phi(j);
@@ -183,7 +225,7 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
                 cpx<T> keep[PSPLIT == 2 ? NBF2 * (R2 / 2) : 1];
 #pragma unroll
                 for (int ps = 0; ps < PSPLIT; ++ps) {
-                    __syncthreads();
+                    xbar<PREF>();
 #pragma unroll
                     for (int q = 0; q < NBF; ++q) {
                         const int j = jof<P>(t, q), k = kmod<Ns>(j), o = (j - k) * R + k - ps * (N / 2), po = phi(o);
@@ -192,7 +234,7 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
                             for (int r = 0; r < R; ++r) s[phi_at<Ns>(o, po, r)] = v[q * R + r];
                         }
                     }
-                    __syncthreads();
+                    xbar<PREF>();
 #pragma unroll
                     for (int q = 0; q < NBF2; ++q) {
                         const int j = jof<P + 1>(t, q), pj = phi(j);
@@ -215,7 +257,7 @@ template <typename T, int N, int TPL, int LPB, bool HALF, typename RL, int FLAGS
                         for (int r = 0; r < R2 / 2; ++r) v[q * R2 + r] = keep[q * (R2 / 2) + r];
                 }
             }
-            passes<P + 1>(v, twp, lds, t);
+            passes_w<P + 1>(v, twp, lds, t, wpre);
         }
     }
 

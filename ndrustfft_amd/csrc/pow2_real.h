@@ -109,7 +109,8 @@ struct ZiPhi { static __device__ __forceinline__ int map(int p) { return p + (p 
 //   CS = 6  the same for DCT-II: y[k] = Re(X[k] c_k) scale, y[n-k] = -Im(X[k] c_k) scale (c_k = aux2[k], src/lib.rs:700-710 through Makhoul)
 // ROWOUT (COL, C2C or R2C): column load, ROW store -- the tile is read with lanes fastest and every lane is written as one
 // contiguous run (pitch_out): the transposing first pass of the row four-step (R2C: of the real four-step, n_out = F + 1 per lane).
-template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = false, bool XCD = false, int CS = 0, bool ROWOUT = false> struct RealPow2Kernel {
+// FFLAGS: flags of the inner Pow2Kernel (32 = the LATENCY form of its passes, for calls of few tiles).
+template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = false, bool XCD = false, int CS = 0, bool ROWOUT = false, int FFLAGS = 0> struct RealPow2Kernel {
     static_assert(CS == 0 || (COL && !XCD && (OP == G_C2C_FWD || OP == G_C2C_INV)), "CS kernels are column C2C kernels");
     static_assert(!ROWOUT || (COL && !XCD && CS == 0 && (OP == G_C2C_FWD || OP == G_C2C_INV || OP == G_R2C_EVEN)), "ROWOUT is a column-load C2C / R2C kernel");
     static_assert(CS < 5 || OP == G_C2C_FWD, "CS = 5 / 6 are forward kernels");
@@ -140,7 +141,7 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
     static constexpr size_t LDS_BYTES = (size_t)LPB * LANE_LDS * 2 * sizeof(T);
     static constexpr bool IN_CPLX = OP == G_C2R_EVEN || OP == G_C2C_FWD || OP == G_C2C_INV;
     static constexpr bool OUT_CPLX = OP == G_R2C_EVEN || OP == G_C2C_FWD || OP == G_C2C_INV;
-    using FFT = Pow2Kernel<T, F, TPL, LPB, false, RL, 0, 1, 0>;
+    using FFT = Pow2Kernel<T, F, TPL, LPB, false, RL, FFLAGS, 1, 0>;
     static constexpr int E = FFT::E;       // = F / TPL unless some pass has a partial last round (pow2_kernel.h)
     // row layout R2C / C2R: the PRE fold reads unit-stride complex elements (ascending, and for C2R also
     // descending), so it loads global memory directly and the LDS staging pass and its barrier are skipped

@@ -16,6 +16,7 @@
 // wave_kernel.h's cross-lane bit swap, emulated with block barriers (emul_runtime.cpp)
 namespace ndfft { void emul_wave_swap(unsigned &lo, unsigned &hi, int tb); }
 #define NDFFT_WAVE_SWAP_OVERRIDE(lo, hi, tb) ::ndfft::emul_wave_swap(lo, hi, tb)
+#define NDFFT_LDS_BARRIER_OVERRIDE() __syncthreads()
 #define __host__
 #define __device__
 #define __global__
