@@ -102,6 +102,8 @@ def test_infinity_cache_residency_model(L):
     a, b, c = dev_buf(big), dev_buf(big), dev_buf(big)
     small = (8 << 20) // (n * 16)
     s1, s2 = dev_buf(small), dev_buf(small)
+    huge = (260 << 20) // (n * 16)               # (allocated up front: addresses the model has never seen)
+    x1, x2, y1 = dev_buf(huge), dev_buf(huge), dev_buf(huge)
     try:
         assert fft(a, b, big) == 0               # never seen: size rule -> plain
         assert fft(a, b, big) == 0               # read a moment ago: reuse distance 0 -> plain
@@ -121,9 +123,15 @@ def test_infinity_cache_residency_model(L):
         assert fft(a, c, big) == 1, "288 MiB of other inputs since a was last read: streaming loads"
         for o in others: assert fft(o, c, big) == 1, "a rotation larger than the cache streams every member"
         for o in others: L.check(L.c.ndfft_dev_free(o))
+        # round 5: a buffer LARGER than the cache (BASELINE configs[2]'s 4097 x 8192 c64 is 64 KiB over 256 MiB): only an immediate re-read keeps the size rule
+        assert fft(x1, y1, huge) == 0        # never seen: size rule (<= 384 MiB -> plain)
+        assert fft(x1, y1, huge) == 0        # read a moment ago: the size rule again
+        assert fft(x2, y1, huge) == 0        # never seen
+        assert fft(x1, y1, huge) == 1, "larger than the cache and another input was read since: streaming loads"
+        assert fft(x2, y1, huge) == 1
     finally:
         L.c.ndfft_set_input_hint(_lib.INPUT_AUTO)
-        for p in (a, b, c, s1, s2): L.check(L.c.ndfft_dev_free(p))
+        for p in (a, b, c, s1, s2, x1, x2, y1): L.check(L.c.ndfft_dev_free(p))
 
 
 def test_host_registration_cache_lru(L):

@@ -164,6 +164,7 @@ def test_fuzz_streaming_loads(L):
         paths = ps.fuzz(L, seed=13, count=250)
         assert len(paths) >= 8, paths
         ps.pow2_real_sizes(L, sizes=(64, 512, 4096), dtypes=(np.float64, np.float32))
+        ps.rader_kernel(L, sizes=(511, 513), col_max_F=0, dtypes=(np.float64,))       # (round 5: streaming staging loads of the Rader rows, symmetric DCT-I form included)
         ps.baseline_length_fixtures(L, np.load(os.path.join(ROOT, "tests", "golden", "baseline_lengths.npz")), device="cuda:0")
     finally:
         L.check(L.c.ndfft_set_input_hint(_lib.INPUT_AUTO))
