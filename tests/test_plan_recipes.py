@@ -49,11 +49,17 @@ def _check_line(d, dtype):
         assert p == _largest_prime(F) and mc * p == F and math.gcd(mc, p) == 1, d
         assert M == p - 1 and _prod(d["radix"]) == M, d
         assert mc1 in BFLY | {1} and mc2 in BFLY | {1} and mc <= (48 if dtype == _lib.F32 else 32), d
-        assert 1 <= tpl and tpl * mc <= 1024 and int(d["lanes"]) >= 1 and int(d["lanes"]) * tpl * mc <= 1024, d
+        # sym_rows (round 5, DCT-I slot with an odd cofactor > 1): only (mc + 1) / 2 of the mc Rader transforms run, on that many groups of tpl threads
+        rows = int(d["sym_rows"]) if "sym_rows" in d else mc
+        if "sym_rows" in d:
+            assert d["slot"] == "DCT1" and mc > 1 and mc % 2 == 1 and rows == (mc + 1) // 2, d
+        assert 1 <= tpl and tpl * rows <= 1024 and int(d["lanes"]) >= 1 and int(d["lanes"]) * tpl * rows <= 1024, d
         radices = [int(r) for r in d["radix"].split(".")]
         assert all(r in BFLY for r in radices), d
         assert e == max(-(-(M // r) // tpl) * r for r in radices) and e <= (32 if dtype == _lib.F32 else 21), d
-        lane = max(mc * (M + (M >> 4) + 2), F + (F >> 4) + 3) | 1
+        zlen = ((p + 1) // 2) * mc if "sym_rows" in d else F
+        zraw = max(zlen + (zlen >> 4) + 3, (F + 2) // 2 if "sym_rows" in d else 0)
+        lane = max(rows * (M + (M >> 4) + 2), zraw) | 1
         assert int(d["lanes"]) * lane * esz <= LDS, d
     if d.get("route") == "jit":
         tpl, e = int(d["tpl"]), int(d["e"])
