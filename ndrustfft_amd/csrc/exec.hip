@@ -491,7 +491,9 @@ static int col_split(const Problem &P, const void *d_in, void *d_out, const FftC
         if (!c2r) {
             // A: column transform of length F1 over a = row / F2; lanes (b, i)
             Q.op = P.op; Q.xlen = F1; Q.ylen = K1; Q.xs = (int64_t)F2 * I; Q.ys = (int64_t)F2 * Cp;
-            Q.keep_out = chunked; Q.stream_in = 0;
+            // (stream_in: the caller's array is read once and must not push the intermediate out of the Infinity Cache -- round 5, A-B-A-B on cfg3-A:
+            //  198-201 -> 188.5-191 us; the C2R form's first stage below: 225 -> 220 us; profiles/r08/r08r_cs_stage_nt_abab.txt)
+            Q.keep_out = chunked; Q.stream_in = (int)NDFFT_DEV_INT("NDFFT_CSA_NT", 1);
             if (split_bi) { Q.b.push_back({(int64_t)F2, I, Cp}); Q.b.push_back({Cc, 1, 1}); }
             else {
                 if (O > 1) Q.b.push_back({O, sin_o, (int64_t)K1 * F2 * I});
@@ -506,7 +508,9 @@ static int col_split(const Problem &P, const void *d_in, void *d_out, const FftC
             // A: Hermitian gather, inverse of length F2 over k2, conj twiddle -> S[o][k1][b][i]
             a.in = in_c; a.out = S;
             a.outer_in = 0; a.outer_out = (int64_t)F2 * Cp; a.elem_in = I; a.elem_out = Cp;
+            a.stream_in = (int)NDFFT_DEV_INT("NDFFT_CS3_NT", 1);
             if ((rc = launch_colsplit<T>(3, true, a, stream))) return rc;
+            a.stream_in = 0;
             // B: column C2R of length F1 over k1
             Q.op = NDFFT_OP_C2R; Q.xlen = K1; Q.ylen = F1; Q.xs = (int64_t)F2 * Cp; Q.ys = (int64_t)F2 * I;
             if (split_bi) { Q.b.push_back({(int64_t)F2, Cp, I}); Q.b.push_back({Cc, 1, 1}); }

@@ -215,14 +215,15 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                     const int64_t ok = L / a.inner;
                     const int k1 = (int)(ok % a.cs_k1n);
                     const cpx<T> *in = (const cpx<T> *)a.in + (ok / a.cs_k1n) * a.cs_outer_in + (L % a.inner);
-                    stage_loop<STEP>(j0, a.n_in,
-                        [&](int j) { const int row = k1 + a.cs_f1 * j; return in[(int64_t)(2 * row > a.cs_n ? a.cs_n - row : row) * a.elem_in]; },
-                        [&](int j, cpx<T> v) {
-                            const int row = k1 + a.cs_f1 * j;
-                            if (2 * row > a.cs_n) v.y = -v.y;
-                            if (row == 0 || 2 * row == a.cs_n) v.y = 0;
-                            ((cpx<T> *)dst)[j] = v;
-                        });
+                    auto put = [&](int j, cpx<T> v) {
+                        const int row = k1 + a.cs_f1 * j;
+                        if (2 * row > a.cs_n) v.y = -v.y;
+                        if (row == 0 || 2 * row == a.cs_n) v.y = 0;
+                        ((cpx<T> *)dst)[j] = v;
+                    };
+                    // (stream_in: the caller's array is read once and must not push the intermediate this stage writes out of the Infinity Cache)
+                    if (a.stream_in) stage_loop<STEP>(j0, a.n_in, [&](int j) { const int row = k1 + a.cs_f1 * j; return gload<T, true>(in + (int64_t)(2 * row > a.cs_n ? a.cs_n - row : row) * a.elem_in); }, put);
+                    else stage_loop<STEP>(j0, a.n_in, [&](int j) { const int row = k1 + a.cs_f1 * j; return in[(int64_t)(2 * row > a.cs_n ? a.cs_n - row : row) * a.elem_in]; }, put);
                 } else if constexpr (IN_CPLX) {
                     const cpx<T> *in = (const cpx<T> *)a.in + base;
                     bool folded = false;
