@@ -582,7 +582,12 @@ static int big_fft(const FftConfig &c, const DevConfig &d, const cpx<T> *zin, in
         a.in = zin; a.out = s1; a.nlanes = L * F2; a.n = F1; a.F = F1; a.n_in = F1; a.n_out = F1; a.scale = (T)1;
         a.inner = F2; a.outer_in = pitch_in; a.outer_out = 0; a.elem_in = F2; a.elem_out = 0; a.pitch_out = K1p;
         a.twp = (const cpx<T> *)dt1->cfg[CFG_MAIN].twp_col;
+        // c128 (the lane-fastest kernels): the caller's array is read once -> streaming loads; the intermediate is re-read by pass 2 -> cache-allocating stores.
+        // A-B-A-B (profiles/r08/r08s_fourstep_pass1_policy_abab.txt): 256 x 65536 203 -> 197 us, 16 x 2^20 260 -> 248 us; either one alone is neutral or worse
+        // (keep alone: 213 us); c64 (staged kernels) 285 -> 291 us with the streaming loads: off there
+        a.stream_in = (int)NDFFT_DEV_INT("NDFFT_FS_P1_NT", sizeof(T) == 8 ? 1 : 0); a.keep_out = (int)NDFFT_DEV_INT("NDFFT_FS_KEEP", sizeof(T) == 8 ? 1 : 0);
         if ((rc = launch_fourstep<T>(1, F1, inverse, a, stream))) return rc;
+        a.stream_in = 0; a.keep_out = 0;
         // pass 2: lanes (l, k1)
         a.in = s1; a.out = zout; a.nlanes = L * F1; a.n = F2; a.F = F2; a.n_in = F2; a.n_out = F2; a.scale = scale;
         a.inner = F1; a.outer_in = (int64_t)F2 * K1p; a.outer_out = pitch_out; a.elem_in = K1p; a.elem_out = F1; a.pitch_out = 0;
