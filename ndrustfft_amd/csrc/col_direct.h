@@ -52,7 +52,7 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, int MODE> st
                     const bool mir = 2 * k > nn;
                     const int64_t src = mir ? nn - k : k;
                     if constexpr (MODE == 7) {
-                        x = ((const cpx<T> *)a.in)[o * a.outer_in + src];
+                        x = a.stream_in ? gload<T, true>((const cpx<T> *)a.in + o * a.outer_in + src) : ((const cpx<T> *)a.in)[o * a.outer_in + src];
                         x.x *= a.scale; x.y *= a.scale;
                         if (src == 0 || 2 * src == nn) x.y = (T)0;
                     } else {

@@ -681,7 +681,11 @@ static int real_fourstep(const Problem &P, int gop, const FftConfig &c, const De
     a.inner = N2; a.outer_in = pin; a.outer_out = 0; a.elem_in = N2; a.elem_out = 0; a.pitch_out = K;
     a.aux1 = (const cpx<T> *)dt1->cfg[CFG_MAIN].aux1; a.twp = (const cpx<T> *)dt1->cfg[CFG_MAIN].twp;
     a.makhoul = gop == G_DCT2_EVEN ? 1 : 0;
+    // streaming loads of the caller's lane in pass 1: R2C re-read 123.5 -> 118 us (HBM-sourced unchanged); not for DCT-II, whose mirror tiles share every line
+    // (134 -> 144 us) -- profiles/r08/r08t_real_fourstep_policy_abab.txt
+    a.stream_in = (int)NDFFT_DEV_INT("NDFFT_RFS_P1_NT", gop == G_DCT2_EVEN ? 0 : 1);
     if ((rc = launch_fourstep_real<T>(1, N1 / 2, a, stream))) return rc;
+    a.stream_in = 0;
     // pass 2: lanes (l, k1)
     a.makhoul = 0;
     a.keep_out = 1;                                  // plain stores at the lines the mirrored rows share
@@ -720,7 +724,9 @@ static int real_fourstep_inv(const Problem &P, int gop, const FftConfig &c, cons
     // runs of consecutive tiles per XCD: the mirrored index N1 - k1 is shifted by one element against the tile grid (and DCT-III's real rows are
     // half lines), so neighbouring tiles share every line
     a.xcd_chunk = (int)NDFFT_DEV_INT("NDFFT_RFS_XCD_CHUNK", 8);
+    a.stream_in = (int)NDFFT_DEV_INT("NDFFT_RFSI_P1_NT", 0);      // (measured: ndifft_r2c re-read 112 -> 125 us with streaming loads of the half spectrum: off)
     if ((rc = launch_fourstep_real<T>(gop == G_DCT3_EVEN ? 5 : 4, N2, a, stream))) return rc;
+    a.stream_in = 0;
     if (sw().rfs_c2r_tile) {   // the column C2R kernel on 128-byte tiles (0: the general column kernel through dispatch())
         const DevTables *dt1;
         if ((rc = get_dev_tables(c.rfs_sub1, &dt1))) return rc;
@@ -760,7 +766,11 @@ static int dct4_fourstep(const Problem &P, const FftConfig &c, const DevConfig &
     a.in = d_in; a.out = s1; a.nlanes = B * F2; a.n = F1; a.F = F1; a.n_in = F1; a.n_out = F1; a.scale = (T)P.scale;
     a.inner = F2; a.outer_in = pin; a.outer_out = 0; a.elem_in = F2; a.elem_out = 0; a.pitch_out = K1p;
     a.twp = (const cpx<T> *)dt1->cfg[CFG_MAIN].twp_col; a.makhoul = 2;
+    // pass 1: streaming loads of the caller's lane, cache-allocating stores of the intermediate (the staged ROWOUT store ignored keep_out until round 5):
+    // nddct4 64 x 262144 f64 157.6 -> 153.3 (stores) -> 148-150 us (both)
+    a.stream_in = (int)NDFFT_DEV_INT("NDFFT_DCT4_P1_NT", 1); a.keep_out = (int)NDFFT_DEV_INT("NDFFT_DCT4_KEEP", 1);
     if ((rc = launch_fourstep<T>(1, F1, false, a, stream))) return rc;
+    a.stream_in = 0;
     // pass 2: lanes (l, k1), real output
     a.makhoul = 0; a.keep_out = 0;
     a.in = s1; a.out = d_out; a.nlanes = B * F1; a.n = F2; a.F = F2; a.n_in = F2; a.n_out = F2; a.scale = (T)1;

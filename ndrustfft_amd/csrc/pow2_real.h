@@ -233,7 +233,10 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                             const T *lane_o = (const T *)a.in + (L / a.inner) * a.outer_in;
                             const int64_t m0 = L % a.inner, nn = 2 * (int64_t)a.n * a.inner;
                             struct XW { T x0, x1; cpx<T> w; };
-                            stage_loop<STEP>(j0, a.n_in,
+                            if (a.stream_in) stage_loop<STEP>(j0, a.n_in,
+                                [&](int j) { const int64_t jj = (int64_t)j * a.inner + m0; XW r; r.x0 = __builtin_nontemporal_load(lane_o + 2 * jj); r.x1 = __builtin_nontemporal_load(lane_o + (nn - 1 - 2 * jj)); r.w = a.aux1[jj]; return r; },
+                                [&](int j, XW r) { ((cpx<T> *)dst)[j] = cmul(mk<T>(r.x0 * a.scale, r.x1 * a.scale), r.w); });
+                            else stage_loop<STEP>(j0, a.n_in,
                                 [&](int j) { const int64_t jj = (int64_t)j * a.inner + m0; XW r; r.x0 = lane_o[2 * jj]; r.x1 = lane_o[nn - 1 - 2 * jj]; r.w = a.aux1[jj]; return r; },
                                 [&](int j, XW r) { ((cpx<T> *)dst)[j] = cmul(mk<T>(r.x0 * a.scale, r.x1 * a.scale), r.w); });
                             folded = true;
@@ -249,7 +252,10 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                         if (a.makhoul) {   // element j of lane (o, n2) is v[m], m = j inner + n2, of the n = this->n * inner long lane o
                             const T *lane_o = (const T *)a.in + (L / a.inner) * a.outer_in;
                             const int64_t m0 = L % a.inner, nn = (int64_t)a.n * a.inner;
-                            stage_loop<STEP>(j0, a.n_in,
+                            if (a.stream_in) stage_loop<STEP>(j0, a.n_in,
+                                [&](int j) { const int64_t m = (int64_t)j * a.inner + m0; return __builtin_nontemporal_load(lane_o + (2 * j < a.n ? 2 * m : 2 * (nn - 1 - m) + 1)); },
+                                [&](int j, T v) { ((T *)dst)[j] = v; });
+                            else stage_loop<STEP>(j0, a.n_in,
                                 [&](int j) { const int64_t m = (int64_t)j * a.inner + m0; return lane_o[2 * j < a.n ? 2 * m : 2 * (nn - 1 - m) + 1]; },
                                 [&](int j, T v) { ((T *)dst)[j] = v; });
                             gathered = true;
@@ -598,6 +604,9 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                 }
             } else if constexpr (OUT_CPLX) {
                 cpx<T> *out = (cpx<T> *)a.out + lane * a.pitch_out;
+                if constexpr (ROWOUT) {   // (an intermediate the next pass re-reads: keep_out = cache-allocating stores)
+                    if (a.keep_out) { for (int q = t; q < a.n_out; q += TPL) out[q] = post_cplx<T, OP, ZiPhi>(a, res, q); return; }
+                }
                 for (int q = t; q < a.n_out; q += TPL) gstore<T, true>(out + q, post_cplx<T, OP, ZiPhi>(a, res, q));
             } else {
                 T *out = (T *)a.out + lane * a.pitch_out;
