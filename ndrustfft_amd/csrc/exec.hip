@@ -683,7 +683,7 @@ static int real_fourstep(const Problem &P, int gop, const FftConfig &c, const De
     a.makhoul = gop == G_DCT2_EVEN ? 1 : 0;
     // streaming loads of the caller's lane in pass 1: R2C re-read 123.5 -> 118 us (HBM-sourced unchanged); not for DCT-II, whose mirror tiles share every line
     // (134 -> 144 us) -- profiles/r08/r08t_real_fourstep_policy_abab.txt
-    a.stream_in = (int)NDFFT_DEV_INT("NDFFT_RFS_P1_NT", gop == G_DCT2_EVEN ? 0 : 1);
+    a.stream_in = gop == G_DCT2_EVEN ? 0 : (int)NDFFT_DEV_INT("NDFFT_RFS_P1_NT", 1);
     if ((rc = launch_fourstep_real<T>(1, N1 / 2, a, stream))) return rc;
     a.stream_in = 0;
     // pass 2: lanes (l, k1)
