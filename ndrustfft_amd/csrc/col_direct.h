@@ -68,6 +68,8 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, int MODE> st
         constexpr int RL_ = RL::at(RL::NP - 1), NBL = F / RL_, NBFL = FFT::slots(RL::NP - 1);
         const int mask = (1 << a.cs_logB) - 1;
         cpx<T> *out = (cpx<T> *)a.out + (o * a.cs_k1n + k1) * a.pitch_out;
+        // (round 5: loading the twiddles of all E outputs before the first store measured WORSE here -- ndifft_r2c 64 x 262144 f64 124 -> 133.5 us, nddct3 153 -> 163.5 us:
+        //  E more complex registers across the store phase; the same change in MODE 9 below is worth 10 %)
 #pragma unroll
         for (int q = 0; q < NBFL; ++q)
 #pragma unroll
@@ -126,6 +128,18 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, int MODE> st
 #pragma unroll
             for (int i = 0; i < E; ++i) { v[i].x *= a.scale; v[i].y *= -a.scale; }   // conj + normalisation (src/lib.rs:326-330)
         }
+        // MODE 9: the post-twiddles c_k of all E outputs are loaded before the first store -- inside the store loop every table load waits behind the previous element's
+        // stores (may-alias), E dependent L2 round trips per tile: nddct4 64 x 262144 f64 147 -> 133 us (round 5; MODE 6 measured the same either way and keeps its loop)
+        cpx<T> ck[MODE == 9 ? E : 1];
+        if constexpr (MODE == 9) {
+#pragma unroll
+            for (int q = 0; q < NBFL; ++q)
+#pragma unroll
+                for (int r = 0; r < RL_; ++r) {
+                    const int kq = t + q * TPL + r * NBL;
+                    ck[q * RL_ + r] = a.aux2[k1 + (int64_t)a.cs_f1 * kq];
+                }
+        }
 #pragma unroll
         for (int q = 0; q < NBFL; ++q)
 #pragma unroll
@@ -139,7 +153,7 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, int MODE> st
                     gstore<T, true>((cpx<T> *)a.out + o * a.outer_out + k1 + (int64_t)kq * a.elem_out, val);
                 } else if constexpr (MODE == 9) {
                     const int64_t k = k1 + (int64_t)a.cs_f1 * kq;
-                    const cpx<T> tk = cmul(val, a.aux2[k]);
+                    const cpx<T> tk = cmul(val, ck[q * RL_ + r]);
                     T *out = (T *)a.out + o * a.outer_out;
                     out[2 * k] = tk.x;                       // plain stores: the mirror tile completes every line in the same L2
                     out[(int64_t)a.cs_n - 1 - 2 * k] = -tk.y;
