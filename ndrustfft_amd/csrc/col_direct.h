@@ -166,6 +166,7 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, int MODE> st
                     const int64_t k = kk + (int64_t)a.cs_f1 * r2;   // 0..n/2, every value once
                     const int64_t ob = o * a.outer_out;
                     if constexpr (MODE == 5) {
+                        if (a.makhoul == 3) { ((T *)a.out)[ob + k] = val.x * a.scale; continue; }     // DCT-I (real_fourstep with dct1): y[k] = Re X[k] / 2 times the pre-scale
                         if ((mir && a.keep_out) || (a.keep_out & 2)) ((cpx<T> *)a.out)[ob + k] = val; else gstore<T, true>((cpx<T> *)a.out + ob + k, val);
                     } else {
                         const cpx<T> tk = cmul(val, a.aux2[k]);

@@ -659,9 +659,12 @@ static int gen_op_of(int op, int n, int *slot) {
 //   (2) complex FFTs of length N2 over n2 with the twiddle W_n^(n2 k1) fused into the load; X[k1 + N1 k2] and, for the other half of every
 //       lane, conj at the mirrored index -- the half spectrum 0..n/2 exactly once; DCT-II multiplies by e^(-i pi k / 2n) and writes y[k], y[n-k]
 // Two passes and an intermediate of n/2 + N2 complex per lane; the packed complex four-step needs a split pass (and a Makhoul pass) around its two.
+// gop = G_DCT1 (round 5): the lane is the even extension of the caller's n = N1 N2 / 2 + 1 points (pass 1 gathers it: makhoul = 3) and pass 2 stores y[k] = Re X[k] / 2 times the
+// pre-scale (src/lib.rs:688-698) for k = 0 .. n - 1 -- c / d are the DCT1 slot's tables then.
 template <typename T>
 static int real_fourstep(const Problem &P, int gop, const FftConfig &c, const DevConfig &d, const void *d_in, void *d_out, int64_t pin, int64_t pout, hipStream_t stream) {
     const int N1 = c.rfs_N1, N2 = c.rfs_N2;
+    const bool dct1 = gop == G_DCT1;
     // k1 = 0..N1/2 of the intermediate on a pitch of whole 128-byte lines (the tiles of pass 2 are 128 bytes of adjacent k1 wide: with the
     // natural pitch N1/2 + 1 every tile row would straddle two lines shared with a tile on another XCD)
     const int K = (N1 / 2 + 1 + (int)(128 / sizeof(cpx<T>)) - 1) & ~((int)(128 / sizeof(cpx<T>)) - 1);
@@ -680,17 +683,17 @@ static int real_fourstep(const Problem &P, int gop, const FftConfig &c, const De
     a.in = d_in; a.out = s1; a.nlanes = B * N2; a.n = N1; a.F = N1 / 2; a.n_in = N1; a.n_out = N1 / 2 + 1; a.scale = (T)1;
     a.inner = N2; a.outer_in = pin; a.outer_out = 0; a.elem_in = N2; a.elem_out = 0; a.pitch_out = K;
     a.aux1 = (const cpx<T> *)dt1->cfg[CFG_MAIN].aux1; a.twp = (const cpx<T> *)dt1->cfg[CFG_MAIN].twp;
-    a.makhoul = gop == G_DCT2_EVEN ? 1 : 0;
+    a.makhoul = gop == G_DCT2_EVEN ? 1 : dct1 ? 3 : 0;
     // streaming loads of the caller's lane in pass 1: R2C re-read 123.5 -> 118 us (HBM-sourced unchanged); not for DCT-II, whose mirror tiles share every line
     // (134 -> 144 us) -- profiles/r08/r08t_real_fourstep_policy_abab.txt
-    a.stream_in = gop == G_DCT2_EVEN ? 0 : (int)NDFFT_DEV_INT("NDFFT_RFS_P1_NT", 1);
+    a.stream_in = (gop == G_DCT2_EVEN || dct1) ? 0 : (int)NDFFT_DEV_INT("NDFFT_RFS_P1_NT", 1);     // (DCT-I reads every element twice, through its own tile and the mirrored one)
     if ((rc = launch_fourstep_real<T>(1, N1 / 2, a, stream))) return rc;
     a.stream_in = 0;
     // pass 2: lanes (l, k1)
-    a.makhoul = 0;
+    a.makhoul = dct1 ? 3 : 0;                        // (3: real outputs Re X[k] a.scale)
     a.keep_out = 1;                                  // plain stores at the lines the mirrored rows share
     a.xcd_chunk = (int)NDFFT_DEV_INT("NDFFT_RFS_XCD_CHUNK", 8);
-    a.in = s1; a.out = d_out; a.nlanes = B * K; a.n = N2; a.F = N2; a.n_in = N2; a.n_out = N2; a.scale = (T)P.scale;
+    a.in = s1; a.out = d_out; a.nlanes = B * K; a.n = N2; a.F = N2; a.n_in = N2; a.n_out = N2; a.scale = dct1 ? (T)(0.5 * P.scale) : (T)P.scale;
     a.inner = K; a.outer_in = (int64_t)N2 * K; a.outer_out = pout; a.elem_in = K; a.elem_out = 0; a.pitch_out = 0;
     a.aux1 = nullptr; a.aux2 = (const cpx<T> *)d.aux2; a.twp = (const cpx<T> *)dt2->cfg[CFG_MAIN].twp_col;
     return launch_fourstep_real<T>(gop == G_DCT2_EVEN ? 3 : 2, N2, a, stream);
@@ -793,7 +796,12 @@ static int dispatch_big(const Problem &P, const void *d_in, void *d_out, const D
         set_last_path(c.bigblue ? "blue_global" : "four_step");
         return rc0;
     }
-    const int rfs_on = real_fourstep_enabled(), rfs_ops = rfs_on == 2 ? 15 : (rfs_on ? c.rfs_ops : 0);
+    const int rfs_on = real_fourstep_enabled(), rfs_ops = rfs_on == 2 ? (c.rfs_ops & 16 ? 16 : 15) : (rfs_on ? c.rfs_ops : 0);
+    if (c.rfs && gop == G_DCT1 && (rfs_ops & 16)) {
+        const int rc0 = real_fourstep<T>(P, gop, c, d, d_in, d_out, pin, pout, stream);
+        set_last_path("real_four_step");
+        return rc0;
+    }
     if (c.rfs && ((gop == G_DCT2_EVEN && (rfs_ops & 4)) || (gop == G_R2C_EVEN && P.scale == 1.0 && (rfs_ops & 1)))) {
         const int rc0 = real_fourstep<T>(P, gop, c, d, d_in, d_out, pin, pout, stream);
         set_last_path("real_four_step");

@@ -401,11 +401,17 @@ static void add_colsplit(ndfft_plan *p) {
 // n = N1 * N2, a real FFT of length N1 = 2^a over the strided index n1 (inner complex FFT N1/2 = 64..1024), then complex FFTs of length
 // N2 = 2^b (64..1024) over n2 for k1 = 0..N1/2 only.  Half the intermediate of the complex four-step on the packed lane, and no
 // separate split pass: two passes over global memory instead of three (R2C) or four (DCT-II).
+static void add_real_fourstep_slot(ndfft_plan *p, FftConfig &c, size_t n, bool dct1);
 static void add_real_fourstep(ndfft_plan *p) {
     if (p->kind != NDFFT_KIND_R2C && p->kind != NDFFT_KIND_DCT) return;
-    const size_t n = p->n;
-    FftConfig &c = p->cfg[CFG_MAIN];
-    if (n == 0 || (n & (n - 1)) || !p->has_cfg[CFG_MAIN] || !c.big || c.bigblue) return;
+    if (p->has_cfg[CFG_MAIN]) add_real_fourstep_slot(p, p->cfg[CFG_MAIN], p->n, false);
+    // DCT-I (round 5): the real-even DFT of length 2 (n - 1) -- where that is a power of two too long for one launch, the same two passes run on the even
+    // extension (gathered by pass 1's load) and pass 2 stores Re X[k] / 2 for k = 0 .. n - 1 instead of the half spectrum: two passes instead of the packed
+    // route's four (PRE, two four-step passes, POST)
+    if (p->kind == NDFFT_KIND_DCT && p->has_cfg[CFG_DCT1] && p->n >= 2) add_real_fourstep_slot(p, p->cfg[CFG_DCT1], 2 * (p->n - 1), true);
+}
+static void add_real_fourstep_slot(ndfft_plan *p, FftConfig &c, size_t n, bool dct1) {
+    if (n == 0 || (n & (n - 1)) || !c.big || c.bigblue) return;
     int e = 0; while (((size_t)1 << e) < n) ++e;
     // The split and the ops that take this route, from the sweep over n = 2^16..2^21 at 2^24 points per array (profiles/r06/r06l_*, r06m_*):
     //   f64: N1 = 2^ceil(e/2), but N1 = 2048 rather than N2 = 1024 at e = 20; faster than the packed route for every op and length (1.02-1.7 x)
@@ -417,7 +423,8 @@ static void add_real_fourstep(ndfft_plan *p) {
     a = std::min(11, std::max(7, a));
     if (e - a > 10) a = e - 10;
     if (e - a < 6) a = e - 6;
-    c.rfs_ops = f32 ? ((e <= 19 ? 1 : 0) | (e <= 20 ? 2 | 4 : 0) | 8) : 15;
+    if (dct1 && f32 && e >= 21) return;      // (measured: f32 n = 2^20 + 1 210 vs 206 us on the packed route -- profiles/r08/r08z_dct1_long_lanes.txt)
+    c.rfs_ops = dct1 ? 16 : f32 ? ((e <= 19 ? 1 : 0) | (e <= 20 ? 2 | 4 : 0) | 8) : 15;      // bit 4: the DCT-I form (DCT1 slot only)
     if (const int v = sw().rfs_logn1; v >= 7 && v <= 11) a = v;   // NDFFT_RFS_LOGN1 (parity tests of every split)
     const int b = e - a;
     if (b < 6 || b > 10 || !fourstep_real_supported(1 << a, 1 << b)) return;

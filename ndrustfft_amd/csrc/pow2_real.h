@@ -252,12 +252,12 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                         if (a.makhoul) {   // element j of lane (o, n2) is v[m], m = j inner + n2, of the n = this->n * inner long lane o
                             const T *lane_o = (const T *)a.in + (L / a.inner) * a.outer_in;
                             const int64_t m0 = L % a.inner, nn = (int64_t)a.n * a.inner;
-                            if (a.stream_in) stage_loop<STEP>(j0, a.n_in,
-                                [&](int j) { const int64_t m = (int64_t)j * a.inner + m0; return __builtin_nontemporal_load(lane_o + (2 * j < a.n ? 2 * m : 2 * (nn - 1 - m) + 1)); },
-                                [&](int j, T v) { ((T *)dst)[j] = v; });
-                            else stage_loop<STEP>(j0, a.n_in,
-                                [&](int j) { const int64_t m = (int64_t)j * a.inner + m0; return lane_o[2 * j < a.n ? 2 * m : 2 * (nn - 1 - m) + 1]; },
-                                [&](int j, T v) { ((T *)dst)[j] = v; });
+                            // makhoul = 1: Makhoul's permutation (DCT-II); makhoul = 3 (round 5): the EVEN EXTENSION e[m] = x[m] (m <= nn/2), x[nn - m] otherwise, of a DCT-I lane of
+                            // nn/2 + 1 points (exec.hip: real_fourstep with dct1 = true)
+                            const bool ext = a.makhoul == 3;
+                            auto src = [&](int j) -> int64_t { const int64_t m = (int64_t)j * a.inner + m0; return ext ? (2 * m <= nn ? m : nn - m) : (2 * j < a.n ? 2 * m : 2 * (nn - 1 - m) + 1); };
+                            if (a.stream_in) stage_loop<STEP>(j0, a.n_in, [&](int j) { return __builtin_nontemporal_load(lane_o + src(j)); }, [&](int j, T v) { ((T *)dst)[j] = v; });
+                            else stage_loop<STEP>(j0, a.n_in, [&](int j) { return lane_o[src(j)]; }, [&](int j, T v) { ((T *)dst)[j] = v; });
                             gathered = true;
                         }
                     }
@@ -427,6 +427,7 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                     // the tile's 128 bytes of adjacent k1 land on one line at k, but on TWO lines at the mirrored index N1 - k1 (shifted by one
                     // element): keep_out = 1 writes those with plain stores so that the L2 merges the pieces of neighbouring tiles
                     if constexpr (CS == 5) {
+                        if (a.makhoul == 3) { ((T *)a.out)[ob + k] = val.x * a.scale; continue; }     // DCT-I: y[k] = Re X[k] / 2 (times the pre-scale), plain 4 / 8-byte stores
                         if (mir && a.keep_out) ((cpx<T> *)a.out)[ob + k] = val; else gstore<T, true>((cpx<T> *)a.out + ob + k, val);
                     } else {
                         const cpx<T> tk = cmul(val, a.aux2[k]);

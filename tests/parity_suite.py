@@ -804,7 +804,11 @@ def long_lanes_four_step(L, full=True):
         assert run_case(L, "nddct4", (2, 1 << 17), 1, np.float32, norm=norm) == "real_four_step"
     assert with_env({"NDFFT_FS_DIRECT": "1"}, lambda: run_case(L, "nddct4", (2, 1 << 16), 1, np.float64)) == "real_four_step"
     assert with_env({"NDFFT_REAL_FOURSTEP": "0"}, lambda: run_case(L, "nddct4", (2, 1 << 16), 1, np.float64)) == "four_step"
-    assert run_case(L, "nddct1", (2, (1 << 16) + 1), 1, np.float64) == "four_step"     # DCT-I keeps the packed route
+    # DCT-I with n - 1 a power of two (round 5): the real four-step on the even extension, 2 (n - 1) = N1 N2; NDFFT_REAL_FOURSTEP=0 keeps the packed route
+    for norm in ("Default", "None"):
+        assert run_case(L, "nddct1", (2, (1 << 16) + 1), 1, np.float64, norm=norm) == "real_four_step"
+    assert run_case(L, "nddct1", (3, (1 << 16) + 1), 1, np.float32, offset=5) == "real_four_step"
+    assert with_env({"NDFFT_REAL_FOURSTEP": "0"}, lambda: run_case(L, "nddct1", (2, (1 << 16) + 1), 1, np.float64)) == "four_step"
     if full:
         for a in ("8", "10", "11"):   # other splits n = N1 * N2 (developer knob of the plan)
             for name in ("nddct2", "nddct3", "ndfft_r2c", "ndifft_r2c"):
