@@ -342,6 +342,9 @@ def table(a):
         run("long nddct2 axis=1 64x262144 f64", nddct2, x, y, hd, 1, x.numel(), max(a.steps // 3, 3))
         run("long nddct3 axis=1 64x262144 f64", nddct3, x, y, hd, 1, x.numel(), max(a.steps // 3, 3))
         run("long nddct4 axis=1 64x262144 f64", nddct4, x, y, hd, 1, x.numel(), max(a.steps // 3, 3))
+        x1 = torch.from_numpy(synth.real_array((63, (1 << 18) + 1))).to(dev); y1 = torch.empty_like(x1)
+        run("long nddct1 axis=1 63x262145 f64", nddct1, x1, y1, DctHandler((1 << 18) + 1), 1, x1.numel(), max(a.steps // 3, 3))
+        del x1, y1
         xh = torch.from_numpy(synth.complex_array((64, (1 << 17) + 1))).to(dev); hr = R2cFftHandler(1 << 18)
         run("long ndfft_r2c axis=1 64x262144 f64", ndfft_r2c, x, xh, hr, 1, (x.numel() + 2 * xh.numel()) // 2, max(a.steps // 3, 3))
         run("long ndifft_r2c axis=1 64x262144 f64", ndifft_r2c, xh, y, hr, 1, (x.numel() + 2 * xh.numel()) // 2, max(a.steps // 3, 3))
