@@ -5,7 +5,7 @@ TAG=${1:-r08p}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest.log 2>&1; echo "pytest exit $?" > $OUT/summary.txt; tail -3 $OUT/pytest.log >> $OUT/summary.txt
 timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench exit $?" >> $OUT/summary.txt
-timeout 2400 python tools/bench_configs.py --steps 50 --preheat-s 10 --repeat 2 --compare profiles/r07/r07p_configs_final_repeat2.jsonl,profiles/r07/r07j_configs_cold.jsonl,profiles/r07/r07d_configs_repeat2.jsonl,profiles/r08/r08l_configs_hbm_first.jsonl,profiles/r08/r08p_configs_final_repeat2.jsonl > $OUT/configs_repeat2.jsonl 2> $OUT/configs.err; echo "table exit $?" >> $OUT/summary.txt
+timeout 2400 python tools/bench_configs.py --steps 50 --preheat-s 10 --repeat 2 --compare profiles/r07/r07p_configs_final_repeat2.jsonl,profiles/r07/r07j_configs_cold.jsonl,profiles/r07/r07d_configs_repeat2.jsonl,profiles/r08/r08l_configs_hbm_first.jsonl,profiles/r08/r08p_configs_final_repeat2.jsonl,profiles/r08/r08v_configs_final_repeat2.jsonl > $OUT/configs_repeat2.jsonl 2> $OUT/configs.err; echo "table exit $?" >> $OUT/summary.txt
 grep "^#" $OUT/configs.err > $OUT/configs_compare.txt
 bash tools/prof_bench.sh $TAG/prof_bench pmc > $OUT/prof_bench.log 2>&1
 bash tools/prof_configs.sh $TAG/prof_configs > $OUT/prof_configs.log 2>&1
