@@ -4,7 +4,7 @@ import numpy as np, torch, synth
 from ndrustfft_amd import DctHandler, nddct1, _lib
 from bench_configs import timeit
 dev = torch.device("cuda:0")
-for n in (512, 220, 514):
+for n in [int(v) for v in sys.argv[1:]] or (512, 220, 514):
     for rdt in (np.float32, np.float64):
         x = torch.from_numpy(synth.real_array(((1 << 25) // n, n), rdt)).to(dev); y = torch.empty_like(x)
         for sym in ("1", "0", "1", "0"):
