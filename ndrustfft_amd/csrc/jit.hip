@@ -812,7 +812,8 @@ bool rader_choose(int dtype, int F, RaderCfg &rc, bool dct1_slot) {
     rc.mc1 = mc; rc.mc2 = 1;
     if (mc > 16) {
         int n1 = 0, n2 = 0;
-        if (mc > (dtype == NDFFT_F32 ? 48 : 32) || !regfft_factor(mc, &n1, &n2) || n1 > 16 || n2 > 16) return false;
+        // (f64: 32; 33 = 11 x 3 in the DCT-I slot only, where it is nddct1 n = 1024: F = 1023 = 33 x 31, otherwise Bluestein at 392 us -- round 5)
+        if (mc > (dtype == NDFFT_F32 ? 48 : (dct1_slot && (mc & 1) ? 33 : 32)) || !regfft_factor(mc, &n1, &n2) || n1 > 16 || n2 > 16) return false;
         rc.mc1 = n1; rc.mc2 = n2;
     }
     // p - 1: 13-smooth, or with ONE factor 17 / 19 (f32: also 23 / 29 / 31) -- a pass of that radix, E >= that many complex registers

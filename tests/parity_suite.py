@@ -993,6 +993,18 @@ def rader_kernel(L, sizes=(31, 62, 97, 103, 306, 511), col_max_F=128, dtypes=(np
                 assert run_case(L, name, (3, n, rows // 2), 1, rdt, offset=n + 1) in ok_col, (name, n, rdt)
 
 
+def dct1_power_of_two_lengths(L):
+    """nddct1 with n a power of two: F = n - 1 = 255 (15 x 17), 511 (7 x 73), 1023 (33 x 31: cofactor 33 = 11 x 3, allowed in the DCT-I slot only) -- the symmetric Rader form
+    (rader_kernel.h: SYM), rows and column tiles, both precisions and normalisations."""
+    for n in (256, 512, 1024):
+        rows = (1 << 17) // n + 3
+        for rdt in (np.float64, np.float32):
+            for norm in ("Default", "None"):
+                assert run_case(L, "nddct1", (rows, n), 1, rdt, norm=norm, offset=n) == "rader_reg", (n, rdt)
+            assert run_case(L, "nddct1", (n, rows + 5), 0, rdt, offset=n + 1) == "rader_col", (n, rdt)
+            assert run_case(L, "nddct1", (2, n, rows // 2), 1, rdt, offset=n + 2) == "rader_col", (n, rdt)
+
+
 def _bluestein_register_kernel(L, sizes, col_max_M):
     for F, M in sizes:
         rows = (1 << 17) // M + 5        # (the library may pick a smooth convolution length down to M / 2: stay above its 2^16-point threshold)

@@ -184,6 +184,7 @@ def test_rader_f32_radix_23_29_31(L):
     """f32 only: p - 1 with one factor 23 / 29 / 31 gets a pass of that radix (139: 138 = 23 x 6, 233: 232 = 29 x 8, 311: 310 = 31 x 10); f64 keeps Bluestein there."""
     ps.rader_kernel(L, sizes=(139, 311), col_max_F=200, dtypes=(np.float32,))
 def test_odd_real_lengths(L): ps.odd_real_lengths(L, sizes=(63, 125, 1001, 3003), dct4=True)
+def test_dct1_power_of_two_lengths(L): ps.dct1_power_of_two_lengths(L)
 def test_rader_kernel_beyond_bluestein(L):
     """F > 4096: Bluestein's M = 2^k >= 2F - 1 no longer fits one launch, Rader's F elements of LDS do (7001, 8191 prime; 8402 = 2 x 4201)."""
     ps.rader_kernel(L, sizes=(8191, 8402), col_max_F=0)

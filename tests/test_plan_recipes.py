@@ -48,7 +48,7 @@ def _check_line(d, dtype):
         mc = mc1 * mc2
         assert p == _largest_prime(F) and mc * p == F and math.gcd(mc, p) == 1, d
         assert M == p - 1 and _prod(d["radix"]) == M, d
-        assert mc1 in BFLY | {1} and mc2 in BFLY | {1} and mc <= (48 if dtype == _lib.F32 else 32), d
+        assert mc1 in BFLY | {1} and mc2 in BFLY | {1} and mc <= (48 if dtype == _lib.F32 else (33 if "sym_rows" in d else 32)), d
         # sym_rows (round 5, DCT-I slot with an odd cofactor > 1): only (mc + 1) / 2 of the mc Rader transforms run, on that many groups of tpl threads
         rows = int(d["sym_rows"]) if "sym_rows" in d else mc
         if "sym_rows" in d:
