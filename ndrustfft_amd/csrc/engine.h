@@ -69,6 +69,9 @@ struct RaderCfg {
     // mc - n1 have mirrored spectra and only rows 0 .. (mc - 1) / 2 run Rader's convolution
     bool sym = false;
     int rows() const { return sym ? (mc + 1) / 2 : mc; }
+    // ... and with cofactor 1 (F = p prime: nddct1 n = 128, 8192) the Rader sequence itself is periodic, a[q + (p-1)/2] = a[q]: a convolution of HALF the length
+    bool half() const { return sym && mc == 1; }
+    int conv_len() const { return half() ? (p - 1) / 2 : p - 1; }
 };
 }  // namespace ndfft
 struct ndfft_plan;

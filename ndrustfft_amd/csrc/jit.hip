@@ -619,7 +619,7 @@ template <typename T> int launch_jit_blue(int gop, const JitCfg &cfg, bool col, 
 // ---- Rader / Good-Thomas kernel (rader_kernel.h) ---------------------------------------------------------------------
 static bool rader_enabled() { return sw().rader; }   // NDFFT_RADER=0 keeps every such length on Bluestein
 static size_t rader_lane_lds(const RaderCfg &rc, bool col) {   // complex elements per lane = RaderKernel::LANE_LDS
-    const size_t M = (size_t)rc.p - 1, F = (size_t)rc.p * rc.mc;
+    const size_t M = (size_t)rc.conv_len(), F = (size_t)rc.p * rc.mc;
     const size_t zlen = rc.sym ? (size_t)((rc.p + 1) / 2) * rc.mc : F;                  // RaderKernel::ZLEN / ZRAW
     const size_t zraw = std::max(zlen + (zlen >> 4) + 3, rc.sym ? (F + 2) / 2 : (size_t)0);
     const size_t sub = M + (M >> 4) + 2, lane = std::max((size_t)rc.rows() * sub, zraw);
@@ -643,18 +643,19 @@ static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg
 static thread_local bool g_rader_planning = false;      // plan_fft_by_cost is called for the Rader kernel (f64 cap 21 instead of 18)
 static thread_local bool g_rader_sym = false;           // ... for its symmetric DCT-I form: f64 cap 16 (nddct1 n = 512, FFT_72 on 4 rows: 9.8 on 5 threads, e = 18,
                                                         //     222 us; on 8 threads, e = 16, two lanes per wave, 142 us -- profiles/r08/r08e_dct1_sym_tune_512.txt)
+static thread_local bool g_rader_half = false;          // ... its half-length form (cofactor 1): f64 cap 18 -- nddct1 n = 1010 f64 87 us at e = 21, 71 us at e = 14; n = 8192 177 us at e = 18, 190 us at e = 15
 static thread_local bool g_rader_sym_full_waves = false;   // ... and only recipes whose lane is a divisor or a multiple of one wave (the cost model's own picks, 9.8 on 5 threads and
                                                            //     12.6 on 6, measured 222 and > 190 us)
 static bool rader_plan_fft(int dtype, int M, RaderCfg &rc, int wide) {
-    g_rader_planning = true; g_rader_sym = rc.sym;
+    g_rader_planning = true; g_rader_sym = rc.sym; g_rader_half = rc.half();
     bool ok = false;
-    if (rc.sym) {
+    if (rc.sym && !rc.half()) {      // (cofactor 1: one row per lane, the ordinary planner -- the full-wave rule put nddct1 n = 128 f32 on 4 threads per lane: 120 us against 69 us)
         g_rader_sym_full_waves = true;
         ok = plan_fft_by_cost(dtype, M, rc.rows(), rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8), rc.fft, wide, nullptr);
         g_rader_sym_full_waves = false;
     }
     if (!ok) ok = plan_fft_by_cost(dtype, M, rc.rows(), rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8), rc.fft, wide, nullptr);
-    g_rader_planning = false; g_rader_sym = false;
+    g_rader_planning = false; g_rader_sym = false; g_rader_half = false;
     return ok;
 }
 // lanes per workgroup for `lt` threads per lane and `lane` bytes of LDS per lane: one wave where a lane needs <= 64 threads, else the
@@ -692,7 +693,7 @@ static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg
     // f64 cap: 18 for the row kernels (1500 = 10.6.5.5 at e = 20 lost 10 %), 21 for the Rader kernel (mc > 0 marks it: 2016 = 16.9.7.2 on 126 threads, e = 21, 146 us
     // against 185 us for 12.12.7.2 on 168 threads, e = 14 -- two full waves against three at 7/8)
     const bool rader_call = g_rader_planning;
-    const int emax = dtype == NDFFT_F32 ? 32 : (wide ? std::max(wide, rader_call ? 21 : 18) : (g_rader_sym ? 16 : rader_call ? 21 : 18)), esoft = dtype == NDFFT_F32 ? 21 : 18;
+    const int emax = dtype == NDFFT_F32 ? 32 : (wide ? std::max(wide, rader_call ? 21 : 18) : (g_rader_half ? 18 : g_rader_sym ? 16 : rader_call ? 21 : 18)), esoft = dtype == NDFFT_F32 ? 21 : 18;
     const double eslope = dtype == NDFFT_F32 ? 0.05 : 0.1;
     // wide: M has one factor 17 or 19 (f32 also 23, 29, 31; Rader for primes like 103, 137, 191, 47, 59): that radix joins the list
     std::vector<int> cand = {16, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
@@ -827,19 +828,20 @@ bool rader_choose(int dtype, int F, RaderCfg &rc, bool dct1_slot) {
     rc.p = p; rc.mc = mc;
     // DCT-I with an odd cofactor > 1 (nddct1 n = 512: F = 511 = 7 x 73): even-symmetric inner FFT input, (mc + 1) / 2 of the mc Rader transforms
     // (developer build: NDFFT_RADER_SYM=0 keeps the full form for A/B runs)
-    rc.sym = dct1_slot && mc > 1 && (mc & 1) && NDFFT_DEV_INT("NDFFT_RADER_SYM", 1) != 0;
+    // (cofactor 1, F prime: the half-length convolution, RaderCfg::half)
+    rc.sym = dct1_slot && (mc & 1) && p > 3 && NDFFT_DEV_INT("NDFFT_RADER_SYM", 1) != 0 && (mc > 1 || NDFFT_DEV_INT("NDFFT_RADER_HALF", 1) != 0);
     if (rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8) > jit_lds_limit()) return false;
     if (const char *e = NDFFT_DEV_STR("NDFFT_RADER_CFG")) {     // developer knob (tools/probes/rader_tune.py): "tpl:r0.r1.r2" for FFT_(p-1), read per plan
         JitCfg &c = rc.fft;
-        c = JitCfg(); c.n = p - 1; c.tpl = atoi(e);
+        c = JitCfg(); c.n = rc.conv_len(); c.tpl = atoi(e);
         const char *q = strchr(e, ':');
         int prod = 1;
         while (q && *q) { const int r = atoi(q + 1); if (r < 2) break; c.radix.push_back(r); prod *= r; q = strchr(q + 1, '.'); }
-        if (c.tpl < 1 || prod != p - 1 || c.tpl * rc.rows() > 1024) return false;
+        if (c.tpl < 1 || prod != rc.conv_len() || c.tpl * rc.rows() > 1024) return false;
         for (int r : c.radix) { const int nb = c.n / r, sl = (nb + c.tpl - 1) / c.tpl; c.e = std::max(c.e, sl * r); if (nb % c.tpl) c.partial = true; }
         return true;
     }
-    return rader_plan_fft(dtype, p - 1, rc, wide);
+    return rader_plan_fft(dtype, rc.conv_len(), rc, wide);
 }
 int rader_col_lanes(int dtype, const RaderCfg &rc) {
     const int lt = rc.fft.tpl * rc.rows();

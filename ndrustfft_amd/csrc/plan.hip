@@ -180,15 +180,22 @@ static void build_rader_tables(FftConfig &c) {
     for (int i = 0; i < M; ++i) { c.rader_tab[i] = (int32_t)x; c.rader_tab[M + (M - i) % M] = (int32_t)x; x = x * g % p; }   // g^i; g^-j = g^(M - j)
     std::vector<long double> br(M), bi(M);
     for (int q = 0; q < M; ++q) { const long double ang = -2.0L * kPiL * (long double)c.rader_tab[M + q] / (long double)p; br[q] = cosl(ang); bi[q] = sinl(ang); }
+    // half-length form (RaderCfg::half: DCT-I with F = p prime, even input): a is periodic with period MC = M / 2, so only the even bins of FFT_M(a) are non-zero and
+    // (a (*) b)[t] = IFFT_MC(FFT_MC(a[0..MC)) . bh)[t], bh = FFT_MC(b[q] + b[q + MC]) / MC   (b[q] + b[q + MC] = 2 cos(2 pi g^-q / p): the table is built from the sum)
+    const int MC = c.radercfg.conv_len();
+    if (c.radercfg.half()) {
+        for (int q = 0; q < MC; ++q) { br[q] += br[q + MC]; bi[q] += bi[q + MC]; }
+        br.resize(MC); bi.resize(MC);
+    }
     dft_ld(br, bi);
     c.rader_bhat = HostTable();
-    for (int k = 0; k < M; ++k) { c.rader_bhat.re.push_back(br[k] / M); c.rader_bhat.im.push_back(bi[k] / M); }
+    for (int k = 0; k < MC; ++k) { c.rader_bhat.re.push_back(br[k] / MC); c.rader_bhat.im.push_back(bi[k] / MC); }
     c.rader_twp = HostTable();
-    build_pass_twiddles(c.rader_twp, c.radercfg.fft.radix, M);
+    build_pass_twiddles(c.rader_twp, c.radercfg.fft.radix, MC);
     c.rader_ctw = HostTable();
     for (int k = 0; k < c.radercfg.mc; ++k) unit(c.rader_ctw, (unsigned long long)k, (unsigned long long)c.radercfg.mc);   // W_mc^k: inner twiddles of a two-factor cofactor
     c.rader_twp2 = HostTable();
-    build_pass_twiddles(c.rader_twp2, std::vector<int>(c.radercfg.fft.radix.rbegin(), c.radercfg.fft.radix.rend()), M);
+    build_pass_twiddles(c.rader_twp2, std::vector<int>(c.radercfg.fft.radix.rbegin(), c.radercfg.fft.radix.rend()), MC);
 }
 
 // fills F, radix / Bluestein, tw (and twM, chirp, bhat); or the four-step split for long lanes
@@ -673,7 +680,7 @@ int ndfft_explain_plan(int kind, int dtype, size_t n, char *buf, size_t buflen) 
         std::string l = std::string("slot=") + slot_name[i] + " F=" + std::to_string(c.F);
         if (c.unsupported) l += " route=unsupported";
         else if (c.rader) l += " route=rader p=" + std::to_string(c.radercfg.p) + " mc=" + std::to_string(c.radercfg.mc1) + "x" + std::to_string(c.radercfg.mc2) + " M=" + std::to_string(c.radercfg.fft.n) +
-                               " tpl=" + std::to_string(c.radercfg.fft.tpl) + " e=" + std::to_string(c.radercfg.fft.e) + " radix=" + radix(c.radercfg.fft.radix) + " lanes=" + std::to_string(c.radercfg.fft.lpb) + (c.radercfg.sym ? " sym_rows=" + std::to_string(c.radercfg.rows()) : std::string());
+                               " tpl=" + std::to_string(c.radercfg.fft.tpl) + " e=" + std::to_string(c.radercfg.fft.e) + " radix=" + radix(c.radercfg.fft.radix) + " lanes=" + std::to_string(c.radercfg.fft.lpb) + (c.radercfg.sym ? " sym_rows=" + std::to_string(c.radercfg.rows()) + (c.radercfg.half() ? " half_conv=1" : "") : std::string());
         else if (c.pow2) l += " route=pow2";
         else if (c.jit) {
             l += " route=jit tpl=" + std::to_string(c.jitcfg.tpl) + " e=" + std::to_string(c.jitcfg.e) + " radix=" + radix(c.jitcfg.radix) + " lanes=" + std::to_string(c.jitcfg.row_lpb);

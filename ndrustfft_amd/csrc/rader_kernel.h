@@ -47,10 +47,15 @@ constexpr int rader_inv_mod(int a, int m) {   // a^-1 mod m for coprime a, m (0 
 // their cofactor transform (POST reads Z[F - j] for the others).
 template <typename T, int P, int MC1, int MC2, int TPL, int LPB, typename RL, int OP, bool COL = false, bool SYM = false> struct RaderKernel {
     static constexpr int MC = MC1 * MC2;
-    static_assert(!SYM || (OP == G_DCT1 && MC > 1 && (MC & 1)), "SYM: DCT-I with an odd cofactor");
+    static_assert(!SYM || (OP == G_DCT1 && (MC & 1)), "SYM: DCT-I with an odd cofactor");
+    // HALF (SYM with cofactor 1, F = P prime: nddct1 n = 128, 8192): the Rader sequence a[q] = z[g^q] is itself periodic, a[q + (P-1)/2] = z[-g^q] = a[q], so FFT_(P-1)(a) has only even
+    // bins and the cyclic convolution collapses to one of HALF the length on a[0 .. (P-1)/2): (a (*) b)[t] = IFFT_M(FFT_M(a) . bh)[t] with M = (P-1)/2 and
+    // bh = FFT_M(b[q] + b[q + M]) / M (plan.hip: build_rader_tables); sum_q a[q] = 2 A[0]; each output is Z[g^-t] = Z[P - g^-t].
+    static constexpr bool HALF = SYM && MC == 1;
+    static constexpr int MT = P - 1;                                // length of the index tables g^i, g^-i
     static constexpr int ROWS = SYM ? (MC + 1) / 2 : MC;            // sub-transforms that run the convolution
     using COF = RegFft2<T, MC1, MC2, 1, false>;
-    static constexpr int M = P - 1, F = P * MC;
+    static constexpr int M = (SYM && MC1 * MC2 == 1) ? (P - 1) / 2 : P - 1, F = P * MC;       // convolution length
     using RLR = RadixReversed<RL>;
     using FFT = Pow2Kernel<T, M, TPL, LPB * ROWS, false, RL, 0, 1, 0>;
     using FFT2 = Pow2Kernel<T, M, TPL, LPB * ROWS, false, RLR, 0, 1, 0>;
@@ -165,7 +170,7 @@ template <typename T, int P, int MC1, int MC2, int TPL, int LPB, typename RL, in
         constexpr int R0 = RL::at(0), NB0 = FFT::nbfly(0), NBF0 = FFT::slots(0);
         constexpr int RLAST = RL::at(RL::NP - 1), NBL = FFT::nbfly(RL::NP - 1), NBFL = FFT::slots(RL::NP - 1);
         constexpr bool FULL0 = FFT::full(0), FULLL = FFT::full(RL::NP - 1);
-        const int32_t *gpow = a.rader_tab, *ginv = a.rader_tab + M;      // g^i mod P, g^-i mod P
+        const int32_t *gpow = a.rader_tab, *ginv = a.rader_tab + MT;     // g^i mod P, g^-i mod P
         const int row0 = (n1 * P) % F;                                    // (n1, n2 = 0)
         const cpx<T> x0 = pre(a, (const void *)lds, row0);
         cpx<T> v[E];
@@ -190,7 +195,7 @@ template <typename T, int P, int MC1, int MC2, int TPL, int LPB, typename RL, in
                 for (int r = 0; r < RLAST; ++r) {
                     cpx<T> c = cmul(v[q * RLAST + r], a.bhat[t + q * TPL + r * NBL]);
                     if (q == 0 && r == 0) {
-                        if (t == 0) { X0 = cadd(x0, v[0]); c = cadd(c, x0); }
+                        if (t == 0) { X0 = HALF ? cadd(x0, cadd(v[0], v[0])) : cadd(x0, v[0]); c = cadd(c, x0); }
                     }
                     v[q * RLAST + r] = cconj(c);
                 }
@@ -204,7 +209,11 @@ template <typename T, int P, int MC1, int MC2, int TPL, int LPB, typename RL, in
             for (int q = 0; q < NBF0; ++q)
                 if (FULL0 || t + q * TPL < NB0) {
 #pragma unroll
-                    for (int r = 0; r < R0; ++r) zz[ZiPhi::map(ginv[t + q * TPL + r * NB0])] = cconj(v[q * R0 + r]);
+                    for (int r = 0; r < R0; ++r) {
+                        int k2 = ginv[t + q * TPL + r * NB0];
+                        if constexpr (HALF) { if (k2 > (P - 1) / 2) k2 = P - k2; }      // Z is even: the compact half (post_r), one place per convolution output
+                        zz[ZiPhi::map(k2)] = cconj(v[q * R0 + r]);
+                    }
                 }
             if (t == 0) zz[0] = X0;
         } else {

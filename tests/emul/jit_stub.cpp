@@ -149,7 +149,8 @@ template int launch_jit_blue<double>(int, const JitCfg &, bool, const RealArgs<d
 // FFT_30 runs with a PARTIAL second pass (6.5 on 5 threads)
 bool rader_choose(int, int F, RaderCfg &rc, bool dct1_slot) {
     rc.fft.vec = 1; rc.fft.lpb = 1;
-    rc.sym = dct1_slot && F == 511;      // DCT-I with an odd cofactor: the symmetric form (4 of the 7 Rader transforms)
+    rc.sym = dct1_slot && (F == 511 || F == 31);      // DCT-I with an odd cofactor: the symmetric form (4 of the 7 Rader transforms); F = 31 prime: the half-length convolution
+    if (F == 31 && rc.sym) { rc.p = 31; rc.mc = 1; rc.mc1 = 1; rc.fft.n = 15; rc.fft.tpl = 3; rc.fft.e = 6; rc.fft.radix = {5, 3}; rc.fft.partial = true; return true; }
     if (F == 31 || F == 62) { rc.p = 31; rc.mc = F / 31; rc.mc1 = rc.mc; rc.fft.n = 30; rc.fft.tpl = 5; rc.fft.e = 10; rc.fft.radix = {6, 5}; rc.fft.partial = true; return true; }
     if (F == 97) { rc.p = 97; rc.mc = 1; rc.fft.n = 96; rc.fft.tpl = 8; rc.fft.e = 12; rc.fft.radix = {6, 4, 4}; return true; }
     if (F == 511) { rc.p = 73; rc.mc = 7; rc.mc1 = 7; rc.fft.n = 72; rc.fft.tpl = 6; rc.fft.e = 12; rc.fft.radix = {6, 4, 3}; return true; }
@@ -182,6 +183,17 @@ template <typename T, int P, int MC1, int MC2, int TPL, typename RL> static int 
 template <typename T> int launch_jit_rader(int gop, const RaderCfg &rc, bool col, const RealArgs<T> &a, hipStream_t s) {
     if (a.nlanes <= 0) return NDFFT_OK;
     { const char *e = getenv("NDFFT_RADER"); if (e && e[0] == '0') return NDFFT_ERR_UNSUPPORTED; }
+    if (rc.sym && rc.p == 31) {
+        if (gop != G_DCT1 || rc.mc != 1) return NDFFT_ERR_UNSUPPORTED;
+        if (col) {
+            using K = RaderKernel<T, 31, 1, 1, 3, 8, RadixList<5, 3>, G_DCT1, true, true>;
+            hipLaunchKernelGGL((k_blue_emul<K, T>), dim3((unsigned)((a.nlanes + 7) / 8)), dim3(K::THREADS), K::LDS_BYTES, s, a);
+        } else {
+            using K = RaderKernel<T, 31, 1, 1, 3, 16, RadixList<5, 3>, G_DCT1, false, true>;
+            hipLaunchKernelGGL((k_blue_emul<K, T>), dim3((unsigned)((a.nlanes + 15) / 16)), dim3(K::THREADS), K::LDS_BYTES, s, a);
+        }
+        return NDFFT_OK;
+    }
     if (rc.sym) {
         if (gop != G_DCT1 || rc.p != 73 || rc.mc != 7) return NDFFT_ERR_UNSUPPORTED;
         if (col) {

@@ -47,12 +47,12 @@ def _check_line(d, dtype):
         mc1, mc2 = (int(x) for x in d["mc"].split("x"))
         mc = mc1 * mc2
         assert p == _largest_prime(F) and mc * p == F and math.gcd(mc, p) == 1, d
-        assert M == p - 1 and _prod(d["radix"]) == M, d
+        assert M == ((p - 1) // 2 if "half_conv" in d else p - 1) and _prod(d["radix"]) == M, d
         assert mc1 in BFLY | {1} and mc2 in BFLY | {1} and mc <= (48 if dtype == _lib.F32 else (33 if "sym_rows" in d else 32)), d
         # sym_rows (round 5, DCT-I slot with an odd cofactor > 1): only (mc + 1) / 2 of the mc Rader transforms run, on that many groups of tpl threads
         rows = int(d["sym_rows"]) if "sym_rows" in d else mc
         if "sym_rows" in d:
-            assert d["slot"] == "DCT1" and mc > 1 and mc % 2 == 1 and rows == (mc + 1) // 2, d
+            assert d["slot"] == "DCT1" and mc % 2 == 1 and rows == (mc + 1) // 2 and (("half_conv" in d) == (mc == 1)), d
         assert 1 <= tpl and tpl * rows <= 1024 and int(d["lanes"]) >= 1 and int(d["lanes"]) * tpl * rows <= 1024, d
         radices = [int(r) for r in d["radix"].split(".")]
         assert all(r in BFLY for r in radices), d
