@@ -814,7 +814,7 @@ bool rader_choose(int dtype, int F, RaderCfg &rc, bool dct1_slot) {
     if (mc > 16) {
         int n1 = 0, n2 = 0;
         // (f64: 32; 33 = 11 x 3 in the DCT-I slot only, where it is nddct1 n = 1024: F = 1023 = 33 x 31, otherwise Bluestein at 392 us -- round 5)
-        if (mc > (dtype == NDFFT_F32 ? 48 : (dct1_slot && (mc & 1) ? 33 : 32)) || !regfft_factor(mc, &n1, &n2) || n1 > 16 || n2 > 16) return false;
+        if (mc > (dtype == NDFFT_F32 ? 48 : (dct1_slot && (mc & 1) ? 33 : 32)) || !regfft_factor(mc, &n1, &n2) || n1 > (dct1_slot ? NDFFT_DEV_INT("NDFFT_RADER_DCT1_MC", 23) : 16) || n2 > 16) return false;   // (DCT-I slot: a prime cofactor 17 / 19 / 23 as ONE butterfly -- nddct1 n = 2048: F = 2047 = 23 x 89)
         rc.mc1 = n1; rc.mc2 = n2;
     }
     // p - 1: 13-smooth, or with ONE factor 17 / 19 (f32: also 23 / 29 / 31) -- a pass of that radix, E >= that many complex registers

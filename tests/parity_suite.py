@@ -994,15 +994,16 @@ def rader_kernel(L, sizes=(31, 62, 97, 103, 306, 511), col_max_F=128, dtypes=(np
 
 
 def dct1_power_of_two_lengths(L):
-    """nddct1 with n a power of two: F = n - 1 = 255 (15 x 17), 511 (7 x 73), 1023 (33 x 31: cofactor 33 = 11 x 3, allowed in the DCT-I slot only) -- the symmetric Rader form
+    """nddct1 with n a power of two: F = n - 1 = 255 (15 x 17), 511 (7 x 73), 1023 (33 x 31: cofactor 33 = 11 x 3, allowed in the DCT-I slot only), 2047 (23 x 89) -- the symmetric Rader form
     (rader_kernel.h: SYM), rows and column tiles, both precisions and normalisations."""
-    for n in (256, 512, 1024):
+    for n in (256, 512, 1024, 2048):       # (2048: F = 2047 = 23 x 89 -- a radix-23 cofactor butterfly, allowed in the DCT-I slot; the column form goes through the transpose route)
         rows = (1 << 17) // n + 3
         for rdt in (np.float64, np.float32):
             for norm in ("Default", "None"):
                 assert run_case(L, "nddct1", (rows, n), 1, rdt, norm=norm, offset=n) == "rader_reg", (n, rdt)
-            assert run_case(L, "nddct1", (n, rows + 5), 0, rdt, offset=n + 1) == "rader_col", (n, rdt)
-            assert run_case(L, "nddct1", (2, n, rows // 2), 1, rdt, offset=n + 2) == "rader_col", (n, rdt)
+            col = ("rader_col",) if n < 2048 else ("rader_col", "transpose+rader_reg")
+            assert run_case(L, "nddct1", (n, rows + 5), 0, rdt, offset=n + 1) in col, (n, rdt)
+            assert run_case(L, "nddct1", (2, n, rows // 2), 1, rdt, offset=n + 2) in col, (n, rdt)
 
 
 def _bluestein_register_kernel(L, sizes, col_max_M):
