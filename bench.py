@@ -25,7 +25,10 @@ blocks under `blocks`, so that one ~2 ms sample does not decide the record.
 More measurements ride in the same JSON line (each its own timed region, after the primary one):
   * roofline.frac_warm / roofline.warm -- the same call on ONE (in, out) pair re-used every step (Infinity-Cache assisted);
   * strong_cfg5 -- BASELINE configs[4]: the 65536x4096 array split in N contiguous row blocks, one per rank
-    (N = 1: the whole 4 GiB + 4 GiB array on one GPU), i.e. STRONG scaling of the north star's multi-GPU target.
+    (N = 1: the whole 4 GiB + 4 GiB array on one GPU), i.e. STRONG scaling of the north star's multi-GPU target;
+  * other_configs (N = 1) -- BASELINE configs[2] and [3] as driver-timed blocks: cfg3-A (ndfft_r2c axis 0, 8192x8192 f32), cfg3-B (ndfft axis 1 on
+    its 4097x8192 c64 output), cfg4 (nddct2 axis 2, 256x256x512 f64), each HBM-sourced over rotating pairs with a numpy spot check;
+  * roofline.frac_from_ms_per_step -- the primary fraction recomputed from the wall-clock ms_per_step instead of the HIP-event launch time.
 """
 import argparse
 import json
@@ -189,6 +192,85 @@ def xgmi_block(dist, torch, dev, rank, ngpu, n, ndfft, FftHandler, sync_all, pro
     return out
 
 
+def other_configs_block(torch, np, synth, lib, dev, timed, steps=20, nblocks=3, ramp_ms=150.0):
+    """BASELINE.json's remaining single-GPU configs as driver-timed blocks (never `value`):
+    cfg3-A ndfft_r2c axis=0 on 8192x8192 f32, cfg3-B ndfft axis=1 on its 4097x8192 c64 output, cfg4 nddct2 axis=2 on 256x256x512 f64.
+    Each: rotating (in, out) pairs whose inputs add up to >= 768 MiB (HBM-sourced, as the primary region), an untimed clock ramp + 5 warm-up calls, `nblocks` blocks of
+    EXACTLY `steps` calls between barrier + synchronize; the median block is reported, with a numpy spot check of a timed output."""
+    from ndrustfft_amd import DctHandler, FftHandler, R2cFftHandler, nddct2, ndfft, ndfft_r2c
+    out = []
+
+    def block(name, fn, h, axis, ins, outs, points, check):
+        nbytes = ins[0].numel() * ins[0].element_size() + outs[0].numel() * outs[0].element_size()
+        cnt = [0]
+
+        def go(_i=0):
+            k = cnt[0] % len(ins); cnt[0] += 1
+            fn(ins[k], outs[k], h, axis)
+        # the synthetic inputs were built on the host while the GPU idled: its clocks need tens of milliseconds of sustained work to come back
+        # (see the primary region's ramp), far more than a few ~100 us launches -- keep it busy for >= ramp_ms, untimed, then the warm-up calls
+        t_r = time.perf_counter()
+        while (time.perf_counter() - t_r) * 1e3 < ramp_ms:
+            for _ in range(20):
+                go()
+            torch.cuda.synchronize()
+        for _ in range(max(5, len(ins))):
+            go()
+        res = sorted((timed(go, steps) for _ in range(nblocks)), key=lambda r: r[0])
+        el, dev_ms = res[len(res) // 2]
+        torch.cuda.synchronize()
+        err = check(ins[0], outs[0])
+        out.append({"workload": name, "steps": steps, "blocks": nblocks, "pairs": len(ins), "algorithmic_bytes_per_launch": nbytes,
+                    "ms_per_step": round(el / steps * 1e3, 5), "avg_launch_us": round(dev_ms / steps * 1e3, 2),
+                    "value": round(points * steps / el / 1e9, 3), "unit": "GFFT-points/s",
+                    "frac": round(nbytes / (dev_ms / 1e3 / steps) / 1e9 / HBM_PEAK_GBS, 4),
+                    "frac_from_ms_per_step": round(nbytes / (el / steps) / 1e9 / HBM_PEAK_GBS, 4),
+                    "path": lib.last_path(), "input_policy": lib.last_input_policy(), "spot_check_rel_err": float(err), "ramp_ms": ramp_ms})
+
+    # ---- cfg3-A then cfg3-B (BASELINE configs[2]): f32, tolerance 1e-4 relative (north_star)
+    n = 8192; m = n // 2 + 1; K = 3
+    xs = [torch.from_numpy(synth.real_array((n, n), np.float32)).to(dev)]
+    xs += [xs[0].clone() for _ in range(K - 1)]                                # distinct buffers (what the cache sees); the same synthetic values
+    ws = [torch.empty((m, n), dtype=torch.complex64, device=dev) for _ in range(K)]
+
+    def chk_r2c(a, b):
+        ref = np.fft.rfft(a[:, :4].cpu().numpy().astype(np.float64), axis=0)
+        e = np.abs(b[:, :4].cpu().numpy() - ref).max() / np.abs(ref).max()
+        assert e < 1e-4, f"cfg3-A output differs from numpy.fft.rfft: {e}"
+        return e
+    block(f"cfg3-A ndfft_r2c axis=0 on {n}x{n} f32 -> {m}x{n} Complex<f32> (BASELINE configs[2], first transform)",
+          ndfft_r2c, R2cFftHandler(n, np.float32), 0, xs, ws, n * n, chk_r2c)
+    del xs
+    os_ = [torch.empty_like(ws[0]) for _ in range(K)]
+
+    def chk_c2c(a, b):
+        ref = np.fft.fft(a[:4].cpu().numpy().astype(np.complex128), axis=1)
+        e = np.abs(b[:4].cpu().numpy() - ref).max() / np.abs(ref).max()
+        assert e < 1e-4, f"cfg3-B output differs from numpy.fft.fft: {e}"
+        return e
+    block(f"cfg3-B ndfft axis=1 on {m}x{n} Complex<f32> (BASELINE configs[2], second transform, on cfg3-A's output)",
+          ndfft, FftHandler(n, np.float32), 1, ws, os_, m * n, chk_c2c)
+    del ws, os_
+
+    # ---- cfg4 (BASELINE configs[3]): f64, tolerance 1e-10 relative
+    shp = (256, 256, 512); nn = shp[2]; K = 3
+    xs = [torch.from_numpy(synth.real_array(shp)).to(dev)]
+    xs += [xs[0].clone() for _ in range(K - 1)]
+    ys = [torch.empty_like(xs[0]) for _ in range(K)]
+
+    def chk_dct2(a, b):
+        j = np.arange(nn)
+        C = 2.0 * np.cos(np.pi * np.outer(j, 2 * j + 1) / (2 * nn))            # y[k] = 2 sum_j x[j] cos(pi k (2j+1) / 2n), src/lib.rs:1257
+        ref = a[0, :4].cpu().numpy() @ C.T
+        e = np.abs(b[0, :4].cpu().numpy() - ref).max() / np.abs(ref).max()
+        assert e < 1e-10, f"cfg4 output differs from the DCT-II definition: {e}"
+        return e
+    block("cfg4 nddct2 axis=2 on 256x256x512 f64 (BASELINE configs[3])", nddct2, DctHandler(nn), 2, xs, ys, shp[0] * shp[1] * shp[2], chk_dct2)
+    del xs, ys
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,6 +284,7 @@ def main():
     ap.add_argument("--no-warm", action="store_true", help="skip the Infinity-Cache-assisted side measurement (one pair re-used every step)")
     ap.add_argument("--strong-steps", type=int, default=20, help="timed steps of the cfg5 strong-scaling block (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the driver-timed blocks of cfg3-A / cfg3-B / cfg4 (`other_configs`)")
     ap.add_argument("--no-no-ramp", action="store_true", help="skip the `no_ramp` side measurement (W warm-ups from an idle GPU, then 20 steps, before the ramp)")
     ap.add_argument("--host-reps", type=int, default=15, help="repetitions of the host-array (PCIe-inclusive) side measurement")
     ap.add_argument("--no-host-api", action="store_true", help="skip the PCIe-inclusive ndfft_exec (host arrays) side measurement")
@@ -217,7 +300,7 @@ def main():
     primary_blocks = warm_blocks = max(1, args.blocks)
     args.cold_pairs = max(2, args.cold_pairs)
     if args.profile_phase:
-        args.no_cpu_baseline = args.no_host_api = args.no_xgmi = True
+        args.no_cpu_baseline = args.no_host_api = args.no_xgmi = args.no_other_configs = True
         if args.profile_phase != "primary":
             primary_steps = 1; primary_blocks = 1; args.warmup = 1; args.ramp_ms = 0.0
         if args.profile_phase != "warm":
@@ -441,6 +524,16 @@ def main():
                   "per_gpu_frac": round(s_bytes / s_kern / 1e9 / HBM_PEAK_GBS, 4), "blocks": s_blocks}
         del xs, ys
 
+    # ------------------------------------------------------------------ the other single-GPU configs of BASELINE.json, N = 1 only
+    others = None
+    if ngpu == 1 and not args.no_other_configs:
+        try:
+            others = other_configs_block(torch, np, synth, lib, dev, timed)
+        except AssertionError:
+            raise                                                             # a wrong result must fail the bench
+        except Exception as ex:                                               # anything else must not cost the primary line
+            others = [{"error": repr(ex)[:300]}]
+
     # ------------------------------------------------------------------ N > 1: the data movement of SURVEY 8e / 8f rank 3 over xGMI
     # (never part of `value`: lanes that are born sharded need none of it).  Root scatter and gather of batch slices
     # (point-to-point groups, one slice per link) and the all-to-all re-shard between the two axis passes of a sharded
@@ -511,6 +604,8 @@ def main():
                 "traffic_note": "PMC bytes from an EARLIER profiling run of this command (not measured by this process)" if cold_traffic is not None else None,
                 "kernel": "k_pow2<double,4096>", "algorithmic_bytes_per_launch": bytes_per_launch,
                 "avg_launch_us": round(kern_s * 1e6, 2),
+                # the same fraction from the line's one wall-clock quantity: algorithmic bytes / ms_per_step (includes the host's launch gaps)
+                "frac_from_ms_per_step": round(bytes_per_launch / (el / primary_steps) / 1e9 / HBM_PEAK_GBS, 4),
                 "source": f"HBM: {args.cold_pairs} rotating (in, out) pairs, footprint {args.cold_pairs * bytes_per_launch} B >> the 256 MiB Infinity Cache; "
                           "median of `blocks`",
                 "pairs": args.cold_pairs, "footprint_bytes": args.cold_pairs * bytes_per_launch, "input_policy": policy,
@@ -547,6 +642,8 @@ def main():
             out["profile_phase"] = args.profile_phase + " (profiling run: not a bench result)"
         if strong:
             out["strong_cfg5"] = strong
+        if others:
+            out["other_configs"] = others
         if xgmi:
             out["xgmi"] = xgmi
         if host_api:

@@ -16,7 +16,17 @@ template <typename T, int OP, int CS> static int launch_cs(const RealArgs<T> &a,
     const int64_t nblk = (a.nlanes + kCsLPB - 1) / kCsLPB;
     if (nblk <= 0) return NDFFT_OK;
     if (nblk > 0x7fffffffLL) return fail(NDFFT_ERR_UNSUPPORTED, "too many lanes for one launch");
-    hipLaunchKernelGGL((k_pow2_real<K, T>), dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, a);
+    // lanes are (o, k1, i): when a row of i is whole tiles the grid is (tiles of i, K1, O) and the kernel reads its position off blockIdx
+    // instead of dividing a flat lane index (pow2_real.h: cs_pos); otherwise the flat 1-D grid
+    const int64_t rows = a.inner > 0 ? a.nlanes / a.inner : 0, O = a.cs_k1n > 0 ? rows / a.cs_k1n : 0;
+    if (NDFFT_DEV_INT("NDFFT_CS_GRID3", 1) && a.inner > 0 && a.inner % kCsLPB == 0 && a.cs_k1n <= 65535 && O >= 1 && O <= 65535 &&
+        O * a.cs_k1n * a.inner == a.nlanes && a.inner / kCsLPB <= 0x7fffffffLL) {
+        RealArgs<T> b = a;
+        b.cs_grid3 = 1;
+        hipLaunchKernelGGL((k_pow2_real<K, T>), dim3((unsigned)(a.inner / kCsLPB), (unsigned)a.cs_k1n, (unsigned)O), dim3(K::THREADS), K::LDS_BYTES, s, b);
+    } else {
+        hipLaunchKernelGGL((k_pow2_real<K, T>), dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, a);
+    }
     NDFFT_HIP(hipGetLastError());
     return NDFFT_OK;
 }

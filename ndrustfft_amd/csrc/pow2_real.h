@@ -38,6 +38,7 @@ template <typename T> struct RealArgs {
     // column four-step (CS kernels, see below): lane L = (o, k1, i) with (o, k1) = divmod(L / inner, cs_k1n)
     const cpx<T> *cs_twlo, *cs_twhi;     // W_N^m = cs_twhi[m >> cs_logB] * cs_twlo[m & (2^cs_logB - 1)], N = cs_n
     int32_t cs_logB, cs_k1n, cs_f1, cs_n;
+    int32_t cs_grid3 = 0;                // CS = 1..3: the grid is (inner / LPB, K1, O) -- blockIdx IS (tile of i, k1, o), no index is divided (inner % LPB == 0, O <= 65535)
     int64_t cs_outer_in, cs_outer_out;   // stride of o on the side that is NOT the dense scratch array
     int64_t cs_pitch;                    // row pitch of that side (= inner unless the block is processed in column chunks)
     const cpx<T> *chirp, *bhat;          // Bluestein kernels (blue_kernel.h): e^{-i pi j^2/F}, FFT_M(conj chirp)/M
@@ -134,7 +135,46 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
     static __device__ __forceinline__ cpx<T> cs_tw(const RealArgs<T> &a, int m) {
         return cmul(a.cs_twhi[m >> a.cs_logB], a.cs_twlo[m & ((1 << a.cs_logB) - 1)]);
     }
+    // the same with a compile-time trip count (the CS stage kernels: n_in == F, a multiple of STEP): no loop, no remainder code
+    template <int STEP, int N, typename LD, typename ST> static __device__ __forceinline__ void stage_fixed(int j0, LD ld, ST st) {
+        static_assert(N % STEP == 0, "stage_fixed: whole rounds only");
+        constexpr int NIT = N / STEP, U = NIT < 8 ? NIT : 8;
+        static_assert(NIT % U == 0, "stage_fixed: whole batches only");
+#pragma unroll
+        for (int b = 0; b < NIT; b += U) {
+            decltype(ld(0)) tmp[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) tmp[u] = ld(j0 + (b + u) * STEP);
+#pragma unroll
+            for (int u = 0; u < U; ++u) st(j0 + (b + u) * STEP, tmp[u]);
+        }
+    }
+    // CS = 1..3: which (o, k1, i) a thread's column is.  cs_grid3: read off blockIdx (round 6: the 64-bit divisions of the flat form and the
+    // table loads inside the store loop made the C2R first stage VALU- / latency-bound: 64.5 us per chunk against 46 us for a copy of its shape)
+    struct CsPos { int64_t o, ii; int k1; bool live; };
+    static __device__ __forceinline__ CsPos cs_pos(const RealArgs<T> &a, int cl) {
+        CsPos p;
+        if (a.cs_grid3) { p.ii = (int64_t)blockIdx.x * LPB + cl; p.k1 = (int)blockIdx.y; p.o = (int64_t)blockIdx.z; p.live = true; }
+        else {
+            const int64_t L = (int64_t)blockIdx.x * LPB + cl;
+            p.live = L < a.nlanes;
+            const int64_t ok = (p.live ? L : 0) / a.inner;
+            p.ii = (p.live ? L : 0) % a.inner; p.k1 = (int)(ok % a.cs_k1n); p.o = ok / a.cs_k1n;
+        }
+        return p;
+    }
     static constexpr int THREADS = TPL * LPB;
+    // CS = 3: the table entries of the conj twiddles W_N^-(q k1) of this thread's outputs q = j0 + i THREADS / LPB.  They are loaded BEFORE the store loop (inside
+    // that loop every table load sat behind the previous iteration's store: 8 dependent round trips): f32 behind the staging loads, in front of the FFT
+    // (2 x 16 VGPRs); f64 all together in front of the first store (64 VGPRs through the FFT made 124-132 in all: one round trip per tile is the cheaper price)
+    template <int NQ> static __device__ __forceinline__ void cs3_twiddles(const RealArgs<T> &a, int k1, int j0, cpx<T> (&hi)[NQ], cpx<T> (&lo)[NQ]) {
+        const int mask = (1 << a.cs_logB) - 1;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int m = (j0 + i * (THREADS / LPB)) * k1;
+            hi[i] = a.cs_twhi[m >> a.cs_logB]; lo[i] = a.cs_twlo[m & mask];
+        }
+    }
     // complex elements per lane: padded Z, or F+1 raw complex.  COL: odd, so adjacent lanes spread over the
     // banks; row: even, so every lane base stays 16-byte aligned for the vector staging stores.
     static constexpr int LANE_LDS = COL ? ((F + (F >> 4) + 2) | 1) : ((F + (F >> 4) + 3) & ~1);
@@ -195,7 +235,38 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
         const bool live = lane < a.nlanes;
         char *lds = smem + (size_t)ll * LANE_LDS * 2 * sizeof(T);
         // ---- stage the raw lane(s) ----
-        if constexpr (COL) {
+        constexpr int CSNQ = (CS >= 1 && CS <= 3) ? F / (THREADS / LPB) : 1;   // outputs per thread of a CS stage kernel
+        cpx<T> csw_hi[CSNQ], csw_lo[CSNQ];                                     // CS = 3: the store twiddles' table entries (cs3_twiddles)
+        if constexpr (CS >= 1 && CS <= 3) {
+            static_assert(F % (THREADS / LPB) == 0, "CS stage kernels: whole staging rounds");
+            const int cl = threadIdx.x % LPB, j0 = threadIdx.x / LPB;
+            const CsPos p = cs_pos(a, cl);
+            constexpr int STEP = THREADS / LPB;
+            char *dst = smem + (size_t)cl * LANE_LDS * 2 * sizeof(T);
+            if (p.live) {
+                if constexpr (CS == 3) {
+                    const cpx<T> *in = (const cpx<T> *)a.in + p.o * a.cs_outer_in + p.ii;
+                    const int k1 = p.k1, f1 = a.cs_f1, nn = a.cs_n;
+                    auto put = [&](int j, cpx<T> v) {
+                        const int row = k1 + f1 * j;
+                        if (2 * row > nn) v.y = -v.y;
+                        if (row == 0 || 2 * row == nn) v.y = 0;
+                        ((cpx<T> *)dst)[j] = v;
+                    };
+                    // (stream_in: the caller's array is read once and must not push the intermediate this stage writes out of the Infinity Cache)
+                    if (a.stream_in) stage_fixed<STEP, F>(j0, [&](int j) { const int row = k1 + f1 * j; return gload<T, true>(in + (int64_t)(2 * row > nn ? nn - row : row) * a.elem_in); }, put);
+                    else stage_fixed<STEP, F>(j0, [&](int j) { const int row = k1 + f1 * j; return in[(int64_t)(2 * row > nn ? nn - row : row) * a.elem_in]; }, put);
+                } else {
+                    const cpx<T> *in = (const cpx<T> *)a.in + (p.o * a.cs_k1n + p.k1) * a.outer_in + p.ii;
+                    const int k1 = p.k1;
+                    struct VW { cpx<T> v, w; };
+                    stage_fixed<STEP, F>(j0,
+                        [&](int j) { VW r; r.v = in[(int64_t)j * a.elem_in]; r.w = cs_tw(a, j * k1); return r; },
+                        [&](int j, VW r) { if constexpr (OP == G_C2C_INV) r.w = cconj(r.w); ((cpx<T> *)dst)[j] = cmul(r.v, r.w); });
+                }
+            }
+            if constexpr (CS == 3 && sizeof(T) == 4) cs3_twiddles(a, p.k1, j0, csw_hi, csw_lo);
+        } else if constexpr (COL) {
             // thread -> (lane cl = tid % LPB fastest, element j = tid / LPB)
             const int cl = threadIdx.x % LPB, j0 = threadIdx.x / LPB;
             const int64_t L = lane0 + cl;
@@ -204,26 +275,13 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                 const int64_t base = (L / a.inner) * a.outer_in + (L % a.inner);
                 char *dst = smem + (size_t)cl * LANE_LDS * 2 * sizeof(T);
                 constexpr int STEP = THREADS / LPB;
-                if constexpr (CS == 1 || CS == 2 || CS >= 4) {
+                if constexpr (CS >= 4) {
                     const cpx<T> *in = (const cpx<T> *)a.in + base;
-                    const int k1 = CS >= 4 ? (int)(L % a.inner) : (int)((L / a.inner) % a.cs_k1n);
+                    const int k1 = (int)(L % a.inner);
                     struct VW { cpx<T> v, w; };
                     stage_loop<STEP>(j0, a.n_in,
                         [&](int j) { VW r; r.v = in[(int64_t)j * a.elem_in]; r.w = cs_tw(a, j * k1); return r; },
                         [&](int j, VW r) { if constexpr (OP == G_C2C_INV) r.w = cconj(r.w); ((cpx<T> *)dst)[j] = cmul(r.v, r.w); });
-                } else if constexpr (CS == 3) {
-                    const int64_t ok = L / a.inner;
-                    const int k1 = (int)(ok % a.cs_k1n);
-                    const cpx<T> *in = (const cpx<T> *)a.in + (ok / a.cs_k1n) * a.cs_outer_in + (L % a.inner);
-                    auto put = [&](int j, cpx<T> v) {
-                        const int row = k1 + a.cs_f1 * j;
-                        if (2 * row > a.cs_n) v.y = -v.y;
-                        if (row == 0 || 2 * row == a.cs_n) v.y = 0;
-                        ((cpx<T> *)dst)[j] = v;
-                    };
-                    // (stream_in: the caller's array is read once and must not push the intermediate this stage writes out of the Infinity Cache)
-                    if (a.stream_in) stage_loop<STEP>(j0, a.n_in, [&](int j) { const int row = k1 + a.cs_f1 * j; return gload<T, true>(in + (int64_t)(2 * row > a.cs_n ? a.cs_n - row : row) * a.elem_in); }, put);
-                    else stage_loop<STEP>(j0, a.n_in, [&](int j) { const int row = k1 + a.cs_f1 * j; return in[(int64_t)(2 * row > a.cs_n ? a.cs_n - row : row) * a.elem_in]; }, put);
                 } else if constexpr (IN_CPLX) {
                     const cpx<T> *in = (const cpx<T> *)a.in + base;
                     bool folded = false;
@@ -359,8 +417,10 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
         if constexpr (COL && !ROWOUT) {
             const int cl = threadIdx.x % LPB, j0 = threadIdx.x / LPB;
             const int64_t L = lane0 + cl;
-            if (L >= a.nlanes) return;
-            const int64_t base = (L / a.inner) * a.outer_out + (L % a.inner);
+            CsPos csp; csp.live = true;
+            int64_t base = 0;
+            if constexpr (CS >= 1 && CS <= 3) { csp = cs_pos(a, cl); if (!csp.live) return; }
+            else { if (L >= a.nlanes) return; base = (L / a.inner) * a.outer_out + (L % a.inner); }
             const cpx<T> *res = (const cpx<T> *)(smem + (size_t)cl * LANE_LDS * 2 * sizeof(T));
             if constexpr (PAIR) {
                 // the split twiddles of this thread's pairs, loaded up front: inside the loops below every iteration would wait for its own table load behind
@@ -398,10 +458,11 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                     }
                 }
             } else if constexpr (CS == 1 || CS == 2) {
-                const int64_t ok = L / a.inner;
-                const int k1 = (int)(ok % a.cs_k1n);
-                cpx<T> *out = (cpx<T> *)a.out + (ok / a.cs_k1n) * a.cs_outer_out + (L % a.inner);   // row 0 of (o, i)
-                for (int q = j0; q < F; q += THREADS / LPB) {
+                const int k1 = csp.k1;
+                cpx<T> *out = (cpx<T> *)a.out + csp.o * a.cs_outer_out + csp.ii;   // row 0 of (o, i)
+#pragma unroll
+                for (int qi = 0; qi < CSNQ; ++qi) {
+                    const int q = j0 + qi * (THREADS / LPB);
                     cpx<T> val = post_cplx<T, OP, ZiPhi>(a, res, q);
                     int kk = k1, r2 = q;
                     bool skip = false;
@@ -438,10 +499,13 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                     }
                 }
             } else if constexpr (CS == 3) {
-                const int k1 = (int)((L / a.inner) % a.cs_k1n);
-                cpx<T> *out = (cpx<T> *)a.out + base;
-                for (int q = j0; q < F; q += THREADS / LPB)
-                    out[(int64_t)q * a.elem_out] = cmul(post_cplx<T, OP, ZiPhi>(a, res, q), cconj(cs_tw(a, q * k1)));
+                cpx<T> *out = (cpx<T> *)a.out + (csp.o * a.cs_k1n + csp.k1) * a.outer_out + csp.ii;
+                if constexpr (sizeof(T) == 8) cs3_twiddles(a, csp.k1, j0, csw_hi, csw_lo);
+#pragma unroll
+                for (int qi = 0; qi < CSNQ; ++qi) {
+                    const int q = j0 + qi * (THREADS / LPB);
+                    out[(int64_t)q * a.elem_out] = cmul(post_cplx<T, OP, ZiPhi>(a, res, q), cconj(cmul(csw_hi[qi], csw_lo[qi])));
+                }
             } else if constexpr (OUT_CPLX) {
                 cpx<T> *out = (cpx<T> *)a.out + base;
                 for (int q = j0; q < a.n_out; q += THREADS / LPB) {

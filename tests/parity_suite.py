@@ -927,7 +927,10 @@ def column_four_step(L):
              ("ndifft_r2c", (8192, 48), 0, np.float64, "Default"), ("ndifft_r2c", (8192, 40), 0, np.float32, "None"),
              ("ndfft_r2c", (2, 8192, 20), 1, np.float32, "Default"), ("ndifft_r2c", (3, 8192, 16), 1, np.float32, "Default"),
              ("ndfft_r2c", (16384, 35), 0, np.float64, "Default"), ("ndifft_r2c", (16384, 32), 0, np.float32, "Default"),
-             ("ndfft", (16384, 19), 0, np.float32, "Default"))
+             ("ndfft", (16384, 19), 0, np.float32, "Default"),
+             # rows of whole tiles (inner a multiple of 32): the stage kernels' 3-D grid (tile of i, k1, o), with and without an outer dimension (round 6)
+             ("ndifft_r2c", (2, 8192, 64), 1, np.float32, "Default"), ("ndifft_r2c", (8192, 96), 0, np.float64, "Default"), ("ndfft", (3, 4096, 32), 1, np.float64, "Default"),
+             ("ndfft_r2c", (2, 8192, 32), 1, np.float64, "None"), ("ndifft", (2, 4096, 64), 1, np.float32, "Default"), ("ndfft_r2c", (8192, 128), 0, np.float32, "Default"))
     for name, shape, axis, rdt, norm in cases:
         assert run_case(L, name, shape, axis, rdt, norm=norm) == "col_split", (name, shape)
     # round 3: per-op, per-dtype lower ends -- f32 C2C and C2R from n = 2048 (first factor 32), f32 R2C from 4096; f64 keeps 4096 / 8192
