@@ -9,7 +9,13 @@ namespace ndfft {
 // must match RealCfg<64> in kernels_pow2_real.hip: the per-pass twiddles come from the length-64 C2C
 // plan's twp_col table
 using CsRL64 = RadixList<8, 8>;
-static constexpr int kCsTPL = 8, kCsLPB = 32;
+#ifndef NDFFT_CS_TPL      // (overridable for variant builds, tools/build_variant.sh)
+#define NDFFT_CS_TPL 8
+#endif
+#ifndef NDFFT_CS_LPB
+#define NDFFT_CS_LPB 32
+#endif
+static constexpr int kCsTPL = NDFFT_CS_TPL, kCsLPB = NDFFT_CS_LPB;
 
 template <typename T, int OP, int CS> static int launch_cs(const RealArgs<T> &a, hipStream_t s) {
     using K = RealPow2Kernel<T, 64, kCsTPL, kCsLPB, CsRL64, OP, true, false, CS>;

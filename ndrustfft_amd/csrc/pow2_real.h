@@ -164,9 +164,11 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
         return p;
     }
     static constexpr int THREADS = TPL * LPB;
-    // CS = 3: the table entries of the conj twiddles W_N^-(q k1) of this thread's outputs q = j0 + i THREADS / LPB.  They are loaded BEFORE the store loop (inside
-    // that loop every table load sat behind the previous iteration's store: 8 dependent round trips): f32 behind the staging loads, in front of the FFT
-    // (2 x 16 VGPRs); f64 all together in front of the first store (64 VGPRs through the FFT made 124-132 in all: one round trip per tile is the cheaper price)
+    // CS = 1..3, the twiddles W_N^(j k1), j < F, of one tile.  With the 3-D grid k1 is the WORKGROUP's: threads 0 .. F-1 load the two table entries of one
+    // twiddle each (in front of the staging loads), multiply and leave the F products in LDS behind the lane regions; everybody reads them from there (CS = 1 / 2
+    // in PRE, CS = 3 in the store loop).  Before round 6 every thread loaded its own 2 x 8 entries -- 32 lanes asking for the same address, 64 wave-level loads per
+    // tile against 32 for the data: the C2R first stage measured 61.5 us per chunk with them and 51.8 without (profiles/r09/r09d_cs3_ablation.txt).
+    // Flat grid (rows of i that are not whole tiles: k1 differs between the lanes of a tile): per-thread table loads as before.
     template <int NQ> static __device__ __forceinline__ void cs3_twiddles(const RealArgs<T> &a, int k1, int j0, cpx<T> (&hi)[NQ], cpx<T> (&lo)[NQ]) {
         const int mask = (1 << a.cs_logB) - 1;
 #pragma unroll
@@ -175,10 +177,12 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
             hi[i] = a.cs_twhi[m >> a.cs_logB]; lo[i] = a.cs_twlo[m & mask];
         }
     }
+    static constexpr bool CSK = CS >= 1 && CS <= 3;
     // complex elements per lane: padded Z, or F+1 raw complex.  COL: odd, so adjacent lanes spread over the
     // banks; row: even, so every lane base stays 16-byte aligned for the vector staging stores.
     static constexpr int LANE_LDS = COL ? ((F + (F >> 4) + 2) | 1) : ((F + (F >> 4) + 3) & ~1);
-    static constexpr size_t LDS_BYTES = (size_t)LPB * LANE_LDS * 2 * sizeof(T);
+    static constexpr size_t LANES_LDS_BYTES = (size_t)LPB * LANE_LDS * 2 * sizeof(T);
+    static constexpr size_t LDS_BYTES = LANES_LDS_BYTES + (CSK ? (size_t)F * 2 * sizeof(T) : 0);   // CS stage kernels: + the tile's F twiddles
     static constexpr bool IN_CPLX = OP == G_C2R_EVEN || OP == G_C2C_FWD || OP == G_C2C_INV;
     static constexpr bool OUT_CPLX = OP == G_R2C_EVEN || OP == G_C2C_FWD || OP == G_C2C_INV;
     using FFT = Pow2Kernel<T, F, TPL, LPB, false, RL, FFLAGS, 1, 0>;
@@ -235,14 +239,20 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
         const bool live = lane < a.nlanes;
         char *lds = smem + (size_t)ll * LANE_LDS * 2 * sizeof(T);
         // ---- stage the raw lane(s) ----
-        constexpr int CSNQ = (CS >= 1 && CS <= 3) ? F / (THREADS / LPB) : 1;   // outputs per thread of a CS stage kernel
-        cpx<T> csw_hi[CSNQ], csw_lo[CSNQ];                                     // CS = 3: the store twiddles' table entries (cs3_twiddles)
-        if constexpr (CS >= 1 && CS <= 3) {
-            static_assert(F % (THREADS / LPB) == 0, "CS stage kernels: whole staging rounds");
+        constexpr int CSNQ = CSK ? F / (THREADS / LPB) : 1;   // outputs per thread of a CS stage kernel
+        cpx<T> *cs_twl = (cpx<T> *)(smem + LANES_LDS_BYTES);   // CS stage kernels, 3-D grid: W_N^(j k1), j < F (see cs3_twiddles)
+        if constexpr (CSK) {
+            static_assert(F % (THREADS / LPB) == 0 && THREADS >= F, "CS stage kernels: whole staging rounds, one thread per twiddle");
             const int cl = threadIdx.x % LPB, j0 = threadIdx.x / LPB;
             const CsPos p = cs_pos(a, cl);
             constexpr int STEP = THREADS / LPB;
             char *dst = smem + (size_t)cl * LANE_LDS * 2 * sizeof(T);
+            const bool g3 = a.cs_grid3 != 0;
+            cpx<T> tw_hi = mk<T>((T)1, (T)0), tw_lo = tw_hi;
+            if (g3 && threadIdx.x < F) {
+                const int m = (int)threadIdx.x * p.k1;
+                tw_hi = a.cs_twhi[m >> a.cs_logB]; tw_lo = a.cs_twlo[m & ((1 << a.cs_logB) - 1)];
+            }
             if (p.live) {
                 if constexpr (CS == 3) {
                     const cpx<T> *in = (const cpx<T> *)a.in + p.o * a.cs_outer_in + p.ii;
@@ -258,14 +268,18 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                     else stage_fixed<STEP, F>(j0, [&](int j) { const int row = k1 + f1 * j; return in[(int64_t)(2 * row > nn ? nn - row : row) * a.elem_in]; }, put);
                 } else {
                     const cpx<T> *in = (const cpx<T> *)a.in + (p.o * a.cs_k1n + p.k1) * a.outer_in + p.ii;
-                    const int k1 = p.k1;
-                    struct VW { cpx<T> v, w; };
-                    stage_fixed<STEP, F>(j0,
-                        [&](int j) { VW r; r.v = in[(int64_t)j * a.elem_in]; r.w = cs_tw(a, j * k1); return r; },
-                        [&](int j, VW r) { if constexpr (OP == G_C2C_INV) r.w = cconj(r.w); ((cpx<T> *)dst)[j] = cmul(r.v, r.w); });
+                    if (g3) {   // plain copy: the twiddle is applied in PRE, from LDS
+                        stage_fixed<STEP, F>(j0, [&](int j) { return in[(int64_t)j * a.elem_in]; }, [&](int j, cpx<T> v) { ((cpx<T> *)dst)[j] = v; });
+                    } else {
+                        const int k1 = p.k1;
+                        struct VW { cpx<T> v, w; };
+                        stage_fixed<STEP, F>(j0,
+                            [&](int j) { VW r; r.v = in[(int64_t)j * a.elem_in]; r.w = cs_tw(a, j * k1); return r; },
+                            [&](int j, VW r) { if constexpr (OP == G_C2C_INV) r.w = cconj(r.w); ((cpx<T> *)dst)[j] = cmul(r.v, r.w); });
+                    }
                 }
             }
-            if constexpr (CS == 3 && sizeof(T) == 4) cs3_twiddles(a, p.k1, j0, csw_hi, csw_lo);
+            if (g3 && threadIdx.x < F) cs_twl[threadIdx.x] = cmul(tw_hi, tw_lo);
         } else if constexpr (COL) {
             // thread -> (lane cl = tid % LPB fastest, element j = tid / LPB)
             const int cl = threadIdx.x % LPB, j0 = threadIdx.x / LPB;
@@ -398,6 +412,17 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                     }
                 }
         }
+        if constexpr (CS == 1 || CS == 2) {
+            if (a.cs_grid3) {   // the stage twiddle W_N^(j k1) (INV: the lane was conjugated above, conj(x conj(w)) = conj(x) w), from the tile's LDS table
+                constexpr int R0 = RL::at(0), NB0 = F / R0, NBF0 = FFT::slots(0);
+#pragma unroll
+                for (int q = 0; q < NBF0; ++q)
+                    if (FFT::full(0) || t + q * TPL < NB0) {
+#pragma unroll
+                        for (int r = 0; r < R0; ++r) v[q * R0 + r] = cmul(v[q * R0 + r], cs_twl[t + q * TPL + r * NB0]);
+                    }
+            }
+        }
         // (the first exchange inside passes() starts with a barrier, so the raw lane is dead by then)
         FFT::template passes<0>(v, a.twp, lds, t);
         // ---- Z in natural order ----
@@ -500,11 +525,20 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                 }
             } else if constexpr (CS == 3) {
                 cpx<T> *out = (cpx<T> *)a.out + (csp.o * a.cs_k1n + csp.k1) * a.outer_out + csp.ii;
-                if constexpr (sizeof(T) == 8) cs3_twiddles(a, csp.k1, j0, csw_hi, csw_lo);
+                if (a.cs_grid3) {
 #pragma unroll
-                for (int qi = 0; qi < CSNQ; ++qi) {
-                    const int q = j0 + qi * (THREADS / LPB);
-                    out[(int64_t)q * a.elem_out] = cmul(post_cplx<T, OP, ZiPhi>(a, res, q), cconj(cmul(csw_hi[qi], csw_lo[qi])));
+                    for (int qi = 0; qi < CSNQ; ++qi) {
+                        const int q = j0 + qi * (THREADS / LPB);
+                        out[(int64_t)q * a.elem_out] = cmul(post_cplx<T, OP, ZiPhi>(a, res, q), cconj(cs_twl[q]));
+                    }
+                } else {
+                    cpx<T> csw_hi[CSNQ], csw_lo[CSNQ];
+                    cs3_twiddles(a, csp.k1, j0, csw_hi, csw_lo);
+#pragma unroll
+                    for (int qi = 0; qi < CSNQ; ++qi) {
+                        const int q = j0 + qi * (THREADS / LPB);
+                        out[(int64_t)q * a.elem_out] = cmul(post_cplx<T, OP, ZiPhi>(a, res, q), cconj(cmul(csw_hi[qi], csw_lo[qi])));
+                    }
                 }
             } else if constexpr (OUT_CPLX) {
                 cpx<T> *out = (cpx<T> *)a.out + base;
