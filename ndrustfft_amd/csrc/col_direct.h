@@ -34,14 +34,30 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, int MODE> st
     using FFT = Pow2Kernel<T, F, TPL, LPB, true, RL, 0, 1, 0>;
     static constexpr int E = FFT::E, THREADS = TPL * LPB;
     static_assert(E * TPL == F, "whole butterfly rounds only");
-    static constexpr size_t LDS_BYTES = FFT::LDS_BYTES;
+    // The four-step twiddle W_N^(i k1) of element i = t + d (d = q TPL + r F/R: E values) of lane k1 is W^(t k1) x W^(d k1).  W^(t k1) is one per thread (two table
+    // loads); the E x LPB values W^(d k1) are a tile's: threads t < E load one each, multiply and leave it in LDS behind the exchange area.  Before round 6 every
+    // thread gathered 2 x E table entries of its own (16 scattered 16-byte loads per thread beside 8 loads of data: 38-54 vector loads per wave, SQ counters in
+    // profiles/r09/r09f_sq_long_round5_kernels.json); the number of complex multiplies per element is unchanged (two).
+    static constexpr bool TWIDDLED = MODE >= 4;
+    static_assert(!TWIDDLED || TPL >= E, "one thread row per step twiddle");
+    static constexpr size_t STEP_BYTES = TWIDDLED ? (size_t)E * LPB * 2 * sizeof(T) : 0;
+    static constexpr size_t LDS_BYTES = FFT::LDS_BYTES + STEP_BYTES;
+    static __device__ __forceinline__ cpx<T> tw_at(const RealArgs<T> &a, int m) { return cmul(a.cs_twhi[m >> a.cs_logB], a.cs_twlo[m & ((1 << a.cs_logB) - 1)]); }
 
     // MODE 7 / 8 (see above)
-    static __device__ __forceinline__ void run_inv(const RealArgs<T> &a, int64_t L, int64_t o, int k1, bool live, int t, char *lds) {
+    static __device__ __forceinline__ void run_inv(const RealArgs<T> &a, int64_t L, int64_t o, int k1, bool live, int t, int cl, char *lds, cpx<T> *stepl) {
         cpx<T> v[E];
         constexpr int R0 = RL::at(0), NB0 = F / R0, NBF0 = FFT::slots(0);
+        constexpr int RL_ = RL::at(RL::NP - 1), NBL = F / RL_, NBFL = FFT::slots(RL::NP - 1);
         const int64_t nn = a.cs_n;
         const T hs = (T)0.5 * a.scale;
+        // the store twiddles' table entries: issued in front of the data loads (older loads return first), combined behind them
+        const int k1s = live ? k1 : 0;
+        cpx<T> s_hi = mk<T>((T)1, (T)0), s_lo = s_hi;
+        const int mask = (1 << a.cs_logB) - 1;
+        if (t < E) { const int m = ((t / RL_) * TPL + (t % RL_) * NBL) * k1s; s_hi = a.cs_twhi[m >> a.cs_logB]; s_lo = a.cs_twlo[m & mask]; }
+        const int mb = t * k1s;
+        const cpx<T> b_hi = a.cs_twhi[mb >> a.cs_logB], b_lo = a.cs_twlo[mb & mask];
 #pragma unroll
         for (int q = 0; q < NBF0; ++q)
 #pragma unroll
@@ -63,19 +79,20 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, int MODE> st
                 }
                 v[q * R0 + r] = x;
             }
+        if (t < E) stepl[t * LPB + cl] = cmul(s_hi, s_lo);
+        const cpx<T> base = cmul(b_hi, b_lo);
+        // (the passes' exchange barriers publish stepl; it lies behind the exchange area and is read only in the store loop)
         FFT::template passes<0>(v, a.twp, lds, t);
         if (!live) return;
-        constexpr int RL_ = RL::at(RL::NP - 1), NBL = F / RL_, NBFL = FFT::slots(RL::NP - 1);
-        const int mask = (1 << a.cs_logB) - 1;
         cpx<T> *out = (cpx<T> *)a.out + (o * a.cs_k1n + k1) * a.pitch_out;
-        // (round 5: loading the twiddles of all E outputs before the first store measured WORSE here -- ndifft_r2c 64 x 262144 f64 124 -> 133.5 us, nddct3 153 -> 163.5 us:
-        //  E more complex registers across the store phase; the same change in MODE 9 below is worth 10 %)
+        // (round 5: loading the table entries of all E outputs before the first store measured WORSE here -- E more complex registers across the store phase; round 6: they
+        //  come from the tile's LDS table, nothing is loaded from global memory between the stores)
 #pragma unroll
         for (int q = 0; q < NBFL; ++q)
 #pragma unroll
             for (int r = 0; r < RL_; ++r) {
-                const int kq = t + q * TPL + r * NBL, m = kq * k1;
-                const cpx<T> u = cmul(v[q * RL_ + r], cmul(a.cs_twhi[m >> a.cs_logB], a.cs_twlo[m & mask]));
+                const int kq = t + q * TPL + r * NBL;
+                const cpx<T> u = cmul(v[q * RL_ + r], cmul(base, stepl[(q * RL_ + r) * LPB + cl]));
                 out[kq] = mk<T>(u.x, -u.y);   // conj(r W^(n2 k1)) = IFFT value times W^(-n2 k1); plain store: the next launch re-reads it
             }
     }
@@ -92,11 +109,20 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, int MODE> st
         const int k1 = (int)(L - o * a.inner);
         // (MODE 5 / 6: the inner index runs over a pitch padded to whole 128-byte lines; k1 > N1/2 is padding)
         const bool live = L < a.nlanes && (MODE < 5 || MODE == 9 || 2 * k1 <= a.cs_f1);
-        if constexpr (MODE == 7 || MODE == 8) { run_inv(a, L, o, k1, live, t, smem + (size_t)cl * FFT::LANE_LDS * sizeof(T)); return; }
+        cpx<T> *stepl = (cpx<T> *)(smem + FFT::LDS_BYTES);
+        if constexpr (MODE == 7 || MODE == 8) { run_inv(a, L, o, k1, live, t, cl, smem + (size_t)cl * FFT::LANE_LDS * sizeof(T), stepl); return; }
         char *lds = smem + (size_t)cl * FFT::LANE_LDS * sizeof(T);
         cpx<T> v[E];
         {
             constexpr int R0 = RL::at(0), NB0 = F / R0, NBF0 = FFT::slots(0);
+            // the load twiddles' table entries, in front of the data loads (see TWIDDLED)
+            cpx<T> s_hi = mk<T>((T)1, (T)0), s_lo = s_hi, b_hi = s_hi, b_lo = s_hi;
+            if constexpr (TWIDDLED) {
+                const int k1s = live ? k1 : 0, mask = (1 << a.cs_logB) - 1;
+                if (t < E) { const int m = ((t / R0) * TPL + (t % R0) * NB0) * k1s; s_hi = a.cs_twhi[m >> a.cs_logB]; s_lo = a.cs_twlo[m & mask]; }
+                const int mb = t * k1s;
+                b_hi = a.cs_twhi[mb >> a.cs_logB]; b_lo = a.cs_twlo[mb & mask];
+            }
             const cpx<T> *in = (const cpx<T> *)a.in + o * a.outer_in + k1;
 #pragma unroll
             for (int q = 0; q < NBF0; ++q)
@@ -110,15 +136,12 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, int MODE> st
 #pragma unroll
                 for (int i = 0; i < E; ++i) v[i].y = -v[i].y;
             }
-            if constexpr (MODE >= 4) {   // W_N^(i k1), after the conjugation: the same table serves both directions
-                const int mask = (1 << a.cs_logB) - 1;
+            if constexpr (TWIDDLED) {   // W_N^(i k1), after the conjugation: the same table serves both directions
+                if (t < E) stepl[t * LPB + cl] = cmul(s_hi, s_lo);
+                __syncthreads();
+                const cpx<T> base = cmul(b_hi, b_lo);
 #pragma unroll
-                for (int q = 0; q < NBF0; ++q)
-#pragma unroll
-                    for (int r = 0; r < R0; ++r) {
-                        const int m = (t + q * TPL + r * NB0) * k1;
-                        v[q * R0 + r] = cmul(v[q * R0 + r], cmul(a.cs_twhi[m >> a.cs_logB], a.cs_twlo[m & mask]));
-                    }
+                for (int e = 0; e < E; ++e) v[e] = cmul(v[e], cmul(base, stepl[e * LPB + cl]));
             }
         }
         FFT::template passes<0>(v, a.twp, lds, t);

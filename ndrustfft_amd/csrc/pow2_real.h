@@ -182,7 +182,8 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
     // banks; row: even, so every lane base stays 16-byte aligned for the vector staging stores.
     static constexpr int LANE_LDS = COL ? ((F + (F >> 4) + 2) | 1) : ((F + (F >> 4) + 3) & ~1);
     static constexpr size_t LANES_LDS_BYTES = (size_t)LPB * LANE_LDS * 2 * sizeof(T);
-    static constexpr size_t LDS_BYTES = LANES_LDS_BYTES + (CSK ? (size_t)F * 2 * sizeof(T) : 0);   // CS stage kernels: + the tile's F twiddles
+    // CS stage kernels: + the tile's F twiddles; CS >= 4 (second pass of the row four-steps): + its E x LPB step twiddles (see the PRE fold)
+    static constexpr size_t LDS_BYTES = LANES_LDS_BYTES + (CSK ? (size_t)F * 2 * sizeof(T) : CS >= 4 ? (size_t)(F / TPL) * LPB * 2 * sizeof(T) : 0);
     static constexpr bool IN_CPLX = OP == G_C2R_EVEN || OP == G_C2C_FWD || OP == G_C2C_INV;
     static constexpr bool OUT_CPLX = OP == G_R2C_EVEN || OP == G_C2C_FWD || OP == G_C2C_INV;
     using FFT = Pow2Kernel<T, F, TPL, LPB, false, RL, FFLAGS, 1, 0>;
@@ -240,7 +241,8 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
         char *lds = smem + (size_t)ll * LANE_LDS * 2 * sizeof(T);
         // ---- stage the raw lane(s) ----
         constexpr int CSNQ = CSK ? F / (THREADS / LPB) : 1;   // outputs per thread of a CS stage kernel
-        cpx<T> *cs_twl = (cpx<T> *)(smem + LANES_LDS_BYTES);   // CS stage kernels, 3-D grid: W_N^(j k1), j < F (see cs3_twiddles)
+        cpx<T> *cs_twl = (cpx<T> *)(smem + LANES_LDS_BYTES);   // CS stage kernels, 3-D grid: W_N^(j k1), j < F (see cs3_twiddles); CS >= 4: the step twiddles [e][lane]
+        cpx<T> cs4_bhi = mk<T>((T)1, (T)0), cs4_blo = cs4_bhi, cs4_shi = cs4_bhi, cs4_slo = cs4_bhi;
         if constexpr (CSK) {
             static_assert(F % (THREADS / LPB) == 0 && THREADS >= F, "CS stage kernels: whole staging rounds, one thread per twiddle");
             const int cl = threadIdx.x % LPB, j0 = threadIdx.x / LPB;
@@ -281,6 +283,18 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
             }
             if (g3 && threadIdx.x < F) cs_twl[threadIdx.x] = cmul(tw_hi, tw_lo);
         } else if constexpr (COL) {
+            if constexpr (CS >= 4) {
+                // The four-step twiddle W_N^(i k1) of element i = t + d (d = q TPL + r F/R0: E values) of this thread's lane (k1 = its inner index) is W^(t k1) x W^(d k1):
+                // one base per thread, E x LPB steps per tile (threads t < E load one each and leave the product in LDS); the table entries are loaded here, in front of
+                // the staging loads.  Before round 6 the staging loop gathered two table entries per ELEMENT (16 scattered loads per thread beside 8 loads of data).
+                static_assert(TPL >= E && E * TPL == F, "CS >= 4: whole butterfly rounds, one thread row per step twiddle");
+                constexpr int R0 = RL::at(0), NB0 = F / R0;
+                const int mask = (1 << a.cs_logB) - 1;
+                const int k1 = (int)(((lane < a.nlanes) ? lane : 0) % a.inner);
+                const int mb = t * k1;
+                cs4_bhi = a.cs_twhi[mb >> a.cs_logB]; cs4_blo = a.cs_twlo[mb & mask];
+                if (t < E) { const int m = ((t / R0) * TPL + (t % R0) * NB0) * k1; cs4_shi = a.cs_twhi[m >> a.cs_logB]; cs4_slo = a.cs_twlo[m & mask]; }
+            }
             // thread -> (lane cl = tid % LPB fastest, element j = tid / LPB)
             const int cl = threadIdx.x % LPB, j0 = threadIdx.x / LPB;
             const int64_t L = lane0 + cl;
@@ -289,13 +303,9 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                 const int64_t base = (L / a.inner) * a.outer_in + (L % a.inner);
                 char *dst = smem + (size_t)cl * LANE_LDS * 2 * sizeof(T);
                 constexpr int STEP = THREADS / LPB;
-                if constexpr (CS >= 4) {
+                if constexpr (CS >= 4) {   // plain copy: the twiddle W_N^(j k1) is applied in PRE (base x step, see there)
                     const cpx<T> *in = (const cpx<T> *)a.in + base;
-                    const int k1 = (int)(L % a.inner);
-                    struct VW { cpx<T> v, w; };
-                    stage_loop<STEP>(j0, a.n_in,
-                        [&](int j) { VW r; r.v = in[(int64_t)j * a.elem_in]; r.w = cs_tw(a, j * k1); return r; },
-                        [&](int j, VW r) { if constexpr (OP == G_C2C_INV) r.w = cconj(r.w); ((cpx<T> *)dst)[j] = cmul(r.v, r.w); });
+                    stage_loop<STEP>(j0, a.n_in, [&](int j) { return in[(int64_t)j * a.elem_in]; }, [&](int j, cpx<T> v) { ((cpx<T> *)dst)[j] = v; });
                 } else if constexpr (IN_CPLX) {
                     const cpx<T> *in = (const cpx<T> *)a.in + base;
                     bool folded = false;
@@ -366,6 +376,7 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                 }
             }
         }
+        if constexpr (CS >= 4) { if (t < E) cs_twl[t * LPB + ll] = cmul(cs4_shi, cs4_slo); }
         if constexpr (!DIRECT_IN) __syncthreads();
         if constexpr (OP == G_DCT3_EVEN) {
             // DCT-III: V[k] = 0.5 s (x[k] - i x[n-k]) e^{+i pi k/(2n)}, k = 0..F (x[n] := 0), computed ONCE per k into the lane
@@ -411,6 +422,11 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                         else v[q * R0 + r] = pre_elem<T, OP, ZiNone>(a, raw, i);
                     }
                 }
+        }
+        if constexpr (CS >= 4) {   // (INV: the lane was conjugated above -- the same table serves both directions)
+            const cpx<T> base = cmul(cs4_bhi, cs4_blo);
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] = cmul(v[e], cmul(base, cs_twl[e * LPB + ll]));
         }
         if constexpr (CS == 1 || CS == 2) {
             if (a.cs_grid3) {   // the stage twiddle W_N^(j k1) (INV: the lane was conjugated above, conj(x conj(w)) = conj(x) w), from the tile's LDS table
