@@ -686,7 +686,15 @@ static int real_fourstep(const Problem &P, int gop, const FftConfig &c, const De
     a.makhoul = gop == G_DCT2_EVEN ? 1 : dct1 ? 3 : 0;
     // streaming loads of the caller's lane in pass 1: R2C re-read 123.5 -> 118 us (HBM-sourced unchanged); not for DCT-II, whose mirror tiles share every line
     // (134 -> 144 us) -- profiles/r08/r08t_real_fourstep_policy_abab.txt
-    a.stream_in = (gop == G_DCT2_EVEN || dct1) ? 0 : (int)NDFFT_DEV_INT("NDFFT_RFS_P1_NT", 1);     // (DCT-I reads every element twice, through its own tile and the mirrored one)
+    // (round 6, A-B-A-B on the developer build, profiles/r09/r09l_rfs_p1_nt_abab.txt: with the lane coming from HBM streaming loads LOSE -- 122 against 119 us --, with a re-read,
+    //  cache-resident lane they win -- 113 against 118 us: a resident lane read with nt loads is not re-allocated and leaves the cache to the intermediate.  So the residency
+    //  model decides: streaming loads only for an input it expects IN the cache.  NDFFT_RFS_P1_NT = 0 / 1 (developer build) forces one form, 2 = the model.)
+    {
+        const long knob = NDFFT_DEV_INT("NDFFT_RFS_P1_NT", 2);
+        const size_t es = sizeof(T);
+        const bool resident = row_load_policy(d_in, (size_t)B * (dct1 ? (size_t)(n / 2 + 1) : (size_t)n) * es, d_out, (size_t)B * (size_t)(gop == G_R2C_EVEN ? (n / 2 + 1) * 2 : dct1 ? n / 2 + 1 : n) * es) == 0;
+        a.stream_in = (gop == G_DCT2_EVEN || dct1) ? 0 : (knob == 2 ? (resident ? 1 : 0) : (int)knob);     // (DCT-I reads every element twice, through its own tile and the mirrored one)
+    }
     if ((rc = launch_fourstep_real<T>(1, N1 / 2, a, stream))) return rc;
     a.stream_in = 0;
     // pass 2: lanes (l, k1)

@@ -116,7 +116,15 @@ static bool jit_choose_partial(int dtype, int n, JitCfg &cfg, int emax_arg = 0) 
     return true;
 }
 
-static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg &out, int wide = 0, double *cost_out = nullptr);
+// what the planner is asked for beyond (M, mc): the Rader kernel's caps (an explicit argument since round 6 -- four thread_local flags before)
+struct FftPlanOpts {
+    bool rader = false;        // planned for the Rader kernel: f64 cap of elements per thread 21 instead of 18
+    bool sym = false;          // ... its symmetric DCT-I form: f64 cap 16 (nddct1 n = 512, FFT_72 on 4 rows: 9.8 on 5 threads, e = 18, 222 us; on 8 threads, e = 16, two lanes
+                               //     per wave, 142 us -- profiles/r08/r08e_dct1_sym_tune_512.txt)
+    bool half = false;         // ... its half-length form (cofactor 1): f64 cap 18 -- nddct1 n = 1010 f64 87 us at e = 21, 71 us at e = 14; n = 8192 177 us at e = 18, 190 us at e = 15
+    bool full_waves = false;   // ... only recipes whose lane is a divisor or a multiple of one wave (the cost model's own picks, 9.8 on 5 threads and 12.6 on 6, measured 222 and > 190 us)
+};
+static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg &out, int wide = 0, double *cost_out = nullptr, const FftPlanOpts &opts = FftPlanOpts());
 static bool jit_choose_default(int dtype, int n, JitCfg &cfg, bool allow_partial);
 // The default recipe ("fewest passes, every radix divides E") gives some lengths 20-30 elements per thread on a handful of threads
 // (F = 48: 8.6 on 2 threads, e = 24; 3000 = 10.10.10.3, e = 30).  Those measure badly -- f64 from e > 18, f32 from e > 24
@@ -639,23 +647,16 @@ static int rader_row_lanes(int dtype, const RaderCfg &rc) { return rader_row_lan
 // cost = passes x (work incl. idle threads of partial rounds) / (fill of the workgroup's waves), 13 % / 5 % off for one- / two-wave
 // workgroups, plus a penalty for many elements per thread (f64: e = 21 costs 5-20 %, e = 24 twice the time) -- fitted to the sweeps
 // under profiles/r04/r04c_rader_tune.txt and r04d_rader_tune_lpb.txt (tools/probes/rader_tune.py).
-static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg &out, int wide, double *cost_out);
-static thread_local bool g_rader_planning = false;      // plan_fft_by_cost is called for the Rader kernel (f64 cap 21 instead of 18)
-static thread_local bool g_rader_sym = false;           // ... for its symmetric DCT-I form: f64 cap 16 (nddct1 n = 512, FFT_72 on 4 rows: 9.8 on 5 threads, e = 18,
-                                                        //     222 us; on 8 threads, e = 16, two lanes per wave, 142 us -- profiles/r08/r08e_dct1_sym_tune_512.txt)
-static thread_local bool g_rader_half = false;          // ... its half-length form (cofactor 1): f64 cap 18 -- nddct1 n = 1010 f64 87 us at e = 21, 71 us at e = 14; n = 8192 177 us at e = 18, 190 us at e = 15
-static thread_local bool g_rader_sym_full_waves = false;   // ... and only recipes whose lane is a divisor or a multiple of one wave (the cost model's own picks, 9.8 on 5 threads and
-                                                           //     12.6 on 6, measured 222 and > 190 us)
 static bool rader_plan_fft(int dtype, int M, RaderCfg &rc, int wide) {
-    g_rader_planning = true; g_rader_sym = rc.sym; g_rader_half = rc.half();
+    FftPlanOpts o; o.rader = true; o.sym = rc.sym; o.half = rc.half();
+    const size_t lane = rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8);
     bool ok = false;
     if (rc.sym && !rc.half()) {      // (cofactor 1: one row per lane, the ordinary planner -- the full-wave rule put nddct1 n = 128 f32 on 4 threads per lane: 120 us against 69 us)
-        g_rader_sym_full_waves = true;
-        ok = plan_fft_by_cost(dtype, M, rc.rows(), rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8), rc.fft, wide, nullptr);
-        g_rader_sym_full_waves = false;
+        o.full_waves = true;
+        ok = plan_fft_by_cost(dtype, M, rc.rows(), lane, rc.fft, wide, nullptr, o);
+        o.full_waves = false;
     }
-    if (!ok) ok = plan_fft_by_cost(dtype, M, rc.rows(), rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8), rc.fft, wide, nullptr);
-    g_rader_planning = false; g_rader_sym = false; g_rader_half = false;
+    if (!ok) ok = plan_fft_by_cost(dtype, M, rc.rows(), lane, rc.fft, wide, nullptr, o);
     return ok;
 }
 // lanes per workgroup for `lt` threads per lane and `lane` bytes of LDS per lane: one wave where a lane needs <= 64 threads, else the
@@ -689,11 +690,11 @@ static int row_lanes_by_fill(int lt, size_t lane, int forced, double *util_out) 
     if (util_out) *util_out = best_util;
     return best;
 }
-static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg &out, int wide, double *cost_out) {
+static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg &out, int wide, double *cost_out, const FftPlanOpts &opts) {
     // f64 cap: 18 for the row kernels (1500 = 10.6.5.5 at e = 20 lost 10 %), 21 for the Rader kernel (mc > 0 marks it: 2016 = 16.9.7.2 on 126 threads, e = 21, 146 us
     // against 185 us for 12.12.7.2 on 168 threads, e = 14 -- two full waves against three at 7/8)
-    const bool rader_call = g_rader_planning;
-    const int emax = dtype == NDFFT_F32 ? 32 : (wide ? std::max(wide, rader_call ? 21 : 18) : (g_rader_half ? 18 : g_rader_sym ? 16 : rader_call ? 21 : 18)), esoft = dtype == NDFFT_F32 ? 21 : 18;
+    const bool rader_call = opts.rader;
+    const int emax = dtype == NDFFT_F32 ? 32 : (wide ? std::max(wide, rader_call ? 21 : 18) : (opts.half ? 18 : opts.sym ? 16 : rader_call ? 21 : 18)), esoft = dtype == NDFFT_F32 ? 21 : 18;
     const double eslope = dtype == NDFFT_F32 ? 0.05 : 0.1;
     // wide: M has one factor 17 or 19 (f32 also 23, 29, 31; Rader for primes like 103, 137, 191, 47, 59): that radix joins the list
     std::vector<int> cand = {16, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
@@ -707,7 +708,7 @@ static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg
         std::sort(tpls.begin(), tpls.end()); tpls.erase(std::unique(tpls.begin(), tpls.end()), tpls.end());
         for (int tpl : tpls) {
             if (tpl < 1 || tpl * mc > 1024) continue;
-            if (g_rader_sym_full_waves && (tpl * mc) % 64 != 0 && 64 % (tpl * mc) != 0) continue;
+            if (opts.full_waves && (tpl * mc) % 64 != 0 && 64 % (tpl * mc) != 0) continue;
             int e = 0; double work = 0; bool partial = false;
             for (int r : cur) { const int nb = M / r, sl = (nb + tpl - 1) / tpl; e = std::max(e, sl * r); work += (double)sl * tpl * r; if (nb % tpl) partial = true; }
             if (e > emax) continue;
@@ -814,7 +815,7 @@ bool rader_choose(int dtype, int F, RaderCfg &rc, bool dct1_slot) {
     if (mc > 16) {
         int n1 = 0, n2 = 0;
         // (f64: 32; 33 = 11 x 3 in the DCT-I slot only, where it is nddct1 n = 1024: F = 1023 = 33 x 31, otherwise Bluestein at 392 us -- round 5)
-        if (mc > (dtype == NDFFT_F32 ? 48 : (dct1_slot && (mc & 1) ? 33 : 32)) || !regfft_factor(mc, &n1, &n2) || n1 > (dct1_slot ? NDFFT_DEV_INT("NDFFT_RADER_DCT1_MC", 23) : 16) || n2 > 16) return false;   // (DCT-I slot: a prime cofactor 17 / 19 / 23 as ONE butterfly -- nddct1 n = 2048: F = 2047 = 23 x 89)
+        if (mc > (dtype == NDFFT_F32 ? 48 : (dct1_slot && (mc & 1) ? 33 : 32)) || !regfft_factor(mc, &n1, &n2) || n1 > ((dct1_slot && (mc & 1)) ? NDFFT_DEV_INT("NDFFT_RADER_DCT1_MC", 23) : 16) || n2 > 16) return false;   // (DCT-I slot, ODD cofactor = the symmetric form only: a prime cofactor 17 / 19 / 23 as ONE butterfly -- nddct1 n = 2048: F = 2047 = 23 x 89; even cofactors 34 / 38 / 46 would build the full form with 34-46 complex registers per column, never measured: they stay on Bluestein)
         rc.mc1 = n1; rc.mc2 = n2;
     }
     // p - 1: 13-smooth, or with ONE factor 17 / 19 (f32: also 23 / 29 / 31) -- a pass of that radix, E >= that many complex registers
@@ -841,7 +842,13 @@ bool rader_choose(int dtype, int F, RaderCfg &rc, bool dct1_slot) {
         for (int r : c.radix) { const int nb = c.n / r, sl = (nb + c.tpl - 1) / c.tpl; c.e = std::max(c.e, sl * r); if (nb % c.tpl) c.partial = true; }
         return true;
     }
-    return rader_plan_fft(dtype, rc.conv_len(), rc, wide);
+    if (rader_plan_fft(dtype, rc.conv_len(), rc, wide)) return true;
+    // no recipe under the symmetric form's caps: the full form (cap 21) may still exist -- before round 6 such a length dropped to Bluestein without trying it
+    if (rc.sym && rc.mc1 <= 16) {
+        rc.sym = false;
+        if (rader_lane_lds(rc, false) * 2 * (dtype == NDFFT_F32 ? 4 : 8) <= jit_lds_limit() && rader_plan_fft(dtype, rc.conv_len(), rc, wide)) return true;
+    }
+    return false;
 }
 int rader_col_lanes(int dtype, const RaderCfg &rc) {
     const int lt = rc.fft.tpl * rc.rows();

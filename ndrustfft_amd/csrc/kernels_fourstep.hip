@@ -86,6 +86,7 @@ template <typename T, int F, int OP, int MODE> static int launch_fsd(const RealA
     return NDFFT_OK;
 }
 
+// (round 6: c64 with ONLY the second pass on the lane-fastest kernel -- its column store writes the same 64-byte rows as the staged form -- measured 32 x 2^20 c64 259 -> 363 us: not kept)
 bool fourstep_supported(int F) { return F == 64 || F == 128 || F == 256 || F == 512 || F == 1024; }
 
 // pass = 1: column load / row store; pass = 2: twiddle by the inner index on load, column store

@@ -244,7 +244,8 @@ template <typename T, int F, int OP> static int launch_real_one(const RealArgs<T
         if constexpr (sizeof(T) == 8 && F >= 256) {
             constexpr int64_t kCus = 256;
             constexpr int SMALL_FLAGS = NDFFT_SMALL_GRID_FLAGS;
-            if (!a.keep_out && !a.makhoul) {
+            // (not for an input the residency model marks HBM-sourced: 32 / 64-byte rows are ruinous there, and a call of few tiles whose array is not cache-resident is rare)
+            if (!a.keep_out && !a.makhoul && !a.stream_in) {
                 if constexpr (!(F >= 1024 && KIND >= 2)) {
                     if constexpr (LPB / 4 >= 4) {
                         if ((a.nlanes + LPB / 2 - 1) / (LPB / 2) < kCus)

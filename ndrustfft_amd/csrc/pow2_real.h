@@ -14,6 +14,9 @@
 #include "pow2_kernel.h"
 #include "realops.h"
 
+#ifndef NDFFT_COL_REAL_U
+#define NDFFT_COL_REAL_U 8
+#endif
 #ifndef NDFFT_ROW_NT_MIN_F
 #define NDFFT_ROW_NT_MIN_F 1024
 #endif
@@ -120,8 +123,7 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
     // (round 5: loading a one- or two-element remainder -- lanes of 2^k + 1 points, the DCT-I bench sizes -- BEFORE the full batches, so that it costs no round trip
     //  of its own, gained 2-7 % on the reference's n x n DCT-I bench shapes and cost the register-capped f32 kernels 6-19 %: 32 x 2^20 c64 281 -> 334 us, ndfft_r2c f32
     //  rows n = 100 .. 512 +6-17 % -- profiles/r08/r08n_configs_compare.txt; not kept)
-    template <int STEP, typename LD, typename ST> static __device__ __forceinline__ void stage_loop(int j0, int n, LD ld, ST st) {
-        constexpr int U = 8;
+    template <int STEP, int U = 8, typename LD, typename ST> static __device__ __forceinline__ void stage_loop(int j0, int n, LD ld, ST st) {
         int j = j0;
         for (; j + (U - 1) * STEP < n; j += U * STEP) {
             decltype(ld(0)) tmp[U];
@@ -303,6 +305,7 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                 const int64_t base = (L / a.inner) * a.outer_in + (L % a.inner);
                 char *dst = smem + (size_t)cl * LANE_LDS * 2 * sizeof(T);
                 constexpr int STEP = THREADS / LPB;
+                constexpr int UR = NDFFT_COL_REAL_U;   // loads in flight per thread of a REAL column tile (2 F / TPL = 16 elements per thread with E = 8)
                 if constexpr (CS >= 4) {   // plain copy: the twiddle W_N^(j k1) is applied in PRE (base x step, see there)
                     const cpx<T> *in = (const cpx<T> *)a.in + base;
                     stage_loop<STEP>(j0, a.n_in, [&](int j) { return in[(int64_t)j * a.elem_in]; }, [&](int j, cpx<T> v) { ((cpx<T> *)dst)[j] = v; });
@@ -338,14 +341,14 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                             // nn/2 + 1 points (exec.hip: real_fourstep with dct1 = true)
                             const bool ext = a.makhoul == 3;
                             auto src = [&](int j) -> int64_t { const int64_t m = (int64_t)j * a.inner + m0; return ext ? (2 * m <= nn ? m : nn - m) : (2 * j < a.n ? 2 * m : 2 * (nn - 1 - m) + 1); };
-                            if (a.stream_in) stage_loop<STEP>(j0, a.n_in, [&](int j) { return __builtin_nontemporal_load(lane_o + src(j)); }, [&](int j, T v) { ((T *)dst)[j] = v; });
-                            else stage_loop<STEP>(j0, a.n_in, [&](int j) { return lane_o[src(j)]; }, [&](int j, T v) { ((T *)dst)[j] = v; });
+                            if (a.stream_in) stage_loop<STEP, UR>(j0, a.n_in, [&](int j) { return __builtin_nontemporal_load(lane_o + src(j)); }, [&](int j, T v) { ((T *)dst)[j] = v; });
+                            else stage_loop<STEP, UR>(j0, a.n_in, [&](int j) { return lane_o[src(j)]; }, [&](int j, T v) { ((T *)dst)[j] = v; });
                             gathered = true;
                         }
                     }
                     if (gathered) {}
-                    else if (a.stream_in) stage_loop<STEP>(j0, a.n_in, [&](int j) { return __builtin_nontemporal_load(in + (int64_t)j * a.elem_in); }, [&](int j, T v) { ((T *)dst)[j] = v; });
-                    else stage_loop<STEP>(j0, a.n_in, [&](int j) { return in[(int64_t)j * a.elem_in]; }, [&](int j, T v) { ((T *)dst)[j] = v; });
+                    else if (a.stream_in) stage_loop<STEP, UR>(j0, a.n_in, [&](int j) { return __builtin_nontemporal_load(in + (int64_t)j * a.elem_in); }, [&](int j, T v) { ((T *)dst)[j] = v; });
+                    else stage_loop<STEP, UR>(j0, a.n_in, [&](int j) { return in[(int64_t)j * a.elem_in]; }, [&](int j, T v) { ((T *)dst)[j] = v; });
                 }
             }
         } else if constexpr (!DIRECT_IN) {

@@ -152,8 +152,9 @@ template <typename T, int P, int MC1, int MC2, int TPL, int LPB, typename RL, in
             } else {
                 const T *in = (const T *)a.in + lsafe * a.pitch_in;
                 T *raw = (T *)lds;
-                // 16-byte staging loads where the lanes are 16-byte aligned in global memory (vec_in) and in LDS (f64: every lane base is), streaming
-                // (nt) when the residency model says the input comes from HBM (stream_in) -- round 5: cfg4 nddct1 from HBM 152 us
+                // 16-byte staging loads where the lanes are 16-byte aligned in global memory (vec_in) and in LDS, streaming (nt) when the residency model says the
+                // input comes from HBM (stream_in) -- round 5: cfg4 nddct1 from HBM 152 us.  F64 ONLY: LANE_LDS is odd (bank spreading), so a lane base in LDS is
+                // 16-byte aligned for 16-byte elements and never for f32's 8-byte ones -- f32 rows keep the 4-byte loads LTHREADS apart (and the 8-byte stores below)
                 if ((LANE_LDS * 2 * sizeof(T)) % 16 == 0 && a.vec_in) {
                     constexpr int W = 16 / sizeof(T);
                     const int nv = a.n_in / W;
@@ -288,7 +289,7 @@ template <typename T, int P, int MC1, int MC2, int TPL, int LPB, typename RL, in
             }
         } else {
             if constexpr (SYM && (LANE_LDS * 2 * sizeof(T)) % 16 == 0) {
-                // DCT-I rows, 16-byte aligned lanes (vec_out): outputs go registers -> LDS (the lane region, natural order) -> 16-byte non-temporal
+                // DCT-I rows, 16-byte aligned lanes (vec_out), f64 only (see the staging loads above): outputs go registers -> LDS (the lane region, natural order) -> 16-byte non-temporal
                 // stores instead of 8-byte stores LTHREADS elements apart (the staged POST of pow2_real.h)
                 if (a.vec_out) {
                     constexpr int NQ = (F + 1 + LTHREADS - 1) / LTHREADS;
