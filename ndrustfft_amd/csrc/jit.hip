@@ -818,10 +818,12 @@ bool rader_choose(int dtype, int F, RaderCfg &rc, bool dct1_slot) {
         if (mc > (dtype == NDFFT_F32 ? 48 : (dct1_slot && (mc & 1) ? 33 : 32)) || !regfft_factor(mc, &n1, &n2) || n1 > ((dct1_slot && (mc & 1)) ? NDFFT_DEV_INT("NDFFT_RADER_DCT1_MC", 23) : 16) || n2 > 16) return false;   // (DCT-I slot, ODD cofactor = the symmetric form only: a prime cofactor 17 / 19 / 23 as ONE butterfly -- nddct1 n = 2048: F = 2047 = 23 x 89; even cofactors 34 / 38 / 46 would build the full form with 34-46 complex registers per column, never measured: they stay on Bluestein)
         rc.mc1 = n1; rc.mc2 = n2;
     }
-    // p - 1: 13-smooth, or with ONE factor 17 / 19 (f32: also 23 / 29 / 31) -- a pass of that radix, E >= that many complex registers
+    // p - 1: 13-smooth, or with ONE factor 17 / 19 / 23 / 29 / 31 -- a pass of that radix, E >= that many complex registers
     int wide = 0;
     { int q = p - 1; for (int f : {2, 3, 5, 7, 11, 13}) while (q % f == 0) q /= f;
-      if (q == 17 || q == 19 || (dtype == NDFFT_F32 && (q == 23 || q == 29 || q == 31))) wide = q; else if (q != 1) return false;
+      // (f64 too since round 6 -- 31 complex doubles are 124 VGPRs, the kernel runs one or two waves per SIMD and still beats Bluestein: ndfft c128 2^24 points n = 139 253 -> 185 us,
+      //  278 251 -> 148, 311 289 -> 231, 622 304 -> 240, 1244 277 -> 246, 233 unchanged at 205 us -- profiles/r09/r09n_rader_wide_f64.txt; NDFFT_RADER_WIDE_F64=0: developer build, A/B)
+      if (q == 17 || q == 19 || ((dtype == NDFFT_F32 || NDFFT_DEV_INT("NDFFT_RADER_WIDE_F64", 1)) && (q == 23 || q == 29 || q == 31))) wide = q; else if (q != 1) return false;
       // (at least 6 butterflies of the wide radix per lane, over all cofactor rows: 47 = 23 x 2 + 1 alone would run on 2 threads per lane -- 300 us against
       //  Bluestein's 118 us for 2^24 points c64; 235 = 5 x 47: 91 against 119 us, 139 = 23 x 6 + 1: 105 against 145 us, 590 = 10 x 59: 82 against 173 us,
       //  profiles/r04/r04za_rader_f32_wide.txt)

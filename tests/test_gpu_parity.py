@@ -181,8 +181,14 @@ def test_rader_two_factor_cofactor_and_wide_radices(L):
     (103, 137, 191; 206 = 2 x 103, 2466 = 18 x 137)."""
     ps.rader_kernel(L, sizes=(306, 513, 2336, 103, 206), col_max_F=600)
 def test_rader_f32_radix_23_29_31(L):
-    """f32 only: p - 1 with one factor 23 / 29 / 31 gets a pass of that radix (139: 138 = 23 x 6, 233: 232 = 29 x 8, 311: 310 = 31 x 10); f64 keeps Bluestein there."""
+    """p - 1 with one factor 23 / 29 / 31 gets a pass of that radix (139: 138 = 23 x 6, 233: 232 = 29 x 8, 311: 310 = 31 x 10)."""
     ps.rader_kernel(L, sizes=(139, 311), col_max_F=200, dtypes=(np.float32,))
+@pytest.mark.gpu
+def test_rader_f64_radix_23_29_31(L):
+    """The same in f64 (round 6; Bluestein before): rows of every op family; column tiles where the lane count allows, else any correct route."""
+    ps.rader_kernel(L, sizes=(139, 233, 311), col_max_F=0, dtypes=(np.float64,))
+    for name, shape, axis in (("ndfft", (139, 2048), 0), ("nddct2", (278, 1024), 0), ("ndfft_r2c", (3, 622, 512), 1)):
+        ps.run_case(L, name, shape, axis, np.float64, offset=7)
 def test_odd_real_lengths(L): ps.odd_real_lengths(L, sizes=(63, 125, 1001, 3003), dct4=True)
 def test_dct1_power_of_two_lengths(L): ps.dct1_power_of_two_lengths(L)
 def test_rader_kernel_beyond_bluestein(L):
