@@ -28,8 +28,8 @@ extern "C" {
 
 #define NDFFT_ABI_VERSION 1
 /* Minor revision: bumped when entry points are ADDED (existing ones keep their meaning).  1 = round-4 exports (ndfft_reload_switches,
- * ndfft_documented_switches, ndfft_set_input_hint ...); 2 = ndfft_abi_minor itself. */
-#define NDFFT_ABI_MINOR 2
+ * ndfft_documented_switches, ndfft_set_input_hint ...); 2 = ndfft_abi_minor itself; 3 = ndfft_jit_prebuild (round 6). */
+#define NDFFT_ABI_MINOR 3
 
 typedef enum {
     NDFFT_OK = 0,
@@ -190,6 +190,14 @@ int ndfft_explain_plan(int kind, int dtype, size_t n, char *buf, size_t buflen);
  * created with. */
 int ndfft_documented_switches(char *buf, size_t buflen);
 int ndfft_reload_switches(void);
+
+/* Build step (no reference counterpart; needs NO GPU): the specialised kernels the reference's own lengths ask for are shipped as code objects beside the library
+ * (<library directory>/jit_prebuilt, looked up read-only after the user's cache) so that a first nd* call on those lengths never waits for hiprtc.  They are BUILD
+ * PRODUCTS: `manifest` (csrc/jit_prebuilt/manifest.txt, tracked) lists the kernels' few-line source texts; this call compiles entries first, first + stride, ... with
+ * hiprtc against the kernel headers embedded in THIS library and writes them into out_dir under the names the library will look up (a hash of source + headers +
+ * options: objects of other kernel text are never picked up).  Counts of entries compiled / already there / failed come back through the pointers (any may be NULL).
+ * __graft_entry__.build() runs it; tools/prebuild_jit.py (on an MI355X) extends the manifest. */
+int ndfft_jit_prebuild(const char *manifest, const char *out_dir, int first, int stride, int *built, int *present, int *failed);
 
 /* ---- device memory helpers for shims that keep arrays resident between nd* calls ----------- */
 int ndfft_dev_alloc(void **d_ptr, size_t bytes);

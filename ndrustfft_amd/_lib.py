@@ -25,7 +25,7 @@ SYMBOLS = [
     "ndfft_exec", "ndfft_exec_device", "ndfft_exec_sharded", "ndfft_exec_sharded_device", "ndfft_last_path", "ndfft_explain_plan",
     "ndfft_dev_alloc", "ndfft_dev_free", "ndfft_dev_upload", "ndfft_dev_download", "ndfft_dev_sync",
     "ndfft_release_workspace", "ndfft_host_alloc", "ndfft_host_free", "ndfft_set_input_hint", "ndfft_host_forget", "ndfft_host_reg_cache", "ndfft_last_input_policy",
-    "ndfft_documented_switches", "ndfft_reload_switches",
+    "ndfft_documented_switches", "ndfft_reload_switches", "ndfft_jit_prebuild",
 ]
 
 
@@ -88,6 +88,8 @@ class Library:
         L.ndfft_last_input_policy.argtypes = []; L.ndfft_last_input_policy.restype = i32
         L.ndfft_documented_switches.argtypes = [ctypes.c_char_p, sz]; L.ndfft_documented_switches.restype = i32
         L.ndfft_reload_switches.argtypes = []; L.ndfft_reload_switches.restype = i32
+        ip = ctypes.POINTER(ctypes.c_int)
+        L.ndfft_jit_prebuild.argtypes = [ctypes.c_char_p, ctypes.c_char_p, i32, i32, ip, ip, ip]; L.ndfft_jit_prebuild.restype = i32
 
     def check(self, status):
         if status == OK:
@@ -103,6 +105,12 @@ class Library:
     def reload_switches(self):
         """Re-read the NDFFT_* environment switches (test hook: the library parses them once; see include/ndfft_mi355x.h)."""
         self.check(self.c.ndfft_reload_switches())
+
+    def jit_prebuild(self, manifest, out_dir, first=0, stride=1):
+        """Compile manifest entries first, first + stride, ... into out_dir (no GPU needed); returns (built, present, failed)."""
+        b, p, f = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        self.check(self.c.ndfft_jit_prebuild(os.fsencode(manifest), os.fsencode(out_dir), first, stride, ctypes.byref(b), ctypes.byref(p), ctypes.byref(f)))
+        return b.value, p.value, f.value
 
     def documented_switches(self):
         buf = ctypes.create_string_buffer(4096)

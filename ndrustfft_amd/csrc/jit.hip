@@ -8,6 +8,8 @@
 #include <dlfcn.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <utime.h>
+#include <algorithm>
 #include <cerrno>
 #include <cstdint>
 #include <cstring>
@@ -18,6 +20,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "engine.h"
 #include "pow2_real.h"
@@ -300,9 +303,48 @@ void write_file_atomic(const std::string &path, const std::string &data) {
     if (!ok || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());
 }
 
+// ---- the shipped code objects as BUILD products (round 6) ---------------------------------------------------------------------
+// jit_prebuilt/ used to hold ~160 tracked .hsaco files that only a GPU box could regenerate and that every edit of a kernel header made stale.  Now the tree tracks a
+// MANIFEST of the specialised kernels' (few-line) source texts -- jit_prebuilt/manifest.txt, appended to by any run with NDFFT_JIT_DUMP_SRC=<file> (tools/prebuild_jit.py
+// on an MI355X: which kernels the reference's own lengths ask for is an exec-time choice) -- and ndfft_jit_prebuild() compiles every entry with hiprtc against the headers
+// embedded in THIS library, under the file names compile_entry() will look up.  hiprtc needs no device: __graft_entry__.build() runs it on the CPU-only build box.
+const char kManifestSep[] = "\n=====NDFFT-JIT-ENTRY=====\n";
+static void dump_source(const std::string &src) {
+    const char *f = getenv("NDFFT_JIT_DUMP_SRC");            // developer flow only (never set on the call path of a product run)
+    if (!f || !*f) return;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> g(mu);
+    FILE *fp = fopen(f, "ab");
+    if (!fp) return;
+    fwrite(src.data(), 1, src.size(), fp); fwrite(kManifestSep, 1, sizeof kManifestSep - 1, fp);
+    fclose(fp);
+}
+// compiles `src` with hiprtc (no device needed); returns the code object, empty on failure
+static std::string rtc_compile(const std::string &src, const std::string &what) {
+    Rtc &r = rtc();
+    const char *hn[] = {"device_common.h", "butterflies.h", "pow2_kernel.h", "realops.h", "pow2_real.h", "blue_kernel.h", "reg_kernel.h", "rader_kernel.h", "plain_kernel.h"};
+    const char *hs[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h, jit_src_realops_h, jit_src_pow2_real_h, jit_src_blue_kernel_h, jit_src_reg_kernel_h, jit_src_rader_kernel_h, jit_src_plain_kernel_h};
+    rtcProgram prog = nullptr;
+    bool ok = r.ok && r.create(&prog, src.c_str(), "k_jit.hip", 9, hs, hn) == 0;
+    if (ok) {
+        ok = r.compile(prog, 4, (const char **)kJitOpts) == 0;
+        if (!ok && sw().jit_verbose) {
+            size_t ls = 0; r.log_size(prog, &ls);
+            std::string log(ls, '\0'); r.log(prog, &log[0]);
+            fprintf(stderr, "ndfft jit: compile of %s failed:\n%s\n", what.c_str(), log.c_str());
+        }
+    }
+    std::string code;
+    if (ok) { size_t cs = 0; ok = r.code_size(prog, &cs) == 0 && cs > 0; if (ok) { code.resize(cs); ok = r.code(prog, &code[0]) == 0; } }
+    if (prog) r.destroy(&prog);
+    if (!ok) code.clear();
+    return code;
+}
+
 static Entry compile_entry(const std::string &src, const std::string &what) {
     Rtc &r = rtc();
     Entry ne;
+    dump_source(src);
     {   // a code object compiled by an earlier process?
         const char *hs0[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h, jit_src_realops_h, jit_src_pow2_real_h, jit_src_blue_kernel_h, jit_src_reg_kernel_h, jit_src_rader_kernel_h, jit_src_plain_kernel_h};
         const std::string path = cache_path(src, hs0, 9);
@@ -320,21 +362,9 @@ static Entry compile_entry(const std::string &src, const std::string &what) {
         ne = Entry();
         if (sw().jit == 2) { ne.failed = true; return ne; }      // NDFFT_JIT=cached: cached / prebuilt code objects only
     }
-    const char *hn[] = {"device_common.h", "butterflies.h", "pow2_kernel.h", "realops.h", "pow2_real.h", "blue_kernel.h", "reg_kernel.h", "rader_kernel.h", "plain_kernel.h"};
     const char *hs[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h, jit_src_realops_h, jit_src_pow2_real_h, jit_src_blue_kernel_h, jit_src_reg_kernel_h, jit_src_rader_kernel_h, jit_src_plain_kernel_h};
-    rtcProgram prog = nullptr;
-    bool ok = r.ok && r.create(&prog, src.c_str(), "k_jit.hip", 9, hs, hn) == 0;
-    if (ok) {
-        ok = r.compile(prog, 4, (const char **)kJitOpts) == 0;
-        if (!ok && sw().jit_verbose) {
-            size_t ls = 0; r.log_size(prog, &ls);
-            std::string log(ls, '\0'); r.log(prog, &log[0]);
-            fprintf(stderr, "ndfft jit: compile of %s failed:\n%s\n", what.c_str(), log.c_str());
-        }
-    }
-    std::string code;
-    if (ok) { size_t cs = 0; ok = r.code_size(prog, &cs) == 0 && cs > 0; if (ok) { code.resize(cs); ok = r.code(prog, &code[0]) == 0; } }
-    if (prog) r.destroy(&prog);
+    const std::string code = rtc_compile(src, what);
+    bool ok = !code.empty();
     if (ok) {
         const hipError_t e1 = hipModuleLoadData(&ne.mod, code.data());
         const hipError_t e2 = e1 == hipSuccess ? hipModuleGetFunction(&ne.fn, ne.mod, "k_jit") : e1;
@@ -898,4 +928,43 @@ template int launch_jit_blue<double>(int, const JitCfg &, bool, const RealArgs<d
 template int launch_jit_real<float>(int, const JitCfg &, bool, const RealArgs<float> &, hipStream_t);
 template int launch_jit_real<double>(int, const JitCfg &, bool, const RealArgs<double> &, hipStream_t);
 
+// ndfft_jit_prebuild (see "the shipped code objects as BUILD products" above): entries [first, first + stride, ...] of the manifest, so that several processes can share it
+int jit_prebuild(const char *manifest, const char *out_dir, int first, int stride, int *built, int *present, int *failed) {
+    *built = *present = *failed = 0;
+    std::string all;
+    if (!manifest || !out_dir || !read_file(manifest, all)) return fail(NDFFT_ERR_INVALID_ARG, "ndfft_jit_prebuild: cannot read the manifest");
+    if (!rtc().ok) return fail(NDFFT_ERR_UNSUPPORTED, "ndfft_jit_prebuild: libhiprtc not available");
+    if (mkdir(out_dir, 0755) != 0 && errno != EEXIST) return fail(NDFFT_ERR_INVALID_ARG, "ndfft_jit_prebuild: cannot create the output directory");
+    const char *hs[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h, jit_src_realops_h, jit_src_pow2_real_h, jit_src_blue_kernel_h, jit_src_reg_kernel_h, jit_src_rader_kernel_h, jit_src_plain_kernel_h};
+    const std::string sep(kManifestSep);
+    std::vector<std::string> srcs;
+    for (size_t pos = 0; pos < all.size();) {
+        const size_t e = all.find(sep, pos);
+        std::string one = all.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
+        pos = e == std::string::npos ? all.size() : e + sep.size();
+        if (one.find("k_jit") == std::string::npos) continue;
+        if (std::find(srcs.begin(), srcs.end(), one) == srcs.end()) srcs.push_back(one);
+    }
+    if (stride < 1) stride = 1;
+    for (size_t i = first < 0 ? 0 : (size_t)first; i < srcs.size(); i += (size_t)stride) {
+        const std::string path = std::string(out_dir) + cache_name(srcs[i], hs, 9);
+        std::string have;
+        if (read_file(path, have)) { (void)utime(path.c_str(), nullptr); ++*present; continue; }   // (touched: the caller removes objects older than its pass = of older kernel text)
+        const std::string code = rtc_compile(srcs[i], "manifest entry " + std::to_string(i));
+        if (code.empty()) { ++*failed; continue; }
+        write_file_atomic(path, code);
+        ++*built;
+    }
+    return NDFFT_OK;
+}
+
 }  // namespace ndfft
+
+extern "C" int ndfft_jit_prebuild(const char *manifest, const char *out_dir, int first, int stride, int *built, int *present, int *failed) {
+    int b = 0, p = 0, f = 0;
+    const int rc = ndfft::jit_prebuild(manifest, out_dir, first, stride, &b, &p, &f);
+    if (built) *built = b;
+    if (present) *present = p;
+    if (failed) *failed = f;
+    return rc;
+}

@@ -21,7 +21,7 @@ int main(void) {
                     (anyfn)ndfft_exec_sharded_device, (anyfn)ndfft_last_path, (anyfn)ndfft_explain_plan, (anyfn)ndfft_dev_alloc, (anyfn)ndfft_dev_free,
                     (anyfn)ndfft_dev_upload, (anyfn)ndfft_dev_download, (anyfn)ndfft_dev_sync, (anyfn)ndfft_release_workspace, (anyfn)ndfft_host_alloc,
                     (anyfn)ndfft_host_free, (anyfn)ndfft_set_input_hint, (anyfn)ndfft_last_input_policy, (anyfn)ndfft_host_reg_cache, (anyfn)ndfft_host_forget,
-                    (anyfn)ndfft_documented_switches, (anyfn)ndfft_reload_switches};
+                    (anyfn)ndfft_documented_switches, (anyfn)ndfft_reload_switches, (anyfn)ndfft_jit_prebuild};
     for (i = 0; i < (int)(sizeof syms / sizeof syms[0]); ++i) if (!syms[i]) return 2;
     if (ndfft_abi_version() != 1 || ndfft_abi_minor() != NDFFT_ABI_MINOR) { printf("abi version\n"); return 1; }
     for (i = 0; i < 24; ++i) data[i] = (double)i;

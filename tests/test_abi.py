@@ -82,3 +82,22 @@ def test_c99_program_runs_readme_case_on_gpu(lib, tmp_path):
     """The same C99 program on the MI355X: README 6 x 4 R2C case (BASELINE configs[0]) and the reference's panic text through the C ABI."""
     out = subprocess.run([_build_c99(tmp_path)], capture_output=True, text=True)
     assert out.returncode == 0 and "README 6x4 case on the GPU" in out.stdout, out.stdout + out.stderr
+
+
+def test_jit_manifest_compiles_without_a_gpu(tmp_path):
+    """The shipped code objects are build products (round 6): every entry of csrc/jit_prebuilt/manifest.txt must compile with hiprtc against the kernel headers
+    embedded in the library -- no device involved -- and __graft_entry__.build() must have left the whole set beside the library.  (A slice of the manifest is
+    compiled afresh here; the directory check covers all of it.)"""
+    import os
+    from ndrustfft_amd import _lib
+    lib = _lib.default()
+    pre = os.path.join(os.path.dirname(_lib.LIB_PATH), "jit_prebuilt")
+    manifest = os.path.join(pre, "manifest.txt")
+    assert os.path.exists(manifest)
+    n_entries = open(manifest).read().count("=====NDFFT-JIT-ENTRY=====")
+    assert n_entries >= 100
+    built, present, failed = lib.jit_prebuild(manifest, str(tmp_path), 0, 16)           # every 16th entry, compiled from scratch
+    assert failed == 0 and present == 0 and built == (n_entries + 15) // 16
+    if os.environ.get("NDFFT_MI355X_LIB") is None and any(f.endswith(".hsaco") for f in os.listdir(pre)):
+        built, present, failed = lib.jit_prebuild(manifest, pre, 0, 1)                  # build() ran: nothing left to compile
+        assert failed == 0 and built == 0 and present == n_entries

@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
-"""Writes the code objects the library would otherwise compile with hiprtc on a FIRST call for the reference's own test / bench /
-example lengths into a directory (run on an MI355X):
+"""Runs every nd* call of the reference's own test / bench / example lengths once, so that the library compiles (hiprtc) the specialised kernels those lengths
+ask for -- which kernels they are is an exec-time choice, hence an MI355X is needed -- and records the kernels' source texts in a MANIFEST:
 
-    NDFFT_JIT_CACHE=gpurun_out/jit_prebuilt NDFFT_JIT_PREBUILT=0 python tools/prebuild_jit.py
+    NDFFT_JIT_DUMP_SRC=gpurun_out/jit_manifest.txt NDFFT_JIT_CACHE=gpurun_out/jit_prebuilt NDFFT_JIT_PREBUILT=0 python tools/prebuild_jit.py
 
-then copy that directory's *.hsaco to ndrustfft_amd/csrc/jit_prebuilt/ (looked up read-only by jit.hip after the user's cache).
+then copy the manifest to ndrustfft_amd/csrc/jit_prebuilt/manifest.txt (tracked).  The code objects themselves are BUILD products since round 6:
+__graft_entry__.build() compiles every manifest entry with hiprtc (ndfft_jit_prebuild, no GPU needed) into ndrustfft_amd/csrc/jit_prebuilt/ (looked up read-only by
+jit.hip after the user's cache), under names that hash the CURRENT kernel headers -- an edit of a kernel header no longer leaves stale objects behind.
 Lengths: 128 / 264 / 512 / 1024 (benches/ndrustfft.rs:6), 129 / 265 / 513 / 1025 (:7), 3 / 6 (tests, examples); ops: ndfft, ndfft_r2c (+ inverses),
 nddct1..4; axis 0 and axis 1; the bench shapes n x n and a large batch (4096 lanes), f64 and f32.  Power-of-two inner lengths and n <= 16 run
 ahead-of-time kernels and need nothing."""
