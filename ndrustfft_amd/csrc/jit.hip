@@ -310,8 +310,9 @@ void write_file_atomic(const std::string &path, const std::string &data) {
 // embedded in THIS library, under the file names compile_entry() will look up.  hiprtc needs no device: __graft_entry__.build() runs it on the CPU-only build box.
 const char kManifestSep[] = "\n=====NDFFT-JIT-ENTRY=====\n";
 static void dump_source(const std::string &src) {
-    const char *f = getenv("NDFFT_JIT_DUMP_SRC");            // developer flow only (never set on the call path of a product run)
-    if (!f || !*f) return;
+    const std::string &fs = sw().jit_dump_src;                // NDFFT_JIT_DUMP_SRC (parsed once, switches.h)
+    if (fs.empty()) return;
+    const char *f = fs.c_str();
     static std::mutex mu;
     std::lock_guard<std::mutex> g(mu);
     FILE *fp = fopen(f, "ab");

@@ -557,6 +557,7 @@ const Switches *parse_switches() {
     str("NDFFT_JIT_CACHE", S->jit_cache_set, S->jit_cache);
     str("NDFFT_JIT_PREBUILT", S->jit_prebuilt_set, S->jit_prebuilt);
     S->jit_verbose = getenv("NDFFT_JIT_VERBOSE") != nullptr;
+    if (const char *e = getenv("NDFFT_JIT_DUMP_SRC")) S->jit_dump_src = e;
     if (const char *e = getenv("XDG_CACHE_HOME")) S->xdg_cache_home = e;
     if (const char *e = getenv("HOME")) S->home = e;
     S->wave = on("NDFFT_WAVE", true); S->tiny = on("NDFFT_TINY", true); S->plain = on("NDFFT_PLAIN", true); S->blue = on("NDFFT_BLUE", true);

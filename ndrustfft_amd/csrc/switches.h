@@ -31,6 +31,7 @@ struct Switches {
     bool jit_prebuilt_set = false;       // NDFFT_JIT_PREBUILT: read-only directory looked up after the cache ("" or 0 = none; default: <library dir>/jit_prebuilt)
     std::string jit_prebuilt;
     bool jit_verbose = false;            // NDFFT_JIT_VERBOSE: say on stderr why a specialisation was declined
+    std::string jit_dump_src;            // NDFFT_JIT_DUMP_SRC: file that every specialised kernel's source text is appended to (tools/prebuild_jit.py writes the manifest of jit_prebuilt/ with it)
     std::string xdg_cache_home, home;    // (not ours: $XDG_CACHE_HOME / $HOME, where the cache lives when NDFFT_JIT_CACHE is unset)
     // ---- kernel routes (exec.hip, jit.hip): 0 closes a route so that the kernel behind it runs (parity tests of every fallback)
     bool wave = true;                    // NDFFT_WAVE: LDS-free wavefront kernel for short dense C2C lanes
@@ -58,7 +59,7 @@ struct Switches {
 
 // the names above, for ndfft_explain_switches() and tests/test_switches.py
 #define NDFFT_DOCUMENTED_SWITCHES                                                                                                  \
-    "NDFFT_JIT", "NDFFT_JIT_CACHE", "NDFFT_JIT_PREBUILT", "NDFFT_JIT_VERBOSE", "NDFFT_WAVE", "NDFFT_TINY", "NDFFT_PLAIN", "NDFFT_BLUE",  \
+    "NDFFT_JIT", "NDFFT_JIT_CACHE", "NDFFT_JIT_PREBUILT", "NDFFT_JIT_VERBOSE", "NDFFT_JIT_DUMP_SRC", "NDFFT_WAVE", "NDFFT_TINY", "NDFFT_PLAIN", "NDFFT_BLUE",  \
     "NDFFT_RADER", "NDFFT_COLSPLIT", "NDFFT_FOURSTEP2", "NDFFT_REAL_FOURSTEP", "NDFFT_FS_DIRECT", "NDFFT_NARROW_DCT",                  \
     "NDFFT_RFS_C2R_TILE", "NDFFT_RFS_LOGN1", "NDFFT_CS_CHUNK_MB", "NDFFT_STREAM_LOADS", "NDFFT_HOST_PIPE",            \
     "NDFFT_HOST_REG_CACHE_MB", "NDFFT_COPY_THREADS", "NDFFT_SHARD_CHUNK_KB", "NDFFT_SHARD_FORCE_REMOTE"
