@@ -73,7 +73,10 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, int MODE> st
                         if (src == 0 || 2 * src == nn) x.y = (T)0;
                     } else {
                         const T *xr = (const T *)a.in + o * a.outer_in;
-                        x = cmul(mk<T>(xr[src] * hs, src ? -xr[nn - src] * hs : (T)0), cconj(a.aux2[src]));
+                        // e^{+i pi src/(2n)}: src = k1 + N1 i, or mirrored (N1 - k1) + N1 (N2 - 1 - i) -- two small tables (engine.h: rfs_c1 / rfs_c2) instead of a stream of n/2 + 1 entries
+                        const int i_ = t + q * TPL + r * NB0;
+                        const cpx<T> cw = a.fc1 ? cmul(a.fc1[mir ? a.cs_f1 - k1 : k1], a.fc2[mir ? F - 1 - i_ : i_]) : a.aux2[src];
+                        x = cmul(mk<T>(xr[src] * hs, src ? -xr[nn - src] * hs : (T)0), cconj(cw));
                     }
                     if (!mir) x.y = -x.y;   // conj of the Hermitian extension (mirrored elements are conjugates already): inverse FFT by forward butterflies
                 }
@@ -192,7 +195,7 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, int MODE> st
                         if (a.makhoul == 3) { ((T *)a.out)[ob + k] = val.x * a.scale; continue; }     // DCT-I (real_fourstep with dct1): y[k] = Re X[k] / 2 times the pre-scale
                         if ((mir && a.keep_out) || (a.keep_out & 2)) ((cpx<T> *)a.out)[ob + k] = val; else gstore<T, true>((cpx<T> *)a.out + ob + k, val);
                     } else {
-                        const cpx<T> tk = cmul(val, a.aux2[k]);
+                        const cpx<T> tk = cmul(val, a.fc1 ? cmul(a.fc1[kk], a.fc2[r2]) : a.aux2[k]);
                         T *out = (T *)a.out + ob;
                         const T y0 = tk.x * a.scale, y1 = -tk.y * a.scale;
                         if ((mir && a.keep_out) || (a.keep_out & 2)) out[k] = y0; else __builtin_nontemporal_store(y0, out + k);

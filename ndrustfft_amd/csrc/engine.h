@@ -109,6 +109,8 @@ struct FftConfig {                 // one complex-FFT-of-length-F recipe + op ta
     int rfs_ops = 0;               // ops for which it measured faster than the packed route: 1 = R2C, 2 = C2R, 4 = DCT-II, 8 = DCT-III
     ndfft_plan *rfs_sub1 = nullptr, *rfs_sub2 = nullptr;
     HostTable rfs_twlo, rfs_twhi;
+    HostTable rfs_c1, rfs_c2;      // DCT plans: e^{-i pi k/(2n)} factored over k = k1 + N1 r: c1[k1] = e^{-i pi k1/(2n)} (k1 = 0..N1), c2[r] = e^{-i pi r/(2 N2)} (r < N2) -- two small
+                                   // cache-resident tables instead of a stream of n/2 + 1 entries per lane beside the data (col_direct.h modes 6 / 8, pow2_real.h CS = 6)
     bool blue_reg_only = false;    // M exceeds the LDS kernel's reach: only the register kernel can run it
     bool bluereg = false;          // blue && M has a register-kernel configuration: blue_kernel.h, specialised with hiprtc
                                    // (jitcfg = configuration for M, twp = its per-pass twiddles)
@@ -126,7 +128,7 @@ struct DevConfig {                 // device copies (typed by dtype) of one FftC
     void *tw = nullptr, *twM = nullptr, *chirp = nullptr, *bhat = nullptr, *aux1 = nullptr, *aux2 = nullptr, *twp = nullptr;
     void *twlo = nullptr, *twhi = nullptr, *twp_col = nullptr, *twp_narrow = nullptr, *twp_jcol = nullptr;
     void *cs_twlo = nullptr, *cs_twhi = nullptr;
-    void *rfs_twlo = nullptr, *rfs_twhi = nullptr;
+    void *rfs_twlo = nullptr, *rfs_twhi = nullptr, *rfs_c1 = nullptr, *rfs_c2 = nullptr;
     void *wave_tw = nullptr;
     void *tinymat[4] = {nullptr, nullptr, nullptr, nullptr};
     void *rader_bhat = nullptr, *rader_twp = nullptr, *rader_twp2 = nullptr, *rader_tab = nullptr, *twp_rev = nullptr, *rader_ctw = nullptr;   // ctw: W_mc^k of a two-factor cofactor

@@ -704,6 +704,7 @@ static int real_fourstep(const Problem &P, int gop, const FftConfig &c, const De
     a.in = s1; a.out = d_out; a.nlanes = B * K; a.n = N2; a.F = N2; a.n_in = N2; a.n_out = N2; a.scale = dct1 ? (T)(0.5 * P.scale) : (T)P.scale;
     a.inner = K; a.outer_in = (int64_t)N2 * K; a.outer_out = pout; a.elem_in = K; a.elem_out = 0; a.pitch_out = 0;
     a.aux1 = nullptr; a.aux2 = (const cpx<T> *)d.aux2; a.twp = (const cpx<T> *)dt2->cfg[CFG_MAIN].twp_col;
+    if (gop == G_DCT2_EVEN && NDFFT_DEV_INT("NDFFT_RFS_FACTORED", 1)) { a.fc1 = (const cpx<T> *)d.rfs_c1; a.fc2 = (const cpx<T> *)d.rfs_c2; }
     return launch_fourstep_real<T>(gop == G_DCT2_EVEN ? 3 : 2, N2, a, stream);
 }
 
@@ -736,6 +737,7 @@ static int real_fourstep_inv(const Problem &P, int gop, const FftConfig &c, cons
     // half lines), so neighbouring tiles share every line
     a.xcd_chunk = (int)NDFFT_DEV_INT("NDFFT_RFS_XCD_CHUNK", 8);
     a.stream_in = (int)NDFFT_DEV_INT("NDFFT_RFSI_P1_NT", 0);      // (measured: ndifft_r2c re-read 112 -> 125 us with streaming loads of the half spectrum: off)
+    if (gop == G_DCT3_EVEN && NDFFT_DEV_INT("NDFFT_RFS_FACTORED", 1)) { a.fc1 = (const cpx<T> *)d.rfs_c1; a.fc2 = (const cpx<T> *)d.rfs_c2; }
     if ((rc = launch_fourstep_real<T>(gop == G_DCT3_EVEN ? 5 : 4, N2, a, stream))) return rc;
     a.stream_in = 0;
     if (sw().rfs_c2r_tile) {   // the column C2R kernel on 128-byte tiles (0: the general column kernel through dispatch())

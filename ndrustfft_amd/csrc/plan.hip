@@ -442,6 +442,10 @@ static void add_real_fourstep_slot(ndfft_plan *p, FftConfig &c, size_t n, bool d
     const int64_t B = 1ll << c.rfs_logB;
     for (int64_t k = 0; k < B && k < (int64_t)n; ++k) unit(c.rfs_twlo, k, n);
     for (int64_t k = 0; k * B < (int64_t)n; ++k) unit(c.rfs_twhi, k * B, n);
+    if (p->kind == NDFFT_KIND_DCT && !dct1) {    // DCT-II / DCT-III post- / pre-twiddle e^{-i pi k/(2n)}, k = k1 + N1 r (see engine.h)
+        for (int k1 = 0; k1 <= c.rfs_N1; ++k1) unit(c.rfs_c1, (unsigned long long)k1, 4ull * n);
+        for (int r = 0; r < c.rfs_N2; ++r) unit(c.rfs_c2, (unsigned long long)r, 4ull * (unsigned long long)c.rfs_N2);
+    }
 }
 
 static void add_narrow_tables(ndfft_plan *p) {
@@ -510,6 +514,8 @@ int get_dev_tables(const ndfft_plan *cplan, const DevTables **out) {
         if ((rc = upload_any(plan->dtype, c.cs_twhi, &d.cs_twhi))) return rc;
         if ((rc = upload_any(plan->dtype, c.rfs_twlo, &d.rfs_twlo))) return rc;
         if ((rc = upload_any(plan->dtype, c.rfs_twhi, &d.rfs_twhi))) return rc;
+        if ((rc = upload_any(plan->dtype, c.rfs_c1, &d.rfs_c1))) return rc;
+        if ((rc = upload_any(plan->dtype, c.rfs_c2, &d.rfs_c2))) return rc;
         if ((rc = upload_any(plan->dtype, c.twp_col, &d.twp_col))) return rc;
         if ((rc = upload_any(plan->dtype, c.twp_jcol, &d.twp_jcol))) return rc;
         if ((rc = upload_any(plan->dtype, c.twp_narrow, &d.twp_narrow))) return rc;
@@ -654,7 +660,7 @@ int ndfft_plan_destroy(ndfft_plan *plan) {
         (void)hipSetDevice(kv.first);
         for (int i = 0; i < CFG_COUNT; ++i) {
             DevConfig &d = kv.second.cfg[i];
-            void *ptrs[] = {d.tw, d.twM, d.chirp, d.bhat, d.aux1, d.aux2, d.twp, d.twlo, d.twhi, d.twp_col, d.twp_jcol, d.twp_narrow, d.cs_twlo, d.cs_twhi, d.rfs_twlo, d.rfs_twhi, d.wave_tw, d.tinymat[0], d.tinymat[1], d.tinymat[2], d.tinymat[3], d.rader_bhat, d.rader_twp, d.rader_twp2, d.rader_tab, d.twp_rev, d.rader_ctw};
+            void *ptrs[] = {d.tw, d.twM, d.chirp, d.bhat, d.aux1, d.aux2, d.twp, d.twlo, d.twhi, d.twp_col, d.twp_jcol, d.twp_narrow, d.cs_twlo, d.cs_twhi, d.rfs_twlo, d.rfs_twhi, d.rfs_c1, d.rfs_c2, d.wave_tw, d.tinymat[0], d.tinymat[1], d.tinymat[2], d.tinymat[3], d.rader_bhat, d.rader_twp, d.rader_twp2, d.rader_tab, d.twp_rev, d.rader_ctw};
             for (void *q : ptrs) if (q) (void)hipFree(q);
         }
     }

@@ -57,6 +57,7 @@ template <typename T> struct RealArgs {
                                          // Makhoul's permutation v[m] = x[2m] (m < n/2), v[m] = x[2(n-1-m)+1] otherwise (DCT-II, n = this->n * inner);
                                          // column C2R kernels (last pass of the inverse real four-step, DCT-III): 1 = the outputs are written through its inverse;
                                          // ROWOUT C2C kernels: 2 = first pass of the fused DCT-IV four-step (the load builds z from the real lane)
+    const cpx<T> *fc1 = nullptr, *fc2 = nullptr;   // real four-step, DCT-II / DCT-III: aux2[k1 + N1 r] = fc1[k1] fc2[r] (engine.h: rfs_c1 / rfs_c2); null = read aux2
     const int32_t *rader_tab = nullptr;  // Rader kernels (rader_kernel.h): g^i mod P (i < P - 1), then g^-i mod P; bhat = FFT_(P-1)(W_P^(g^-q)) / (P - 1),
                                          // twp / twp_rev = per-pass twiddles of FFT_(P-1) with the radix list front to back / back to front
 };
@@ -535,7 +536,7 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                         if (a.makhoul == 3) { ((T *)a.out)[ob + k] = val.x * a.scale; continue; }     // DCT-I: y[k] = Re X[k] / 2 (times the pre-scale), plain 4 / 8-byte stores
                         if (mir && a.keep_out) ((cpx<T> *)a.out)[ob + k] = val; else gstore<T, true>((cpx<T> *)a.out + ob + k, val);
                     } else {
-                        const cpx<T> tk = cmul(val, a.aux2[k]);
+                        const cpx<T> tk = cmul(val, a.fc1 ? cmul(a.fc1[kk], a.fc2[r2]) : a.aux2[k]);
                         T *out = (T *)a.out + ob;
                         const T y0 = tk.x * a.scale, y1 = -tk.y * a.scale;
                         if (mir && a.keep_out) out[k] = y0; else __builtin_nontemporal_store(y0, out + k);

@@ -275,3 +275,10 @@ int launch_jit_regreal(int dtype, int gop, int n, int f1, int f2, bool stage, co
     return dtype == NDFFT_F32 ? regreal_T<float>(gop, n, f1, f2, stage, a, s) : regreal_T<double>(gop, n, f1, f2, stage, a, s);
 }
 }
+// (no hiprtc in the emulation: the build step of the real library has nothing to do here)
+extern "C" int ndfft_jit_prebuild(const char *, const char *, int, int, int *built, int *present, int *failed) {
+    if (built) *built = 0;
+    if (present) *present = 0;
+    if (failed) *failed = 0;
+    return NDFFT_ERR_UNSUPPORTED;
+}
