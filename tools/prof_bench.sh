@@ -51,7 +51,7 @@ def pick(ph, grid_lanes):
 tag = os.path.basename(os.path.dirname(out)) if os.path.basename(out) == "prof_bench" else os.path.basename(out)
 tj = {"4096x4096": pick("warm", 4096), "4096x4096_cold_rotating": pick("primary", 4096), "65536x4096": pick("strong", 65536),
       "kernel_source_sha": subprocess.check_output(["python3", os.path.join(root, "tools", "pmc_source_sha.py")], text=True).strip(),
-      "source": f"profiles/r08/{tag}_pmc_bench_summary.json (tools/prof_bench.sh {tag} pmc: separate FETCH_SIZE / WRITE_SIZE --pmc passes of `bench.py --profile-phase ...`, "
+      "source": f"profiles/r09/{tag}_pmc_bench_summary.json (tools/prof_bench.sh {tag} pmc: separate FETCH_SIZE / WRITE_SIZE --pmc passes of `bench.py --profile-phase ...`, "
                 "x2 gfx950 read correction on FETCH_SIZE; kernel k_pow2<Pow2Kernel<double,4096,512,...>>)"}
 json.dump(tj, open(f"{out}/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(tj, indent=1))
