@@ -65,6 +65,8 @@ extern "C" {
     pub fn ndfft_explain_plan(kind: c_int, dtype: c_int, n: usize, buf: *mut c_char, buflen: usize) -> c_int;
     pub fn ndfft_documented_switches(buf: *mut c_char, buflen: usize) -> c_int;
     pub fn ndfft_reload_switches() -> c_int;
+    /// Build step (no GPU needed): compiles the manifest of specialised kernels into `out_dir` (see include/ndfft_mi355x.h); a `build.rs` calls it once.
+    pub fn ndfft_jit_prebuild(manifest: *const c_char, out_dir: *const c_char, first: c_int, stride: c_int, built: *mut c_int, present: *mut c_int, failed: *mut c_int) -> c_int;
     // device-resident arrays (no reference counterpart)
     pub fn ndfft_exec_device(
         plan: *const ndfft_plan, op: c_int, d_input: *const c_void, d_output: *mut c_void, ndim: c_int,
