@@ -585,7 +585,8 @@ template <typename T> int launch_jit_real(int gop, const JitCfg &cfg, bool col, 
     if (e.failed) return NDFFT_ERR_UNSUPPORTED;
     const int F = cfg.n;
     const size_t lane_lds = col ? (size_t)((F + (F >> 4) + 2) | 1) : (size_t)((F + (F >> 4) + 3) & ~1);
-    const size_t lds = (size_t)lpb * lane_lds * 2 * sizeof(T);
+    const size_t lanes_lds = (size_t)lpb * lane_lds * 2 * sizeof(T);
+    const size_t lds = lanes_lds + (col ? col_post_table_bytes(F, 2 * sizeof(T), gop, lanes_lds) : 0);     // = RealPow2Kernel::LDS_BYTES (pow2_real.h: the column tiles' POST tables)
     if (lds > jit_lds_limit()) return NDFFT_ERR_UNSUPPORTED;
     const int64_t nblk = (a.nlanes + lpb - 1) / lpb;
     if (nblk <= 0) return NDFFT_OK;

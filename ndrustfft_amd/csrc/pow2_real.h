@@ -26,6 +26,23 @@ namespace ndfft {
 template <bool C, typename A, typename B> struct cond_type { typedef A type; };
 template <typename A, typename B> struct cond_type<false, A, B> { typedef B type; };
 
+// Column tiles (COL kernels), POST tables through LDS (round 6).  In the column store map (thread = element-row j0 x lane cl, lanes fastest) the split twiddles aux1[k] and
+// DCT-II's aux2[k] depend on the element only: all LPB lanes of a row ask for the SAME table entry -- 5 (R2C, DCT-I) or 15 (DCT-II) wave-level gathers per thread with one or
+// two distinct addresses each, beside 8-16 loads of data (the finding of the column four-step's stage kernels, profiles/r09/r09d_cs3_ablation.txt).  The workgroup loads the
+// F/2 + 1 (+ F + 1) entries once, coalesced, and everybody reads LDS.  Only where the extra bytes do not cost a resident workgroup; host (jit.hip) and device use this one rule.
+__host__ __device__ constexpr size_t col_post_table_entries(int F, int op) {
+    return (op == G_R2C_EVEN || op == G_DCT1) ? (size_t)(F / 2 + 1) : op == G_DCT2_EVEN ? (size_t)(F / 2 + 1) + (size_t)(F + 1) : 0;
+}
+__host__ __device__ constexpr size_t col_post_table_bytes(int F, size_t cpx_bytes, int op, size_t lanes_bytes) {
+#ifdef NDFFT_NO_COL_POST_TABLE
+    return 0;
+#else
+    return (col_post_table_entries(F, op) && lanes_bytes &&
+            (size_t)(160 * 1024) / (lanes_bytes + col_post_table_entries(F, op) * cpx_bytes) == (size_t)(160 * 1024) / lanes_bytes)
+               ? col_post_table_entries(F, op) * cpx_bytes : 0;
+#endif
+}
+
 template <typename T> struct RealArgs {
     const void *in; void *out;
     int64_t nlanes, pitch_in, pitch_out;   // row layout: pitches in elements of the in / out element type
@@ -186,7 +203,8 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
     static constexpr int LANE_LDS = COL ? ((F + (F >> 4) + 2) | 1) : ((F + (F >> 4) + 3) & ~1);
     static constexpr size_t LANES_LDS_BYTES = (size_t)LPB * LANE_LDS * 2 * sizeof(T);
     // CS stage kernels: + the tile's F twiddles; CS >= 4 (second pass of the row four-steps): + its E x LPB step twiddles (see the PRE fold)
-    static constexpr size_t LDS_BYTES = LANES_LDS_BYTES + (CSK ? (size_t)F * 2 * sizeof(T) : CS >= 4 ? (size_t)(F / TPL) * LPB * 2 * sizeof(T) : 0);
+    static constexpr size_t TBL_BYTES = (COL && !XCD && CS == 0 && !ROWOUT) ? col_post_table_bytes(F, 2 * sizeof(T), OP, LANES_LDS_BYTES) : 0;   // col_post_table_bytes above
+    static constexpr size_t LDS_BYTES = LANES_LDS_BYTES + (CSK ? (size_t)F * 2 * sizeof(T) : CS >= 4 ? (size_t)(F / TPL) * LPB * 2 * sizeof(T) : TBL_BYTES);
     static constexpr bool IN_CPLX = OP == G_C2R_EVEN || OP == G_C2C_FWD || OP == G_C2C_INV;
     static constexpr bool OUT_CPLX = OP == G_R2C_EVEN || OP == G_C2C_FWD || OP == G_C2C_INV;
     using FFT = Pow2Kernel<T, F, TPL, LPB, false, RL, FFLAGS, 1, 0>;
@@ -204,7 +222,8 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
     // every output derived from the spectrum pair (k, F-k), in four fixed slots (q < 0: slot unused)
     template <typename OT> struct PairOut { OT v[4]; int q[4]; };
     template <typename OT> static __device__ __forceinline__ PairOut<OT> post_pair(const RealArgs<T> &a, const cpx<T> *res, int k) { return post_pair<OT>(a, res, k, a.aux1[k]); }
-    template <typename OT> static __device__ __forceinline__ PairOut<OT> post_pair(const RealArgs<T> &a, const cpx<T> *res, int k, cpx<T> wk) {
+    template <typename OT> static __device__ __forceinline__ PairOut<OT> post_pair(const RealArgs<T> &a, const cpx<T> *res, int k, cpx<T> wk) { return post_pair<OT>(a, res, k, wk, a.aux2); }
+    template <typename OT> static __device__ __forceinline__ PairOut<OT> post_pair(const RealArgs<T> &a, const cpx<T> *res, int k, cpx<T> wk, const cpx<T> *aux2) {
         PairOut<OT> r;
         cpx<T> xk, xf;
         r2c_split_pair<T, ZiPhi>(res, k, F, wk, xk, xf);
@@ -216,7 +235,7 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
             r.v[0] = (T)0.5 * xk.x; r.v[2] = (T)0.5 * xf.x; r.v[1] = 0; r.v[3] = 0;
         } else {   // G_DCT2_EVEN: y[k] = Re(X[k] c_k), y[n-k] = -Im(X[k] c_k)
             const int n = 2 * F;
-            const cpx<T> tk = cmul(xk, a.aux2[k]), tf = cmul(xf, a.aux2[kf]);
+            const cpx<T> tk = cmul(xk, aux2[k]), tf = cmul(xf, aux2[kf]);
             r.v[0] = tk.x; r.v[1] = -tk.y; r.v[2] = tf.x; r.v[3] = -tf.y;
             r.q[1] = k > 0 ? n - k : -1;
             r.q[3] = (kf != k && kf < F) ? n - kf : -1;
@@ -246,6 +265,8 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
         constexpr int CSNQ = CSK ? F / (THREADS / LPB) : 1;   // outputs per thread of a CS stage kernel
         cpx<T> *cs_twl = (cpx<T> *)(smem + LANES_LDS_BYTES);   // CS stage kernels, 3-D grid: W_N^(j k1), j < F (see cs3_twiddles); CS >= 4: the step twiddles [e][lane]
         cpx<T> cs4_bhi = mk<T>((T)1, (T)0), cs4_blo = cs4_bhi, cs4_shi = cs4_bhi, cs4_slo = cs4_bhi;
+        constexpr int TBL_ENTRIES = (int)(TBL_BYTES / (2 * sizeof(T))), TBL_PER_THREAD = TBL_BYTES ? (TBL_ENTRIES + THREADS - 1) / THREADS : 1;
+        cpx<T> tbl_v[TBL_PER_THREAD];
         if constexpr (CSK) {
             static_assert(F % (THREADS / LPB) == 0 && THREADS >= F, "CS stage kernels: whole staging rounds, one thread per twiddle");
             const int cl = threadIdx.x % LPB, j0 = threadIdx.x / LPB;
@@ -297,6 +318,15 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                 const int mb = t * k1;
                 cs4_bhi = a.cs_twhi[mb >> a.cs_logB]; cs4_blo = a.cs_twlo[mb & mask];
                 if (t < E) { const int m = ((t / R0) * TPL + (t % R0) * NB0) * k1; cs4_shi = a.cs_twhi[m >> a.cs_logB]; cs4_slo = a.cs_twlo[m & mask]; }
+            }
+            if constexpr (TBL_BYTES != 0) {   // the POST tables of this tile, issued in front of the staging loads (see col_post_table_bytes)
+                constexpr int N1 = F / 2 + 1;
+#pragma unroll
+                for (int i = 0; i < TBL_PER_THREAD; ++i) {
+                    const int idx = (int)threadIdx.x + i * THREADS;
+                    if (idx < N1) tbl_v[i] = a.aux1[idx];
+                    else if (idx < TBL_ENTRIES) tbl_v[i] = a.aux2[idx - N1];
+                }
             }
             // thread -> (lane cl = tid % LPB fastest, element j = tid / LPB)
             const int cl = threadIdx.x % LPB, j0 = threadIdx.x / LPB;
@@ -381,6 +411,10 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
             }
         }
         if constexpr (CS >= 4) { if (t < E) cs_twl[t * LPB + ll] = cmul(cs4_shi, cs4_slo); }
+        if constexpr (TBL_BYTES != 0) {
+#pragma unroll
+            for (int i = 0; i < TBL_PER_THREAD; ++i) { const int idx = (int)threadIdx.x + i * THREADS; if (idx < TBL_ENTRIES) cs_twl[idx] = tbl_v[i]; }
+        }
         if constexpr (!DIRECT_IN) __syncthreads();
         if constexpr (OP == G_DCT3_EVEN) {
             // DCT-III: V[k] = 0.5 s (x[k] - i x[n-k]) e^{+i pi k/(2n)}, k = 0..F (x[n] := 0), computed ONCE per k into the lane
@@ -472,15 +506,16 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                 // the previous iteration's stores (F / TPL / 2 + 1 = 5 dependent round trips with E = 8)
                 constexpr int NIT = (F / 2 + TPL) / TPL;
                 cpx<T> w1[NIT];
+                const cpx<T> *aux1p = TBL_BYTES != 0 ? cs_twl : a.aux1, *aux2p = TBL_BYTES != 0 ? cs_twl + (F / 2 + 1) : a.aux2;
 #pragma unroll
-                for (int i = 0; i < NIT; ++i) { const int k = j0 + i * TPL; if (k <= F / 2) w1[i] = a.aux1[k]; }
+                for (int i = 0; i < NIT; ++i) { const int k = j0 + i * TPL; if (k <= F / 2) w1[i] = aux1p[k]; }
                 if constexpr (OUT_CPLX) {
                     cpx<T> *out = (cpx<T> *)a.out + base;
 #pragma unroll
                     for (int i = 0; i < NIT; ++i) {
                         const int k = j0 + i * TPL;
                         if (k > F / 2) break;
-                        const PairOut<cpx<T>> r = post_pair<cpx<T>>(a, res, k, w1[i]);
+                        const PairOut<cpx<T>> r = post_pair<cpx<T>>(a, res, k, w1[i], aux2p);
 #pragma unroll
                         for (int z = 0; z < 4; ++z)
                             if (r.q[z] >= 0) {
@@ -493,7 +528,7 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                     for (int i = 0; i < NIT; ++i) {
                         const int k = j0 + i * TPL;
                         if (k > F / 2) break;
-                        const PairOut<T> r = post_pair<T>(a, res, k, w1[i]);
+                        const PairOut<T> r = post_pair<T>(a, res, k, w1[i], aux2p);
 #pragma unroll
                         for (int z = 0; z < 4; ++z)
                             if (r.q[z] >= 0) {
