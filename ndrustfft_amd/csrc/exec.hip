@@ -446,6 +446,8 @@ static int col_split(const Problem &P, const void *d_in, void *d_out, const FftC
     // cache-allocating stores and re-read by stage B before much of it has left the 256 MiB Infinity Cache.
     // Measured (8192x8192 f32 R2C axis 0): one chunk 248 us, two chunks (136 MiB each) 212 us, three 228 us;
     // small chunks LOSE (32 MiB: 293 us, 8 MiB: 628 us): every chunk costs two launches of a few microseconds.
+    // (round 6: odd chunks on a SECOND stream with a scratch array of their own, so that one chunk's launches drain under the other's work -- measured no better at any chunk size:
+    //  cfg3-A 178 us (one stream, two chunks) against 184 (two streams, two chunks) / 183 (two streams, four chunks), cfg3-A' 193 against 219 / 192; profiles/r09/r09t_cs_two_streams_negative.txt)
     int64_t C = I;
     {
         const int64_t target = (int64_t)sw().cs_chunk_mb << 20;   // NDFFT_CS_CHUNK_MB (0 = one chunk)
