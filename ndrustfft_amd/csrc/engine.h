@@ -87,6 +87,7 @@ struct FftConfig {                 // one complex-FFT-of-length-F recipe + op ta
     HostTable twp;                 // per-pass transposed twiddles
     HostTable twp_rev;             // bluereg: the same for the radix list back to front (second FFT of the convolution)
     HostTable twp_col;             // C2C slot only: twiddles in the radix order of the column kernel (pow2_real.h)
+    HostTable twp_col_w;           // C2C n = 1024 only: the same for the E = 16 recipe 16.8.8 of the four-step passes (kernels_fourstep.hip: wide)
     HostTable twp_narrow;          // twiddles in the radix order of the narrow (XCD-aware) column kernel
     HostTable tinymat[4];          // MAIN slot, n = 2..16: the real-data transforms as dense real matrices (tinymat_kernel.h);
                                    // R2C plans: [0] R2C, [1] C2R; DCT plans: [0..3] DCT-I..IV; stored two reals per (re, im) entry
@@ -126,7 +127,7 @@ struct FftConfig {                 // one complex-FFT-of-length-F recipe + op ta
 
 struct DevConfig {                 // device copies (typed by dtype) of one FftConfig
     void *tw = nullptr, *twM = nullptr, *chirp = nullptr, *bhat = nullptr, *aux1 = nullptr, *aux2 = nullptr, *twp = nullptr;
-    void *twlo = nullptr, *twhi = nullptr, *twp_col = nullptr, *twp_narrow = nullptr, *twp_jcol = nullptr;
+    void *twlo = nullptr, *twhi = nullptr, *twp_col = nullptr, *twp_col_w = nullptr, *twp_narrow = nullptr, *twp_jcol = nullptr;
     void *cs_twlo = nullptr, *cs_twhi = nullptr;
     void *rfs_twlo = nullptr, *rfs_twhi = nullptr, *rfs_c1 = nullptr, *rfs_c2 = nullptr;
     void *wave_tw = nullptr;
@@ -239,6 +240,8 @@ template <typename T> int launch_colsplit(int cs, bool inverse, const RealArgs<T
 
 // kernels_fourstep.hip : the two passes of the row four-step on the column kernels (no transpose launch)
 bool fourstep_supported(int F);
+void fourstep_build_wide_twiddles(int F, HostTable &out);       // empty unless F has a wide (E = 16) recipe
+bool fourstep_wide(int dtype, int pass, int F);                 // this pass of length F runs the wide recipe (the caller then passes twp_col_w and RealArgs::wide = 1)
 template <typename T> int launch_fourstep(int pass, int F, bool inverse, const RealArgs<T> &a, hipStream_t s);
 // kernels_fourstep_real.hip : the passes of the REAL four-step (stage: 1 = real column FFT, row store; 2 = twiddled column pass
 // writing the half spectrum (R2C) ; 3 = the same writing DCT-II outputs ; 4 / 5 = first pass of the inverse direction, C2R / DCT-III ; 6 = second pass of the fused DCT-IV four-step ; 7 = last pass of the inverse direction, column C2R)

@@ -583,7 +583,9 @@ static int big_fft(const FftConfig &c, const DevConfig &d, const cpx<T> *zin, in
         // pass 1: lanes (l, n2)
         a.in = zin; a.out = s1; a.nlanes = L * F2; a.n = F1; a.F = F1; a.n_in = F1; a.n_out = F1; a.scale = (T)1;
         a.inner = F2; a.outer_in = pitch_in; a.outer_out = 0; a.elem_in = F2; a.elem_out = 0; a.pitch_out = K1p;
-        a.twp = (const cpx<T> *)dt1->cfg[CFG_MAIN].twp_col;
+        const int dti = sizeof(T) == 8 ? NDFFT_F64 : NDFFT_F32;
+        const bool w1 = fourstep_wide(dti, 1, F1) && dt1->cfg[CFG_MAIN].twp_col_w, w2 = fourstep_wide(dti, 2, F2) && dt2->cfg[CFG_MAIN].twp_col_w;
+        a.twp = (const cpx<T> *)(w1 ? dt1->cfg[CFG_MAIN].twp_col_w : dt1->cfg[CFG_MAIN].twp_col); a.wide = w1 ? 1 : 0;
         // c128 (the lane-fastest kernels): the caller's array is read once -> streaming loads; the intermediate is re-read by pass 2 -> cache-allocating stores.
         // A-B-A-B (profiles/r08/r08s_fourstep_pass1_policy_abab.txt): 256 x 65536 203 -> 197 us, 16 x 2^20 260 -> 248 us; either one alone is neutral or worse
         // (keep alone: 213 us); c64 (staged kernels) 285 -> 291 us with the streaming loads: off there
@@ -593,7 +595,7 @@ static int big_fft(const FftConfig &c, const DevConfig &d, const cpx<T> *zin, in
         // pass 2: lanes (l, k1)
         a.in = s1; a.out = zout; a.nlanes = L * F1; a.n = F2; a.F = F2; a.n_in = F2; a.n_out = F2; a.scale = scale;
         a.inner = F1; a.outer_in = (int64_t)F2 * K1p; a.outer_out = pitch_out; a.elem_in = K1p; a.elem_out = F1; a.pitch_out = 0;
-        a.twp = (const cpx<T> *)dt2->cfg[CFG_MAIN].twp_col;
+        a.twp = (const cpx<T> *)(w2 ? dt2->cfg[CFG_MAIN].twp_col_w : dt2->cfg[CFG_MAIN].twp_col); a.wide = w2 ? 1 : 0;
         return launch_fourstep<T>(2, F2, inverse, a, stream);
     }
     if ((rc = get_scratch(3, stream, (size_t)(L * F) * esz, &s2))) return rc;

@@ -89,8 +89,40 @@ template <typename T, int F, int OP, int MODE> static int launch_fsd(const RealA
 // (round 6: c64 with ONLY the second pass on the lane-fastest kernel -- its column store writes the same 64-byte rows as the staged form -- measured 32 x 2^20 c64 259 -> 363 us: not kept)
 bool fourstep_supported(int F) { return F == 64 || F == 128 || F == 256 || F == 512 || F == 1024; }
 
+// The WIDE recipe of the 1024-point passes (round 6): 64 threads x 16 elements per lane, radix 16.8.8, on the lane-fastest kernel.  With E = 8 a 1024-point lane needs 128 threads,
+// and 1024 threads hold 8 lanes -- for c128 the tiles were cut to 4 lanes (64-byte rows) to keep two workgroups per CU, for c64 8 lanes ARE 64-byte rows.  With E = 16 the same
+// threads hold twice the lanes: c128 8 lanes x 64 threads (128-byte rows, 70 KiB of half-exchange LDS), c64 would be 16 lanes x 64 threads = 1024 threads (see fourstep_wide: not built).
+using WideRL = RadixList<16, 8, 8>;
+static constexpr int kWideTPL = 64;
+void fourstep_build_wide_twiddles(int F, HostTable &out) { if (F == 1024) build_tw<WideRL>(out); }
+bool fourstep_wide(int dtype, int pass, int F) {
+    if (F != 1024) return false;
+    const long k = NDFFT_DEV_INT("NDFFT_FS_WIDE", 1);          // developer build: 0 = off (A/B)
+    if (!k || sw().fs_direct == 0) return false;
+    // (c64: 16 lanes x 64 threads = 1024 threads would need <= 64 VGPRs for two workgroups per CU -- the E = 16 recipe spills ~4 KiB per thread under that cap: f64 only)
+    return dtype == NDFFT_F64;
+}
+template <typename K, typename T, int MW> __global__ __launch_bounds__(K::THREADS, MW) void k_col_direct_w(const RealArgs<T> a) { K::run(a); }
+template <typename T, int OP, int MODE> static int launch_fsd_wide(const RealArgs<T> &a, hipStream_t s) {
+    constexpr int LPB = 8;                                       // 128-byte rows of c128
+    using K = ColDirectKernel<T, 1024, kWideTPL, LPB, WideRL, OP, MODE>;
+    constexpr int MW = 4;                                        // 512 threads, <= 128 VGPRs: two workgroups per CU
+    static_assert(K::LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+    NDFFT_ENSURE_LDS_ATTR((k_col_direct_w<K, T, MW>));
+    const int64_t nblk = (a.nlanes + LPB - 1) / LPB;
+    if (nblk <= 0) return NDFFT_OK;
+    if (nblk > 0x7fffffffLL) return fail(NDFFT_ERR_UNSUPPORTED, "too many lanes for one launch");
+    hipLaunchKernelGGL((k_col_direct_w<K, T, MW>), dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, a);
+    NDFFT_HIP(hipGetLastError());
+    return NDFFT_OK;
+}
+
 // pass = 1: column load / row store; pass = 2: twiddle by the inner index on load, column store
 template <typename T> int launch_fourstep(int pass, int F, bool inverse, const RealArgs<T> &a, hipStream_t s) {
+    if constexpr (sizeof(T) == 8) if (a.wide && F == 1024 && !a.makhoul) {
+        if (pass == 1) return inverse ? launch_fsd_wide<T, G_C2C_INV, 0>(a, s) : launch_fsd_wide<T, G_C2C_FWD, 0>(a, s);
+        return inverse ? launch_fsd_wide<T, G_C2C_INV, 4>(a, s) : launch_fsd_wide<T, G_C2C_FWD, 4>(a, s);
+    }
 #define NDFFT_FS_CASE(F_)                                                                                              \
     case F_:                                                                                                           \
         if (fs_direct<T>() && !a.makhoul) {   /* (the fused DCT-IV first pass exists in the staged form only) */                \

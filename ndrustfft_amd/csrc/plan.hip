@@ -265,6 +265,7 @@ static void build_plan_tables(ndfft_plan *p) {
         build_fft(m, n, p->dtype);
         if (pow2_supported(p->dtype, n)) { m.pow2 = true; pow2_build_twiddles(p->dtype, n, m.twp); }
         if (pow2_real_supported(n)) pow2_real_build_twiddles(n, m.twp_col);
+        fourstep_build_wide_twiddles(n, m.twp_col_w);
         if (wave_supported(n) || n <= 128) for (int k = 0; k < n; ++k) unit(m.wave_tw, k, n);   // W_n^k: wavefront and thread-per-lane kernels
         if (!m.pow2 && !m.blue && jit_choose(p->dtype, n, m.jitcfg, true)) {
             m.jit = true; jit_build_twiddles(m.jitcfg, m.twp);
@@ -517,6 +518,7 @@ int get_dev_tables(const ndfft_plan *cplan, const DevTables **out) {
         if ((rc = upload_any(plan->dtype, c.rfs_c1, &d.rfs_c1))) return rc;
         if ((rc = upload_any(plan->dtype, c.rfs_c2, &d.rfs_c2))) return rc;
         if ((rc = upload_any(plan->dtype, c.twp_col, &d.twp_col))) return rc;
+        if ((rc = upload_any(plan->dtype, c.twp_col_w, &d.twp_col_w))) return rc;
         if ((rc = upload_any(plan->dtype, c.twp_jcol, &d.twp_jcol))) return rc;
         if ((rc = upload_any(plan->dtype, c.twp_narrow, &d.twp_narrow))) return rc;
         if ((rc = upload_any(plan->dtype, c.wave_tw, &d.wave_tw))) return rc;
@@ -660,7 +662,7 @@ int ndfft_plan_destroy(ndfft_plan *plan) {
         (void)hipSetDevice(kv.first);
         for (int i = 0; i < CFG_COUNT; ++i) {
             DevConfig &d = kv.second.cfg[i];
-            void *ptrs[] = {d.tw, d.twM, d.chirp, d.bhat, d.aux1, d.aux2, d.twp, d.twlo, d.twhi, d.twp_col, d.twp_jcol, d.twp_narrow, d.cs_twlo, d.cs_twhi, d.rfs_twlo, d.rfs_twhi, d.rfs_c1, d.rfs_c2, d.wave_tw, d.tinymat[0], d.tinymat[1], d.tinymat[2], d.tinymat[3], d.rader_bhat, d.rader_twp, d.rader_twp2, d.rader_tab, d.twp_rev, d.rader_ctw};
+            void *ptrs[] = {d.tw, d.twM, d.chirp, d.bhat, d.aux1, d.aux2, d.twp, d.twlo, d.twhi, d.twp_col, d.twp_col_w, d.twp_jcol, d.twp_narrow, d.cs_twlo, d.cs_twhi, d.rfs_twlo, d.rfs_twhi, d.rfs_c1, d.rfs_c2, d.wave_tw, d.tinymat[0], d.tinymat[1], d.tinymat[2], d.tinymat[3], d.rader_bhat, d.rader_twp, d.rader_twp2, d.rader_tab, d.twp_rev, d.rader_ctw};
             for (void *q : ptrs) if (q) (void)hipFree(q);
         }
     }

@@ -75,6 +75,7 @@ template <typename T> struct RealArgs {
                                          // column C2R kernels (last pass of the inverse real four-step, DCT-III): 1 = the outputs are written through its inverse;
                                          // ROWOUT C2C kernels: 2 = first pass of the fused DCT-IV four-step (the load builds z from the real lane)
     const cpx<T> *fc1 = nullptr, *fc2 = nullptr;   // real four-step, DCT-II / DCT-III: aux2[k1 + N1 r] = fc1[k1] fc2[r] (engine.h: rfs_c1 / rfs_c2); null = read aux2
+    int32_t wide = 0;                    // four-step passes of 1024 points: 1 = twp holds the twiddles of the E = 16 recipe 16.8.8 (kernels_fourstep.hip)
     const int32_t *rader_tab = nullptr;  // Rader kernels (rader_kernel.h): g^i mod P (i < P - 1), then g^-i mod P; bhat = FFT_(P-1)(W_P^(g^-q)) / (P - 1),
                                          // twp / twp_rev = per-pass twiddles of FFT_(P-1) with the radix list front to back / back to front
 };
