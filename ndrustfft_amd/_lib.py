@@ -89,7 +89,11 @@ class Library:
         L.ndfft_documented_switches.argtypes = [ctypes.c_char_p, sz]; L.ndfft_documented_switches.restype = i32
         L.ndfft_reload_switches.argtypes = []; L.ndfft_reload_switches.restype = i32
         ip = ctypes.POINTER(ctypes.c_int)
-        L.ndfft_jit_prebuild.argtypes = [ctypes.c_char_p, ctypes.c_char_p, i32, i32, ip, ip, ip]; L.ndfft_jit_prebuild.restype = i32
+        try:
+            L.ndfft_jit_prebuild.argtypes = [ctypes.c_char_p, ctypes.c_char_p, i32, i32, ip, ip, ip]; L.ndfft_jit_prebuild.restype = i32
+        except AttributeError:      # a side build older than ABI minor 3 loaded through NDFFT_MI355X_LIB (A-B runs against earlier rounds); tests/test_abi.py checks the product's exports
+            if not os.environ.get("NDFFT_MI355X_LIB"):
+                raise
 
     def check(self, status):
         if status == OK:
