@@ -421,6 +421,8 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
             // DCT-III: V[k] = 0.5 s (x[k] - i x[n-k]) e^{+i pi k/(2n)}, k = 0..F (x[n] := 0), computed ONCE per k into the lane
             // region (over the raw lane); the PRE fold below then needs V[i] and V[F-i] only.  pre_elem would build both
             // from four raw reads, two table loads and two complex multiplies per element -- each V[k] twice.
+            // (round 6: the fold reading x[k] and x[n-k] from GLOBAL memory itself -- no staged raw lane, one LDS round trip and two barriers fewer, but 18 eight-byte loads per
+            //  thread instead of 8 sixteen-byte ones -- measured cfg4 nddct3 97.5 -> 102.2 us: not kept)
             constexpr int NK = (F + 1 + TPL - 1) / TPL;
             cpx<T> vk[NK];
             const T *xr = (const T *)lds;
