@@ -87,6 +87,7 @@ struct FftConfig {                 // one complex-FFT-of-length-F recipe + op ta
     HostTable twp;                 // per-pass transposed twiddles
     HostTable twp_rev;             // bluereg: the same for the radix list back to front (second FFT of the convolution)
     HostTable twp_col;             // C2C slot only: twiddles in the radix order of the column kernel (pow2_real.h)
+    bool fs_jit = false; JitCfg fs_jitcfg; HostTable twp_fs;   // C2C, smooth non-power-of-two n <= 2048: recipe + per-pass twiddles of the hiprtc four-step passes (jit.hip: launch_jit_fourstep)
     HostTable twp_col_w;           // C2C n = 1024 only: the same for the E = 16 recipe 16.8.8 of the four-step passes (kernels_fourstep.hip: wide)
     HostTable twp_narrow;          // twiddles in the radix order of the narrow (XCD-aware) column kernel
     HostTable tinymat[4];          // MAIN slot, n = 2..16: the real-data transforms as dense real matrices (tinymat_kernel.h);
@@ -127,7 +128,7 @@ struct FftConfig {                 // one complex-FFT-of-length-F recipe + op ta
 
 struct DevConfig {                 // device copies (typed by dtype) of one FftConfig
     void *tw = nullptr, *twM = nullptr, *chirp = nullptr, *bhat = nullptr, *aux1 = nullptr, *aux2 = nullptr, *twp = nullptr;
-    void *twlo = nullptr, *twhi = nullptr, *twp_col = nullptr, *twp_col_w = nullptr, *twp_narrow = nullptr, *twp_jcol = nullptr;
+    void *twlo = nullptr, *twhi = nullptr, *twp_col = nullptr, *twp_col_w = nullptr, *twp_fs = nullptr, *twp_narrow = nullptr, *twp_jcol = nullptr;
     void *cs_twlo = nullptr, *cs_twhi = nullptr;
     void *rfs_twlo = nullptr, *rfs_twhi = nullptr, *rfs_c1 = nullptr, *rfs_c2 = nullptr;
     void *wave_tw = nullptr;
@@ -239,6 +240,9 @@ int colsplit_tile_lanes();
 template <typename T> int launch_colsplit(int cs, bool inverse, const RealArgs<T> &a, hipStream_t s);
 
 // kernels_fourstep.hip : the two passes of the row four-step on the column kernels (no transpose launch)
+bool jit_fourstep_choose(int dtype, int n, JitCfg &cfg);        // plan time: the recipe of those passes for a smooth non-power-of-two factor n (false: none)
+bool jit_fourstep_ok(int dtype, const JitCfg &cfg);             // a smooth non-power-of-two factor whose four-step passes can be specialised with hiprtc (jit.hip)
+template <typename T> int launch_jit_fourstep(int pass, bool inverse, const JitCfg &cfg, const RealArgs<T> &a, hipStream_t s);
 bool fourstep_supported(int F);
 void fourstep_build_wide_twiddles(int F, HostTable &out);       // empty unless F has a wide (E = 16) recipe
 bool fourstep_wide(int dtype, int pass, int F);                 // this pass of length F runs the wide recipe (the caller then passes twp_col_w and RealArgs::wide = 1)

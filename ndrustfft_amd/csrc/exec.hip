@@ -569,8 +569,12 @@ static int big_fft(const FftConfig &c, const DevConfig &d, const cpx<T> *zin, in
     //   (1) length-F1 FFTs over the strided n1 axis, column load, stored TRANSPOSED as s1[n2][k1] (row store)
     //   (2) length-F2 FFTs over n2 of s1 (stride F1, adjacent k1 contiguous), twiddle W_F^(n2 k1) on load, stored at
     //       k1 + F1 k2 = natural order.   256 x 65536 c128: 317 us (three passes) -> see DESIGN.md section 3.5
-    if (fourstep_supported(F1) && fourstep_supported(F2) && !c.sub1->cfg[CFG_MAIN].twp_col.re.empty() &&
-        !c.sub2->cfg[CFG_MAIN].twp_col.re.empty() && fourstep2_enabled()) {
+    // (round 6: a smooth NON-power-of-two factor runs the same two passes on kernels specialised with hiprtc -- jit.hip: launch_jit_fourstep -- instead of the six-pass transpose route)
+    const int dti = sizeof(T) == 8 ? NDFFT_F64 : NDFFT_F32;
+    const FftConfig &sc1 = c.sub1->cfg[CFG_MAIN], &sc2 = c.sub2->cfg[CFG_MAIN];
+    const int kind1 = (fourstep_supported(F1) && !sc1.twp_col.re.empty()) ? 1 : (sc1.fs_jit && jit_fourstep_ok(dti, sc1.fs_jitcfg)) ? 2 : 0;
+    const int kind2 = (fourstep_supported(F2) && !sc2.twp_col.re.empty()) ? 1 : (sc2.fs_jit && jit_fourstep_ok(dti, sc2.fs_jitcfg)) ? 2 : 0;
+    if (kind1 && kind2 && fourstep2_enabled()) {
         const DevTables *dt1, *dt2;
         if ((rc = get_dev_tables(c.sub1, &dt1)) || (rc = get_dev_tables(c.sub2, &dt2))) return rc;
         RealArgs<T> a;
@@ -583,20 +587,19 @@ static int big_fft(const FftConfig &c, const DevConfig &d, const cpx<T> *zin, in
         // pass 1: lanes (l, n2)
         a.in = zin; a.out = s1; a.nlanes = L * F2; a.n = F1; a.F = F1; a.n_in = F1; a.n_out = F1; a.scale = (T)1;
         a.inner = F2; a.outer_in = pitch_in; a.outer_out = 0; a.elem_in = F2; a.elem_out = 0; a.pitch_out = K1p;
-        const int dti = sizeof(T) == 8 ? NDFFT_F64 : NDFFT_F32;
-        const bool w1 = fourstep_wide(dti, 1, F1) && dt1->cfg[CFG_MAIN].twp_col_w, w2 = fourstep_wide(dti, 2, F2) && dt2->cfg[CFG_MAIN].twp_col_w;
-        a.twp = (const cpx<T> *)(w1 ? dt1->cfg[CFG_MAIN].twp_col_w : dt1->cfg[CFG_MAIN].twp_col); a.wide = w1 ? 1 : 0;
+        const bool w1 = kind1 == 1 && fourstep_wide(dti, 1, F1) && dt1->cfg[CFG_MAIN].twp_col_w, w2 = kind2 == 1 && fourstep_wide(dti, 2, F2) && dt2->cfg[CFG_MAIN].twp_col_w;
+        a.twp = (const cpx<T> *)(kind1 == 2 ? dt1->cfg[CFG_MAIN].twp_fs : w1 ? dt1->cfg[CFG_MAIN].twp_col_w : dt1->cfg[CFG_MAIN].twp_col); a.wide = w1 ? 1 : 0;
         // c128 (the lane-fastest kernels): the caller's array is read once -> streaming loads; the intermediate is re-read by pass 2 -> cache-allocating stores.
         // A-B-A-B (profiles/r08/r08s_fourstep_pass1_policy_abab.txt): 256 x 65536 203 -> 197 us, 16 x 2^20 260 -> 248 us; either one alone is neutral or worse
         // (keep alone: 213 us); c64 (staged kernels) 285 -> 291 us with the streaming loads: off there
         a.stream_in = (int)NDFFT_DEV_INT("NDFFT_FS_P1_NT", sizeof(T) == 8 ? 1 : 0); a.keep_out = (int)NDFFT_DEV_INT("NDFFT_FS_KEEP", sizeof(T) == 8 ? 1 : 0);
-        if ((rc = launch_fourstep<T>(1, F1, inverse, a, stream))) return rc;
+        if ((rc = kind1 == 2 ? launch_jit_fourstep<T>(1, inverse, sc1.fs_jitcfg, a, stream) : launch_fourstep<T>(1, F1, inverse, a, stream))) return rc;
         a.stream_in = 0; a.keep_out = 0;
         // pass 2: lanes (l, k1)
         a.in = s1; a.out = zout; a.nlanes = L * F1; a.n = F2; a.F = F2; a.n_in = F2; a.n_out = F2; a.scale = scale;
         a.inner = F1; a.outer_in = (int64_t)F2 * K1p; a.outer_out = pitch_out; a.elem_in = K1p; a.elem_out = F1; a.pitch_out = 0;
-        a.twp = (const cpx<T> *)(w2 ? dt2->cfg[CFG_MAIN].twp_col_w : dt2->cfg[CFG_MAIN].twp_col); a.wide = w2 ? 1 : 0;
-        return launch_fourstep<T>(2, F2, inverse, a, stream);
+        a.twp = (const cpx<T> *)(kind2 == 2 ? dt2->cfg[CFG_MAIN].twp_fs : w2 ? dt2->cfg[CFG_MAIN].twp_col_w : dt2->cfg[CFG_MAIN].twp_col); a.wide = w2 ? 1 : 0;
+        return kind2 == 2 ? launch_jit_fourstep<T>(2, inverse, sc2.fs_jitcfg, a, stream) : launch_fourstep<T>(2, F2, inverse, a, stream);
     }
     if ((rc = get_scratch(3, stream, (size_t)(L * F) * esz, &s2))) return rc;
     // Fused three-pass form when both halves run on the register kernels:

@@ -128,7 +128,7 @@ struct FftPlanOpts {
     bool full_waves = false;   // ... only recipes whose lane is a divisor or a multiple of one wave (the cost model's own picks, 9.8 on 5 threads and 12.6 on 6, measured 222 and > 190 us)
 };
 static bool plan_fft_by_cost(int dtype, int M, int mc, size_t lane_bytes, JitCfg &out, int wide = 0, double *cost_out = nullptr, const FftPlanOpts &opts = FftPlanOpts());
-static bool jit_choose_default(int dtype, int n, JitCfg &cfg, bool allow_partial);
+static bool jit_choose_default(int dtype, int n, JitCfg &cfg, bool allow_partial, int emax_override = 0);
 // The default recipe ("fewest passes, every radix divides E") gives some lengths 20-30 elements per thread on a handful of threads
 // (F = 48: 8.6 on 2 threads, e = 24; 3000 = 10.10.10.3, e = 30).  Those measure badly -- f64 from e > 18, f32 from e > 24
 // (profiles/r04/r04j_realplan_ab.txt: nddct2 / ndfft_r2c n = 96, 120, 300, 360, 1200, 3000, 6000 gain 1.3-2.9x; recipes with e <= 12 were as good
@@ -177,13 +177,13 @@ static bool jit_choose_impl(int dtype, int n, JitCfg &cfg, bool allow_partial, b
     if (plan_fft_by_cost(dtype, n, 1, lane, alt)) { alt.vec = 1; alt.row_lpb = alt.lpb; cfg = alt; }
     return true;
 }
-static bool jit_choose_default(int dtype, int n, JitCfg &cfg, bool allow_partial) {
+static bool jit_choose_default(int dtype, int n, JitCfg &cfg, bool allow_partial, int emax_override) {
     // one lane's half exchange (n reals, padded) must fit the 160 KiB of LDS: n <= 19274 (f64) / 32768 (f32, capped)
     const size_t lane_lds = ((size_t)n + ((size_t)n >> 4) + 1) * (dtype == NDFFT_F32 ? 4 : 8);
     if (jit_disabled() || n < 12 || n > 32768 || lane_lds > jit_lds_limit() || pow2_supported(dtype, n)) return false;
     {   int m = n; for (int p : {2, 3, 5, 7, 11, 13}) while (m % p == 0) m /= p; if (m != 1) return false; }
     // E complex registers per thread: 2E (f32) / 4E (f64) VGPRs of data.  Mixed 2-3-5 lengths need E = 30.
-    const int emax = dtype == NDFFT_F32 ? 32 : 30;
+    const int emax = emax_override > 0 ? emax_override : dtype == NDFFT_F32 ? 32 : 30;
     const int cand[] = {16, 13, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
     std::vector<int> best, cur;
     int best_e = 0;
@@ -596,6 +596,70 @@ template <typename T> int launch_jit_real(int gop, const JitCfg &cfg, bool col, 
     NDFFT_HIP(hipModuleLaunchKernel(e.fn, (unsigned)nblk, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, s, params, nullptr));
     return NDFFT_OK;
 }
+// The two passes of the ROW four-step (exec.hip: big_fft) for a smooth NON-power-of-two factor cfg.n (round 6): the column kernels of pow2_real.h specialised like every other smooth
+// length -- pass 1 = column load / ROW store (ROWOUT), pass 2 = four-step twiddle on load / column store (CS = 4) -- so that such lanes take two passes over HBM like the powers of two
+// instead of the six of the transpose route (ndfft 85 x 196608 c128: 562 us).  Whole butterfly rounds only (the CS = 4 twiddle code), tiles of 128-byte rows.
+static int jit_fourstep_lanes(int dtype, const JitCfg &cfg) {
+    for (int l : {dtype == NDFFT_F32 ? 16 : 8, 8})
+        if (l * cfg.tpl <= 1024) return l;
+    return 0;
+}
+static size_t jit_fourstep_lds(int dtype, const JitCfg &cfg, int lpb, int pass) {
+    const size_t csz = dtype == NDFFT_F32 ? 8 : 16;
+    const size_t lanes = (size_t)lpb * (size_t)((cfg.n + (cfg.n >> 4) + 2) | 1) * csz;
+    return lanes + (pass == 2 ? (size_t)(cfg.n / cfg.tpl) * lpb * csz : 0);      // = RealPow2Kernel::LDS_BYTES (CS = 4: + the tile's step twiddles)
+}
+bool jit_fourstep_ok(int dtype, const JitCfg &cfg) {
+    if (!rtc().ok || jit_disabled() || !NDFFT_DEV_INT("NDFFT_JIT_FOURSTEP", 1)) return false;
+    if (cfg.n < 16 || cfg.tpl < 1 || cfg.radix.empty() || cfg.partial || cfg.e * cfg.tpl != cfg.n) return false;
+    const int lpb = jit_fourstep_lanes(dtype, cfg);
+    return lpb > 0 && jit_fourstep_lds(dtype, cfg, lpb, 2) <= jit_lds_limit();
+}
+// Plan time: the recipe of a smooth non-power-of-two factor n for those passes -- whole butterfly rounds, and few enough elements per thread that a tile still brings a useful number
+// of waves (a tile is 8 / 16 lanes x n / E threads): E <= 16 (f64) / 24 (f32) where such a recipe exists, else the default whole-round recipe
+bool jit_fourstep_choose(int dtype, int n, JitCfg &cfg) {
+    if (jit_disabled() || n < 48 || n > 2048 || pow2_supported(dtype, n)) return false;
+    // fewest passes at any E first; then the smallest cap on E whose recipe needs at most one pass more (320 f64: 10.4.4.2 at E = 20, not the six passes E <= 16 would force;
+    // 384 f64: 6.4.4.4 at E = 12 rather than 8.8.6 at E = 24 on 16 threads per lane)
+    JitCfg cmin;
+    if (!jit_choose_default(dtype, n, cmin, false)) return false;
+    JitCfg c = cmin;
+    for (int cap : {10, 12, 16, 20, 24}) {
+        if (cap >= cmin.e) break;
+        JitCfg t;
+        if (jit_choose_default(dtype, n, t, false, cap) && !t.partial && t.radix.size() <= cmin.radix.size() + 1) { c = t; break; }
+    }
+    if (c.partial || c.e * c.tpl != n) return false;
+    const int lpb = jit_fourstep_lanes(dtype, c);
+    if (lpb <= 0 || jit_fourstep_lds(dtype, c, lpb, 2) > jit_lds_limit()) return false;
+    cfg = c;
+    return true;
+}
+template <typename T> int launch_jit_fourstep(int pass, bool inverse, const JitCfg &cfg, const RealArgs<T> &a, hipStream_t s) {
+    const int dtype = sizeof(T) == 4 ? NDFFT_F32 : NDFFT_F64;
+    if (!jit_fourstep_ok(dtype, cfg)) return NDFFT_ERR_UNSUPPORTED;
+    const int lpb = jit_fourstep_lanes(dtype, cfg), threads = cfg.tpl * lpb;
+    int dev = 0;
+    NDFFT_HIP(hipGetDevice(&dev));
+    const char *tn = sizeof(T) == 4 ? "float" : "double";
+    const std::string inst = std::string("RealPow2Kernel<") + tn + ", " + std::to_string(cfg.n) + ", " + std::to_string(cfg.tpl) + ", " + std::to_string(lpb) + ", RadixList<" + radix_list(cfg) + ">, " +
+                             std::to_string(inverse ? G_C2C_INV : G_C2C_FWD) + ", true, false, " + (pass == 1 ? "0, true" : "4, false") + ">";
+    const std::string src = std::string("#include \"pow2_real.h\"\nusing namespace ndfft;\nextern \"C\" __global__ __launch_bounds__(") + std::to_string(threads) +
+                            ") void k_jit(const RealArgs<" + tn + "> a) { " + inst + "::run(a); }\n";
+    const Entry e = get_or_compile("dev" + std::to_string(dev) + ":" + inst, src, inst);
+    if (e.failed) return NDFFT_ERR_UNSUPPORTED;
+    const size_t lds = jit_fourstep_lds(dtype, cfg, lpb, pass);
+    const int64_t nblk = (a.nlanes + lpb - 1) / lpb;
+    if (nblk <= 0) return NDFFT_OK;
+    if (nblk > 0x7fffffffLL) return NDFFT_ERR_UNSUPPORTED;
+    RealArgs<T> arg = a;
+    void *params[] = {(void *)&arg};
+    NDFFT_HIP(hipModuleLaunchKernel(e.fn, (unsigned)nblk, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, s, params, nullptr));
+    return NDFFT_OK;
+}
+template int launch_jit_fourstep<float>(int, bool, const JitCfg &, const RealArgs<float> &, hipStream_t);
+template int launch_jit_fourstep<double>(int, bool, const JitCfg &, const RealArgs<double> &, hipStream_t);
+
 // PlainRealKernel (plain_kernel.h): the odd-n forms of the real-data ops for a smooth inner FFT length cfg.n, rows and column tiles
 template <typename T> int launch_jit_plain(int gop, const JitCfg &cfg, bool col, const RealArgs<T> &a, hipStream_t s) {
     if (!rtc().ok) return NDFFT_ERR_UNSUPPORTED;

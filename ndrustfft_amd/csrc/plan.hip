@@ -266,6 +266,7 @@ static void build_plan_tables(ndfft_plan *p) {
         if (pow2_supported(p->dtype, n)) { m.pow2 = true; pow2_build_twiddles(p->dtype, n, m.twp); }
         if (pow2_real_supported(n)) pow2_real_build_twiddles(n, m.twp_col);
         fourstep_build_wide_twiddles(n, m.twp_col_w);
+        if (!m.pow2 && jit_fourstep_choose(p->dtype, n, m.fs_jitcfg)) { m.fs_jit = true; jit_build_twiddles(m.fs_jitcfg, m.twp_fs); }
         if (wave_supported(n) || n <= 128) for (int k = 0; k < n; ++k) unit(m.wave_tw, k, n);   // W_n^k: wavefront and thread-per-lane kernels
         if (!m.pow2 && !m.blue && jit_choose(p->dtype, n, m.jitcfg, true)) {
             m.jit = true; jit_build_twiddles(m.jitcfg, m.twp);
@@ -519,6 +520,7 @@ int get_dev_tables(const ndfft_plan *cplan, const DevTables **out) {
         if ((rc = upload_any(plan->dtype, c.rfs_c2, &d.rfs_c2))) return rc;
         if ((rc = upload_any(plan->dtype, c.twp_col, &d.twp_col))) return rc;
         if ((rc = upload_any(plan->dtype, c.twp_col_w, &d.twp_col_w))) return rc;
+        if ((rc = upload_any(plan->dtype, c.twp_fs, &d.twp_fs))) return rc;
         if ((rc = upload_any(plan->dtype, c.twp_jcol, &d.twp_jcol))) return rc;
         if ((rc = upload_any(plan->dtype, c.twp_narrow, &d.twp_narrow))) return rc;
         if ((rc = upload_any(plan->dtype, c.wave_tw, &d.wave_tw))) return rc;
@@ -662,7 +664,7 @@ int ndfft_plan_destroy(ndfft_plan *plan) {
         (void)hipSetDevice(kv.first);
         for (int i = 0; i < CFG_COUNT; ++i) {
             DevConfig &d = kv.second.cfg[i];
-            void *ptrs[] = {d.tw, d.twM, d.chirp, d.bhat, d.aux1, d.aux2, d.twp, d.twlo, d.twhi, d.twp_col, d.twp_col_w, d.twp_jcol, d.twp_narrow, d.cs_twlo, d.cs_twhi, d.rfs_twlo, d.rfs_twhi, d.rfs_c1, d.rfs_c2, d.wave_tw, d.tinymat[0], d.tinymat[1], d.tinymat[2], d.tinymat[3], d.rader_bhat, d.rader_twp, d.rader_twp2, d.rader_tab, d.twp_rev, d.rader_ctw};
+            void *ptrs[] = {d.tw, d.twM, d.chirp, d.bhat, d.aux1, d.aux2, d.twp, d.twlo, d.twhi, d.twp_col, d.twp_col_w, d.twp_fs, d.twp_jcol, d.twp_narrow, d.cs_twlo, d.cs_twhi, d.rfs_twlo, d.rfs_twhi, d.rfs_c1, d.rfs_c2, d.wave_tw, d.tinymat[0], d.tinymat[1], d.tinymat[2], d.tinymat[3], d.rader_bhat, d.rader_twp, d.rader_twp2, d.rader_tab, d.twp_rev, d.rader_ctw};
             for (void *q : ptrs) if (q) (void)hipFree(q);
         }
     }
@@ -694,8 +696,10 @@ int ndfft_explain_plan(int kind, int dtype, size_t n, char *buf, size_t buflen) 
         else if (c.jit) {
             l += " route=jit tpl=" + std::to_string(c.jitcfg.tpl) + " e=" + std::to_string(c.jitcfg.e) + " radix=" + radix(c.jitcfg.radix) + " lanes=" + std::to_string(c.jitcfg.row_lpb);
             if (c.jit_col_alt) l += " col_tpl=" + std::to_string(c.jitcfg_col.tpl) + " col_e=" + std::to_string(c.jitcfg_col.e) + " col_radix=" + radix(c.jitcfg_col.radix);
+            if (c.fs_jit) l += " fs_tpl=" + std::to_string(c.fs_jitcfg.tpl) + " fs_e=" + std::to_string(c.fs_jitcfg.e) + " fs_radix=" + radix(c.fs_jitcfg.radix);   // as a four-step factor (jit.hip: jit_fourstep_choose)
         }
         else if (c.big && !c.bigblue) l += " route=four_step F1=" + std::to_string(c.F1) + " F2=" + std::to_string(c.F2) +
+                                           ((c.sub1 && c.sub1->cfg[CFG_MAIN].fs_jit) || (c.sub2 && c.sub2->cfg[CFG_MAIN].fs_jit) ? std::string(" jit_passes=") + (c.sub1->cfg[CFG_MAIN].fs_jit ? "1" : "") + (c.sub2->cfg[CFG_MAIN].fs_jit ? "2" : "") : std::string()) +
                                            (c.rfs ? " real_four_step=" + std::to_string(c.rfs_N1) + "x" + std::to_string(c.rfs_N2) + " ops=" + std::to_string(c.rfs_ops) : std::string());
         else if (c.F <= 1) l += " route=trivial";
         else if (!c.blue && !c.big) l += " route=lds radix=" + radix(c.radix);

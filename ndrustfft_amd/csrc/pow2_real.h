@@ -265,7 +265,8 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
         // ---- stage the raw lane(s) ----
         constexpr int CSNQ = CSK ? F / (THREADS / LPB) : 1;   // outputs per thread of a CS stage kernel
         cpx<T> *cs_twl = (cpx<T> *)(smem + LANES_LDS_BYTES);   // CS stage kernels, 3-D grid: W_N^(j k1), j < F (see cs3_twiddles); CS >= 4: the step twiddles [e][lane]
-        cpx<T> cs4_bhi = mk<T>((T)1, (T)0), cs4_blo = cs4_bhi, cs4_shi = cs4_bhi, cs4_slo = cs4_bhi;
+        constexpr int CS4_NS = CS >= 4 ? (E + TPL - 1) / TPL : 1;
+        cpx<T> cs4_bhi = mk<T>((T)1, (T)0), cs4_blo = cs4_bhi, cs4_shi[CS4_NS], cs4_slo[CS4_NS];
         constexpr int TBL_ENTRIES = (int)(TBL_BYTES / (2 * sizeof(T))), TBL_PER_THREAD = TBL_BYTES ? (TBL_ENTRIES + THREADS - 1) / THREADS : 1;
         cpx<T> tbl_v[TBL_PER_THREAD];
         if constexpr (CSK) {
@@ -312,13 +313,18 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                 // The four-step twiddle W_N^(i k1) of element i = t + d (d = q TPL + r F/R0: E values) of this thread's lane (k1 = its inner index) is W^(t k1) x W^(d k1):
                 // one base per thread, E x LPB steps per tile (threads t < E load one each and leave the product in LDS); the table entries are loaded here, in front of
                 // the staging loads.  Before round 6 the staging loop gathered two table entries per ELEMENT (16 scattered loads per thread beside 8 loads of data).
-                static_assert(TPL >= E && E * TPL == F, "CS >= 4: whole butterfly rounds, one thread row per step twiddle");
+                static_assert(E * TPL == F, "CS >= 4: whole butterfly rounds");
                 constexpr int R0 = RL::at(0), NB0 = F / R0;
                 const int mask = (1 << a.cs_logB) - 1;
                 const int k1 = (int)(((lane < a.nlanes) ? lane : 0) % a.inner);
                 const int mb = t * k1;
                 cs4_bhi = a.cs_twhi[mb >> a.cs_logB]; cs4_blo = a.cs_twlo[mb & mask];
-                if (t < E) { const int m = ((t / R0) * TPL + (t % R0) * NB0) * k1; cs4_shi = a.cs_twhi[m >> a.cs_logB]; cs4_slo = a.cs_twlo[m & mask]; }
+                // (thread row t owns the steps e = t, t + TPL, ...: one where TPL >= E -- every ahead-of-time recipe --, more for the hiprtc recipes with E > TPL)
+#pragma unroll
+                for (int i = 0; i < CS4_NS; ++i) {
+                    const int e = t + i * TPL;
+                    if (e < E) { const int m = ((e / R0) * TPL + (e % R0) * NB0) * k1; cs4_shi[i] = a.cs_twhi[m >> a.cs_logB]; cs4_slo[i] = a.cs_twlo[m & mask]; }
+                }
             }
             if constexpr (TBL_BYTES != 0) {   // the POST tables of this tile, issued in front of the staging loads (see col_post_table_bytes)
                 constexpr int N1 = F / 2 + 1;
@@ -411,7 +417,10 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                 }
             }
         }
-        if constexpr (CS >= 4) { if (t < E) cs_twl[t * LPB + ll] = cmul(cs4_shi, cs4_slo); }
+        if constexpr (CS >= 4) {
+#pragma unroll
+            for (int i = 0; i < CS4_NS; ++i) { const int e = t + i * TPL; if (e < E) cs_twl[e * LPB + ll] = cmul(cs4_shi[i], cs4_slo[i]); }
+        }
         if constexpr (TBL_BYTES != 0) {
 #pragma unroll
             for (int i = 0; i < TBL_PER_THREAD; ++i) { const int idx = (int)threadIdx.x + i * THREADS; if (idx < TBL_ENTRIES) cs_twl[idx] = tbl_v[i]; }

@@ -275,6 +275,13 @@ int launch_jit_regreal(int dtype, int gop, int n, int f1, int f2, bool stage, co
     return dtype == NDFFT_F32 ? regreal_T<float>(gop, n, f1, f2, stage, a, s) : regreal_T<double>(gop, n, f1, f2, stage, a, s);
 }
 }
+namespace ndfft {
+bool jit_fourstep_ok(int, const JitCfg &) { return false; }
+bool jit_fourstep_choose(int, int, JitCfg &) { return false; }      // (no hiprtc in the emulation: non-power-of-two four-step factors keep the transpose route)
+template <typename T> int launch_jit_fourstep(int, bool, const JitCfg &, const RealArgs<T> &, hipStream_t) { return NDFFT_ERR_UNSUPPORTED; }
+template int launch_jit_fourstep<float>(int, bool, const JitCfg &, const RealArgs<float> &, hipStream_t);
+template int launch_jit_fourstep<double>(int, bool, const JitCfg &, const RealArgs<double> &, hipStream_t);
+}
 // (no hiprtc in the emulation: the build step of the real library has nothing to do here)
 extern "C" int ndfft_jit_prebuild(const char *, const char *, int, int, int *built, int *present, int *failed) {
     if (built) *built = 0;

@@ -774,6 +774,11 @@ def long_lanes_four_step(L, full=True):
     if full:
         cases += [("ndfft", (2, 1 << 20), 1, np.float64, "four_step"), ("ndfft", (2, 1 << 20), 1, np.float32, "four_step"), ("ndifft", (3, 1 << 19), 1, np.float32, "four_step"), ("ndifft", (1, 1 << 22), 1, np.float32, "four_step"),
                   ("nddct2", (3, 1 << 18), 1, np.float64, "real_four_step"), ("ndfft_r2c", (2, 3 * (1 << 17)), 1, np.float32, "four_step")]
+    if full:   # round 6: smooth NON-power-of-two factors run the two four-step passes on hiprtc-specialised kernels (one factor or both), every op through the packed route
+        cases += [("ndfft", (2, 196608), 1, np.float64, "four_step"), ("ndifft", (3, 163840), 1, np.float32, "four_step"), ("ndfft", (2, 200000), 1, np.float64, "four_step"),
+                  ("ndifft", (2, 147456), 1, np.float64, "four_step"), ("ndfft", (5, 100000), 1, np.float32, "four_step"), ("nddct2", (2, 196608), 1, np.float64, "four_step"),
+                  ("ndfft_r2c", (2, 163840), 1, np.float32, "four_step"), ("ndifft_r2c", (2, 200000), 1, np.float64, "four_step"), ("nddct1", (2, 147457), 1, np.float64, "four_step"),
+                  ("nddct4", (2, 196608), 1, np.float32, "four_step"), ("nddct3", (2, 120000), 1, np.float64, "four_step")]
     for name, shape, axis, rdt, want in cases:
         assert run_case(L, name, shape, axis, rdt) == want, (name, shape)
     # REAL four-step (round 3): R2C (f64) and DCT-II of power-of-two lanes in two passes -- real FFTs of length N1 over the strided index, row store of the
