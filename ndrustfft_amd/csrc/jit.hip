@@ -598,7 +598,7 @@ template <typename T> int launch_jit_real(int gop, const JitCfg &cfg, bool col, 
 }
 // The two passes of the ROW four-step (exec.hip: big_fft) for a smooth NON-power-of-two factor cfg.n (round 6): the column kernels of pow2_real.h specialised like every other smooth
 // length -- pass 1 = column load / ROW store (ROWOUT), pass 2 = four-step twiddle on load / column store (CS = 4) -- so that such lanes take two passes over HBM like the powers of two
-// instead of the six of the transpose route (ndfft 85 x 196608 c128: 562 us).  Whole butterfly rounds only (the CS = 4 twiddle code), tiles of 128-byte rows.
+// instead of the six of the transpose route (ndfft 85 x 196608 c128: 562 -> 238 us).  Whole or partial butterfly rounds, tiles of 128-byte rows.
 static int jit_fourstep_lanes(int dtype, const JitCfg &cfg) {
     for (int l : {dtype == NDFFT_F32 ? 16 : 8, 8})
         if (l * cfg.tpl <= 1024) return l;
@@ -607,11 +607,12 @@ static int jit_fourstep_lanes(int dtype, const JitCfg &cfg) {
 static size_t jit_fourstep_lds(int dtype, const JitCfg &cfg, int lpb, int pass) {
     const size_t csz = dtype == NDFFT_F32 ? 8 : 16;
     const size_t lanes = (size_t)lpb * (size_t)((cfg.n + (cfg.n >> 4) + 2) | 1) * csz;
-    return lanes + (pass == 2 ? (size_t)(cfg.n / cfg.tpl) * lpb * csz : 0);      // = RealPow2Kernel::LDS_BYTES (CS = 4: + the tile's step twiddles)
+    const int r0 = cfg.radix.empty() ? 1 : cfg.radix[0], e0 = ((cfg.n / r0 + cfg.tpl - 1) / cfg.tpl) * r0;      // RealPow2Kernel::CS4_E0
+    return lanes + (pass == 2 ? (size_t)e0 * lpb * csz : 0);      // = RealPow2Kernel::LDS_BYTES (CS = 4: + the tile's step twiddles)
 }
 bool jit_fourstep_ok(int dtype, const JitCfg &cfg) {
     if (!rtc().ok || jit_disabled() || !NDFFT_DEV_INT("NDFFT_JIT_FOURSTEP", 1)) return false;
-    if (cfg.n < 16 || cfg.tpl < 1 || cfg.radix.empty() || cfg.partial || cfg.e * cfg.tpl != cfg.n) return false;
+    if (cfg.n < 16 || cfg.tpl < 1 || cfg.radix.empty()) return false;
     const int lpb = jit_fourstep_lanes(dtype, cfg);
     return lpb > 0 && jit_fourstep_lds(dtype, cfg, lpb, 2) <= jit_lds_limit();
 }
@@ -621,15 +622,18 @@ bool jit_fourstep_choose(int dtype, int n, JitCfg &cfg) {
     if (jit_disabled() || n < 48 || n > 2048 || pow2_supported(dtype, n)) return false;
     // fewest passes at any E first; then the smallest cap on E whose recipe needs at most one pass more (320 f64: 10.4.4.2 at E = 20, not the six passes E <= 16 would force;
     // 384 f64: 6.4.4.4 at E = 12 rather than 8.8.6 at E = 24 on 16 threads per lane)
-    JitCfg cmin;
-    if (!jit_choose_default(dtype, n, cmin, false)) return false;
-    JitCfg c = cmin;
-    for (int cap : {10, 12, 16, 20, 24}) {
-        if (cap >= cmin.e) break;
-        JitCfg t;
-        if (jit_choose_default(dtype, n, t, false, cap) && !t.partial && t.radix.size() <= cmin.radix.size() + 1) { c = t; break; }
+    JitCfg cmin, c;
+    if (jit_choose_default(dtype, n, cmin, false) && !cmin.partial && cmin.e <= (dtype == NDFFT_F32 ? 32 : 24)) {
+        c = cmin;
+        for (int cap : {10, 12, 16, 20}) {
+            if (cap >= cmin.e) break;
+            JitCfg t;
+            if (jit_choose_default(dtype, n, t, false, cap) && !t.partial && t.radix.size() <= cmin.radix.size() + 1) { c = t; break; }
+        }
+    } else {
+        // no whole-round recipe with a bearable E (factors 7 / 11 / 13, mixed 2-3-5): the rows' recipe with partial rounds (the planner's pick by cost)
+        if (!jit_choose(dtype, n, c, true) || c.e > (dtype == NDFFT_F32 ? 32 : 24)) return false;
     }
-    if (c.partial || c.e * c.tpl != n) return false;
     const int lpb = jit_fourstep_lanes(dtype, c);
     if (lpb <= 0 || jit_fourstep_lds(dtype, c, lpb, 2) > jit_lds_limit()) return false;
     cfg = c;

@@ -215,9 +215,16 @@ static void build_fft(FftConfig &c, int F, int dtype) {
     if (smooth || !(blue_lds || blue_reg)) {
         // long lane: F = F1 * F2 with both halves inside one launch, as square as possible
         c.radix.clear();
-        int best = 0;
+        // (round 6: among the splits, the most square one whose BOTH factors can run the two-pass form -- a power of two with a column kernel, or a smooth length with a
+        //  whole-round hiprtc recipe, jit.hip: jit_fourstep_choose -- wins over a squarer one that would take the six-pass transpose route)
+        int best = 0, best2 = 0;
+        auto two_pass_factor = [&](int f) { JitCfg t; return fourstep_supported(f) || jit_fourstep_choose(dtype, f, t); };
         for (int d = 2; (int64_t)d * d <= F; ++d)
-            if (F % d == 0 && single_kernel_ok(d, dtype) && single_kernel_ok(F / d, dtype)) best = d;
+            if (F % d == 0 && single_kernel_ok(d, dtype) && single_kernel_ok(F / d, dtype)) {
+                best = d;
+                if (two_pass_factor(d) && two_pass_factor(F / d)) best2 = d;
+            }
+        if (best2) best = best2;
         if (!best) {
             // a prime factor too large for any single launch: Bluestein over global memory -- chirp multiply,
             // FFT_M through the power-of-two row path (its own four-step when M > 16384), * bhat, FFT_M, chirp

@@ -204,8 +204,10 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
     static constexpr int LANE_LDS = COL ? ((F + (F >> 4) + 2) | 1) : ((F + (F >> 4) + 3) & ~1);
     static constexpr size_t LANES_LDS_BYTES = (size_t)LPB * LANE_LDS * 2 * sizeof(T);
     // CS stage kernels: + the tile's F twiddles; CS >= 4 (second pass of the row four-steps): + its E x LPB step twiddles (see the PRE fold)
+    // CS >= 4: elements per thread of the FIRST pass, whole or partial rounds: ceil(F / (R0 TPL)) butterflies of radix R0 (= F / TPL with whole rounds)
+    static constexpr int CS4_E0 = ((F / RL::at(0) + TPL - 1) / TPL) * RL::at(0);
     static constexpr size_t TBL_BYTES = (COL && !XCD && CS == 0 && !ROWOUT) ? col_post_table_bytes(F, 2 * sizeof(T), OP, LANES_LDS_BYTES) : 0;   // col_post_table_bytes above
-    static constexpr size_t LDS_BYTES = LANES_LDS_BYTES + (CSK ? (size_t)F * 2 * sizeof(T) : CS >= 4 ? (size_t)(F / TPL) * LPB * 2 * sizeof(T) : TBL_BYTES);
+    static constexpr size_t LDS_BYTES = LANES_LDS_BYTES + (CSK ? (size_t)F * 2 * sizeof(T) : CS >= 4 ? (size_t)CS4_E0 * LPB * 2 * sizeof(T) : TBL_BYTES);
     static constexpr bool IN_CPLX = OP == G_C2R_EVEN || OP == G_C2C_FWD || OP == G_C2C_INV;
     static constexpr bool OUT_CPLX = OP == G_R2C_EVEN || OP == G_C2C_FWD || OP == G_C2C_INV;
     using FFT = Pow2Kernel<T, F, TPL, LPB, false, RL, FFLAGS, 1, 0>;
@@ -265,7 +267,7 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
         // ---- stage the raw lane(s) ----
         constexpr int CSNQ = CSK ? F / (THREADS / LPB) : 1;   // outputs per thread of a CS stage kernel
         cpx<T> *cs_twl = (cpx<T> *)(smem + LANES_LDS_BYTES);   // CS stage kernels, 3-D grid: W_N^(j k1), j < F (see cs3_twiddles); CS >= 4: the step twiddles [e][lane]
-        constexpr int CS4_NS = CS >= 4 ? (E + TPL - 1) / TPL : 1;
+        constexpr int CS4_NS = CS >= 4 ? (CS4_E0 + TPL - 1) / TPL : 1;
         cpx<T> cs4_bhi = mk<T>((T)1, (T)0), cs4_blo = cs4_bhi, cs4_shi[CS4_NS], cs4_slo[CS4_NS];
         constexpr int TBL_ENTRIES = (int)(TBL_BYTES / (2 * sizeof(T))), TBL_PER_THREAD = TBL_BYTES ? (TBL_ENTRIES + THREADS - 1) / THREADS : 1;
         cpx<T> tbl_v[TBL_PER_THREAD];
@@ -313,7 +315,6 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                 // The four-step twiddle W_N^(i k1) of element i = t + d (d = q TPL + r F/R0: E values) of this thread's lane (k1 = its inner index) is W^(t k1) x W^(d k1):
                 // one base per thread, E x LPB steps per tile (threads t < E load one each and leave the product in LDS); the table entries are loaded here, in front of
                 // the staging loads.  Before round 6 the staging loop gathered two table entries per ELEMENT (16 scattered loads per thread beside 8 loads of data).
-                static_assert(E * TPL == F, "CS >= 4: whole butterfly rounds");
                 constexpr int R0 = RL::at(0), NB0 = F / R0;
                 const int mask = (1 << a.cs_logB) - 1;
                 const int k1 = (int)(((lane < a.nlanes) ? lane : 0) % a.inner);
@@ -323,7 +324,7 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
 #pragma unroll
                 for (int i = 0; i < CS4_NS; ++i) {
                     const int e = t + i * TPL;
-                    if (e < E) { const int m = ((e / R0) * TPL + (e % R0) * NB0) * k1; cs4_shi[i] = a.cs_twhi[m >> a.cs_logB]; cs4_slo[i] = a.cs_twlo[m & mask]; }
+                    if (e < CS4_E0) { const int m = ((e / R0) * TPL + (e % R0) * NB0) * k1; cs4_shi[i] = a.cs_twhi[m >> a.cs_logB]; cs4_slo[i] = a.cs_twlo[m & mask]; }
                 }
             }
             if constexpr (TBL_BYTES != 0) {   // the POST tables of this tile, issued in front of the staging loads (see col_post_table_bytes)
@@ -419,7 +420,7 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
         }
         if constexpr (CS >= 4) {
 #pragma unroll
-            for (int i = 0; i < CS4_NS; ++i) { const int e = t + i * TPL; if (e < E) cs_twl[e * LPB + ll] = cmul(cs4_shi[i], cs4_slo[i]); }
+            for (int i = 0; i < CS4_NS; ++i) { const int e = t + i * TPL; if (e < CS4_E0) cs_twl[e * LPB + ll] = cmul(cs4_shi[i], cs4_slo[i]); }
         }
         if constexpr (TBL_BYTES != 0) {
 #pragma unroll
@@ -476,7 +477,8 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
         if constexpr (CS >= 4) {   // (INV: the lane was conjugated above -- the same table serves both directions)
             const cpx<T> base = cmul(cs4_bhi, cs4_blo);
 #pragma unroll
-            for (int e = 0; e < E; ++e) v[e] = cmul(v[e], cmul(base, cs_twl[e * LPB + ll]));
+            for (int e = 0; e < CS4_E0; ++e)      // (a partial last round: the thread's element does not exist -- the PRE loop above left it alone, so do we)
+                if (FFT::full(0) || t + (e / RL::at(0)) * TPL < F / RL::at(0)) v[e] = cmul(v[e], cmul(base, cs_twl[e * LPB + ll]));
         }
         if constexpr (CS == 1 || CS == 2) {
             if (a.cs_grid3) {   // the stage twiddle W_N^(j k1) (INV: the lane was conjugated above, conj(x conj(w)) = conj(x) w), from the tile's LDS table

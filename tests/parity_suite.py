@@ -778,7 +778,10 @@ def long_lanes_four_step(L, full=True):
         cases += [("ndfft", (2, 196608), 1, np.float64, "four_step"), ("ndifft", (3, 163840), 1, np.float32, "four_step"), ("ndfft", (2, 200000), 1, np.float64, "four_step"),
                   ("ndifft", (2, 147456), 1, np.float64, "four_step"), ("ndfft", (5, 100000), 1, np.float32, "four_step"), ("nddct2", (2, 196608), 1, np.float64, "four_step"),
                   ("ndfft_r2c", (2, 163840), 1, np.float32, "four_step"), ("ndifft_r2c", (2, 200000), 1, np.float64, "four_step"), ("nddct1", (2, 147457), 1, np.float64, "four_step"),
-                  ("nddct4", (2, 196608), 1, np.float32, "four_step"), ("nddct3", (2, 120000), 1, np.float64, "four_step")]
+                  ("nddct4", (2, 196608), 1, np.float32, "four_step"), ("nddct3", (2, 120000), 1, np.float64, "four_step"),
+                  # factors without a whole-round recipe (7 / 11 / 13, 675 = 5.5.3.3.3): partial rounds in both passes
+                  ("ndfft", (2, 524160), 1, np.float64, "four_step"), ("ndifft", (3, 128700), 1, np.float32, "four_step"), ("ndfft", (2, 394875), 1, np.float64, "four_step"),
+                  ("nddct2", (2, 240570), 1, np.float32, "four_step")]
     for name, shape, axis, rdt, want in cases:
         assert run_case(L, name, shape, axis, rdt) == want, (name, shape)
     # REAL four-step (round 3): R2C (f64) and DCT-II of power-of-two lanes in two passes -- real FFTs of length N1 over the strided index, row store of the

@@ -68,6 +68,15 @@ def _check_line(d, dtype):
         radices = [int(r) for r in d["radix"].split(".")]
         assert _prod(d["radix"]) == F and all(2 <= r <= 16 for r in radices) and tpl >= 1, d
         assert e == max(-(-(F // r) // tpl) * r for r in radices) and e <= 32, d
+    if "fs_tpl" in d:      # round 6: the recipe this length runs as a FACTOR of a row four-step (hiprtc passes, jit.hip: jit_fourstep_choose)
+        tpl, e = int(d["fs_tpl"]), int(d["fs_e"])
+        radices = [int(r) for r in d["fs_radix"].split(".")]
+        assert _prod(d["fs_radix"]) == F and all(2 <= r <= 16 for r in radices) and 48 <= F <= 2048, d
+        assert e == max(-(-(F // r) // tpl) * r for r in radices) and e <= (32 if dtype == _lib.F32 else 24), d
+        lanes = 16 if (dtype == _lib.F32 and 16 * tpl <= 1024) else 8
+        assert lanes * tpl <= 1024, d
+        e0 = -(-(F // radices[0]) // tpl) * radices[0]
+        assert lanes * (((F + (F >> 4) + 2) | 1) + e0) * esz <= LDS, d
     if "blueM" in d:
         M = int(d["blueM"])
         assert M >= 2 * F - 1, d
@@ -97,6 +106,8 @@ def test_recipes_are_self_consistent(lib, dtype):
                 _check_line(d, dtype)
                 seen.add(d.get("route"))
     assert {"rader", "jit", "pow2", "four_step"} <= seen, seen
+    # a long smooth lane whose factors are not powers of two plans the two-pass form with hiprtc passes
+    assert "jit_passes=2" in lib.explain_plan(_lib.KIND_C2C, dtype, 196608) and "jit_passes=12" in lib.explain_plan(_lib.KIND_C2C, dtype, 200000)
     assert seen & {"blue_reg", "blue_lds", "blue_global"}, seen
 
 
