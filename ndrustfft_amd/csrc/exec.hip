@@ -678,6 +678,12 @@ static int real_fourstep(const Problem &P, int gop, const FftConfig &c, const De
     const int64_t n = (int64_t)N1 * N2, B = P.nlanes;
     const DevTables *dt1, *dt2;
     int rc;
+    // (round 6: a factor that is not a power of two runs its pass on a kernel specialised with hiprtc -- plan.hip: add_real_fourstep_smooth; NDFFT_ERR_UNSUPPORTED before
+    //  anything is launched when that is not to be had: the caller falls back to the packed route)
+    const int dti = sizeof(T) == 8 ? NDFFT_F64 : NDFFT_F32;
+    const FftConfig &rc1 = c.rfs_sub1->cfg[CFG_MAIN], &rc2 = c.rfs_sub2->cfg[CFG_MAIN];
+    const bool jit1 = !fourstep_supported(N1 / 2), jit2 = !fourstep_supported(N2);
+    if ((jit1 && !(rc1.jit && jit_rfs1_ok(dti, rc1.jitcfg))) || (jit2 && !(rc2.fs_jit && jit_fourstep_ok(dti, rc2.fs_jitcfg)))) return NDFFT_ERR_UNSUPPORTED;
     if ((rc = get_dev_tables(c.rfs_sub1, &dt1)) || (rc = get_dev_tables(c.rfs_sub2, &dt2))) return rc;
     void *s1;
     if ((rc = get_scratch(4, stream, (size_t)(B * N2 * K) * sizeof(cpx<T>), &s1))) return rc;
@@ -702,7 +708,7 @@ static int real_fourstep(const Problem &P, int gop, const FftConfig &c, const De
         const bool resident = row_load_policy(d_in, (size_t)B * (dct1 ? (size_t)(n / 2 + 1) : (size_t)n) * es, d_out, (size_t)B * (size_t)(gop == G_R2C_EVEN ? (n / 2 + 1) * 2 : dct1 ? n / 2 + 1 : n) * es) == 0;
         a.stream_in = (gop == G_DCT2_EVEN || dct1) ? 0 : (knob == 2 ? (resident ? 1 : 0) : (int)knob);     // (DCT-I reads every element twice, through its own tile and the mirrored one)
     }
-    if ((rc = launch_fourstep_real<T>(1, N1 / 2, a, stream))) return rc;
+    if ((rc = jit1 ? launch_jit_fourstep<T>(11, false, rc1.jitcfg, a, stream) : launch_fourstep_real<T>(1, N1 / 2, a, stream))) return rc;
     a.stream_in = 0;
     // pass 2: lanes (l, k1)
     a.makhoul = dct1 ? 3 : 0;                        // (3: real outputs Re X[k] a.scale)
@@ -710,8 +716,9 @@ static int real_fourstep(const Problem &P, int gop, const FftConfig &c, const De
     a.xcd_chunk = (int)NDFFT_DEV_INT("NDFFT_RFS_XCD_CHUNK", 8);
     a.in = s1; a.out = d_out; a.nlanes = B * K; a.n = N2; a.F = N2; a.n_in = N2; a.n_out = N2; a.scale = dct1 ? (T)(0.5 * P.scale) : (T)P.scale;
     a.inner = K; a.outer_in = (int64_t)N2 * K; a.outer_out = pout; a.elem_in = K; a.elem_out = 0; a.pitch_out = 0;
-    a.aux1 = nullptr; a.aux2 = (const cpx<T> *)d.aux2; a.twp = (const cpx<T> *)dt2->cfg[CFG_MAIN].twp_col;
+    a.aux1 = nullptr; a.aux2 = (const cpx<T> *)d.aux2; a.twp = (const cpx<T> *)(jit2 ? dt2->cfg[CFG_MAIN].twp_fs : dt2->cfg[CFG_MAIN].twp_col);
     if (gop == G_DCT2_EVEN && NDFFT_DEV_INT("NDFFT_RFS_FACTORED", 1)) { a.fc1 = (const cpx<T> *)d.rfs_c1; a.fc2 = (const cpx<T> *)d.rfs_c2; }
+    if (jit2) return launch_jit_fourstep<T>(gop == G_DCT2_EVEN ? 13 : 12, false, rc2.fs_jitcfg, a, stream);
     return launch_fourstep_real<T>(gop == G_DCT2_EVEN ? 3 : 2, N2, a, stream);
 }
 
@@ -813,16 +820,16 @@ static int dispatch_big(const Problem &P, const void *d_in, void *d_out, const D
         set_last_path(c.bigblue ? "blue_global" : "four_step");
         return rc0;
     }
-    const int rfs_on = real_fourstep_enabled(), rfs_ops = rfs_on == 2 ? (c.rfs_ops & 16 ? 16 : 15) : (rfs_on ? c.rfs_ops : 0);
+    // (a plan whose factors are not powers of two has the forward ops only, and its passes need hiprtc: NDFFT_ERR_UNSUPPORTED from real_fourstep = nothing launched, packed route below)
+    const bool rfs_smooth = c.rfs && (((c.rfs_N1 & (c.rfs_N1 - 1)) != 0) || ((c.rfs_N2 & (c.rfs_N2 - 1)) != 0));
+    const int rfs_on = real_fourstep_enabled(), rfs_ops = (rfs_on == 2 ? (c.rfs_ops & 16 ? 16 : 15) : (rfs_on ? c.rfs_ops : 0)) & (rfs_smooth ? (c.rfs_ops & (1 | 4 | 16)) : 31);
     if (c.rfs && gop == G_DCT1 && (rfs_ops & 16)) {
         const int rc0 = real_fourstep<T>(P, gop, c, d, d_in, d_out, pin, pout, stream);
-        set_last_path("real_four_step");
-        return rc0;
+        if (!(rfs_smooth && rc0 == NDFFT_ERR_UNSUPPORTED)) { set_last_path("real_four_step"); return rc0; }
     }
     if (c.rfs && ((gop == G_DCT2_EVEN && (rfs_ops & 4)) || (gop == G_R2C_EVEN && P.scale == 1.0 && (rfs_ops & 1)))) {
         const int rc0 = real_fourstep<T>(P, gop, c, d, d_in, d_out, pin, pout, stream);
-        set_last_path("real_four_step");
-        return rc0;
+        if (!(rfs_smooth && rc0 == NDFFT_ERR_UNSUPPORTED)) { set_last_path("real_four_step"); return rc0; }
     }
     if (gop == G_DCT4_EVEN && rfs_on && c.big && !c.bigblue && fourstep_supported(c.F1) && fourstep_supported(c.F2) && !c.sub1->cfg[CFG_MAIN].twp_col.re.empty() &&
         !c.sub2->cfg[CFG_MAIN].twp_col.re.empty() && fourstep2_enabled()) {

@@ -639,20 +639,35 @@ bool jit_fourstep_choose(int dtype, int n, JitCfg &cfg) {
     cfg = c;
     return true;
 }
-template <typename T> int launch_jit_fourstep(int pass, bool inverse, const JitCfg &cfg, const RealArgs<T> &a, hipStream_t s) {
+// the first pass of the REAL four-step (exec.hip: real_fourstep) for a real FFT length N1 = 2 cfg.n that is not a power of two: lanes of 128-byte REAL rows, halved like RfsGeom
+static int jit_rfs1_lanes(int dtype, const JitCfg &cfg) {
+    const size_t lane = (size_t)((cfg.n + (cfg.n >> 4) + 2) | 1) * 2 * (dtype == NDFFT_F32 ? 4 : 8);
+    int l = dtype == NDFFT_F32 ? 32 : 16;
+    while (l > 8 && (l * cfg.tpl > 1024 || (size_t)l * lane > 80 * 1024)) l /= 2;
+    return (l * cfg.tpl <= 1024 && (size_t)l * lane <= jit_lds_limit()) ? l : 0;
+}
+bool jit_rfs1_ok(int dtype, const JitCfg &cfg) {
+    if (!rtc().ok || jit_disabled() || !NDFFT_DEV_INT("NDFFT_JIT_FOURSTEP", 1)) return false;
+    return cfg.n >= 16 && cfg.tpl >= 1 && !cfg.radix.empty() && jit_rfs1_lanes(dtype, cfg) > 0;
+}
+// kind: 1 = complex pass 1 (ROWOUT), 2 = complex pass 2 (CS 4), 11 = real pass 1 (R2C, ROWOUT), 12 / 13 = real pass 2 (CS 5: R2C / DCT-I, CS 6: DCT-II)
+template <typename T> int launch_jit_fourstep(int kind, bool inverse, const JitCfg &cfg, const RealArgs<T> &a, hipStream_t s) {
     const int dtype = sizeof(T) == 4 ? NDFFT_F32 : NDFFT_F64;
-    if (!jit_fourstep_ok(dtype, cfg)) return NDFFT_ERR_UNSUPPORTED;
-    const int lpb = jit_fourstep_lanes(dtype, cfg), threads = cfg.tpl * lpb;
+    const bool real1 = kind == 11;
+    if (real1 ? !jit_rfs1_ok(dtype, cfg) : !jit_fourstep_ok(dtype, cfg)) return NDFFT_ERR_UNSUPPORTED;
+    const int lpb = real1 ? jit_rfs1_lanes(dtype, cfg) : jit_fourstep_lanes(dtype, cfg), threads = cfg.tpl * lpb;
+    const int pass = (kind == 1 || kind == 11) ? 1 : 2;
     int dev = 0;
     NDFFT_HIP(hipGetDevice(&dev));
     const char *tn = sizeof(T) == 4 ? "float" : "double";
     const std::string inst = std::string("RealPow2Kernel<") + tn + ", " + std::to_string(cfg.n) + ", " + std::to_string(cfg.tpl) + ", " + std::to_string(lpb) + ", RadixList<" + radix_list(cfg) + ">, " +
-                             std::to_string(inverse ? G_C2C_INV : G_C2C_FWD) + ", true, false, " + (pass == 1 ? "0, true" : "4, false") + ">";
+                             std::to_string(real1 ? G_R2C_EVEN : inverse ? G_C2C_INV : G_C2C_FWD) + ", true, false, " +
+                             (pass == 1 ? std::string("0, true") : std::to_string(kind == 12 ? 5 : kind == 13 ? 6 : 4) + ", false") + ">";
     const std::string src = std::string("#include \"pow2_real.h\"\nusing namespace ndfft;\nextern \"C\" __global__ __launch_bounds__(") + std::to_string(threads) +
                             ") void k_jit(const RealArgs<" + tn + "> a) { " + inst + "::run(a); }\n";
     const Entry e = get_or_compile("dev" + std::to_string(dev) + ":" + inst, src, inst);
     if (e.failed) return NDFFT_ERR_UNSUPPORTED;
-    const size_t lds = jit_fourstep_lds(dtype, cfg, lpb, pass);
+    const size_t lds = jit_fourstep_lds(dtype, cfg, lpb, pass);      // (real pass 1: the lane region of F complex = the raw real lane; no POST table with ROWOUT)
     const int64_t nblk = (a.nlanes + lpb - 1) / lpb;
     if (nblk <= 0) return NDFFT_OK;
     if (nblk > 0x7fffffffLL) return NDFFT_ERR_UNSUPPORTED;

@@ -426,8 +426,44 @@ static void add_real_fourstep(ndfft_plan *p) {
     // route's four (PRE, two four-step passes, POST)
     if (p->kind == NDFFT_KIND_DCT && p->has_cfg[CFG_DCT1] && p->n >= 2) add_real_fourstep_slot(p, p->cfg[CFG_DCT1], 2 * (p->n - 1), true);
 }
+// ... and for a smooth lane length that is NOT a power of two (round 6), forward ops only (R2C, DCT-II, DCT-I): n = N1 N2 with N1 and N2 even (the real FFT over n1 runs
+// through a complex FFT of N1 / 2; pass 2 splits the mirrored half of its outputs at N2 / 2), each factor a power of two with ahead-of-time passes or a smooth length
+// whose pass can be specialised with hiprtc (jit.hip); the most square such pair.  The inverse ops keep the packed route there.
+static bool add_real_fourstep_smooth(ndfft_plan *p, FftConfig &c, size_t n, bool dct1) {
+    if (n % 4 || n > ((size_t)1 << 24) || !NDFFT_DEV_INT("NDFFT_RFS_SMOOTH", 1)) return false;
+    { size_t m = n; for (int q : {2, 3, 5, 7, 11, 13}) while (m % q == 0) m /= q; if (m != 1) return false; }
+    auto aot = [](size_t f) { return f == 64 || f == 128 || f == 256 || f == 512 || f == 1024; };
+    auto ok1 = [&](size_t N1) { JitCfg t; return N1 % 2 == 0 && (aot(N1 / 2) || (N1 / 2 >= 48 && N1 / 2 <= 2048 && jit_choose_real(p->dtype, (int)(N1 / 2), t) && t.e <= (p->dtype == NDFFT_F32 ? 32 : 24))); };
+    auto ok2 = [&](size_t N2) { JitCfg t; return N2 % 2 == 0 && (aot(N2) || jit_fourstep_choose(p->dtype, (int)N2, t)); };
+    size_t best1 = 0, best2 = 0; double bestd = 1e30;
+    for (size_t N2 = 64; N2 <= 2048 && N2 * 64 <= n; N2 += 2) {
+        if (n % N2) continue;
+        const size_t N1 = n / N2;
+        if (N1 < 128 || N1 > 4096 || !ok2(N2) || !ok1(N1)) continue;
+        // f64: pass 2 of a power-of-two N2 is the lane-fastest kernel (col_direct.h), of any other N2 the staged column kernel -- measured nddct2 85 x 196608 f64 191 us as 512 x 384
+        // against 144 us for 102 x 163840 as 320 x 512: a power-of-two N2 is worth a less square split
+        const double dd = std::fabs(std::log((double)N1 / (double)N2)) + ((p->dtype == NDFFT_F64 && !aot(N2)) ? 0.7 : 0.0) + (!aot(N1 / 2) ? 0.1 : 0.0);
+        if (dd < bestd) { bestd = dd; best1 = N1; best2 = N2; }
+    }
+    if (!best1) return false;
+    int e = 0; while (((size_t)1 << e) < n) ++e;
+    c.rfs_ops = dct1 ? 16 : (1 | 4);
+    c.rfs = true; c.rfs_N1 = (int)best1; c.rfs_N2 = (int)best2;
+    c.rfs_sub1 = make_plan(NDFFT_KIND_R2C, p->dtype, best1);
+    c.rfs_sub2 = make_plan(NDFFT_KIND_C2C, p->dtype, best2);
+    c.rfs_logB = (e + 1) / 2;
+    const int64_t B = 1ll << c.rfs_logB;
+    for (int64_t k = 0; k < B && k < (int64_t)n; ++k) unit(c.rfs_twlo, k, n);
+    for (int64_t k = 0; k * B < (int64_t)n; ++k) unit(c.rfs_twhi, k * B, n);
+    if (p->kind == NDFFT_KIND_DCT && !dct1) {
+        for (int k1 = 0; k1 <= c.rfs_N1; ++k1) unit(c.rfs_c1, (unsigned long long)k1, 4ull * n);
+        for (int r = 0; r < c.rfs_N2; ++r) unit(c.rfs_c2, (unsigned long long)r, 4ull * (unsigned long long)c.rfs_N2);
+    }
+    return true;
+}
 static void add_real_fourstep_slot(ndfft_plan *p, FftConfig &c, size_t n, bool dct1) {
-    if (n == 0 || (n & (n - 1)) || !c.big || c.bigblue) return;
+    if (n == 0 || !c.big || c.bigblue) return;
+    if (n & (n - 1)) { (void)add_real_fourstep_smooth(p, c, n, dct1); return; }
     int e = 0; while (((size_t)1 << e) < n) ++e;
     // The split and the ops that take this route, from the sweep over n = 2^16..2^21 at 2^24 points per array (profiles/r06/r06l_*, r06m_*):
     //   f64: N1 = 2^ceil(e/2), but N1 = 2048 rather than N2 = 1024 at e = 20; faster than the packed route for every op and length (1.02-1.7 x)
