@@ -348,6 +348,17 @@ def table(a):
         xh = torch.from_numpy(synth.complex_array((64, (1 << 17) + 1))).to(dev); hr = R2cFftHandler(1 << 18)
         run("long ndfft_r2c axis=1 64x262144 f64", ndfft_r2c, x, xh, hr, 1, (x.numel() + 2 * xh.numel()) // 2, max(a.steps // 3, 3))
         run("long ndifft_r2c axis=1 64x262144 f64", ndifft_r2c, xh, y, hr, 1, (x.numel() + 2 * xh.numel()) // 2, max(a.steps // 3, 3))
+        del x, y, xh
+        # smooth lane lengths that are NOT powers of two (round 6: two passes on hiprtc-specialised four-step kernels; the six-pass transpose route before)
+        for n, rows in ((196608, 85), (1000000, 16)):
+            x = torch.from_numpy(synth.complex_array((rows, n))).to(dev); y = torch.empty_like(x)
+            run(f"long-smooth ndfft axis=1 {rows}x{n} complex128", ndfft, x, y, FftHandler(n), 1, x.numel(), max(a.steps // 3, 3))
+            del x, y
+        x = torch.from_numpy(synth.real_array((85, 196608))).to(dev); y = torch.empty_like(x)
+        run("long-smooth nddct2 axis=1 85x196608 f64", nddct2, x, y, DctHandler(196608), 1, x.numel(), max(a.steps // 3, 3))
+        run("long-smooth nddct3 axis=1 85x196608 f64", nddct3, x, y, DctHandler(196608), 1, x.numel(), max(a.steps // 3, 3))
+        xh = torch.empty((85, 196608 // 2 + 1), dtype=torch.complex128, device=dev)
+        run("long-smooth ndfft_r2c axis=1 85x196608 f64", ndfft_r2c, x, xh, R2cFftHandler(196608), 1, (x.numel() + 2 * xh.numel()) // 2, max(a.steps // 3, 3))
     if a.only == "radercol":
         x = torch.from_numpy(synth.real_array((512, 256 * 256))).to(dev); y = torch.empty_like(x)
         run("nddct1 axis=0 512x65536 f64", nddct1, x, y, DctHandler(512), 0, x.numel(), a.steps)
