@@ -39,7 +39,7 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, int MODE> st
     // thread gathered 2 x E table entries of its own (16 scattered 16-byte loads per thread beside 8 loads of data: 38-54 vector loads per wave, SQ counters in
     // profiles/r09/r09f_sq_long_round5_kernels.json); the number of complex multiplies per element is unchanged (two).
     static constexpr bool TWIDDLED = MODE >= 4;
-    static_assert(!TWIDDLED || TPL >= E, "one thread row per step twiddle");
+    static constexpr int NSTEP = (E + TPL - 1) / TPL;      // step twiddles per thread row: 1 for every ahead-of-time recipe (TPL >= E), more for hiprtc recipes with E > TPL
     static constexpr size_t STEP_BYTES = TWIDDLED ? (size_t)E * LPB * 2 * sizeof(T) : 0;
     static constexpr size_t LDS_BYTES = FFT::LDS_BYTES + STEP_BYTES;
     static __device__ __forceinline__ cpx<T> tw_at(const RealArgs<T> &a, int m) { return cmul(a.cs_twhi[m >> a.cs_logB], a.cs_twlo[m & ((1 << a.cs_logB) - 1)]); }
@@ -53,9 +53,10 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, int MODE> st
         const T hs = (T)0.5 * a.scale;
         // the store twiddles' table entries: issued in front of the data loads (older loads return first), combined behind them
         const int k1s = live ? k1 : 0;
-        cpx<T> s_hi = mk<T>((T)1, (T)0), s_lo = s_hi;
+        cpx<T> s_hi[NSTEP], s_lo[NSTEP];
         const int mask = (1 << a.cs_logB) - 1;
-        if (t < E) { const int m = ((t / RL_) * TPL + (t % RL_) * NBL) * k1s; s_hi = a.cs_twhi[m >> a.cs_logB]; s_lo = a.cs_twlo[m & mask]; }
+#pragma unroll
+        for (int i = 0; i < NSTEP; ++i) { const int e = t + i * TPL; if (e < E) { const int m = ((e / RL_) * TPL + (e % RL_) * NBL) * k1s; s_hi[i] = a.cs_twhi[m >> a.cs_logB]; s_lo[i] = a.cs_twlo[m & mask]; } }
         const int mb = t * k1s;
         const cpx<T> b_hi = a.cs_twhi[mb >> a.cs_logB], b_lo = a.cs_twlo[mb & mask];
 #pragma unroll
@@ -82,7 +83,8 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, int MODE> st
                 }
                 v[q * R0 + r] = x;
             }
-        if (t < E) stepl[t * LPB + cl] = cmul(s_hi, s_lo);
+#pragma unroll
+        for (int i = 0; i < NSTEP; ++i) { const int e = t + i * TPL; if (e < E) stepl[e * LPB + cl] = cmul(s_hi[i], s_lo[i]); }
         const cpx<T> base = cmul(b_hi, b_lo);
         // (the passes' exchange barriers publish stepl; it lies behind the exchange area and is read only in the store loop)
         FFT::template passes<0>(v, a.twp, lds, t);
@@ -119,10 +121,11 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, int MODE> st
         {
             constexpr int R0 = RL::at(0), NB0 = F / R0, NBF0 = FFT::slots(0);
             // the load twiddles' table entries, in front of the data loads (see TWIDDLED)
-            cpx<T> s_hi = mk<T>((T)1, (T)0), s_lo = s_hi, b_hi = s_hi, b_lo = s_hi;
+            cpx<T> s_hi[NSTEP], s_lo[NSTEP], b_hi = mk<T>((T)1, (T)0), b_lo = b_hi;
             if constexpr (TWIDDLED) {
                 const int k1s = live ? k1 : 0, mask = (1 << a.cs_logB) - 1;
-                if (t < E) { const int m = ((t / R0) * TPL + (t % R0) * NB0) * k1s; s_hi = a.cs_twhi[m >> a.cs_logB]; s_lo = a.cs_twlo[m & mask]; }
+#pragma unroll
+                for (int i = 0; i < NSTEP; ++i) { const int e = t + i * TPL; if (e < E) { const int m = ((e / R0) * TPL + (e % R0) * NB0) * k1s; s_hi[i] = a.cs_twhi[m >> a.cs_logB]; s_lo[i] = a.cs_twlo[m & mask]; } }
                 const int mb = t * k1s;
                 b_hi = a.cs_twhi[mb >> a.cs_logB]; b_lo = a.cs_twlo[mb & mask];
             }
@@ -140,7 +143,8 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, int MODE> st
                 for (int i = 0; i < E; ++i) v[i].y = -v[i].y;
             }
             if constexpr (TWIDDLED) {   // W_N^(i k1), after the conjugation: the same table serves both directions
-                if (t < E) stepl[t * LPB + cl] = cmul(s_hi, s_lo);
+#pragma unroll
+                for (int i = 0; i < NSTEP; ++i) { const int e = t + i * TPL; if (e < E) stepl[e * LPB + cl] = cmul(s_hi[i], s_lo[i]); }
                 __syncthreads();
                 const cpx<T> base = cmul(b_hi, b_lo);
 #pragma unroll

@@ -242,7 +242,8 @@ template <typename T> int launch_colsplit(int cs, bool inverse, const RealArgs<T
 // kernels_fourstep.hip : the two passes of the row four-step on the column kernels (no transpose launch)
 bool jit_fourstep_choose(int dtype, int n, JitCfg &cfg);        // plan time: the recipe of those passes for a smooth non-power-of-two factor n (false: none)
 bool jit_fourstep_ok(int dtype, const JitCfg &cfg);
-bool jit_rfs1_ok(int dtype, const JitCfg &cfg);                 // the real four-step's first pass (real FFT of length 2 cfg.n over the strided index) can be specialised with hiprtc             // a smooth non-power-of-two factor whose four-step passes can be specialised with hiprtc (jit.hip)
+bool jit_rfs1_ok(int dtype, const JitCfg &cfg);
+bool jit_rfsi_ok(int dtype, const JitCfg &cfg);                 // ... and the inverse direction's first pass (col_direct.h modes 7 / 8; whole butterfly rounds only)                 // the real four-step's first pass (real FFT of length 2 cfg.n over the strided index) can be specialised with hiprtc             // a smooth non-power-of-two factor whose four-step passes can be specialised with hiprtc (jit.hip)
 template <typename T> int launch_jit_fourstep(int pass, bool inverse, const JitCfg &cfg, const RealArgs<T> &a, hipStream_t s);
 bool fourstep_supported(int F);
 void fourstep_build_wide_twiddles(int F, HostTable &out);       // empty unless F has a wide (E = 16) recipe

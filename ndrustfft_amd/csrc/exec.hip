@@ -734,6 +734,14 @@ static int real_fourstep_inv(const Problem &P, int gop, const FftConfig &c, cons
     const int64_t n = (int64_t)N1 * N2, B = P.nlanes;
     const DevTables *dt2;
     int rc;
+    // (round 6: N2 not a power of two -> pass 1 on the hiprtc form of the lane-fastest kernel; N1 / 2 not a power of two -> pass 2 through dispatch(): the general column C2R kernel, hiprtc too)
+    const int dti = sizeof(T) == 8 ? NDFFT_F64 : NDFFT_F32;
+    const FftConfig &rc2 = c.rfs_sub2->cfg[CFG_MAIN];
+    const bool jit2 = !fourstep_supported(N2), aot1 = fourstep_supported(N1 / 2);
+    if (jit2 && !(rc2.fs_jit && jit_rfsi_ok(dti, rc2.fs_jitcfg))) return NDFFT_ERR_UNSUPPORTED;
+    // DCT-III writes its outputs through the inverse of Makhoul's permutation in the LAST pass: only the column-tile kernels do that (RealArgs::makhoul), and dispatch() may
+    // pick another kernel for a length that is not a power of two (a small call runs the generic kernel) -- so DCT-III needs the ahead-of-time last pass
+    if (gop == G_DCT3_EVEN && !aot1) return NDFFT_ERR_UNSUPPORTED;
     if ((rc = get_dev_tables(c.rfs_sub2, &dt2))) return rc;
     void *s1;
     // (no pitch padding here: with + 128 B per row ndifft_r2c 64 x 262144 f64 measured 112 -> 118 us, nddct3 unchanged -- profiles/r08/r08k_longlanes_pad.txt)
@@ -746,15 +754,15 @@ static int real_fourstep_inv(const Problem &P, int gop, const FftConfig &c, cons
     a.cs_k1n = Kx; a.cs_f1 = N1; a.cs_n = (int)n; a.cs_outer_in = 0; a.cs_outer_out = 0; a.cs_pitch = 0;
     a.in = d_in; a.out = s1; a.nlanes = B * Kp; a.n = N2; a.F = N2; a.n_in = N2; a.n_out = N2; a.scale = (T)P.scale;
     a.inner = Kp; a.outer_in = pin; a.outer_out = 0; a.elem_in = N1; a.elem_out = 0; a.pitch_out = N2p;
-    a.twp = (const cpx<T> *)dt2->cfg[CFG_MAIN].twp_col;
+    a.twp = (const cpx<T> *)(jit2 ? dt2->cfg[CFG_MAIN].twp_fs : dt2->cfg[CFG_MAIN].twp_col);
     // runs of consecutive tiles per XCD: the mirrored index N1 - k1 is shifted by one element against the tile grid (and DCT-III's real rows are
     // half lines), so neighbouring tiles share every line
     a.xcd_chunk = (int)NDFFT_DEV_INT("NDFFT_RFS_XCD_CHUNK", 8);
     a.stream_in = (int)NDFFT_DEV_INT("NDFFT_RFSI_P1_NT", 0);      // (measured: ndifft_r2c re-read 112 -> 125 us with streaming loads of the half spectrum: off)
     if (gop == G_DCT3_EVEN && NDFFT_DEV_INT("NDFFT_RFS_FACTORED", 1)) { a.fc1 = (const cpx<T> *)d.rfs_c1; a.fc2 = (const cpx<T> *)d.rfs_c2; }
-    if ((rc = launch_fourstep_real<T>(gop == G_DCT3_EVEN ? 5 : 4, N2, a, stream))) return rc;
+    if ((rc = jit2 ? launch_jit_fourstep<T>(gop == G_DCT3_EVEN ? 15 : 14, false, rc2.fs_jitcfg, a, stream) : launch_fourstep_real<T>(gop == G_DCT3_EVEN ? 5 : 4, N2, a, stream))) return rc;
     a.stream_in = 0;
-    if (sw().rfs_c2r_tile) {   // the column C2R kernel on 128-byte tiles (0: the general column kernel through dispatch())
+    if (sw().rfs_c2r_tile && aot1) {   // the column C2R kernel on 128-byte tiles (0: the general column kernel through dispatch())
         const DevTables *dt1;
         if ((rc = get_dev_tables(c.rfs_sub1, &dt1))) return rc;
         a.xcd_chunk = 0; a.keep_out = 0;
@@ -822,7 +830,7 @@ static int dispatch_big(const Problem &P, const void *d_in, void *d_out, const D
     }
     // (a plan whose factors are not powers of two has the forward ops only, and its passes need hiprtc: NDFFT_ERR_UNSUPPORTED from real_fourstep = nothing launched, packed route below)
     const bool rfs_smooth = c.rfs && (((c.rfs_N1 & (c.rfs_N1 - 1)) != 0) || ((c.rfs_N2 & (c.rfs_N2 - 1)) != 0));
-    const int rfs_on = real_fourstep_enabled(), rfs_ops = (rfs_on == 2 ? (c.rfs_ops & 16 ? 16 : 15) : (rfs_on ? c.rfs_ops : 0)) & (rfs_smooth ? (c.rfs_ops & (1 | 4 | 16)) : 31);
+    const int rfs_on = real_fourstep_enabled(), rfs_ops = (rfs_on == 2 ? (c.rfs_ops & 16 ? 16 : 15) : (rfs_on ? c.rfs_ops : 0)) & (rfs_smooth ? c.rfs_ops : 31);
     if (c.rfs && gop == G_DCT1 && (rfs_ops & 16)) {
         const int rc0 = real_fourstep<T>(P, gop, c, d, d_in, d_out, pin, pout, stream);
         if (!(rfs_smooth && rc0 == NDFFT_ERR_UNSUPPORTED)) { set_last_path("real_four_step"); return rc0; }
@@ -839,8 +847,7 @@ static int dispatch_big(const Problem &P, const void *d_in, void *d_out, const D
     }
     if (c.rfs && ((gop == G_C2R_EVEN && (rfs_ops & 2)) || (gop == G_DCT3_EVEN && (rfs_ops & 8)))) {
         const int rc0 = real_fourstep_inv<T>(P, gop, c, d, d_in, d_out, pin, pout, stream);
-        set_last_path("real_four_step");
-        return rc0;
+        if (!(rfs_smooth && rc0 == NDFFT_ERR_UNSUPPORTED)) { set_last_path("real_four_step"); return rc0; }
     }
     RealArgs<T> a;
     a.in = d_in; a.out = d_out; a.nlanes = P.nlanes; a.pitch_in = pin; a.pitch_out = pout;

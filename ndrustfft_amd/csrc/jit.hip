@@ -25,6 +25,10 @@
 #include "engine.h"
 #include "pow2_real.h"
 #include "jit_sources.inc"
+// the kernel headers embedded for hiprtc (Makefile: _build/jit_sources.inc), in one place: names as the kernels #include them, and their text
+static const char *const kJitHdrNames[] = {"device_common.h", "butterflies.h", "pow2_kernel.h", "realops.h", "pow2_real.h", "blue_kernel.h", "reg_kernel.h", "rader_kernel.h", "plain_kernel.h", "col_direct.h"};
+static const char *const kJitHdrSrc[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h, jit_src_realops_h, jit_src_pow2_real_h, jit_src_blue_kernel_h, jit_src_reg_kernel_h, jit_src_rader_kernel_h, jit_src_plain_kernel_h, jit_src_col_direct_h};
+static constexpr int kNJitHdr = 10;
 
 namespace ndfft {
 
@@ -323,10 +327,9 @@ static void dump_source(const std::string &src) {
 // compiles `src` with hiprtc (no device needed); returns the code object, empty on failure
 static std::string rtc_compile(const std::string &src, const std::string &what) {
     Rtc &r = rtc();
-    const char *hn[] = {"device_common.h", "butterflies.h", "pow2_kernel.h", "realops.h", "pow2_real.h", "blue_kernel.h", "reg_kernel.h", "rader_kernel.h", "plain_kernel.h"};
-    const char *hs[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h, jit_src_realops_h, jit_src_pow2_real_h, jit_src_blue_kernel_h, jit_src_reg_kernel_h, jit_src_rader_kernel_h, jit_src_plain_kernel_h};
+    const char **hn = (const char **)kJitHdrNames, **hs = (const char **)kJitHdrSrc;
     rtcProgram prog = nullptr;
-    bool ok = r.ok && r.create(&prog, src.c_str(), "k_jit.hip", 9, hs, hn) == 0;
+    bool ok = r.ok && r.create(&prog, src.c_str(), "k_jit.hip", kNJitHdr, hs, hn) == 0;
     if (ok) {
         ok = r.compile(prog, 4, (const char **)kJitOpts) == 0;
         if (!ok && sw().jit_verbose) {
@@ -347,15 +350,15 @@ static Entry compile_entry(const std::string &src, const std::string &what) {
     Entry ne;
     dump_source(src);
     {   // a code object compiled by an earlier process?
-        const char *hs0[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h, jit_src_realops_h, jit_src_pow2_real_h, jit_src_blue_kernel_h, jit_src_reg_kernel_h, jit_src_rader_kernel_h, jit_src_plain_kernel_h};
-        const std::string path = cache_path(src, hs0, 9);
+        const char *const *hs0 = kJitHdrSrc;
+        const std::string path = cache_path(src, hs0, kNJitHdr);
         std::string code;
         if (!path.empty() && read_file(path, code) && hipModuleLoadData(&ne.mod, code.data()) == hipSuccess &&
             hipModuleGetFunction(&ne.fn, ne.mod, "k_jit") == hipSuccess)
             return ne;
         (void)hipGetLastError();
         ne = Entry();
-        const std::string pre = prebuilt_path(cache_name(src, hs0, 9));    // shipped with the library
+        const std::string pre = prebuilt_path(cache_name(src, hs0, kNJitHdr));    // shipped with the library
         if (!pre.empty() && read_file(pre, code) && hipModuleLoadData(&ne.mod, code.data()) == hipSuccess &&
             hipModuleGetFunction(&ne.fn, ne.mod, "k_jit") == hipSuccess)
             return ne;
@@ -363,7 +366,7 @@ static Entry compile_entry(const std::string &src, const std::string &what) {
         ne = Entry();
         if (sw().jit == 2) { ne.failed = true; return ne; }      // NDFFT_JIT=cached: cached / prebuilt code objects only
     }
-    const char *hs[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h, jit_src_realops_h, jit_src_pow2_real_h, jit_src_blue_kernel_h, jit_src_reg_kernel_h, jit_src_rader_kernel_h, jit_src_plain_kernel_h};
+    const char *const *hs = kJitHdrSrc;
     const std::string code = rtc_compile(src, what);
     bool ok = !code.empty();
     if (ok) {
@@ -374,7 +377,7 @@ static Entry compile_entry(const std::string &src, const std::string &what) {
     } else if (sw().jit_verbose) {
         fprintf(stderr, "ndfft jit: no code object for %s (hiprtc %s)\n", what.c_str(), r.ok ? "present" : "missing");
     }
-    if (ok) { const std::string path = cache_path(src, hs, 9); if (!path.empty()) write_file_atomic(path, code); }
+    if (ok) { const std::string path = cache_path(src, hs, kNJitHdr); if (!path.empty()) write_file_atomic(path, code); }
     if (!ok) { (void)hipGetLastError(); ne.failed = true; }
     return ne;
 }
@@ -650,8 +653,43 @@ bool jit_rfs1_ok(int dtype, const JitCfg &cfg) {
     if (!rtc().ok || jit_disabled() || !NDFFT_DEV_INT("NDFFT_JIT_FOURSTEP", 1)) return false;
     return cfg.n >= 16 && cfg.tpl >= 1 && !cfg.radix.empty() && jit_rfs1_lanes(dtype, cfg) > 0;
 }
-// kind: 1 = complex pass 1 (ROWOUT), 2 = complex pass 2 (CS 4), 11 = real pass 1 (R2C, ROWOUT), 12 / 13 = real pass 2 (CS 5: R2C / DCT-I, CS 6: DCT-II)
+// the first pass of the INVERSE real four-step (col_direct.h modes 7 / 8: C2R, DCT-III) for a complex length cfg.n that is not a power of two: the lane-fastest kernel, whole rounds only
+static size_t jit_rfsi_lds(int dtype, const JitCfg &cfg, int lpb) {
+    const size_t rsz = dtype == NDFFT_F32 ? 4 : 8;
+    return (size_t)lpb * (size_t)(cfg.n + (cfg.n >> NDFFT_PHI_SHIFT) + 1) * rsz + (size_t)cfg.e * lpb * 2 * rsz;      // ColDirectKernel::LDS_BYTES: half exchange + step twiddles
+}
+bool jit_rfsi_ok(int dtype, const JitCfg &cfg) {
+    if (!rtc().ok || jit_disabled() || !NDFFT_DEV_INT("NDFFT_JIT_FOURSTEP", 1)) return false;
+    if (cfg.n < 16 || cfg.tpl < 1 || cfg.radix.empty() || cfg.partial || cfg.e * cfg.tpl != cfg.n) return false;
+    const int lpb = jit_fourstep_lanes(dtype, cfg);
+    return lpb > 0 && jit_rfsi_lds(dtype, cfg, lpb) <= jit_lds_limit();
+}
+template <typename T> static int launch_jit_rfsi(int mode, const JitCfg &cfg, const RealArgs<T> &a, hipStream_t s) {
+    const int dtype = sizeof(T) == 4 ? NDFFT_F32 : NDFFT_F64;
+    if (!jit_rfsi_ok(dtype, cfg)) return NDFFT_ERR_UNSUPPORTED;
+    const int lpb = jit_fourstep_lanes(dtype, cfg), threads = cfg.tpl * lpb;
+    int dev = 0;
+    NDFFT_HIP(hipGetDevice(&dev));
+    const char *tn = sizeof(T) == 4 ? "float" : "double";
+    const std::string inst = std::string("ColDirectKernel<") + tn + ", " + std::to_string(cfg.n) + ", " + std::to_string(cfg.tpl) + ", " + std::to_string(lpb) + ", RadixList<" + radix_list(cfg) + ">, " +
+                             std::to_string(G_C2C_FWD) + ", " + std::to_string(mode) + ">";
+    const std::string src = std::string("#include \"col_direct.h\"\nusing namespace ndfft;\nextern \"C\" __global__ __launch_bounds__(") + std::to_string(threads) +
+                            ") void k_jit(const RealArgs<" + tn + "> a) { " + inst + "::run(a); }\n";
+    const Entry e = get_or_compile("dev" + std::to_string(dev) + ":" + inst, src, inst);
+    if (e.failed) return NDFFT_ERR_UNSUPPORTED;
+    const size_t lds = jit_rfsi_lds(dtype, cfg, lpb);
+    const int64_t nblk = (a.nlanes + lpb - 1) / lpb;
+    if (nblk <= 0) return NDFFT_OK;
+    if (nblk > 0x7fffffffLL) return NDFFT_ERR_UNSUPPORTED;
+    RealArgs<T> arg = a;
+    void *params[] = {(void *)&arg};
+    NDFFT_HIP(hipModuleLaunchKernel(e.fn, (unsigned)nblk, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, s, params, nullptr));
+    return NDFFT_OK;
+}
+// kind: 1 = complex pass 1 (ROWOUT), 2 = complex pass 2 (CS 4), 11 = real pass 1 (R2C, ROWOUT), 12 / 13 = real pass 2 (CS 5: R2C / DCT-I, CS 6: DCT-II),
+//       14 / 15 = inverse real pass 1 (col_direct.h modes 7 / 8: C2R / DCT-III)
 template <typename T> int launch_jit_fourstep(int kind, bool inverse, const JitCfg &cfg, const RealArgs<T> &a, hipStream_t s) {
+    if (kind == 14 || kind == 15) return launch_jit_rfsi<T>(kind == 14 ? 7 : 8, cfg, a, s);
     const int dtype = sizeof(T) == 4 ? NDFFT_F32 : NDFFT_F64;
     const bool real1 = kind == 11;
     if (real1 ? !jit_rfs1_ok(dtype, cfg) : !jit_fourstep_ok(dtype, cfg)) return NDFFT_ERR_UNSUPPORTED;
@@ -1020,7 +1058,7 @@ int jit_prebuild(const char *manifest, const char *out_dir, int first, int strid
     if (!manifest || !out_dir || !read_file(manifest, all)) return fail(NDFFT_ERR_INVALID_ARG, "ndfft_jit_prebuild: cannot read the manifest");
     if (!rtc().ok) return fail(NDFFT_ERR_UNSUPPORTED, "ndfft_jit_prebuild: libhiprtc not available");
     if (mkdir(out_dir, 0755) != 0 && errno != EEXIST) return fail(NDFFT_ERR_INVALID_ARG, "ndfft_jit_prebuild: cannot create the output directory");
-    const char *hs[] = {jit_src_device_common_h, jit_src_butterflies_h, jit_src_pow2_kernel_h, jit_src_realops_h, jit_src_pow2_real_h, jit_src_blue_kernel_h, jit_src_reg_kernel_h, jit_src_rader_kernel_h, jit_src_plain_kernel_h};
+    const char *const *hs = kJitHdrSrc;
     const std::string sep(kManifestSep);
     std::vector<std::string> srcs;
     for (size_t pos = 0; pos < all.size();) {
@@ -1032,7 +1070,7 @@ int jit_prebuild(const char *manifest, const char *out_dir, int first, int strid
     }
     if (stride < 1) stride = 1;
     for (size_t i = first < 0 ? 0 : (size_t)first; i < srcs.size(); i += (size_t)stride) {
-        const std::string path = std::string(out_dir) + cache_name(srcs[i], hs, 9);
+        const std::string path = std::string(out_dir) + cache_name(srcs[i], hs, kNJitHdr);
         std::string have;
         if (read_file(path, have)) { (void)utime(path.c_str(), nullptr); ++*present; continue; }   // (touched: the caller removes objects older than its pass = of older kernel text)
         const std::string code = rtc_compile(srcs[i], "manifest entry " + std::to_string(i));

@@ -426,7 +426,7 @@ static void add_real_fourstep(ndfft_plan *p) {
     // route's four (PRE, two four-step passes, POST)
     if (p->kind == NDFFT_KIND_DCT && p->has_cfg[CFG_DCT1] && p->n >= 2) add_real_fourstep_slot(p, p->cfg[CFG_DCT1], 2 * (p->n - 1), true);
 }
-// ... and for a smooth lane length that is NOT a power of two (round 6), forward ops only (R2C, DCT-II, DCT-I): n = N1 N2 with N1 and N2 even (the real FFT over n1 runs
+// ... and for a smooth lane length that is NOT a power of two (round 6; R2C, DCT-II, DCT-I, and C2R / DCT-III where N2 allows): n = N1 N2 with N1 and N2 even (the real FFT over n1 runs
 // through a complex FFT of N1 / 2; pass 2 splits the mirrored half of its outputs at N2 / 2), each factor a power of two with ahead-of-time passes or a smooth length
 // whose pass can be specialised with hiprtc (jit.hip); the most square such pair.  The inverse ops keep the packed route there.
 static bool add_real_fourstep_smooth(ndfft_plan *p, FftConfig &c, size_t n, bool dct1) {
@@ -447,7 +447,10 @@ static bool add_real_fourstep_smooth(ndfft_plan *p, FftConfig &c, size_t n, bool
     }
     if (!best1) return false;
     int e = 0; while (((size_t)1 << e) < n) ++e;
-    c.rfs_ops = dct1 ? 16 : (1 | 4);
+    // inverse ops (C2R, DCT-III) too where pass 1 of that direction exists for N2: the lane-fastest kernel, ahead of time for a power of two, hiprtc for a whole-round recipe
+    bool inv_ok = aot(best2);
+    if (!inv_ok) { JitCfg t; inv_ok = jit_fourstep_choose(p->dtype, (int)best2, t) && !t.partial && t.e * t.tpl == (int)best2; }
+    c.rfs_ops = dct1 ? 16 : ((1 | 4) | (inv_ok ? (2 | 8) : 0));
     c.rfs = true; c.rfs_N1 = (int)best1; c.rfs_N2 = (int)best2;
     c.rfs_sub1 = make_plan(NDFFT_KIND_R2C, p->dtype, best1);
     c.rfs_sub2 = make_plan(NDFFT_KIND_C2C, p->dtype, best2);

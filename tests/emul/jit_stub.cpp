@@ -278,7 +278,8 @@ int launch_jit_regreal(int dtype, int gop, int n, int f1, int f2, bool stage, co
 namespace ndfft {
 bool jit_fourstep_ok(int, const JitCfg &) { return false; }
 bool jit_fourstep_choose(int, int, JitCfg &) { return false; }
-bool jit_rfs1_ok(int, const JitCfg &) { return false; }      // (no hiprtc in the emulation: non-power-of-two four-step factors keep the transpose route)
+bool jit_rfs1_ok(int, const JitCfg &) { return false; }
+bool jit_rfsi_ok(int, const JitCfg &) { return false; }      // (no hiprtc in the emulation: non-power-of-two four-step factors keep the transpose route)
 template <typename T> int launch_jit_fourstep(int, bool, const JitCfg &, const RealArgs<T> &, hipStream_t) { return NDFFT_ERR_UNSUPPORTED; }
 template int launch_jit_fourstep<float>(int, bool, const JitCfg &, const RealArgs<float> &, hipStream_t);
 template int launch_jit_fourstep<double>(int, bool, const JitCfg &, const RealArgs<double> &, hipStream_t);

@@ -767,8 +767,8 @@ def long_lanes_four_step(L, full=True):
     smooth_fwd = ("real_four_step", "four_step")
     cases = [("ndfft", (2, 32768), 1, np.float64, "four_step"), ("ndifft", (2, 32768), 1, np.float64, "four_step"),
              ("ndfft", (3, 6000), 1, np.float64, "four_step"), ("ndfft_r2c", (2, 20000), 1, np.float64, smooth_fwd),
-             ("ndifft_r2c", (2, 20000), 1, np.float64, "four_step"), ("nddct2", (2, 12000), 1, np.float64, smooth_fwd),
-             ("nddct3", (2, 12000), 1, np.float64, "four_step"), ("nddct1", (2, 10001), 1, np.float64, smooth_fwd),
+             ("ndifft_r2c", (2, 20000), 1, np.float64, smooth_fwd), ("nddct2", (2, 12000), 1, np.float64, smooth_fwd),
+             ("nddct3", (2, 12000), 1, np.float64, smooth_fwd), ("nddct1", (2, 10001), 1, np.float64, smooth_fwd),
              ("nddct4", (2, 12000), 1, np.float64, "four_step"), ("ndfft", (2, 65536), 1, np.float32, "four_step"),
              ("ndfft", (20000, 3), 0, np.float64, "transpose+four_step"), ("ndfft_r2c", (2, 9999), 1, np.float64, "four_step"),
              ("nddct2", (2, 9999), 1, np.float32, "four_step"),
@@ -781,10 +781,14 @@ def long_lanes_four_step(L, full=True):
                # the forward real ops (R2C, DCT-II, DCT-I with 2 (n - 1) smooth) on the REAL four-step with hiprtc passes
         cases += [("ndfft", (2, 196608), 1, np.float64, "four_step"), ("ndifft", (3, 163840), 1, np.float32, "four_step"), ("ndfft", (2, 200000), 1, np.float64, "four_step"),
                   ("ndifft", (2, 147456), 1, np.float64, "four_step"), ("ndfft", (5, 100000), 1, np.float32, "four_step"), ("nddct2", (2, 196608), 1, np.float64, "real_four_step"),
-                  ("ndfft_r2c", (2, 163840), 1, np.float32, "real_four_step"), ("ndifft_r2c", (2, 200000), 1, np.float64, "four_step"), ("nddct1", (2, 147457), 1, np.float64, "real_four_step"),
-                  ("nddct4", (2, 196608), 1, np.float32, "four_step"), ("nddct3", (2, 120000), 1, np.float64, "four_step"),
+                  ("ndfft_r2c", (2, 163840), 1, np.float32, "real_four_step"), ("ndifft_r2c", (2, 200000), 1, np.float64, smooth_fwd), ("nddct1", (2, 147457), 1, np.float64, "real_four_step"),
+                  ("nddct4", (2, 196608), 1, np.float32, "four_step"), ("nddct3", (2, 120000), 1, np.float64, smooth_fwd),
                   ("ndfft_r2c", (3, 200000), 1, np.float64, "real_four_step"), ("nddct2", (2, 120000), 1, np.float32, "real_four_step"), ("nddct1", (3, 196609), 1, np.float32, "real_four_step"),
                   ("ndfft_r2c", (2, 524160), 1, np.float64, "real_four_step"), ("nddct2", (5, 147456), 1, np.float64, "real_four_step"),
+                  # the inverse direction where the second factor has a power-of-two or whole-round recipe (else the packed route)
+                  ("ndifft_r2c", (2, 196608), 1, np.float64, "real_four_step"), ("nddct3", (3, 163840), 1, np.float32, smooth_fwd), ("ndifft_r2c", (3, 200000), 1, np.float32, smooth_fwd),
+                  ("nddct3", (2, 147456), 1, np.float64, smooth_fwd), ("nddct3", (2, 200000), 1, np.float64, smooth_fwd), ("ndifft_r2c", (2, 524160), 1, np.float64, smooth_fwd),
+                  ("ndifft_r2c", (5, 147456), 1, np.float64, "real_four_step"), ("nddct3", (2, 98304), 1, np.float32, smooth_fwd),
                   # factors without a whole-round recipe (7 / 11 / 13, 675 = 5.5.3.3.3): partial rounds in both passes
                   ("ndfft", (2, 524160), 1, np.float64, "four_step"), ("ndifft", (3, 128700), 1, np.float32, "four_step"), ("ndfft", (2, 394875), 1, np.float64, "four_step"),
                   ("nddct2", (2, 240570), 1, np.float32, "four_step")]
