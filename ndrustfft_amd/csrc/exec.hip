@@ -741,7 +741,9 @@ static int real_fourstep_inv(const Problem &P, int gop, const FftConfig &c, cons
     if (jit2 && !(rc2.fs_jit && jit_rfsi_ok(dti, rc2.fs_jitcfg))) return NDFFT_ERR_UNSUPPORTED;
     // DCT-III writes its outputs through the inverse of Makhoul's permutation in the LAST pass: only the column-tile kernels do that (RealArgs::makhoul), and dispatch() may
     // pick another kernel for a length that is not a power of two (a small call runs the generic kernel) -- so DCT-III needs the ahead-of-time last pass
-    if (gop == G_DCT3_EVEN && !aot1) return NDFFT_ERR_UNSUPPORTED;
+    const FftConfig &rc1 = c.rfs_sub1->cfg[CFG_MAIN];
+    const bool jit_last = gop == G_DCT3_EVEN && !aot1;       // ... or the hiprtc column tile of that length, launched HERE (not through dispatch(), which may pick another kernel for a small call)
+    if (jit_last && !(rc1.jit && jit_col_lanes(dti, rc1.jitcfg, false) > 0)) return NDFFT_ERR_UNSUPPORTED;
     if ((rc = get_dev_tables(c.rfs_sub2, &dt2))) return rc;
     void *s1;
     // (no pitch padding here: with + 128 B per row ndifft_r2c 64 x 262144 f64 measured 112 -> 118 us, nddct3 unchanged -- profiles/r08/r08k_longlanes_pad.txt)
@@ -762,14 +764,15 @@ static int real_fourstep_inv(const Problem &P, int gop, const FftConfig &c, cons
     if (gop == G_DCT3_EVEN && NDFFT_DEV_INT("NDFFT_RFS_FACTORED", 1)) { a.fc1 = (const cpx<T> *)d.rfs_c1; a.fc2 = (const cpx<T> *)d.rfs_c2; }
     if ((rc = jit2 ? launch_jit_fourstep<T>(gop == G_DCT3_EVEN ? 15 : 14, false, rc2.fs_jitcfg, a, stream) : launch_fourstep_real<T>(gop == G_DCT3_EVEN ? 5 : 4, N2, a, stream))) return rc;
     a.stream_in = 0;
-    if (sw().rfs_c2r_tile && aot1) {   // the column C2R kernel on 128-byte tiles (0: the general column kernel through dispatch())
+    if ((sw().rfs_c2r_tile && aot1) || jit_last) {   // the column C2R kernel on 128-byte tiles (0: the general column kernel through dispatch())
         const DevTables *dt1;
         if ((rc = get_dev_tables(c.rfs_sub1, &dt1))) return rc;
-        a.xcd_chunk = 0; a.keep_out = 0;
+        a.xcd_chunk = 0; a.keep_out = 0; a.fc1 = nullptr; a.fc2 = nullptr;
         a.in = s1; a.out = d_out; a.nlanes = B * N2; a.n = N1; a.F = N1 / 2; a.n_in = Kx; a.n_out = N1; a.scale = (T)1;
         a.inner = N2; a.outer_in = (int64_t)Kx * N2p; a.outer_out = pout; a.elem_in = N2p; a.elem_out = N2; a.pitch_in = 0; a.pitch_out = 0;
         a.aux1 = (const cpx<T> *)dt1->cfg[CFG_MAIN].aux1; a.twp = (const cpx<T> *)dt1->cfg[CFG_MAIN].twp;
         a.makhoul = gop == G_DCT3_EVEN ? 1 : 0;
+        if (jit_last) return launch_jit_real<T>(G_C2R_EVEN, rc1.jitcfg, true, a, stream);
         return launch_fourstep_real<T>(7, N1 / 2, a, stream);
     }
     Problem Q;
@@ -783,7 +786,7 @@ static int real_fourstep_inv(const Problem &P, int gop, const FftConfig &c, cons
 // DCT-IV of a long even lane, n = 2 F, F = F1 * F2 powers of two: the complex four-step of length F with the fold z[j] = (x[2j] + i x[n-1-2j]) s w_j built by
 // pass 1's load and the outputs y[2k] = Re(Z[k] c_k), y[n-1-2k] = -Im(Z[k] c_k) written by pass 2's store -- two passes instead of four.
 template <typename T>
-static int dct4_fourstep(const Problem &P, const FftConfig &c, const DevConfig &d, const void *d_in, void *d_out, int64_t pin, int64_t pout, hipStream_t stream) {
+static int dct4_fourstep(const Problem &P, const FftConfig &c, const DevConfig &d, const void *d_in, void *d_out, int64_t pin, int64_t pout, hipStream_t stream, bool jit1 = false, bool jit2 = false) {
     const int F1 = c.F1, F2 = c.F2;
     const int64_t F = (int64_t)F1 * F2, B = P.nlanes;
     const DevTables *dt1, *dt2;
@@ -800,17 +803,18 @@ static int dct4_fourstep(const Problem &P, const FftConfig &c, const DevConfig &
     // pass 1: lanes (l, n2) of the REAL input
     a.in = d_in; a.out = s1; a.nlanes = B * F2; a.n = F1; a.F = F1; a.n_in = F1; a.n_out = F1; a.scale = (T)P.scale;
     a.inner = F2; a.outer_in = pin; a.outer_out = 0; a.elem_in = F2; a.elem_out = 0; a.pitch_out = K1p;
-    a.twp = (const cpx<T> *)dt1->cfg[CFG_MAIN].twp_col; a.makhoul = 2;
+    a.twp = (const cpx<T> *)(jit1 ? dt1->cfg[CFG_MAIN].twp_fs : dt1->cfg[CFG_MAIN].twp_col); a.makhoul = 2;
     // pass 1: streaming loads of the caller's lane, cache-allocating stores of the intermediate (the staged ROWOUT store ignored keep_out until round 5):
     // nddct4 64 x 262144 f64 157.6 -> 153.3 (stores) -> 148-150 us (both)
     a.stream_in = (int)NDFFT_DEV_INT("NDFFT_DCT4_P1_NT", 1); a.keep_out = (int)NDFFT_DEV_INT("NDFFT_DCT4_KEEP", 1);
-    if ((rc = launch_fourstep<T>(1, F1, false, a, stream))) return rc;
+    if ((rc = jit1 ? launch_jit_fourstep<T>(1, false, c.sub1->cfg[CFG_MAIN].fs_jitcfg, a, stream) : launch_fourstep<T>(1, F1, false, a, stream))) return rc;
     a.stream_in = 0;
     // pass 2: lanes (l, k1), real output
     a.makhoul = 0; a.keep_out = 0;
     a.in = s1; a.out = d_out; a.nlanes = B * F1; a.n = F2; a.F = F2; a.n_in = F2; a.n_out = F2; a.scale = (T)1;
     a.inner = F1; a.outer_in = (int64_t)F2 * K1p; a.outer_out = pout; a.elem_in = K1p; a.elem_out = 0; a.pitch_out = 0;
-    a.twp = (const cpx<T> *)dt2->cfg[CFG_MAIN].twp_col;
+    a.twp = (const cpx<T> *)(jit2 ? dt2->cfg[CFG_MAIN].twp_fs : dt2->cfg[CFG_MAIN].twp_col);
+    if (jit2) return launch_jit_fourstep<T>(16, false, c.sub2->cfg[CFG_MAIN].fs_jitcfg, a, stream);
     return launch_fourstep_real<T>(6, F2, a, stream);
 }
 
@@ -839,9 +843,12 @@ static int dispatch_big(const Problem &P, const void *d_in, void *d_out, const D
         const int rc0 = real_fourstep<T>(P, gop, c, d, d_in, d_out, pin, pout, stream);
         if (!(rfs_smooth && rc0 == NDFFT_ERR_UNSUPPORTED)) { set_last_path("real_four_step"); return rc0; }
     }
-    if (gop == G_DCT4_EVEN && rfs_on && c.big && !c.bigblue && fourstep_supported(c.F1) && fourstep_supported(c.F2) && !c.sub1->cfg[CFG_MAIN].twp_col.re.empty() &&
-        !c.sub2->cfg[CFG_MAIN].twp_col.re.empty() && fourstep2_enabled()) {
-        const int rc0 = dct4_fourstep<T>(P, c, d, d_in, d_out, pin, pout, stream);
+    // (round 6: a factor that is not a power of two on the hiprtc forms of the same two kernels -- pass 1 the staged ROWOUT kernel, pass 2 the lane-fastest one, whole rounds)
+    const int dti4 = sizeof(T) == 8 ? NDFFT_F64 : NDFFT_F32;
+    auto d4_kind1 = [&]() { const FftConfig &s1c = c.sub1->cfg[CFG_MAIN]; return (fourstep_supported(c.F1) && !s1c.twp_col.re.empty()) ? 1 : (s1c.fs_jit && jit_fourstep_ok(dti4, s1c.fs_jitcfg)) ? 2 : 0; };
+    auto d4_kind2 = [&]() { const FftConfig &s2c = c.sub2->cfg[CFG_MAIN]; return (fourstep_supported(c.F2) && !s2c.twp_col.re.empty()) ? 1 : (s2c.fs_jit && jit_rfsi_ok(dti4, s2c.fs_jitcfg)) ? 2 : 0; };
+    if (gop == G_DCT4_EVEN && rfs_on && c.big && !c.bigblue && fourstep2_enabled() && d4_kind1() && d4_kind2()) {
+        const int rc0 = dct4_fourstep<T>(P, c, d, d_in, d_out, pin, pout, stream, d4_kind1() == 2, d4_kind2() == 2);
         set_last_path("real_four_step");
         return rc0;
     }

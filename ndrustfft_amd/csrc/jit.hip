@@ -689,7 +689,7 @@ template <typename T> static int launch_jit_rfsi(int mode, const JitCfg &cfg, co
 // kind: 1 = complex pass 1 (ROWOUT), 2 = complex pass 2 (CS 4), 11 = real pass 1 (R2C, ROWOUT), 12 / 13 = real pass 2 (CS 5: R2C / DCT-I, CS 6: DCT-II),
 //       14 / 15 = inverse real pass 1 (col_direct.h modes 7 / 8: C2R / DCT-III)
 template <typename T> int launch_jit_fourstep(int kind, bool inverse, const JitCfg &cfg, const RealArgs<T> &a, hipStream_t s) {
-    if (kind == 14 || kind == 15) return launch_jit_rfsi<T>(kind == 14 ? 7 : 8, cfg, a, s);
+    if (kind == 14 || kind == 15 || kind == 16) return launch_jit_rfsi<T>(kind == 14 ? 7 : kind == 15 ? 8 : 9, cfg, a, s);      // (16: second pass of the fused DCT-IV four-step, mode 9)
     const int dtype = sizeof(T) == 4 ? NDFFT_F32 : NDFFT_F64;
     const bool real1 = kind == 11;
     if (real1 ? !jit_rfs1_ok(dtype, cfg) : !jit_fourstep_ok(dtype, cfg)) return NDFFT_ERR_UNSUPPORTED;

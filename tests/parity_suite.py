@@ -769,7 +769,7 @@ def long_lanes_four_step(L, full=True):
              ("ndfft", (3, 6000), 1, np.float64, "four_step"), ("ndfft_r2c", (2, 20000), 1, np.float64, smooth_fwd),
              ("ndifft_r2c", (2, 20000), 1, np.float64, smooth_fwd), ("nddct2", (2, 12000), 1, np.float64, smooth_fwd),
              ("nddct3", (2, 12000), 1, np.float64, smooth_fwd), ("nddct1", (2, 10001), 1, np.float64, smooth_fwd),
-             ("nddct4", (2, 12000), 1, np.float64, "four_step"), ("ndfft", (2, 65536), 1, np.float32, "four_step"),
+             ("nddct4", (2, 12000), 1, np.float64, smooth_fwd), ("ndfft", (2, 65536), 1, np.float32, "four_step"),
              ("ndfft", (20000, 3), 0, np.float64, "transpose+four_step"), ("ndfft_r2c", (2, 9999), 1, np.float64, "four_step"),
              ("nddct2", (2, 9999), 1, np.float32, "four_step"),
              # R2C without its PRE pass / C2R without its POST pass (the real lane addressed as complex), two-pass power-of-two route
@@ -782,7 +782,8 @@ def long_lanes_four_step(L, full=True):
         cases += [("ndfft", (2, 196608), 1, np.float64, "four_step"), ("ndifft", (3, 163840), 1, np.float32, "four_step"), ("ndfft", (2, 200000), 1, np.float64, "four_step"),
                   ("ndifft", (2, 147456), 1, np.float64, "four_step"), ("ndfft", (5, 100000), 1, np.float32, "four_step"), ("nddct2", (2, 196608), 1, np.float64, "real_four_step"),
                   ("ndfft_r2c", (2, 163840), 1, np.float32, "real_four_step"), ("ndifft_r2c", (2, 200000), 1, np.float64, smooth_fwd), ("nddct1", (2, 147457), 1, np.float64, "real_four_step"),
-                  ("nddct4", (2, 196608), 1, np.float32, "four_step"), ("nddct3", (2, 120000), 1, np.float64, smooth_fwd),
+                  ("nddct4", (2, 196608), 1, np.float32, smooth_fwd), ("nddct3", (2, 120000), 1, np.float64, smooth_fwd),
+                  ("nddct4", (3, 163840), 1, np.float64, "real_four_step"), ("nddct4", (2, 200000), 1, np.float64, smooth_fwd), ("nddct4", (2, 524160), 1, np.float32, smooth_fwd),
                   ("ndfft_r2c", (3, 200000), 1, np.float64, "real_four_step"), ("nddct2", (2, 120000), 1, np.float32, "real_four_step"), ("nddct1", (3, 196609), 1, np.float32, "real_four_step"),
                   ("ndfft_r2c", (2, 524160), 1, np.float64, "real_four_step"), ("nddct2", (5, 147456), 1, np.float64, "real_four_step"),
                   # the inverse direction where the second factor has a power-of-two or whole-round recipe (else the packed route)
