@@ -108,6 +108,12 @@ def test_recipes_are_self_consistent(lib, dtype):
     assert {"rader", "jit", "pow2", "four_step"} <= seen, seen
     # a long smooth lane whose factors are not powers of two plans the two-pass form with hiprtc passes
     assert "jit_passes=2" in lib.explain_plan(_lib.KIND_C2C, dtype, 196608) and "jit_passes=12" in lib.explain_plan(_lib.KIND_C2C, dtype, 200000)
+    # ... and its real ops plan the real four-step on even factors N1 x N2 = n (f64: biased to a power-of-two N2); odd lengths and lengths not divisible by 4 do not
+    m = re.search(r"real_four_step=(\d+)x(\d+) ops=(\d+)", lib.explain_plan(_lib.KIND_R2C, dtype, 196608))
+    assert m and int(m.group(1)) * int(m.group(2)) == 196608 and int(m.group(1)) % 2 == 0 and int(m.group(2)) % 2 == 0 and int(m.group(3)) & 1, m
+    if dtype == _lib.F64:
+        assert m.group(2) == "512", m.group(0)
+    assert "real_four_step" not in lib.explain_plan(_lib.KIND_R2C, dtype, 196610) and "real_four_step" not in lib.explain_plan(_lib.KIND_DCT, dtype, 3 ** 11)
     assert seen & {"blue_reg", "blue_lds", "blue_global"}, seen
 
 
