@@ -34,7 +34,7 @@ __host__ __device__ constexpr size_t col_post_table_entries(int F, int op) {
     return (op == G_R2C_EVEN || op == G_DCT1) ? (size_t)(F / 2 + 1) : op == G_DCT2_EVEN ? (size_t)(F / 2 + 1) + (size_t)(F + 1) : 0;
 }
 __host__ __device__ constexpr size_t col_post_table_bytes(int F, size_t cpx_bytes, int op, size_t lanes_bytes) {
-#ifdef NDFFT_NO_COL_POST_TABLE
+#ifdef NDFFT_NO_COL_POST_TABLE      // (A-B builds: define it for the kernels_*.hip units only -- the hiprtc kernels always carry the table, and jit.hip's host-side LDS size must match THEM)
     return 0;
 #else
     return (col_post_table_entries(F, op) && lanes_bytes &&
