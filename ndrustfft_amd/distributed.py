@@ -55,6 +55,32 @@ def _slice(t, d, lo, hi):
     return t[tuple(idx)]
 
 
+def _exchange(sends, recvs, group=None):
+    """One group of pairwise isend / irecv: `sends` = [(tensor, peer)], `recvs` = [(tensor, peer)] (contiguous tensors).
+    RCCL ("nccl") moves device tensors over xGMI directly.  The gloo backend only carries host memory: device tensors are
+    staged through host copies there (what the 2-rank tests on ONE GPU use -- RCCL refuses two ranks on one device --, so
+    that the exchange logic runs with device-resident shards and the HIP kernels as the local executor)."""
+    if not sends and not recvs:
+        return
+    stage = dist.get_backend(group) == "gloo"
+    ops, host_recv, keep = [], [], []
+    for t, peer in sends:
+        w = t.cpu() if (stage and t.is_cuda) else t
+        keep.append(w)
+        ops.append(dist.P2POp(dist.isend, w, peer, group))
+    for t, peer in recvs:
+        if stage and t.is_cuda:
+            h = torch.empty(t.shape, dtype=t.dtype, device="cpu")
+            host_recv.append((t, h))
+            ops.append(dist.P2POp(dist.irecv, h, peer, group))
+        else:
+            ops.append(dist.P2POp(dist.irecv, t, peer, group))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    for t, h in host_recv:
+        t.copy_(h)
+
+
 def scatter_lanes(full, shape, dtype, axis, root=0, device=None, group=None):
     """Root holds `full` (torch tensor of `shape`); every rank returns its contiguous shard.
     Point-to-point: root posts one isend per peer, peers one irecv (7 concurrent xGMI links from
@@ -63,23 +89,19 @@ def scatter_lanes(full, shape, dtype, axis, root=0, device=None, group=None):
     lshape, d, _ = local_shape(shape, axis, rank, world)
     bounds = shard_bounds(shape[d], world)
     if rank == root:
-        ops, keep = [], []
+        sends = []
         mine = None
         for r, (lo, hi) in enumerate(bounds):
             piece = _slice(full, d, lo, hi).contiguous()
             if r == root:
                 mine = piece.clone() if piece.data_ptr() == full.data_ptr() else piece
             elif piece.numel():
-                keep.append(piece)
-                ops.append(dist.P2POp(dist.isend, piece, r, group))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+                sends.append((piece, r))
+        _exchange(sends, [], group)
         return mine
     out = torch.empty(lshape, dtype=dtype, device=device)
     if out.numel():
-        for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, out, root, group)]):
-            w.wait()
+        _exchange([], [(out, root)], group)
     return out
 
 
@@ -92,7 +114,7 @@ def gather_lanes(local, full_shape, axis_out_shape_dim, root=0, out=None, group=
     if rank == root:
         if out is None:
             out = torch.empty(full_shape, dtype=local.dtype, device=local.device)
-        ops, bufs = [], []
+        recvs, bufs = [], []
         for r, (lo, hi) in enumerate(bounds):
             if r == root:
                 _slice(out, d, lo, hi).copy_(local)
@@ -101,16 +123,13 @@ def gather_lanes(local, full_shape, axis_out_shape_dim, root=0, out=None, group=
             buf = torch.empty(s, dtype=local.dtype, device=local.device)
             if buf.numel():
                 bufs.append((buf, lo, hi))
-                ops.append(dist.P2POp(dist.irecv, buf, r, group))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+                recvs.append((buf, r))
+        _exchange([], recvs, group)
         for buf, lo, hi in bufs:
             _slice(out, d, lo, hi).copy_(buf)
         return out
     if local.numel():
-        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, local.contiguous(), root, group)]):
-            w.wait()
+        _exchange([(local.contiguous(), root)], [], group)
     return None
 
 
@@ -149,7 +168,7 @@ def reshard(local, global_shape, d_from, d_to, group=None):
     bt = shard_bounds(global_shape[d_to], world)
     oshape = list(global_shape); oshape[d_to] = bt[rank][1] - bt[rank][0]
     out = torch.empty(oshape, dtype=local.dtype, device=local.device)
-    ops, recvs, keep = [], [], []
+    sends, recvs, placed = [], [], []
     for q in range(world):
         # block that stays on / goes to q: my d_from rows, q's d_to range
         piece = _slice(local, d_to, bt[q][0], bt[q][1])
@@ -157,17 +176,14 @@ def reshard(local, global_shape, d_from, d_to, group=None):
             _slice(out, d_from, bf[rank][0], bf[rank][1]).copy_(piece)
             continue
         if piece.numel():
-            piece = piece.contiguous(); keep.append(piece)
-            ops.append(dist.P2POp(dist.isend, piece, q, group))
+            sends.append((piece.contiguous(), q))
         rshape = list(oshape); rshape[d_from] = bf[q][1] - bf[q][0]
         buf = torch.empty(rshape, dtype=local.dtype, device=local.device)
         if buf.numel():
-            recvs.append((buf, bf[q][0], bf[q][1]))
-            ops.append(dist.P2POp(dist.irecv, buf, q, group))
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-    for buf, lo, hi in recvs:
+            placed.append((buf, bf[q][0], bf[q][1]))
+            recvs.append((buf, q))
+    _exchange(sends, recvs, group)
+    for buf, lo, hi in placed:
         _slice(out, d_from, lo, hi).copy_(buf)
     return out
 
