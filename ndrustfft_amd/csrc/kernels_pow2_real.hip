@@ -100,6 +100,13 @@ template <typename K, typename T> static int launch_k(const RealArgs<T> &a, int 
     return NDFFT_OK;
 }
 
+// developer macro (variant builds only): 1 = the real-lane tiles of F = 1024 (nddct1 n = 1025, 8 lanes x 1024 threads) may narrow to 4 lanes too.  Measured by row pitch
+// (profiles/r09/r09x_dct1_1025_narrow_tiles_by_pitch.txt, tools/probes/col_pitch_probe.py, HIP-graph replay): 1025 x W f64, 8 lanes: 10.8 us flat from W = 512 to 1088
+// at pitches that are multiples of 64 bytes, 13.4 us at the reference's W = 1025 (pitch 8200: every 64-byte row segment straddles two 64-byte chunks); 4 lanes:
+// 8.7 us at W = 512 (128 tiles) rising to 11.6 us at W = 1024 (256 tiles) and 18.0 us at W = 1025 (32-byte segments, misaligned).  So: not kept.
+#ifndef NDFFT_SMALL_GRID_REAL_1024
+#define NDFFT_SMALL_GRID_REAL_1024 0
+#endif
 #ifndef NDFFT_COL_LANES_F32
 #define NDFFT_COL_LANES_F32 32
 #endif
@@ -246,7 +253,7 @@ template <typename T, int F, int OP> static int launch_real_one(const RealArgs<T
             constexpr int SMALL_FLAGS = NDFFT_SMALL_GRID_FLAGS;
             // (not for an input the residency model marks HBM-sourced: 32 / 64-byte rows are ruinous there, and a call of few tiles whose array is not cache-resident is rare)
             if (!a.keep_out && !a.makhoul && !a.stream_in) {
-                if constexpr (!(F >= 1024 && KIND >= 2)) {
+                if constexpr (!(F >= 1024 && KIND >= 2) || NDFFT_SMALL_GRID_REAL_1024) {
                     if constexpr (LPB / 4 >= 4) {
                         if ((a.nlanes + LPB / 2 - 1) / (LPB / 2) < kCus)
                             return launch_k<RealPow2Kernel<T, F, TPL, LPB / 4, typename RealCfg<F>::RL, OP, true, false, 0, false, SMALL_FLAGS>, T>(a, LPB / 4, s);
