@@ -595,6 +595,7 @@ template <typename T> int launch_jit_real(int gop, const JitCfg &cfg, bool col, 
     if (nblk <= 0) return NDFFT_OK;
     if (nblk > 0x7fffffffLL) return NDFFT_ERR_UNSUPPORTED;
     RealArgs<T> arg = a;
+    if (col) real_args_set_inner_shift(arg, lpb);
     void *params[] = {(void *)&arg};
     NDFFT_HIP(hipModuleLaunchKernel(e.fn, (unsigned)nblk, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, s, params, nullptr));
     return NDFFT_OK;
@@ -710,6 +711,7 @@ template <typename T> int launch_jit_fourstep(int kind, bool inverse, const JitC
     if (nblk <= 0) return NDFFT_OK;
     if (nblk > 0x7fffffffLL) return NDFFT_ERR_UNSUPPORTED;
     RealArgs<T> arg = a;
+    real_args_set_inner_shift(arg, lpb);
     void *params[] = {(void *)&arg};
     NDFFT_HIP(hipModuleLaunchKernel(e.fn, (unsigned)nblk, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds, s, params, nullptr));
     return NDFFT_OK;

@@ -61,7 +61,9 @@ template <typename T, int F, int OP, int CS, bool ROWOUT> static int launch_fs(c
     const int64_t nblk = (a.nlanes + LPB - 1) / LPB;
     if (nblk <= 0) return NDFFT_OK;
     if (nblk > 0x7fffffffLL) return fail(NDFFT_ERR_UNSUPPORTED, "too many lanes for one launch");
-    hipLaunchKernelGGL((k_fs_staged<K, T, FsStagedWaves<T>::value>), dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, a);
+    RealArgs<T> b = a;
+    real_args_set_inner_shift(b, LPB);
+    hipLaunchKernelGGL((k_fs_staged<K, T, FsStagedWaves<T>::value>), dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, b);
     NDFFT_HIP(hipGetLastError());
     return NDFFT_OK;
 }

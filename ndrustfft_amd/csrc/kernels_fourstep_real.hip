@@ -68,7 +68,9 @@ template <typename T, int F, int STAGE> static int launch_rfs(const RealArgs<T> 
     const int64_t nblk = (a.nlanes + LPB - 1) / LPB;
     if (nblk <= 0) return NDFFT_OK;
     if (nblk > 0x7fffffffLL) return fail(NDFFT_ERR_UNSUPPORTED, "too many lanes for one launch");
-    hipLaunchKernelGGL((k_rfs_staged<K, T, RfsStagedWaves<T>::value>), dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, a);
+    RealArgs<T> b = a;
+    real_args_set_inner_shift(b, LPB);
+    hipLaunchKernelGGL((k_rfs_staged<K, T, RfsStagedWaves<T>::value>), dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, b);
     NDFFT_HIP(hipGetLastError());
     return NDFFT_OK;
 }
@@ -102,7 +104,9 @@ template <typename T, int F> static int launch_rfs_c2r(const RealArgs<T> &a, hip
     const int64_t nblk = (a.nlanes + LPB - 1) / LPB;
     if (nblk <= 0) return NDFFT_OK;
     if (nblk > 0x7fffffffLL) return fail(NDFFT_ERR_UNSUPPORTED, "too many lanes for one launch");
-    hipLaunchKernelGGL((k_rfs_staged<K, T, RfsStagedWaves<T>::value>), dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, a);
+    RealArgs<T> b = a;
+    real_args_set_inner_shift(b, LPB);
+    hipLaunchKernelGGL((k_rfs_staged<K, T, RfsStagedWaves<T>::value>), dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, b);
     NDFFT_HIP(hipGetLastError());
     return NDFFT_OK;
 }

@@ -95,6 +95,7 @@ template <typename K, typename T> static int launch_k(const RealArgs<T> &a, int 
             b.xcd_chunk = xcd_chunk_for((size_t)lpb * (size_t)a.n_in * esz, nblk);
         }
     }
+    if (a.inner > 1) real_args_set_inner_shift(b, lpb);
     hipLaunchKernelGGL((k_real_aot<K, T, RealAotWaves<K, T>::value>), dim3((unsigned)nblk), dim3(K::THREADS), K::LDS_BYTES, s, b);
     NDFFT_HIP(hipGetLastError());
     return NDFFT_OK;

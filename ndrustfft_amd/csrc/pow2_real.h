@@ -67,6 +67,7 @@ template <typename T> struct RealArgs {
     int32_t chunk_out = 0;               // row R2C: output lanes are dense (pitch == F + 1) and the array is 16-byte aligned: the workgroup's
                                          // output lanes form ONE contiguous chunk, staged in LDS and stored with coalesced 16-byte accesses
     int32_t xcd_chunk = 0;               // non-XCD kernels: XCD-aware workgroup -> tile map (device_common.h: xcd_block), 0 = identity
+    int32_t inner_shift = -1;            // column tiles: log2(inner) when inner is a power of two that is a multiple of the tile width (set by the launcher): lane -> (o, i) by shift / mask
     int32_t stream_in = 0;               // 1 = streaming (nt) loads of the input.  COL kernels: it is read once and must not push the intermediate of a
                                          // two-stage route out of the Infinity Cache; row kernels (16-byte staging loads): the input comes from HBM
     const cpx<T> *twp_rev = nullptr;     // Bluestein / Rader kernels: per-pass twiddles of the SAME radix list taken back to front (second FFT of the convolution)
@@ -79,6 +80,20 @@ template <typename T> struct RealArgs {
     const int32_t *rader_tab = nullptr;  // Rader kernels (rader_kernel.h): g^i mod P (i < P - 1), then g^-i mod P; bhat = FFT_(P-1)(W_P^(g^-q)) / (P - 1),
                                          // twp / twp_rev = per-pass twiddles of FFT_(P-1) with the radix list front to back / back to front
 };
+
+// launcher side of RealArgs::inner_shift (see RealPow2Kernel::lane_split): lpb = lanes per column tile
+#ifndef NDFFT_NO_INNER_SHIFT
+template <typename T> __host__ __device__ inline void real_args_set_inner_shift(RealArgs<T> &b, int lpb) {
+    b.inner_shift = -1;
+    if (lpb > 0 && (lpb & (lpb - 1)) == 0 && b.inner >= lpb && (b.inner & (b.inner - 1)) == 0) {
+        int s = 0;
+        while (((int64_t)1 << s) < b.inner) ++s;
+        b.inner_shift = s;
+    }
+}
+#else
+template <typename T> __host__ __device__ inline void real_args_set_inner_shift(RealArgs<T> &b, int) { b.inner_shift = -1; }
+#endif
 
 // RL back to front: the second FFT of a convolution (Bluestein, Rader) runs the passes in reverse order, so that the register pattern it
 // starts from (t + q TPL + r M / R_last) IS the pattern the first one ends in -- the pointwise product never goes through LDS
@@ -185,6 +200,12 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
         return p;
     }
     static constexpr int THREADS = TPL * LPB;
+    // lane L = lane0 + cl of a column tile -> (outer index o, inner index i).  The general form divides a 64-bit lane index per thread (about 60 VALU instructions of
+    // the ~650 a column-tile wave issues); with inner a power of two that whole tiles divide, o is the TILE's (a scalar shift) and i a mask and an add.
+    static __device__ __forceinline__ void lane_split(const RealArgs<T> &a, int64_t lane0, int cl, int64_t &o, int64_t &i) {
+        if (a.inner_shift >= 0) { o = lane0 >> a.inner_shift; i = (lane0 & (((int64_t)1 << a.inner_shift) - 1)) + cl; }
+        else { const int64_t L = lane0 + cl; o = L / a.inner; i = L % a.inner; }
+    }
     // CS = 1..3, the twiddles W_N^(j k1), j < F, of one tile.  With the 3-D grid k1 is the WORKGROUP's: threads 0 .. F-1 load the two table entries of one
     // twiddle each (in front of the staging loads), multiply and leave the F products in LDS behind the lane regions; everybody reads them from there (CS = 1 / 2
     // in PRE, CS = 3 in the store loop).  Before round 6 every thread loaded its own 2 x 8 entries -- 32 lanes asking for the same address, 64 wave-level loads per
@@ -317,7 +338,8 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                 // the staging loads.  Before round 6 the staging loop gathered two table entries per ELEMENT (16 scattered loads per thread beside 8 loads of data).
                 constexpr int R0 = RL::at(0), NB0 = F / R0;
                 const int mask = (1 << a.cs_logB) - 1;
-                const int k1 = (int)(((lane < a.nlanes) ? lane : 0) % a.inner);
+                int64_t k1o, k1i; lane_split(a, lane0, ll, k1o, k1i);
+                const int k1 = lane < a.nlanes ? (int)k1i : 0;
                 const int mb = t * k1;
                 cs4_bhi = a.cs_twhi[mb >> a.cs_logB]; cs4_blo = a.cs_twlo[mb & mask];
                 // (thread row t owns the steps e = t, t + TPL, ...: one where TPL >= E -- every ahead-of-time recipe --, more for the hiprtc recipes with E > TPL)
@@ -340,8 +362,9 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
             const int cl = threadIdx.x % LPB, j0 = threadIdx.x / LPB;
             const int64_t L = lane0 + cl;
             // (CS = 5 / 6: the inner index k1 runs over a pitch padded to whole 128-byte lines; lanes k1 > N1/2 are padding)
-            if (L < a.nlanes && (CS < 5 || 2 * (L % a.inner) <= a.cs_f1)) {
-                const int64_t base = (L / a.inner) * a.outer_in + (L % a.inner);
+            int64_t Lo, Li; lane_split(a, lane0, cl, Lo, Li);
+            if (L < a.nlanes && (CS < 5 || 2 * Li <= a.cs_f1)) {
+                const int64_t base = Lo * a.outer_in + Li;
                 char *dst = smem + (size_t)cl * LANE_LDS * 2 * sizeof(T);
                 constexpr int STEP = THREADS / LPB;
                 constexpr int UR = NDFFT_COL_REAL_U;   // loads in flight per thread of a REAL column tile (2 F / TPL = 16 elements per thread with E = 8)
@@ -354,8 +377,8 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                     if constexpr (ROWOUT && OP == G_C2C_FWD) {
                         if (a.makhoul == 2) {   // first pass of the fused DCT-IV four-step: element j of lane (o, n2) is z[jj] = (x[2 jj] + i x[n-1-2 jj]) s e^(-i pi (4 jj + 1) / 4n),
                                                 // jj = j inner + n2, built from the REAL lane o of n = 2 this->n inner points (realops.h: G_DCT4_EVEN)
-                            const T *lane_o = (const T *)a.in + (L / a.inner) * a.outer_in;
-                            const int64_t m0 = L % a.inner, nn = 2 * (int64_t)a.n * a.inner;
+                            const T *lane_o = (const T *)a.in + Lo * a.outer_in;
+                            const int64_t m0 = Li, nn = 2 * (int64_t)a.n * a.inner;
                             struct XW { T x0, x1; cpx<T> w; };
                             if (a.stream_in) stage_loop<STEP>(j0, a.n_in,
                                 [&](int j) { const int64_t jj = (int64_t)j * a.inner + m0; XW r; r.x0 = __builtin_nontemporal_load(lane_o + 2 * jj); r.x1 = __builtin_nontemporal_load(lane_o + (nn - 1 - 2 * jj)); r.w = a.aux1[jj]; return r; },
@@ -374,8 +397,8 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                     bool gathered = false;
                     if constexpr (ROWOUT) {
                         if (a.makhoul) {   // element j of lane (o, n2) is v[m], m = j inner + n2, of the n = this->n * inner long lane o
-                            const T *lane_o = (const T *)a.in + (L / a.inner) * a.outer_in;
-                            const int64_t m0 = L % a.inner, nn = (int64_t)a.n * a.inner;
+                            const T *lane_o = (const T *)a.in + Lo * a.outer_in;
+                            const int64_t m0 = Li, nn = (int64_t)a.n * a.inner;
                             // makhoul = 1: Makhoul's permutation (DCT-II); makhoul = 3 (round 5): the EVEN EXTENSION e[m] = x[m] (m <= nn/2), x[nn - m] otherwise, of a DCT-I lane of
                             // nn/2 + 1 points (exec.hip: real_fourstep with dct1 = true)
                             const bool ext = a.makhoul == 3;
@@ -512,8 +535,9 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
             const int64_t L = lane0 + cl;
             CsPos csp; csp.live = true;
             int64_t base = 0;
+            int64_t Lo = 0, Li = 0;
             if constexpr (CS >= 1 && CS <= 3) { csp = cs_pos(a, cl); if (!csp.live) return; }
-            else { if (L >= a.nlanes) return; base = (L / a.inner) * a.outer_out + (L % a.inner); }
+            else { if (L >= a.nlanes) return; lane_split(a, lane0, cl, Lo, Li); base = Lo * a.outer_out + Li; }
             const cpx<T> *res = (const cpx<T> *)(smem + (size_t)cl * LANE_LDS * 2 * sizeof(T));
             if constexpr (PAIR) {
                 // the split twiddles of this thread's pairs, loaded up front: inside the loops below every iteration would wait for its own table load behind
@@ -568,9 +592,9 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                     if (!skip) gstore<T, true>(out + (int64_t)kk * a.cs_pitch + (int64_t)r2 * a.elem_out, val);
                 }
             } else if constexpr (CS == 5 || CS == 6) {
-                const int k1 = (int)(L % a.inner);
+                const int k1 = (int)Li;
                 if (2 * k1 > a.cs_f1) return;
-                const int64_t ob = (L / a.inner) * a.outer_out;   // output lane o
+                const int64_t ob = Lo * a.outer_out;   // output lane o
                 for (int q = j0; q < F; q += THREADS / LPB) {
                     cpx<T> val = post_cplx<T, OP, ZiPhi>(a, res, q);
                     int kk = k1, r2 = q;
@@ -619,8 +643,8 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
                 T *out = (T *)a.out + base;
                 if constexpr (OP == G_C2R_EVEN && !XCD) {
                     if (a.makhoul) {   // last pass of the inverse real four-step, DCT-III: element q of lane (o, n2) is v[m], m = q inner + n2 -> y[2m] / y[2(n-1-m)+1]
-                        T *lane_o = (T *)a.out + (L / a.inner) * a.outer_out;
-                        const int64_t m0 = L % a.inner, nn = (int64_t)a.n_out * a.inner;
+                        T *lane_o = (T *)a.out + Lo * a.outer_out;
+                        const int64_t m0 = Li, nn = (int64_t)a.n_out * a.inner;
                         for (int q = j0; q < a.n_out; q += THREADS / LPB) {
                             const int64_t m = (int64_t)q * a.inner + m0;
                             lane_o[2 * q < a.n_out ? 2 * m : 2 * (nn - 1 - m) + 1] = post_real<T, OP, ZiPhi>(a, res, q);
