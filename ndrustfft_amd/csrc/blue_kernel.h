@@ -27,8 +27,8 @@ template <typename T, int M, int TPL, int LPB, typename RL, int OP, bool COL = f
     using FFT = Pow2Kernel<T, M, TPL, LPB, false, RL, 0, 1, 0>;
     using FFT2 = Pow2Kernel<T, M, TPL, LPB, false, RadixReversed<RL>, 0, 1, 0>;   // the passes back to front (pow2_real.h: RadixReversed)
 
-    template <int STEP, typename LD, typename ST> static __device__ __forceinline__ void stage_loop(int j0, int n, LD ld, ST st) {
-        constexpr int U = 8;
+    // (the remainder in batches of U / 2, U / 4, ...: see pow2_real.h stage_loop -- one load at a time is one round trip to memory each)
+    template <int STEP, int U = 8, typename LD, typename ST> static __device__ __forceinline__ void stage_loop(int j0, int n, LD ld, ST st) {
         int j = j0;
         for (; j + (U - 1) * STEP < n; j += U * STEP) {
             decltype(ld(0)) tmp[U];
@@ -37,7 +37,8 @@ template <typename T, int M, int TPL, int LPB, typename RL, int OP, bool COL = f
 #pragma unroll
             for (int u = 0; u < U; ++u) st(j + u * STEP, tmp[u]);
         }
-        for (; j < n; j += STEP) st(j, ld(j));
+        if constexpr (U >= 4) stage_loop<STEP, U / 2>(j, n, ld, st);
+        else for (; j < n; j += STEP) st(j, ld(j));
     }
 
     // FFT input element i (before the chirp) from the raw lane

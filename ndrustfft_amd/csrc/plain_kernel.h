@@ -21,8 +21,8 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
     static constexpr bool OUT_CPLX = OP == G_R2C_EVEN || OP == G_R2C_ODD || OP == G_C2C_FWD || OP == G_C2C_INV;
     static_assert(FFT::LANE_LDS <= LANE_LDS, "exchange region");
 
-    template <int STEP, typename LD, typename ST> static __device__ __forceinline__ void stage_loop(int j0, int n, LD ld, ST st) {
-        constexpr int U = 8;
+    // (the remainder in batches of U / 2, U / 4, ...: see pow2_real.h stage_loop -- one load at a time is one round trip to memory each)
+    template <int STEP, int U = 8, typename LD, typename ST> static __device__ __forceinline__ void stage_loop(int j0, int n, LD ld, ST st) {
         int j = j0;
         for (; j + (U - 1) * STEP < n; j += U * STEP) {
             decltype(ld(0)) tmp[U];
@@ -31,7 +31,8 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
 #pragma unroll
             for (int u = 0; u < U; ++u) st(j + u * STEP, tmp[u]);
         }
-        for (; j < n; j += STEP) st(j, ld(j));
+        if constexpr (U >= 4) stage_loop<STEP, U / 2>(j, n, ld, st);
+        else for (; j < n; j += STEP) st(j, ld(j));
     }
 
     static __device__ __forceinline__ cpx<T> pre(const RealArgs<T> &a, const void *raw, int i) {

@@ -157,6 +157,13 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
     // (round 5: loading a one- or two-element remainder -- lanes of 2^k + 1 points, the DCT-I bench sizes -- BEFORE the full batches, so that it costs no round trip
     //  of its own, gained 2-7 % on the reference's n x n DCT-I bench shapes and cost the register-capped f32 kernels 6-19 %: 32 x 2^20 c64 281 -> 334 us, ndfft_r2c f32
     //  rows n = 100 .. 512 +6-17 % -- profiles/r08/r08n_configs_compare.txt; not kept)
+    // The remainder after the batches of U goes in batches of U / 2, U / 4, ... (round 6).  Before, it ran one load at a time -- `global_load; s_waitcnt vmcnt(0)` in a
+    // loop, found in the ISA --, and f32 rows have (2 F / 4) / TPL = E / 2 = 4 sixteen-byte loads per thread, FEWER than one batch of 8: four dependent round trips to
+    // memory per lane; every real f32 row kernel sat at 0.43-0.59 of the roofline beside 0.70 for the C2C ones (ndfft_r2c f32 rows n = 4096: 35.6 -> 31.6 us,
+    // 8192 x 8192: 125.4 -> 117.0 us, profiles/r09/r09y_row_tail_staging_abab.txt).  The same loop serves the other shared-memory kernels (plain / Rader / Bluestein).
+    // Not in the column tiles of power-of-two F (their trip counts are whole batches; the dead remainder code cost the register-capped f32 first passes of the
+    // row four-step 12 more bytes of scratch and the f64 ones 14 VGPRs).
+    static constexpr bool STAGE_TAIL = !COL || (F & (F - 1)) != 0;
     template <int STEP, int U = 8, typename LD, typename ST> static __device__ __forceinline__ void stage_loop(int j0, int n, LD ld, ST st) {
         int j = j0;
         for (; j + (U - 1) * STEP < n; j += U * STEP) {
@@ -166,7 +173,8 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
 #pragma unroll
             for (int u = 0; u < U; ++u) st(j + u * STEP, tmp[u]);
         }
-        for (; j < n; j += STEP) st(j, ld(j));
+        if constexpr (STAGE_TAIL && U >= 4) stage_loop<STEP, U / 2>(j, n, ld, st);
+        else for (; j < n; j += STEP) st(j, ld(j));
     }
     static __device__ __forceinline__ cpx<T> cs_tw(const RealArgs<T> &a, int m) {
         return cmul(a.cs_twhi[m >> a.cs_logB], a.cs_twlo[m & ((1 << a.cs_logB) - 1)]);
@@ -236,6 +244,7 @@ template <typename T, int F, int TPL, int LPB, typename RL, int OP, bool COL = f
     // row layout R2C / C2R: the PRE fold reads unit-stride complex elements (ascending, and for C2R also
     // descending), so it loads global memory directly and the LDS staging pass and its barrier are skipped
     // (f64 only: 16-byte elements; for f32 the 16-byte vector staging loads measure faster than 8-byte direct ones)
+    // (round 6, after the staging loop's remainder was fixed -- stage_loop below: direct 8-byte loads for f32 R2C rows measured +2 ... +4 % against the staged form, profiles/r09/r09y_direct32_abab.txt)
     static constexpr bool DIRECT_IN = !COL && sizeof(T) == 8 && (OP == G_R2C_EVEN || OP == G_C2R_EVEN);
     // ops whose POST is the real-FFT split: outputs k and F-k share one pair of LDS reads and one twiddle
     static constexpr bool PAIR = OP == G_R2C_EVEN || OP == G_DCT1 || OP == G_DCT2_EVEN;

@@ -78,8 +78,8 @@ template <typename T, int P, int MC1, int MC2, int TPL, int LPB, typename RL, in
     static constexpr int PINV = rader_inv_mod(P, MC), MINV = rader_inv_mod(MC, P);   // P^-1 mod MC, MC^-1 mod P
     static_assert(FFT::LANE_LDS <= SUB_LDS, "exchange region of one sub-transform");
 
-    template <int STEP, typename LD, typename ST> static __device__ __forceinline__ void stage_loop(int j0, int n, LD ld, ST st) {
-        constexpr int U = 8;
+    // (the remainder in batches of U / 2, U / 4, ...: see pow2_real.h stage_loop -- one load at a time is one round trip to memory each)
+    template <int STEP, int U = 8, typename LD, typename ST> static __device__ __forceinline__ void stage_loop(int j0, int n, LD ld, ST st) {
         int j = j0;
         for (; j + (U - 1) * STEP < n; j += U * STEP) {
             decltype(ld(0)) tmp[U];
@@ -88,7 +88,8 @@ template <typename T, int P, int MC1, int MC2, int TPL, int LPB, typename RL, in
 #pragma unroll
             for (int u = 0; u < U; ++u) st(j + u * STEP, tmp[u]);
         }
-        for (; j < n; j += STEP) st(j, ld(j));
+        if constexpr (U >= 4) stage_loop<STEP, U / 2>(j, n, ld, st);
+        else for (; j < n; j += STEP) st(j, ld(j));
     }
 
     // inner-FFT input element i (natural order) from the raw lane
