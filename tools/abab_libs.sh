@@ -9,6 +9,6 @@ for round in 1 2 3; do
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        r = json.loads(l); print('%-10s round $round  %8.2f us  %-14s %s' % ('$name', r['us'], r.get('path'), r['workload']))"
+        r = json.loads(l); print('%-10s round $round  %8.2f us  %-14s %s' % ('$name', r['us'], r.get('path'), r['workload'])); ('us_reread' in r and r.get('pairs', 1) > 1) and print('%-10s round $round  %8.2f us  %-14s %s [re-read]' % ('$name', r['us_reread'], r.get('path'), r['workload']))"
   done
 done
