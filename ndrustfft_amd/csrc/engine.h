@@ -273,6 +273,7 @@ void shard_release_all();   // shard.hip: every shard worker frees its chunk buf
 bool jit_choose_col(int dtype, int n, const JitCfg &row_cfg, JitCfg &col_cfg);   // true: column tiles of a C2C plan should use col_cfg instead of row_cfg
 void jit_build_twiddles(const JitCfg &cfg, HostTable &out);
 int launch_jit_c2c(int dtype, const JitCfg &cfg, int nt, const Pow2Args &a, hipStream_t s);
+bool jit_c2c_row_vec(int dtype, JitCfg &cfg);   // f32 C2C rows: true = cfg was changed to the same radix list on half the threads (twice the elements), which can use 16-byte accesses (jit.hip)
 int jit_col_lanes(int dtype, const JitCfg &cfg, bool c2c = false);   // c2c: a 4-lane tile is acceptable (complex output rows)
 // thread-per-lane two-factor kernels (reg_kernel.h), specialised with hiprtc
 bool regfft_factor(int n, int *n1, int *n2);

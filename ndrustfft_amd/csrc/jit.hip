@@ -167,6 +167,7 @@ static bool jit_choose_impl(int dtype, int n, JitCfg &cfg, bool allow_partial, b
                 for (int r : c.radix) { const int nb = n / r, sl = (nb + c.tpl - 1) / c.tpl; c.e = std::max(c.e, sl * r); if (nb % c.tpl) c.partial = true; }
                 c.lpb = c.row_lpb > 0 ? c.row_lpb : (c.tpl >= 64 ? 1 : std::max(1, 64 / c.tpl));
                 if (c.row_lpb == 0) c.row_lpb = c.lpb;
+                if (dtype == NDFFT_F32 && !c.partial && (c.e / c.radix.front()) % 2 == 0 && (c.e / c.radix.back()) % 2 == 0) c.vec = 2;
                 cfg = c;
                 return true;
             }
@@ -424,10 +425,25 @@ std::string radix_list(const JitCfg &cfg) {
 }
 }  // namespace
 
+// f32 C2C rows whose default recipe ("fewest passes, smallest E") leaves ONE butterfly per thread in the first or the last pass cannot use the 16-byte
+// (two-element) global accesses (Pow2Kernel: VEC = 2) and sat at 0.55 of the roofline beside 0.70-0.72 for the power-of-two lengths.  The same radix list on HALF
+// the threads with twice the elements (whole rounds stay whole, the twiddle tables depend on the radix list only) has an even number everywhere:
+// c64 n = 1000 (10.10.10: 100 threads x 10 -> 50 x 20) 61.7 -> 52.3 us (profiles/r09/r09y_c64_vec_knob.txt).  Not for the re-planned / partial-round recipes.
+bool jit_c2c_row_vec(int dtype, JitCfg &cfg) {
+    if (dtype != NDFFT_F32 || cfg.vec != 1 || cfg.partial || cfg.row_lpb != 0 || cfg.tpl < 2 || (cfg.tpl & 1) || 2 * cfg.e > 24) return false;
+    if (!NDFFT_DEV_INT("NDFFT_JIT_ROW_VEC", 1)) return false;
+    for (int r : cfg.radix) if (cfg.e % r) return false;      // (whole rounds in every pass)
+    cfg.e *= 2; cfg.tpl /= 2; cfg.vec = 2;
+    return true;
+}
+
 // returns NDFFT_OK and launches, or NDFFT_ERR_UNSUPPORTED if no specialised kernel can be had (caller falls back)
-int launch_jit_c2c(int dtype, const JitCfg &cfg_in, int nt, const Pow2Args &a, hipStream_t s) {
+int launch_jit_c2c(int dtype, const JitCfg &cfg_plan, int nt, const Pow2Args &a, hipStream_t s) {
     if (!rtc().ok) return NDFFT_ERR_UNSUPPORTED;
-    const bool vec_ok = cfg_in.vec == 2 && a.pitch_in % 2 == 0 && a.pitch_out % 2 == 0 && ((uintptr_t)a.in % 16) == 0 && ((uintptr_t)a.out % 16) == 0;
+    const bool aligned = a.pitch_in % 2 == 0 && a.pitch_out % 2 == 0 && ((uintptr_t)a.in % 16) == 0 && ((uintptr_t)a.out % 16) == 0;
+    JitCfg cfg_in = cfg_plan;
+    if (aligned) { JitCfg cv = cfg_plan; if (jit_c2c_row_vec(dtype, cv)) cfg_in = cv; }
+    const bool vec_ok = cfg_in.vec == 2 && aligned;
     const int vec = vec_ok ? 2 : 1;
     int dev = 0;
     NDFFT_HIP(hipGetDevice(&dev));

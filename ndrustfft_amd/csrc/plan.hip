@@ -741,6 +741,7 @@ int ndfft_explain_plan(int kind, int dtype, size_t n, char *buf, size_t buflen) 
         else if (c.pow2) l += " route=pow2";
         else if (c.jit) {
             l += " route=jit tpl=" + std::to_string(c.jitcfg.tpl) + " e=" + std::to_string(c.jitcfg.e) + " radix=" + radix(c.jitcfg.radix) + " lanes=" + std::to_string(c.jitcfg.row_lpb);
+            if (i == CFG_MAIN && p->kind == NDFFT_KIND_C2C) { JitCfg cv = c.jitcfg; if (jit_c2c_row_vec(p->dtype, cv)) l += " rowvec_tpl=" + std::to_string(cv.tpl) + " rowvec_e=" + std::to_string(cv.e); }   // 16-byte-aligned f32 rows
             if (c.jit_col_alt) l += " col_tpl=" + std::to_string(c.jitcfg_col.tpl) + " col_e=" + std::to_string(c.jitcfg_col.e) + " col_radix=" + radix(c.jitcfg_col.radix);
             if (c.fs_jit) l += " fs_tpl=" + std::to_string(c.fs_jitcfg.tpl) + " fs_e=" + std::to_string(c.fs_jitcfg.e) + " fs_radix=" + radix(c.fs_jitcfg.radix);   // as a four-step factor (jit.hip: jit_fourstep_choose)
         }

@@ -23,6 +23,7 @@ bool jit_choose(int, int n, JitCfg &cfg, bool allow_partial) {
 }
 bool jit_choose_real(int dtype, int F, JitCfg &cfg) { return jit_choose(dtype, F, cfg, true); }
 bool jit_choose_col(int, int, const JitCfg &, JitCfg &) { return false; }   // (no hiprtc in the emulation: no separate column recipe)
+bool jit_c2c_row_vec(int, JitCfg &) { return false; }
 // the CPU build keeps Bluestein on powers of two (M = 64 and 256 are instantiated below) except for F = 263, which gets the smooth length 550 = 11.10.5 on 55 threads
 // (a PARTIAL first round: 50 butterflies of radix 11) like the product's blue_pick_len would choose
 int blue_pick_len(int, int F, int m_pow2) { return F == 263 ? 550 : m_pow2; }

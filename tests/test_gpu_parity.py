@@ -189,6 +189,27 @@ def test_rader_f64_radix_23_29_31(L):
     ps.rader_kernel(L, sizes=(139, 233, 311), col_max_F=0, dtypes=(np.float64,))
     for name, shape, axis in (("ndfft", (139, 2048), 0), ("nddct2", (278, 1024), 0), ("ndfft_r2c", (3, 622, 512), 1)):
         ps.run_case(L, name, shape, axis, np.float64, offset=7)
+def test_c64_rows_on_half_the_threads(L):
+    """Round 6 (jit.hip: jit_c2c_row_vec): f32 C2C rows of the 14 lengths whose default recipe has one butterfly per thread in its first or last pass run the same
+    radix list on half the threads with 16-byte accesses -- against the oracle, both directions; and from a base pointer that is only 8-byte aligned (plain recipe)."""
+    import torch
+    from ndrustfft_amd import FftHandler, ndfft
+    for n in (432, 500, 648, 1000, 1296, 2500, 2592, 3888, 5184):
+        rows = max(64, (1 << 18) // n)
+        for name in ("ndfft", "ndifft"):
+            assert ps.run_case(L, name, (rows, n), 1, np.float32, offset=n) == "jit_reg", (name, n)
+    n, rows = 1000, 300
+    x = synth.complex_array((rows, n), np.complex64)
+    ref = np.fft.fft(x.astype(np.complex128), axis=1)
+    for shift in (0, 1):
+        buf = torch.zeros(rows * n + shift, dtype=torch.complex64, device="cuda:0"); out = torch.zeros(rows * n + shift, dtype=torch.complex64, device="cuda:0")
+        xd = buf[shift:].view(rows, n); yd = out[shift:].view(rows, n)
+        xd.copy_(torch.from_numpy(x))
+        assert xd.data_ptr() % 16 == 8 * shift
+        ndfft(xd, yd, FftHandler(n, np.float32), 1)
+        torch.cuda.synchronize()
+        err = np.abs(yd.cpu().numpy() - ref).max() / np.abs(ref).max()
+        assert err < 1e-5 and _lib.default().last_path() == "jit_reg", (shift, err)
 def test_odd_real_lengths(L): ps.odd_real_lengths(L, sizes=(63, 125, 1001, 3003), dct4=True)
 def test_dct1_power_of_two_lengths(L): ps.dct1_power_of_two_lengths(L)
 def test_rader_kernel_beyond_bluestein(L):

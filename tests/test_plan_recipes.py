@@ -138,3 +138,10 @@ def test_known_recipes(lib):
     d = _fields(lib.explain_plan(_lib.KIND_C2C, _lib.F32, 100).splitlines()[0])
     assert d["radix"] == "5.5.4" and d["col_radix"] == "10.10" and d["col_tpl"] == "10"
     assert not any("col_tpl" in lib.explain_plan(_lib.KIND_C2C, _lib.F64, n) for n in (100, 144, 220))
+    # round 6: f32 C2C rows whose default recipe has one butterfly per thread in the first or last pass run the same radix list on half the threads
+    # (16-byte accesses): exactly these 14 lengths up to 8192, never f64, never a partial-round or re-planned recipe
+    rv = [n for n in range(256, 8193) if "rowvec_tpl" in lib.explain_plan(_lib.KIND_C2C, _lib.F32, n).splitlines()[0]]
+    assert rv == [432, 500, 576, 648, 864, 1000, 1296, 2000, 2500, 2592, 3456, 3888, 5000, 5184], rv
+    d = _fields(lib.explain_plan(_lib.KIND_C2C, _lib.F32, 1000).splitlines()[0])
+    assert (d["tpl"], d["e"], d["rowvec_tpl"], d["rowvec_e"], d["radix"]) == ("100", "10", "50", "20", "10.10.10"), d
+    assert "rowvec" not in lib.explain_plan(_lib.KIND_C2C, _lib.F64, 1000) and "rowvec" not in lib.explain_plan(_lib.KIND_C2C, _lib.F32, 264)
