@@ -22,7 +22,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(f"{out}/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "ndfft" not in k:
+        if "ndfft" not in k and "k_jit" not in k:      # (hiprtc kernels are all called k_jit: grid / workgroup / VGPRs tell them apart)
             continue
         key = re.sub(r"\s+", "", k)[:230] + " grid=" + r["Grid_Size"] + " wg=" + r.get("Workgroup_Size", "?") + " vgpr=" + r.get("VGPR_Count", r.get("Arch_VGPR_Count", "?")) + " lds=" + r.get("LDS_Block_Size", "?")
         acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
